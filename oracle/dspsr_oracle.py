@@ -1,0 +1,777 @@
+"""CPU ORACLE (test infrastructure -- NOT product code).
+
+A numpy restatement of the reference algorithm for the one hot path
+    8-bit voltages -> dsp::Filterbank (-F N:D) -> dsp::Detection -> dsp::Fold
+of demorest/dspsr.  Only tests/, __graft_entry__.smoke() and the cpu_baseline
+leg of bench.py may import this module; the product (dspsr_amd/) must never do so.
+
+PARITY STATUS: "parity unpinned" at the PSRCHIVE boundary.
+  The reference holds no golden vectors / known-answer tests for this path
+   and cannot be built here (needs PSRCHIVE + autotools +
+  FFTW).  What IS pinned:
+    * cross_detect / stokes_detect / optimal_fft_length: checked against the
+      reference's own C files compiled unmodified into oracle/_ref (tests/test_oracle_ref.py);
+    * the FFT conventions (forward e^{-i}, backward e^{+i}, both unnormalised) are those the
+      reference's own CUDA twin requests from cuFFT (Signal/General/FilterbankCUDA.cu:92,232,258)
+      and are cross-checked between numpy pocketfft and the independent C FFT in oracle_c.c;
+    * everything else is restated line by line with file:line citations below.
+  Third-party pieces NOT in /root/reference (PSRCHIVE, version unpinned by configure.ac:74-78):
+    FTransform (FFT), Pulsar::Predictor (TEMPO polyco), JenetAnderson98 (8-bit LUT spacing), MJD.
+
+All citations are relative to /root/reference.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# Observation + DADA header  (Kernel/Classes/ASCIIObservation.C:82-415, DADAFile.C:33-180)
+# --------------------------------------------------------------------------------------
+
+DADA_HDR_SIZE = 4096  # DADAFile.C:33-110 default header size
+
+
+@dataclass
+class Observation:
+    """Minimal dsp::Observation (Kernel/Classes/dsp/Observation.h) for this path."""
+    centre_frequency: float = 1382.0   # MHz
+    bandwidth: float = -400.0          # MHz, signed
+    nchan: int = 1
+    npol: int = 2
+    ndim: int = 1                      # 1 => Nyquist (real), 2 => Analytic (complex)  ASCIIObservation.C:227-244
+    nbit: int = 8
+    tsamp_us: float = 0.00125
+    dispersion_measure: float = 0.0
+    machine: str = "DADA"
+    source: str = "J0000+0000"
+    telescope: str = "PKS"
+    utc_start: str = "2010-04-13-02:05:45"
+    obs_offset: int = 0
+    dual_sideband: int = -1            # Observation.C:63,80-87
+    dc_centred: bool = False
+    swap: bool = False
+    scale: float = 1.0
+    start_seconds: float = 0.0         # seconds since utc_start of first sample
+
+    @property
+    def rate(self) -> float:           # samples per second  ASCIIObservation.C:298-377
+        return 1e6 / self.tsamp_us
+
+    @property
+    def state(self) -> str:
+        return "Nyquist" if self.ndim == 1 else "Analytic"
+
+    def get_dual_sideband(self) -> bool:   # Observation.C:80-87
+        if self.dual_sideband != -1:
+            return self.dual_sideband == 1
+        return self.state == "Analytic"
+
+
+def parse_dada_header(raw: bytes) -> dict:
+    """ascii_header_get semantics: 'KEY value' per line, '#' starts a comment."""
+    out = {}
+    text = raw.split(b"\0", 1)[0].decode("ascii", "replace")
+    for line in text.splitlines():
+        line = line.split("#", 1)[0].strip()
+        if not line:
+            continue
+        parts = line.split(None, 1)
+        if len(parts) == 2:
+            out[parts[0]] = parts[1].strip()
+    return out
+
+
+def observation_from_header(h: dict) -> Observation:
+    o = Observation()
+    o.centre_frequency = float(h["FREQ"])
+    o.bandwidth = float(h["BW"])
+    o.nchan = int(h.get("NCHAN", 1))
+    o.npol = int(h["NPOL"])
+    o.ndim = int(h.get("NDIM", 1))
+    o.nbit = int(h["NBIT"])
+    o.tsamp_us = float(h["TSAMP"])
+    o.machine = h.get("INSTRUMENT", "DADA")
+    o.source = h.get("SOURCE", "")
+    o.telescope = h.get("TELESCOPE", "")
+    o.utc_start = h.get("UTC_START", o.utc_start)
+    o.obs_offset = int(h.get("OBS_OFFSET", 0))
+    if "DSB" in h:
+        o.dual_sideband = 1 if int(h["DSB"]) == 1 else 0
+    if "DM" in h:
+        o.dispersion_measure = float(h["DM"])
+    bytes_per_samp = o.nchan * o.npol * o.ndim * o.nbit // 8
+    o.start_seconds = (o.obs_offset // bytes_per_samp) / o.rate
+    return o
+
+
+# --------------------------------------------------------------------------------------
+# 8-bit unpack (a15)
+#   BitTable::generate_unique_values  Kernel/Classes/BitTable.C:165-218
+#   GenericEightBitUnpackerCUDA.cu:45,88-93:  float = (int8 + 0.5) * scale
+#   byte order: BitUnpacker.C:48-80  (nskip = npol*nchan*ndim, offset (c*npol+p)*ndim+d)
+#   CASPSR: 4 bytes pol0 then 4 bytes pol1  CASPSRUnpacker.C:132-187
+# --------------------------------------------------------------------------------------
+
+# JenetAnderson98::get_optimal_spacing(8) lives in PSRCHIVE (ext, unpinned).  Value of the
+# published JA98 table for 8 bits; it only fixes one global scale constant S8.
+JA98_SPACING_8BIT = 0.02957
+
+
+def _normal_cdf(x: float) -> float:
+    return 0.5 * (1.0 + math.erf(x / math.sqrt(2.0)))
+
+
+def eight_bit_scale(spacing: float = JA98_SPACING_8BIT) -> float:
+    """BitTable::generate_unique_values scale for nbit=8 TwosComplement (BitTable.C:165-218)."""
+    unique_values = 256
+    output_spacing = 1.0 / unique_values
+    output_middle = (unique_values - 1) / 2.0
+    input_middle = unique_values // 2
+    cumulative_probability = 0.0
+    variance = 0.0
+    for i in range(unique_values):
+        output = (i - output_middle) * output_spacing
+        if i < input_middle:
+            threshold = float((i + 1) - input_middle) * spacing
+            cumulative = _normal_cdf(threshold)
+            interval = cumulative - cumulative_probability
+            cumulative_probability = cumulative
+            variance += output * output * interval
+    variance *= 2.0
+    scale = 1.0 / math.sqrt(variance)
+    return scale * output_spacing
+
+
+S8 = np.float32(eight_bit_scale())
+
+
+def unpack_8bit(raw: np.ndarray, obs: Observation, scale=S8) -> np.ndarray:
+    """raw int8 bytes -> float32 [nchan][npol][ndat*ndim] (FPT order).
+
+    value = (float(int8) + 0.5f) * scale  (GenericEightBitUnpackerCUDA.cu:45)."""
+    raw = np.asarray(raw).view(np.int8)
+    nchan, npol, ndim = obs.nchan, obs.npol, obs.ndim
+    if obs.machine == "CASPSR":
+        assert nchan == 1 and npol == 2 and ndim == 1
+        g = raw[: (raw.size // 8) * 8].reshape(-1, 2, 4)
+        v = g.transpose(1, 0, 2).reshape(1, 2, -1)
+    else:
+        nskip = nchan * npol * ndim
+        ndat = raw.size // nskip
+        v = raw[: ndat * nskip].reshape(ndat, nchan, npol, ndim).transpose(1, 2, 0, 3)
+        v = v.reshape(nchan, npol, ndat * ndim)
+    return ((v.astype(np.float32) + np.float32(0.5)) * np.float32(scale)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# optimal FFT length (a5)   Signal/General/optimize_fft.c:63-127
+# --------------------------------------------------------------------------------------
+
+def optimal_fft_length(nbadperfft: int, nfft_max: int = 0) -> int:
+    if not nbadperfft:
+        return -1
+    nfft_min = int(math.pow(2.0, math.ceil(math.log(nbadperfft) / math.log(2.0))))
+    if nfft_max and nfft_max < nfft_min:
+        return -1
+    nfft = nfft_min
+    # at nfft == nbadperfft the C code divides by zero -> +inf timescale
+    def ts(n):
+        d = float(n - nbadperfft)
+        o = float(n) * math.log(n)
+        return o / d if d != 0.0 else math.inf
+    timescale = ts(nfft)
+    while nfft_max == 0 or nfft * 2 < nfft_max:
+        prev = timescale
+        nfft *= 2
+        timescale = ts(nfft)
+        if timescale > prev:
+            nfft //= 2
+            break
+    return nfft
+
+
+# --------------------------------------------------------------------------------------
+# Dedispersion response (a4, a5, a6)
+# --------------------------------------------------------------------------------------
+
+DM_DISPERSION = 2.41e-4          # Dedispersion.C:28
+SMEARING_BUFFER = 0.1            # Dedispersion.C:30
+SMEARING_SAMPLES_THRESHOLD = 16 * 1024 * 1024   # Dedispersion.C:214
+
+
+class OracleError(Exception):
+    """Stands in for the reference's `Error` exceptions (ext, PSRCHIVE)."""
+
+
+@dataclass
+class Dedispersion:
+    """dsp::Dedispersion + the dsp::Response bookkeeping it inherits."""
+    centre_frequency: float = 0.0
+    bandwidth: float = 0.0
+    dispersion_measure: float = 0.0
+    nchan: int = 1
+    ndat: int = 0                 # frequency resolution (freq_res)
+    dc_centred: bool = False
+    doppler_shift: float = 1.0
+    frequency_resolution_set: bool = False
+    ndat_max: int = 0
+    impulse_pos: int = 0
+    impulse_neg: int = 0
+    whole_swapped: bool = False
+    swap_divisions: int = 0
+    response_dc_centred: bool = False
+    buffer: np.ndarray | None = None     # complex64 [nchan*ndat]
+    supported_channels: list = field(default_factory=list)
+
+    # -- Dedispersion.C:383-430 -------------------------------------------------------
+    def smearing_time(self, half: int) -> float:
+        abs_bw = abs(self.bandwidth)
+        ch_abs_bw = abs_bw / float(self.nchan)
+        lower_ch_cfreq = self.centre_frequency - (abs_bw - ch_abs_bw) / 2.0
+        for ok in self.supported_channels:
+            if ok:
+                break
+            lower_ch_cfreq += ch_abs_bw
+        if half:
+            ch_abs_bw /= 2.0
+            lower_ch_cfreq += float(half) * ch_abs_bw
+        f1 = lower_ch_cfreq - abs(0.5 * ch_abs_bw)        # :343-346
+        f2 = lower_ch_cfreq + abs(0.5 * ch_abs_bw)
+        dispersion = self.dispersion_measure / DM_DISPERSION   # :354-355
+        return dispersion * (1.0 / (f1 * f1) - 1.0 / (f2 * f2))
+
+    # -- Dedispersion.C:432-475 -------------------------------------------------------
+    def smearing_samples(self, half: int) -> int:
+        tsmear = self.smearing_time(half)
+        ch_abs_bw = abs(self.bandwidth) / float(self.nchan)
+        sampling_rate = ch_abs_bw * 1e6
+        tsmear *= (1.0 + SMEARING_BUFFER)
+        return int(math.ceil(tsmear * sampling_rate))
+
+    # -- Dedispersion.C:216-248 -------------------------------------------------------
+    def prepare(self):
+        threshold = SMEARING_SAMPLES_THRESHOLD // self.nchan
+        self.supported_channels = [True] * self.nchan
+        ichan = 0
+        while True:
+            self.impulse_neg = self.smearing_samples(-1)
+            if self.impulse_neg <= threshold:
+                break
+            self.supported_channels[ichan] = False
+            ichan += 1
+            if ichan == self.nchan:
+                raise OracleError("dsp::Dedispersion::prepare smearing samples=%u exceeds threshold=%u"
+                                  % (self.impulse_neg, threshold))
+        self.impulse_pos = self.smearing_samples(1)
+
+    # -- Response.C:259-275 -----------------------------------------------------------
+    def get_minimum_ndat(self) -> int:
+        impulse_tot = float(self.impulse_pos + self.impulse_neg)
+        if impulse_tot == 0:
+            return 0
+        m = int(math.pow(2.0, math.ceil(math.log(impulse_tot) / math.log(2.0))))
+        while m <= impulse_tot:
+            m *= 2
+        return m
+
+    # -- Response.C:328-344 -----------------------------------------------------------
+    def check_ndat(self):
+        if self.ndat_max and self.ndat > self.ndat_max:
+            raise OracleError("Response::check_ndat specified maximum ndat (%d) < specified ndat (%d)"
+                              % (self.ndat_max, self.ndat))
+        ndat_min = self.get_minimum_ndat()
+        if self.ndat < ndat_min:
+            raise OracleError("dsp::Response::check_ndat specified ndat (%d) < required minimum ndat (%d)"
+                              % (self.ndat, ndat_min))
+
+    # -- Response.C:282-311 -----------------------------------------------------------
+    def set_optimal_ndat(self):
+        ndat_min = self.get_minimum_ndat()
+        if self.ndat_max and self.ndat_max < ndat_min:
+            raise OracleError("Response::set_optimal_ndat specified maximum ndat (%d) < required minimum ndat (%d)"
+                              % (self.ndat_max, ndat_min))
+        n = optimal_fft_length(self.impulse_pos + self.impulse_neg, self.ndat_max)
+        if n < 0:
+            raise OracleError("Response::set_optimal_ndat optimal_fft_length failed")
+        self.ndat = n
+
+    def set_frequency_resolution(self, nfft: int):      # Dedispersion.C:133-140
+        self.ndat = nfft
+        self.frequency_resolution_set = True
+
+    # -- Dedispersion.C:478-556 : phases in double, stored as float -------------------
+    def build_phases(self, ndat: int, nchan: int) -> np.ndarray:
+        centrefreq = self.centre_frequency / self.doppler_shift
+        bw = self.bandwidth / self.doppler_shift
+        sign = bw / abs(bw)
+        chanwidth = bw / float(nchan)
+        binwidth = chanwidth / float(ndat)
+        lower_cfreq = centrefreq - 0.5 * bw
+        if not self.dc_centred:
+            lower_cfreq += 0.5 * chanwidth
+        dispersion_per_mhz = 1e6 * self.dispersion_measure / DM_DISPERSION
+        phases = np.empty(ndat * nchan, dtype=np.float32)
+        ipt = np.arange(ndat, dtype=np.float64)
+        freq = ipt * binwidth - 0.5 * chanwidth
+        for ichan in range(nchan):
+            chan_cfreq = lower_cfreq + float(ichan) * chanwidth
+            coeff = -sign * 2 * math.pi * dispersion_per_mhz / (chan_cfreq * chan_cfreq)
+            ph = coeff * (freq * freq) / (chan_cfreq + freq)      # + delay_phase (=0, no -K)
+            phases[ichan * ndat:(ichan + 1) * ndat] = ph.astype(np.float32)
+        return phases
+
+    # -- Dedispersion.C:291-331 -------------------------------------------------------
+    def build(self):
+        if self.frequency_resolution_set:
+            self.check_ndat()
+        else:
+            self.set_optimal_ndat()
+        phases = self.build_phases(self.ndat, self.nchan)
+        # std::polar(float(1.0), phase): float cos/sin of the float phase
+        ph64 = phases.astype(np.float64)
+        buf = (np.cos(ph64).astype(np.float32) + 1j * np.sin(ph64).astype(np.float32)).astype(np.complex64)
+        buf[0] = 0                                    # :323 always zap DC channel
+        self.buffer = buf
+        self.whole_swapped = False
+        self.swap_divisions = 0
+
+    # -- Response.C:649-700 -----------------------------------------------------------
+    def doswap(self, divisions: int = 1):
+        npts = self.ndat * self.nchan
+        half = npts // (2 * divisions)
+        b = self.buffer.reshape(divisions, 2, half)
+        self.buffer = np.ascontiguousarray(b[:, ::-1, :]).reshape(-1)
+        if divisions == 1:
+            self.whole_swapped = not self.whole_swapped
+        elif divisions == self.swap_divisions:
+            self.swap_divisions = 0
+        else:
+            self.swap_divisions = divisions
+
+    # -- Shape.C:222-266 : Shape[i] = Shape[i+rotbin] (complex elements) --------------
+    def rotate(self, rotbin: int):
+        self.buffer = np.roll(self.buffer, -rotbin)
+
+    # -- Response.C:132-181 -----------------------------------------------------------
+    def response_match(self, obs: Observation):
+        if obs.nchan == 1:
+            if obs.get_dual_sideband() and not self.whole_swapped:
+                self.doswap()
+        else:
+            if obs.dc_centred and not self.response_dc_centred:
+                if self.swap_divisions:
+                    self.doswap(self.swap_divisions)
+                self.rotate(-int(self.ndat // 2))
+                self.response_dc_centred = True
+            if obs.get_dual_sideband() and self.swap_divisions != obs.nchan:
+                self.doswap(obs.nchan)
+            if obs.swap and not self.whole_swapped:
+                self.doswap()
+
+    # -- Dedispersion.C:167-197,261-283 -----------------------------------------------
+    def match(self, obs: Observation, channels: int = 0):
+        self.centre_frequency = obs.centre_frequency
+        self.bandwidth = obs.bandwidth
+        self.dispersion_measure = obs.dispersion_measure
+        self.dc_centred = obs.dc_centred
+        self.nchan = channels if channels else obs.nchan
+        self.prepare()
+        self.build()
+        self.response_match(obs)
+        self.buffer[0] = 0                           # :278 buffer[0] = buffer[1] = 0.0
+        return self
+
+
+# --------------------------------------------------------------------------------------
+# Filterbank (a1, a2, a3)
+# --------------------------------------------------------------------------------------
+
+@dataclass
+class FilterbankPlan:
+    """Quantities derived in dsp::Filterbank::make_preparations (Filterbank.C:55-263)."""
+    nchan: int
+    input_nchan: int
+    nchan_subband: int
+    freq_res: int
+    n_fft: int
+    nfilt_pos: int
+    nfilt_neg: int
+    nfilt_tot: int
+    nsamp_fft: int
+    nsamp_overlap: int
+    nsamp_step: int
+    nkeep: int
+    scalefac: float
+    real_input: bool
+
+
+def filterbank_plan(obs: Observation, nchan: int, response: Dedispersion | None,
+                    freq_res: int = 1) -> FilterbankPlan:
+    if nchan < obs.nchan:
+        raise OracleError("dsp::Filterbank::make_preparations output nchan=%d < input nchan=%d" % (nchan, obs.nchan))
+    if nchan % obs.nchan != 0:
+        raise OracleError("dsp::Filterbank::make_preparations output nchan=%d not a multiple of input nchan=%d"
+                          % (nchan, obs.nchan))
+    nchan_subband = nchan // obs.nchan                       # :68
+    nfilt_pos = nfilt_neg = 0
+    if response is not None:
+        nfilt_pos, nfilt_neg = response.impulse_pos, response.impulse_neg   # :90-91
+        freq_res = response.ndat                                             # :93
+        if freq_res == 0:
+            raise OracleError("dsp::Filterbank::make_preparations Response.ndat = 0")
+    n_fft = nchan_subband * freq_res                         # :107
+    scalefac = float(n_fft) * float(freq_res)                # :124-125 (FTransform unnormalized)
+    nfilt_tot = nfilt_pos + nfilt_neg                        # :131
+    if obs.state == "Nyquist":                               # :139-148
+        nsamp_fft = 2 * n_fft
+        nsamp_overlap = 2 * nfilt_tot * nchan_subband
+    elif obs.state == "Analytic":
+        nsamp_fft = n_fft
+        nsamp_overlap = nfilt_tot * nchan_subband
+    else:
+        raise OracleError("dsp::Filterbank::make_preparations invalid input data state")
+    nsamp_step = nsamp_fft - nsamp_overlap                   # :155
+    return FilterbankPlan(nchan, obs.nchan, nchan_subband, freq_res, n_fft, nfilt_pos, nfilt_neg, nfilt_tot,
+                          nsamp_fft, nsamp_overlap, nsamp_step, freq_res - nfilt_tot, scalefac,
+                          obs.state == "Nyquist")
+
+
+def filterbank_npart(plan: FilterbankPlan, ndat: int) -> int:
+    """Filterbank::resize_output (Filterbank.C:389-430)."""
+    if plan.nsamp_step == 0:
+        raise OracleError("dsp::Filterbank::resize_output nsamp_step == 0 ... not properly prepared")
+    if ndat > plan.nsamp_overlap:
+        return (ndat - plan.nsamp_overlap) // plan.nsamp_step
+    return 0
+
+
+def filterbank_output_observation(obs: Observation, plan: FilterbankPlan) -> Observation:
+    """Filterbank::prepare_output metadata (Filterbank.C:265-379)."""
+    out = Observation(**obs.__dict__)
+    out.nchan = plan.nchan
+    out.ndim = 2
+    out.scale = obs.scale * plan.scalefac                    # :328 rescale
+    ratechange = float(plan.freq_res) / float(plan.nsamp_fft)     # :338-339
+    out.tsamp_us = 1e6 / (obs.rate * ratechange)
+    if plan.freq_res == 1:
+        out.dual_sideband = 1
+    out.dc_centred = bool(plan.freq_res % 2)                 # :348
+    if obs.get_dual_sideband():                              # :358-364
+        if obs.nchan > 1:
+            pass   # nsub_swap: bookkeeping only
+        else:
+            out.swap = True
+    out.start_seconds = obs.start_seconds + plan.nfilt_pos / out.rate    # :370 change_start_time(nfilt_pos)
+    return out
+
+
+def filterbank(unpacked: np.ndarray, plan: FilterbankPlan, kernel: np.ndarray | None,
+               npart: int | None = None, dtype=np.float32) -> np.ndarray:
+    """dsp::Filterbank::filterbank CPU branch (Filterbank.C:561-662) + Response::operate (Response.C:385-444).
+
+    unpacked: float [input_nchan][npol][ndat*ndim] -> complex [nchan][npol][npart*nkeep].
+    dtype float32 follows the reference (FFTW single precision); float64 is the high-precision twin."""
+    cdt = np.complex64 if dtype == np.float32 else np.complex128
+    input_nchan, npol, nfloat = unpacked.shape
+    ndim = 1 if plan.real_input else 2
+    ndat = nfloat // ndim
+    if npart is None:
+        npart = filterbank_npart(plan, ndat)
+    N, M, C = plan.n_fft, plan.freq_res, plan.nchan_subband
+    out = np.zeros((plan.nchan, npol, npart * plan.nkeep), dtype=cdt)
+    in_step = plan.nsamp_step * ndim                         # :517
+    for ichan in range(input_nchan):
+        for ipart in range(npart):
+            for ipol in range(npol):
+                x = unpacked[ichan, ipol, ipart * in_step: ipart * in_step + plan.nsamp_fft * ndim].astype(dtype)
+                if plan.real_input:
+                    spec = np.fft.rfft(x)[:N]                 # frc1d: first N of the N+1 bins  :591
+                else:
+                    spec = np.fft.fft(x.view(cdt))            # fcc1d  :593
+                spec = spec.astype(cdt)
+                if kernel is not None:                        # Response::operate  :611-613
+                    spec = (spec * kernel[ichan * N:(ichan + 1) * N].astype(cdt)).astype(cdt)
+                if M == 1:                                    # :621-631
+                    out[ichan * C:(ichan + 1) * C, ipol, ipart] = spec
+                    continue
+                # bcc1d unnormalised backward FFT per sub-channel  :640-652
+                t = (np.fft.ifft(spec.reshape(C, M), axis=1) * M).astype(cdt)
+                out[ichan * C:(ichan + 1) * C, ipol, ipart * plan.nkeep:(ipart + 1) * plan.nkeep] = \
+                    t[:, plan.nfilt_pos: plan.nfilt_pos + plan.nkeep]
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Detection (a7, a8)   cross_detect.ic:23-43, stokes_detect.ic:21-44, Detection.C:218-474
+# --------------------------------------------------------------------------------------
+
+def detect_products(fb: np.ndarray, state: str = "Coherence") -> np.ndarray:
+    """complex [nchan][2][ndat] -> float [nchan][4][ndat] (product-major, layout-free)."""
+    p, q = fb[:, 0, :], fb[:, 1, :]
+    f = np.float32 if fb.dtype == np.complex64 else np.float64
+    pr, pi, qr, qi = p.real.astype(f), p.imag.astype(f), q.real.astype(f), q.imag.astype(f)
+    pp = pr * pr + pi * pi
+    qq = qr * qr + qi * qi
+    re = pr * qr + pi * qi
+    im = pr * qi - pi * qr
+    if state == "Coherence":
+        prod = [pp, qq, re, im]
+    elif state == "Stokes":
+        two = f(2.0)
+        prod = [pp + qq, pp - qq, two * re, two * im]
+    else:
+        raise OracleError("dsp::Detection invalid state " + state)
+    return np.stack(prod, axis=1)
+
+
+def detect_layout(prod: np.ndarray, ndim: int) -> np.ndarray:
+    """Arrange [nchan][4][ndat] products as the TimeSeries Detection writes (Detection.C:423-474):
+       ndim=1 -> [nchan][npol=4][ndat]; ndim=2 -> [nchan][npol=2][ndat][2]; ndim=4 -> [nchan][npol=1][ndat][4]."""
+    nchan, _, ndat = prod.shape
+    if ndim == 1:
+        return prod.copy()
+    if ndim == 2:
+        return np.stack([np.stack([prod[:, 0], prod[:, 1]], axis=-1),
+                         np.stack([prod[:, 2], prod[:, 3]], axis=-1)], axis=1)
+    if ndim == 4:
+        return np.stack([prod[:, 0], prod[:, 1], prod[:, 2], prod[:, 3]], axis=-1)[:, None]
+    raise OracleError("dsp::Detection::get_result_pointers invalid ndim=%d" % ndim)
+
+
+def square_law(fb: np.ndarray, state: str = "PPQQ") -> np.ndarray:
+    """Detection::square_law for Analytic input (Detection.C:218-320): [nchan][npol][ndat] complex ->
+    PPQQ: [nchan][2][ndat]; Intensity: [nchan][1][ndat] (pol sum)."""
+    f = np.float32 if fb.dtype == np.complex64 else np.float64
+    re, im = fb.real.astype(f), fb.imag.astype(f)
+    out = re * re
+    out = out + im * im
+    if state == "Intensity" and fb.shape[1] == 2:
+        return (out[:, 0:1] + out[:, 1:2])
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Fold (a9 - a13)
+# --------------------------------------------------------------------------------------
+
+@dataclass
+class Polyco:
+    """TEMPO polyco block (ext: PSRCHIVE Pulsar::Predictor); restated from the TEMPO definition:
+       phase(t) = RPHASE + 60 DT F0 + sum_k c_k DT^k ; freq(t) = F0 + (1/60) sum_k k c_k DT^(k-1),
+       DT = (t - TMID) * 1440 minutes.  File layout: Benchmark/vela.polyco:1-7."""
+    tmid_day: int
+    tmid_frac: float
+    rphase_int: int
+    rphase_frac: float
+    f0: float
+    span_min: float
+    coef: np.ndarray
+
+    @staticmethod
+    def parse(text: str) -> "Polyco":
+        tok = text.replace("D", "E").split()
+        # line1: name date utc tmid dm doppler log10rms ; line2: rphase f0 site span ncoef freq
+        tmid = tok[3]
+        day, frac = tmid.split(".")
+        rph = tok[7]
+        ri, rf = rph.split(".")
+        ncoef = int(tok[11])
+        coef = np.array([float(t) for t in tok[13:13 + ncoef]], dtype=np.float64)
+        return Polyco(int(day), float("0." + frac), int(ri), float("0." + rf), float(tok[8]), float(tok[10]), coef)
+
+    def _dt_min(self, mjd_day: int, mjd_sec: float) -> float:
+        return ((mjd_day - self.tmid_day) + (mjd_sec / 86400.0 - self.tmid_frac)) * 1440.0
+
+    def phase_frac(self, mjd_day: int, mjd_sec: float) -> float:
+        dt = self._dt_min(mjd_day, mjd_sec)
+        poly = 0.0
+        for c in self.coef[::-1]:
+            poly = poly * dt + c
+        spin = 60.0 * dt * self.f0
+        ph = (self.rphase_frac + (spin - math.floor(spin))) + poly
+        return ph - math.floor(ph)
+
+    def frequency(self, mjd_day: int, mjd_sec: float) -> float:
+        dt = self._dt_min(mjd_day, mjd_sec)
+        d = 0.0
+        for k in range(len(self.coef) - 1, 0, -1):
+            d = d * dt + k * self.coef[k]
+        return self.f0 + d / 60.0
+
+
+def utc_to_mjd(utc: str) -> tuple[int, float]:
+    """YYYY-MM-DD-hh:mm:ss -> (integer MJD, seconds of day).  (MJD class is ext.)"""
+    y, mo, d, hms = utc.split("-")
+    h, mi, s = hms.split(":")
+    y, mo, d = int(y), int(mo), int(d)
+    a = (14 - mo) // 12
+    yy = y + 4800 - a
+    mm = mo + 12 * a - 3
+    jdn = d + (153 * mm + 2) // 5 + 365 * yy + yy // 4 - yy // 100 + yy // 400 - 32045
+    return jdn - 2400001, int(h) * 3600.0 + int(mi) * 60.0 + float(s)
+
+
+@dataclass
+class PhaseSeries:
+    """dsp::PhaseSeries (Signal/Pulsar/dsp/PhaseSeries.h:163-200): profile sums + hits."""
+    nchan: int
+    npol: int
+    ndim: int
+    nbin: int
+    data: np.ndarray = None          # [nchan][npol][nbin][ndim]
+    hits: np.ndarray = None          # [nbin] uint32
+    integration_length: float = 0.0
+    ndat_total: int = 0
+    folding_period: float = 0.0
+
+    def __post_init__(self):
+        if self.data is None:
+            self.data = np.zeros((self.nchan, self.npol, self.nbin, self.ndim), dtype=np.float32)
+        if self.hits is None:
+            self.hits = np.zeros(self.nbin, dtype=np.uint32)
+
+    def zero(self):
+        self.data[...] = 0
+        self.hits[...] = 0
+        self.integration_length = 0.0
+        self.ndat_total = 0
+
+    def combine(self, other: "PhaseSeries"):          # PhaseSeries.C:442-484
+        self.data += other.data
+        self.hits += other.hits
+        self.integration_length += other.integration_length
+        self.ndat_total += other.ndat_total
+
+
+@dataclass
+class FoldConfig:
+    nbin: int
+    folding_period: float = 0.0          # seconds; >0 => constant period (Fold.C:945-947)
+    polyco: Polyco | None = None
+    reference_phase: float = 0.0         # Fold.C:75-76
+    reference_epoch_seconds: float = 0.0  # seconds relative to utc_start (MJD zero is ext)
+
+
+def fold_phase(cfg: FoldConfig, obs: Observation, t_seconds: float) -> tuple[float, float]:
+    """get_phi / get_pfold (Fold.C:943-958).  t_seconds is relative to obs.utc_start."""
+    if cfg.folding_period > 0.0:
+        phi = math.fmod(t_seconds - cfg.reference_epoch_seconds, cfg.folding_period) / cfg.folding_period \
+            - cfg.reference_phase
+        return phi, cfg.folding_period
+    day, sec = utc_to_mjd(obs.utc_start)
+    sec += t_seconds
+    phi = cfg.polyco.phase_frac(day, sec) - cfg.reference_phase
+    return phi, 1.0 / cfg.polyco.frequency(day, sec)
+
+
+def fold_binplan(phi: float, phase_per_sample: float, nbin: int, ndat_fold: int) -> np.ndarray:
+    """The sequential double recurrence of Fold.C:744-787 (no weights, no zeroed samples)."""
+    plan = np.empty(ndat_fold, dtype=np.uint32)
+    double_nbin = float(nbin)
+    for i in range(ndat_fold):
+        phi -= math.floor(phi)
+        ibin = int(phi * double_nbin)
+        phi += phase_per_sample
+        assert ibin < nbin
+        plan[i] = ibin
+    return plan
+
+
+def fold(detected: np.ndarray, obs: Observation, cfg: FoldConfig, out: PhaseSeries,
+         idat_start: int = 0, ndat_fold: int | None = None) -> np.ndarray:
+    """dsp::Fold::fold (Fold.C:626-906), FPT order.  detected: [nchan][npol][ndat][ndim] float.
+    Accumulates strictly in time order per (chan,pol,bin,dim) like the CPU loop :835-891."""
+    nchan, npol, ndat, ndim = detected.shape
+    if ndat_fold is None:
+        ndat_fold = ndat - idat_start
+    if idat_start + ndat_fold > ndat:
+        raise OracleError("dsp::Fold:fold idat_start + ndat_fold > ndat")
+    mid = float(idat_start) + 0.5                             # :651
+    t0 = obs.start_seconds + mid / obs.rate                   # :653-654
+    phi, pfold = fold_phase(cfg, obs, t0)
+    out.folding_period = pfold
+    sampling_interval = 1.0 / obs.rate                        # :718
+    phase_per_sample = sampling_interval / pfold              # :720
+    plan = fold_binplan(phi, phase_per_sample, cfg.nbin, ndat_fold)
+    out.hits += np.bincount(plan, minlength=cfg.nbin).astype(np.uint32)      # :783
+    out.integration_length += float(ndat_fold) / obs.rate     # :792,802
+    out.ndat_total += ndat_fold                               # :803
+    seg = detected[:, :, idat_start:idat_start + ndat_fold, :]
+    # sequential-in-time accumulation, vectorised over (chan,pol,dim): identical add order per bin
+    order = np.argsort(plan, kind="stable")
+    sp = plan[order]
+    bounds = np.flatnonzero(np.diff(sp)) + 1
+    starts = np.concatenate(([0], bounds))
+    ends = np.concatenate((bounds, [sp.size]))
+    acc_dtype = out.data.dtype
+    for s, e in zip(starts, ends):
+        b = int(sp[s])
+        acc = out.data[:, :, b, :].copy()
+        for i in order[s:e]:
+            acc = (acc + seg[:, :, i, :].astype(acc_dtype)).astype(acc_dtype)
+        out.data[:, :, b, :] = acc
+    return plan
+
+
+def archive_profile(ps: PhaseSeries, scale: float) -> np.ndarray:
+    """dsp::Archiver::set normalisation (Archiver.C:773-893): amp = sum / (scale * hits);
+    zero-hit bins take the mean of the others."""
+    hits = ps.hits.astype(np.float64)
+    amps = np.zeros_like(ps.data, dtype=np.float64)
+    ok = hits > 0
+    amps[:, :, ok, :] = ps.data[:, :, ok, :].astype(np.float64) / (scale * hits[ok])[None, None, :, None]
+    if (~ok).any() and ok.any():
+        amps[:, :, ~ok, :] = amps[:, :, ok, :].mean(axis=2, keepdims=True)
+    return amps.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# Sub-integration division in seconds (a12)   TimeDivide.C:440-459,503-540
+# --------------------------------------------------------------------------------------
+
+def subint_boundaries(obs: Observation, division_seconds: float, t_seconds: float) -> tuple[int, float, int]:
+    """-> (division index, lower bound in seconds snapped to samples, division_ndat).
+    Division start_time is the observation start (first call, TimeDivide.C:380-436)."""
+    start = obs.start_seconds
+    seconds = max(t_seconds, start) - start
+    division = int(seconds / division_seconds)
+    mjd1 = start + float(division) * division_seconds
+    mjd2 = start + float(division + 1) * division_seconds
+    rate = obs.rate
+    samples = int(round((mjd1 - start) * rate))               # lrint
+    lower = start + samples / rate
+    division_ndat = int(round((mjd2 - lower) * rate))
+    return division, lower, division_ndat
+
+
+# --------------------------------------------------------------------------------------
+# End-to-end convenience used by tests / cpu_baseline
+# --------------------------------------------------------------------------------------
+
+def run_pipeline(raw: np.ndarray, obs: Observation, nchan: int, dm: float, nbin: int,
+                 folding_period: float = 0.0, polyco: Polyco | None = None, freq_res: int = 0,
+                 state: str = "Coherence", ndim: int = 4, dtype=np.float32, block_parts: int = 0):
+    """raw bytes -> PhaseSeries, one block (or blocks of `block_parts` parts with overlap carry-over,
+    reproducing Filterbank.C:443-444 InputBuffering semantics)."""
+    obs = Observation(**obs.__dict__)
+    obs.dispersion_measure = dm
+    resp = Dedispersion()
+    if freq_res:
+        resp.set_frequency_resolution(freq_res)
+    resp.match(obs, nchan)
+    plan = filterbank_plan(obs, nchan, resp)
+    unpacked = unpack_8bit(raw, obs)
+    fb = filterbank(unpacked, plan, resp.buffer, dtype=dtype)
+    fobs = filterbank_output_observation(obs, plan)
+    prod = detect_products(fb, state)
+    det = detect_layout(prod, ndim)
+    if ndim == 1:
+        det = det[..., None]
+    ps = PhaseSeries(nchan, det.shape[1], det.shape[3], nbin,
+                     data=np.zeros((nchan, det.shape[1], nbin, det.shape[3]), dtype=dtype))
+    cfg = FoldConfig(nbin=nbin, folding_period=folding_period, polyco=polyco)
+    fold(det, fobs, cfg, ps)
+    return ps, plan, resp, fb, det
