@@ -1,0 +1,107 @@
+// Context (one per pipeline thread / GPU, one stream: SingleThread.C:213-290) and the
+// dsp::Memory operations (Kernel/Classes/dsp/Memory.h:18-34, CUDA impl MemoryCUDA.C:47-106).
+#include <math.h>
+
+#include <vector>
+
+#include "engine_internal.h"
+
+using namespace dspsr_amd;
+
+extern "C" const char* dspsr_amd_version(void) { return "dspsr_amd 0.1 (gfx950)"; }
+
+extern "C" int dspsr_amd_ctx_create(int device, void* hip_stream, dspsr_amd_ctx** out)
+{
+  if (!out) return DSPSR_AMD_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return DSPSR_AMD_EHIP;
+  if (device < 0 || device >= ndev) return DSPSR_AMD_EINVAL;
+  if (hipSetDevice(device) != hipSuccess) return DSPSR_AMD_EHIP;
+  dspsr_amd_ctx* ctx = new dspsr_amd_ctx;
+  ctx->device = device;
+  ctx->error[0] = 0;
+  ctx->own_stream = (hip_stream == nullptr);
+  ctx->stream = (hipStream_t)hip_stream;
+  if (ctx->own_stream && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return DSPSR_AMD_EHIP;
+  }
+  std::vector<cf> tw(TWN);
+  for (int j = 0; j < TWN; j++) {
+    const double a = -2.0 * M_PI * (double)j / (double)TWN;
+    tw[j] = make_float2((float)cos(a), (float)sin(a));
+  }
+  if (hipMalloc((void**)&ctx->tw, TWN * sizeof(cf)) != hipSuccess ||
+      hipMemcpy(ctx->tw, tw.data(), TWN * sizeof(cf), hipMemcpyHostToDevice) != hipSuccess) {
+    delete ctx;
+    return DSPSR_AMD_ENOMEM;
+  }
+  *out = ctx;
+  return DSPSR_AMD_OK;
+}
+
+extern "C" void dspsr_amd_ctx_destroy(dspsr_amd_ctx* ctx)
+{
+  if (!ctx) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->tw) (void)hipFree(ctx->tw);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* dspsr_amd_last_error(const dspsr_amd_ctx* ctx) { return ctx ? ctx->error : "null context"; }
+
+extern "C" int dspsr_amd_stream_sync(dspsr_amd_ctx* ctx)
+{
+  if (!ctx) return DSPSR_AMD_EINVAL;
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_stream_sync: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_malloc(dspsr_amd_ctx* ctx, size_t nbytes, void** ptr)
+{
+  if (!ctx || !ptr) return DSPSR_AMD_EINVAL;
+  *ptr = nullptr;
+  if (nbytes == 0) return DSPSR_AMD_OK;
+  hipError_t e = hipMalloc(ptr, nbytes);
+  if (e != hipSuccess)
+    return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_malloc: hipMalloc(%zu): %s", nbytes, hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_free(dspsr_amd_ctx* ctx, void* ptr)
+{
+  if (!ctx) return DSPSR_AMD_EINVAL;
+  if (!ptr) return DSPSR_AMD_OK;
+  hipError_t e = hipFree(ptr);
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_free: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_zero(dspsr_amd_ctx* ctx, void* ptr, size_t nbytes)
+{
+  if (!ctx || (!ptr && nbytes)) return DSPSR_AMD_EINVAL;
+  if (!nbytes) return DSPSR_AMD_OK;
+  hipError_t e = hipMemsetAsync(ptr, 0, nbytes, ctx->stream);
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_zero: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_copy(dspsr_amd_ctx* ctx, void* dst, const void* src, size_t nbytes, int kind)
+{
+  if (!ctx || ((!dst || !src) && nbytes)) return DSPSR_AMD_EINVAL;
+  if (!nbytes) return DSPSR_AMD_OK;
+  hipMemcpyKind k;
+  switch (kind) {
+    case DSPSR_AMD_H2D: k = hipMemcpyHostToDevice; break;
+    case DSPSR_AMD_D2H: k = hipMemcpyDeviceToHost; break;
+    case DSPSR_AMD_D2D: k = hipMemcpyDeviceToDevice; break;
+    default: return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_copy: invalid kind %d", kind);
+  }
+  hipError_t e = hipMemcpyAsync(dst, src, nbytes, k, ctx->stream);
+  if (e == hipSuccess && kind == DSPSR_AMD_D2H) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_copy: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}

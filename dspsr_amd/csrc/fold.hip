@@ -1,0 +1,258 @@
+// dsp::Fold::Engine for gfx950 (Signal/Pulsar/dsp/Fold.h:249-312).
+// Reference: host plan loop Fold.C:744-787, CPU accumulate Fold.C:835-891, CUDA twin FoldCUDA.cu
+// (set_bin run-length builder :84-113, send_binplan :154-198, fold1bin* kernels :208-576).
+//
+// Differences by design (DESIGN.md "Fold"): the reference GPU kernels sum each run-length
+// interval from zero and atomicAdd it into the profile (order-dependent float sums).  Here
+// every (chan, pol, bin) accumulator is owned by exactly one thread that walks the bin's
+// intervals in time order and adds sample by sample, i.e. the SAME association order as the
+// CPU loop Fold.C:844-852 -- results are deterministic and bit-identical to the CPU fold of
+// the same detected samples.
+#include <algorithm>
+#include <math.h>
+#include <vector>
+
+#include "engine_internal.h"
+
+namespace dspsr_amd {
+
+struct Interval { uint64_t offset; uint32_t hits; uint32_t pad; };   // sorted by (bin, time)
+
+template <int NDIM>
+__global__ void k_fold(const float* __restrict__ in, const uint64_t chan_stride, const uint64_t pol_stride,
+                       float* __restrict__ prof, const uint32_t nbin, const uint32_t* __restrict__ bin_start,
+                       const Interval* __restrict__ iv)
+{
+  const uint32_t ipol = blockIdx.x, npol = gridDim.x, ichan = blockIdx.y;
+  const float* __restrict__ row = in + ichan * chan_stride + ipol * pol_stride;
+  float* __restrict__ out = prof + ((uint64_t)ichan * npol + ipol) * nbin * NDIM;
+  for (uint32_t b = threadIdx.x; b < nbin; b += blockDim.x) {
+    const uint32_t i0 = bin_start[b], i1 = bin_start[b + 1];
+    if (i0 == i1) continue;
+    float acc[NDIM];
+#pragma unroll
+    for (int d = 0; d < NDIM; d++) acc[d] = out[b * NDIM + d];
+    for (uint32_t i = i0; i < i1; i++) {
+      const Interval v = iv[i];
+      const float* __restrict__ x = row + v.offset * NDIM;
+      for (uint32_t h = 0; h < v.hits; h++) {
+        if (NDIM == 4) {
+          const float4 s = ((const float4*)x)[h];
+          acc[0] += s.x; acc[1 % NDIM] += s.y; acc[2 % NDIM] += s.z; acc[3 % NDIM] += s.w;
+        } else if (NDIM == 2) {
+          const float2 s = ((const float2*)x)[h];
+          acc[0] += s.x; acc[1 % NDIM] += s.y;
+        } else {
+          acc[0] += x[h];
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < NDIM; d++) out[b * NDIM + d] = acc[d];
+  }
+}
+
+struct RunBin { uint32_t ibin, hits; uint64_t offset; };   // FoldCUDA.h:19-24
+
+}  // namespace dspsr_amd
+
+using namespace dspsr_amd;
+
+struct dspsr_amd_fold {
+  dspsr_amd_ctx* ctx;
+  uint32_t nchan = 0, npol = 0, ndim = 0, nbin = 0;
+  float* profile = nullptr;
+  size_t profile_floats = 0;
+  // run-length plan, as CUDA::FoldEngine (FoldCUDA.cu:64-113)
+  std::vector<RunBin> binplan;
+  uint32_t current_bin = 0, current_hits = 0, folding_nbin = 0;
+  uint64_t ndat_fold = 0;
+  // device copies
+  uint32_t* d_bin_start = nullptr;
+  Interval* d_iv = nullptr;
+  size_t d_bin_start_cap = 0, d_iv_cap = 0;
+  std::vector<uint32_t> h_bin_start;
+  std::vector<Interval> h_iv;
+};
+
+extern "C" int dspsr_amd_fold_create(dspsr_amd_ctx* ctx, dspsr_amd_fold** out)
+{
+  if (!ctx || !out) return DSPSR_AMD_EINVAL;
+  dspsr_amd_fold* f = new dspsr_amd_fold;
+  f->ctx = ctx;
+  *out = f;
+  return DSPSR_AMD_OK;
+}
+
+extern "C" void dspsr_amd_fold_destroy(dspsr_amd_fold* f)
+{
+  if (!f) return;
+  (void)hipStreamSynchronize(f->ctx->stream);
+  if (f->profile) (void)hipFree(f->profile);
+  if (f->d_bin_start) (void)hipFree(f->d_bin_start);
+  if (f->d_iv) (void)hipFree(f->d_iv);
+  delete f;
+}
+
+extern "C" int dspsr_amd_fold_set_shape(dspsr_amd_fold* f, uint32_t nchan, uint32_t npol, uint32_t ndim, uint32_t nbin)
+{
+  if (!f) return DSPSR_AMD_EINVAL;
+  if (ndim != 1 && ndim != 2 && ndim != 4)
+    return ctx_fail(f->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_fold_set_shape: ndim=%u not in {1,2,4}", ndim);
+  if (!nchan || !npol || !nbin) return ctx_fail(f->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_fold_set_shape: zero dimension");
+  const size_t need = (size_t)nchan * npol * nbin * ndim;
+  if (need != f->profile_floats) {
+    // PhaseSeries::mixable/resize on a changed shape starts a new, zeroed profile (Fold.C:495-508)
+    (void)hipStreamSynchronize(f->ctx->stream);
+    if (f->profile) (void)hipFree(f->profile);
+    f->profile = nullptr;
+    if (hipMalloc((void**)&f->profile, need * sizeof(float)) != hipSuccess)
+      return ctx_fail(f->ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_fold_set_shape: hipMalloc(%zu floats) failed", need);
+    f->profile_floats = need;
+    (void)hipMemsetAsync(f->profile, 0, need * sizeof(float), f->ctx->stream);
+  }
+  f->nchan = nchan; f->npol = npol; f->ndim = ndim; f->nbin = nbin;
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_fold_set_nbin(dspsr_amd_fold* f, uint32_t nbin)   // FoldCUDA.cu:64-70
+{
+  if (!f) return DSPSR_AMD_EINVAL;
+  f->current_bin = f->folding_nbin = nbin;
+  f->current_hits = 0;
+  f->ndat_fold = 0;
+  f->binplan.clear();
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_fold_set_ndat(dspsr_amd_fold* f, uint64_t ndat, uint64_t /*idat_start*/)  // :72-82
+{
+  if (!f) return DSPSR_AMD_EINVAL;
+  if (f->binplan.capacity() < ndat) f->binplan.reserve(ndat < (1u << 20) ? ndat : (1u << 20));
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_fold_set_bin(dspsr_amd_fold* f, uint64_t idat, double d_ibin, double /*bins_per_sample*/)
+{
+  if (!f) return DSPSR_AMD_EINVAL;
+  const uint32_t ibin = (uint32_t)d_ibin;                 // FoldCUDA.cu:87
+  if (ibin != f->current_bin) {
+    if (!f->binplan.empty()) f->binplan.back().hits = f->current_hits;
+    RunBin start; start.offset = idat; start.ibin = ibin; start.hits = 0;
+    f->binplan.push_back(start);
+    f->current_bin = ibin;
+    f->current_hits = 0;
+  }
+  f->ndat_fold++;
+  f->current_hits++;
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_fold_set_bins(dspsr_amd_fold* f, double phi, double phase_per_sample, uint64_t ndat,
+                                       uint64_t idat_start, uint32_t* hits_host, uint64_t* ndat_folded)
+{
+  if (!f) return DSPSR_AMD_EINVAL;
+  if (!f->folding_nbin) return ctx_fail(f->ctx, DSPSR_AMD_ESTATE, "dsp::Fold::fold nbin not set");
+  const double double_nbin = (double)f->folding_nbin;     // Fold.C:719
+  uint64_t folded = 0;
+  for (uint64_t idat = idat_start; idat < idat_start + ndat; idat++) {   // Fold.C:744-787
+    phi -= floor(phi);
+    const double double_ibin = phi * double_nbin;
+    const uint32_t ibin = (uint32_t)double_ibin;
+    phi += phase_per_sample;
+    if (ibin >= f->folding_nbin)
+      return ctx_fail(f->ctx, DSPSR_AMD_EINVAL, "dsp::Fold::fold ibin=%u >= nbin=%u", ibin, f->folding_nbin);
+    dspsr_amd_fold_set_bin(f, idat, double_ibin, phase_per_sample * double_nbin);
+    if (hits_host) hits_host[ibin]++;
+    folded++;
+  }
+  if (ndat_folded) *ndat_folded = folded;
+  return DSPSR_AMD_OK;
+}
+
+extern "C" uint64_t dspsr_amd_fold_get_ndat_folded(const dspsr_amd_fold* f) { return f ? f->ndat_fold : 0; }
+extern "C" float* dspsr_amd_fold_profiles_dev(dspsr_amd_fold* f) { return f ? f->profile : nullptr; }
+
+extern "C" int dspsr_amd_fold_zero(dspsr_amd_fold* f)
+{
+  if (!f) return DSPSR_AMD_EINVAL;
+  if (f->profile) (void)hipMemsetAsync(f->profile, 0, f->profile_floats * sizeof(float), f->ctx->stream);
+  return DSPSR_AMD_OK;
+}
+
+template <typename T> static bool grow(T** p, size_t* cap, size_t need)
+{
+  if (need <= *cap) return true;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  size_t n = need + need / 2;
+  if (hipMalloc((void**)p, n * sizeof(T)) != hipSuccess) { *cap = 0; return false; }
+  *cap = n;
+  return true;
+}
+
+extern "C" int dspsr_amd_fold_fold(dspsr_amd_fold* f, const float* in_dev, uint64_t in_chan_stride,
+                                   uint64_t in_pol_stride)
+{
+  if (!f || !in_dev) return DSPSR_AMD_EINVAL;
+  dspsr_amd_ctx* ctx = f->ctx;
+  if (!f->profile) return ctx_fail(ctx, DSPSR_AMD_ESTATE, "dspsr_amd_fold_fold: set_shape not called");
+  if (f->folding_nbin != f->nbin)    // Fold.C:806-809
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dsp::Fold::fold folding_nbin != output->nbin (%u != %u)",
+                    f->folding_nbin, f->nbin);
+  if (f->binplan.empty()) return DSPSR_AMD_OK;             // send_binplan :160-161
+  if (f->current_hits) f->binplan.back().hits = f->current_hits;   // :163-164
+  f->current_hits = 0;
+
+  // bucket the time-ordered intervals by phase bin (stable => time order kept inside a bin)
+  const uint32_t nbin = f->nbin;
+  const size_t niv = f->binplan.size();
+  f->h_bin_start.assign(nbin + 1, 0);
+  for (const RunBin& r : f->binplan) f->h_bin_start[r.ibin + 1]++;
+  for (uint32_t b = 0; b < nbin; b++) f->h_bin_start[b + 1] += f->h_bin_start[b];
+  f->h_iv.resize(niv);
+  {
+    std::vector<uint32_t> cursor(f->h_bin_start.begin(), f->h_bin_start.end() - 1);
+    for (const RunBin& r : f->binplan) {
+      Interval v; v.offset = r.offset; v.hits = r.hits; v.pad = 0;
+      f->h_iv[cursor[r.ibin]++] = v;
+    }
+  }
+  // a previous fold may still be reading the device plan
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: %s", hipGetErrorString(e));
+  if (!grow(&f->d_bin_start, &f->d_bin_start_cap, nbin + 1) || !grow(&f->d_iv, &f->d_iv_cap, niv))
+    return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_fold_fold: plan allocation failed");
+  e = hipMemcpyAsync(f->d_bin_start, f->h_bin_start.data(), (nbin + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
+                     ctx->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(f->d_iv, f->h_iv.data(), niv * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: plan copy: %s", hipGetErrorString(e));
+
+  uint32_t threads = nbin < 1024 ? ((nbin + 63) / 64) * 64 : 1024;
+  dim3 grid(f->npol, f->nchan);
+  if (f->ndim == 4)
+    hipLaunchKernelGGL(k_fold<4>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride, in_pol_stride,
+                       f->profile, nbin, f->d_bin_start, f->d_iv);
+  else if (f->ndim == 2)
+    hipLaunchKernelGGL(k_fold<2>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride, in_pol_stride,
+                       f->profile, nbin, f->d_bin_start, f->d_iv);
+  else
+    hipLaunchKernelGGL(k_fold<1>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride, in_pol_stride,
+                       f->profile, nbin, f->d_bin_start, f->d_iv);
+  e = hipGetLastError();
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: %s", hipGetErrorString(e));
+  f->binplan.clear();
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_fold_synch(dspsr_amd_fold* f, float* profile_host)   // FoldCUDA.cu:127-152
+{
+  if (!f || !profile_host) return DSPSR_AMD_EINVAL;
+  if (!f->profile) return ctx_fail(f->ctx, DSPSR_AMD_ESTATE, "dspsr_amd_fold_synch: no profile");
+  hipError_t e = hipMemcpyAsync(profile_host, f->profile, f->profile_floats * sizeof(float), hipMemcpyDeviceToHost,
+                                f->ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(f->ctx->stream);
+  if (e != hipSuccess) return ctx_fail(f->ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_synch: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}

@@ -1,0 +1,227 @@
+// Host-side preparation that the reference also performs on the host:
+//   dsp::Dedispersion   Signal/General/Dedispersion.C:216-248 (prepare), :291-331 (build),
+//                       :383-475 (smearing), :478-556 (phases)
+//   dsp::Response       Signal/General/Response.C:132-181 (match ordering), :259-344 (ndat rules),
+//                       :649-700 (doswap);  dsp::Shape::rotate  Shape.C:222-266
+//   optimal_fft_length  Signal/General/optimize_fft.c:63-127
+//   BitTable scale      Kernel/Classes/BitTable.C:165-218
+//   Fold bin plan       Signal/Pulsar/Fold.C:744-787
+// The kernel is built in double, phases are rounded to float exactly where the reference rounds
+// them (vector<float> phases), so the device receives the same numbers the CUDA engine would.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <complex>
+#include <vector>
+
+#include "../../include/dspsr_amd.h"
+
+namespace {
+
+const double dm_dispersion = 2.41e-4;                      // Dedispersion.C:28
+const double smearing_buffer = 0.1;                        // Dedispersion.C:30
+const unsigned smearing_samples_threshold = 16 * 1024 * 1024;   // Dedispersion.C:214
+
+struct Dedisp {
+  double centre_frequency, bandwidth, dm;
+  unsigned nchan;
+  std::vector<bool> supported;
+
+  double delay_time(double f1, double f2) const            // :348-356
+  {
+    const double dispersion = dm / dm_dispersion;
+    return dispersion * (1.0 / (f1 * f1) - 1.0 / (f2 * f2));
+  }
+  double smearing_time(int half) const                     // :383-430
+  {
+    const double abs_bw = fabs(bandwidth);
+    double ch_abs_bw = abs_bw / double(nchan);
+    double lower_ch_cfreq = centre_frequency - (abs_bw - ch_abs_bw) / 2.0;
+    unsigned ichan = 0;
+    while (ichan < supported.size() && !supported[ichan]) { lower_ch_cfreq += ch_abs_bw; ichan++; }
+    if (half) { ch_abs_bw /= 2.0; lower_ch_cfreq += double(half) * ch_abs_bw; }
+    return delay_time(lower_ch_cfreq - fabs(0.5 * ch_abs_bw), lower_ch_cfreq + fabs(0.5 * ch_abs_bw));
+  }
+  unsigned smearing_samples(int half) const                // :432-475
+  {
+    double tsmear = smearing_time(half);
+    const double sampling_rate = fabs(bandwidth) / double(nchan) * 1e6;
+    tsmear *= (1.0 + smearing_buffer);
+    return unsigned(ceil(tsmear * sampling_rate));
+  }
+};
+
+unsigned minimum_ndat(unsigned pos, unsigned neg)          // Response.C:259-275
+{
+  const double impulse_tot = pos + neg;
+  if (impulse_tot == 0) return 0;
+  unsigned min = unsigned(pow(2.0, ceil(log(impulse_tot) / log(2.0))));
+  while (min <= impulse_tot) min *= 2;
+  return min;
+}
+
+void swap_halves(std::complex<float>* buf, uint64_t npts, unsigned divisions)   // Response.C:649-700
+{
+  const uint64_t half = npts / (2 * divisions);
+  for (unsigned d = 0; d < divisions; d++) {
+    std::complex<float>* p1 = buf + 2 * half * d;
+    std::swap_ranges(p1, p1 + half, p1 + half);
+  }
+}
+
+bool get_dual_sideband(const dspsr_amd_dedispersion_config* c)   // Observation.C:80-87
+{
+  if (c->dual_sideband != -1) return c->dual_sideband == 1;
+  return c->ndim == 2;
+}
+
+int fail(char* errbuf, size_t errlen, const char* fmt, unsigned a, unsigned b)
+{
+  if (errbuf && errlen) snprintf(errbuf, errlen, fmt, a, b);
+  return DSPSR_AMD_EINVAL;
+}
+
+}  // namespace
+
+extern "C" uint64_t dspsr_amd_optimal_fft_length(uint64_t nbadperfft, uint64_t nfft_max)   // optimize_fft.c:63-127
+{
+  if (!nbadperfft) return (uint64_t)-1;
+  uint64_t nfft_min = (uint64_t)pow(2.0, ceil(log((double)nbadperfft) / log(2.0)));
+  if (nfft_max && nfft_max < nfft_min) return (uint64_t)-1;
+  uint64_t nfft = nfft_min;
+  double timescale = ((double)nfft * log((double)nfft)) / (double)(nfft - nbadperfft);
+  while (nfft_max == 0 || nfft * 2 < nfft_max) {
+    const double prev = timescale;
+    nfft *= 2;
+    timescale = ((double)nfft * log((double)nfft)) / (double)(nfft - nbadperfft);
+    if (timescale > prev) { nfft /= 2; break; }
+  }
+  return nfft;
+}
+
+extern "C" int dspsr_amd_dedispersion_prepare(const dspsr_amd_dedispersion_config* cfg,
+                                              dspsr_amd_dedispersion_info* info, char* errbuf, size_t errlen)
+{
+  if (!cfg || !info || !cfg->nchan || cfg->bandwidth == 0.0) return DSPSR_AMD_EINVAL;
+  Dedisp d;
+  d.centre_frequency = cfg->centre_frequency;
+  d.bandwidth = cfg->bandwidth;
+  d.dm = cfg->dispersion_measure;
+  d.nchan = cfg->nchan;
+  d.supported.assign(cfg->nchan, true);
+  const unsigned threshold = smearing_samples_threshold / cfg->nchan;        // Dedispersion.C:216-240
+  unsigned ichan = 0, neg;
+  while ((neg = d.smearing_samples(-1)) > threshold) {
+    d.supported[ichan] = false;
+    ichan++;
+    if (ichan == cfg->nchan)
+      return fail(errbuf, errlen, "dsp::Dedispersion::prepare smearing samples=%u exceeds threshold=%u", neg, threshold);
+  }
+  info->impulse_neg = neg;
+  info->impulse_pos = d.smearing_samples(1);
+  info->minimum_ndat = minimum_ndat(info->impulse_pos, info->impulse_neg);
+  if (cfg->freq_res) {                                                          // Response::check_ndat :328-344
+    if (cfg->ndat_max && cfg->freq_res > cfg->ndat_max)
+      return fail(errbuf, errlen, "Response::check_ndat specified maximum ndat (%d) < specified ndat (%d)",
+                  cfg->ndat_max, cfg->freq_res);
+    if (cfg->freq_res < info->minimum_ndat)
+      return fail(errbuf, errlen, "dsp::Response::check_ndat specified ndat (%d) < required minimum ndat (%d)",
+                  cfg->freq_res, info->minimum_ndat);
+    info->ndat = cfg->freq_res;
+  } else {                                                                      // set_optimal_ndat :282-311
+    if (cfg->ndat_max && cfg->ndat_max < info->minimum_ndat)
+      return fail(errbuf, errlen,
+                  "Response::set_optimal_ndat specified maximum ndat (%d) < required minimum ndat (%d)",
+                  cfg->ndat_max, info->minimum_ndat);
+    if (info->impulse_pos + info->impulse_neg == 0) {
+      info->ndat = 1;   // DM = 0: no smearing; caller should pass an explicit resolution
+    } else {
+      const uint64_t n = dspsr_amd_optimal_fft_length(info->impulse_pos + info->impulse_neg, cfg->ndat_max);
+      if (n == (uint64_t)-1) return fail(errbuf, errlen, "Response::set_optimal_ndat optimal_fft_length failed%s", 0, 0);
+      info->ndat = (uint32_t)n;
+    }
+  }
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_dedispersion_build(const dspsr_amd_dedispersion_config* cfg, uint32_t ndat,
+                                            float* kernel_host)
+{
+  if (!cfg || !kernel_host || !ndat || !cfg->nchan || cfg->bandwidth == 0.0) return DSPSR_AMD_EINVAL;
+  const unsigned nchan = cfg->nchan;
+  std::complex<float>* phasors = reinterpret_cast<std::complex<float>*>(kernel_host);
+
+  // Dedispersion::build(vector<float>&, ndat, nchan)  :478-556  (Doppler_shift = 1, no fractional delay)
+  const double centrefreq = cfg->centre_frequency, bw = cfg->bandwidth;
+  const double sign = bw / fabs(bw);
+  const double chanwidth = bw / double(nchan);
+  const double binwidth = chanwidth / double(ndat);
+  double lower_cfreq = centrefreq - 0.5 * bw;
+  if (!cfg->dc_centred) lower_cfreq += 0.5 * chanwidth;
+  const double dispersion_per_MHz = 1e6 * cfg->dispersion_measure / dm_dispersion;
+  for (unsigned ichan = 0; ichan < nchan; ichan++) {
+    const double chan_cfreq = lower_cfreq + double(ichan) * chanwidth;
+    const double coeff = -sign * 2 * M_PI * dispersion_per_MHz / (chan_cfreq * chan_cfreq);
+    const uint64_t spt = (uint64_t)ichan * ndat;
+    for (unsigned ipt = 0; ipt < ndat; ipt++) {
+      const double freq = double(ipt) * binwidth - 0.5 * chanwidth;
+      const float phase = float(coeff * (freq * freq) / (chan_cfreq + freq));   // stored as float :545
+      phasors[spt + ipt] = std::polar(float(1.0), phase);                       // :320
+    }
+  }
+  phasors[0] = 0;                                                                // :323
+
+  // Response::match(const Observation*, unsigned)  Response.C:132-181
+  const uint64_t npts = (uint64_t)nchan * ndat;
+  if (cfg->input_nchan == 1) {
+    if (get_dual_sideband(cfg)) swap_halves(phasors, npts, 1);
+  } else {
+    if (cfg->dc_centred) {
+      // Dedispersion::prepare copied dc_centred from the input, so Response::dc_centred is already
+      // true here and the half-channel rotate (Shape.C:222-266) is skipped -- same as the reference.
+    }
+    if (get_dual_sideband(cfg)) swap_halves(phasors, npts, cfg->input_nchan);
+    if (cfg->swap) swap_halves(phasors, npts, 1);
+  }
+  phasors[0] = 0;                                                                // Dedispersion.C:278
+  return DSPSR_AMD_OK;
+}
+
+extern "C" double dspsr_amd_eight_bit_scale(double input_spacing)               // BitTable.C:165-218
+{
+  const unsigned unique_values = 256;
+  const double output_spacing = 1.0 / double(unique_values);
+  const double output_middle = double(unique_values - 1) / 2.0;
+  const unsigned input_middle = unique_values / 2;
+  double cumulative_probability = 0.0, variance = 0.0;
+  for (unsigned i = 0; i < unique_values; i++) {
+    const double output = (double(i) - output_middle) * output_spacing;
+    if (i < input_middle) {
+      const double threshold = double(int(i + 1) - int(input_middle)) * input_spacing;
+      const double cumulative = 0.5 * (1.0 + erf(threshold / sqrt(2.0)));   // NormalDistribution (ext)
+      const double interval = cumulative - cumulative_probability;
+      cumulative_probability = cumulative;
+      variance += output * output * interval;
+    }
+  }
+  variance *= 2.0;
+  return (1.0 / sqrt(variance)) * output_spacing;
+}
+
+extern "C" int dspsr_amd_fold_binplan(double phi, double phase_per_sample, uint32_t nbin, uint64_t ndat,
+                                      uint32_t* binplan, uint32_t* hits)         // Fold.C:744-787
+{
+  if (!nbin || (!binplan && ndat)) return DSPSR_AMD_EINVAL;
+  const double double_nbin = double(nbin);
+  for (uint64_t idat = 0; idat < ndat; idat++) {
+    phi -= floor(phi);
+    const unsigned ibin = unsigned(phi * double_nbin);
+    phi += phase_per_sample;
+    if (ibin >= nbin) return DSPSR_AMD_EINVAL;
+    binplan[idat] = ibin;
+    if (hits) hits[ibin]++;
+  }
+  return DSPSR_AMD_OK;
+}

@@ -1,0 +1,301 @@
+"""Host-side mirror of the reference's Engine plug-in interfaces, over the C-ABI.
+
+Names, argument meaning and error behaviour follow the reference classes:
+  dsp::Filterbank::Engine  (Signal/General/dsp/FilterbankEngine.h:15-44): setup / perform / finish
+  dsp::Detection::Engine   (Signal/General/dsp/Detection.h:98-106): polarimetry / square_law
+  dsp::Fold::Engine        (Signal/Pulsar/dsp/Fold.h:249-312): set_nbin / set_ndat / set_bin / fold / synch / zero
+  dsp::Dedispersion        (Signal/General/Dedispersion.C): prepare / build / match (host side)
+Errors the reference throws as `Error` surface as DspsrAmdError with the same message text.
+
+torch is used only to own device memory and streams; every computation goes through
+libdspsr_amd.so (hand-written HIP).  TimeSeries are torch tensors in FPT order:
+  voltages   float32 [nchan][npol][ndat*ndim]
+  detected   float32 [nchan][npol_out][ndat*ndim_out]
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+
+
+class DspsrAmdError(RuntimeError):
+    """Counterpart of the reference's `Error` exception."""
+
+
+def _check(ctx_handle, code, where):
+    if code != 0:
+        msg = lib.dspsr_amd_last_error(ctx_handle).decode() if ctx_handle else ""
+        raise DspsrAmdError("%s failed (%d): %s" % (where, code, msg))
+
+
+class Context:
+    """One per pipeline thread/GPU, bound to one HIP stream (SingleThread.C:213-290)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        h = C.c_void_p()
+        code = lib.dspsr_amd_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if code != 0:
+            raise DspsrAmdError("dspsr_amd_ctx_create(device=%d) failed (%d): no usable HIP device" % (device, code))
+        self.handle = h
+        self.device = device
+
+    def synchronize(self):
+        _check(self.handle, lib.dspsr_amd_stream_sync(self.handle), "dspsr_amd_stream_sync")
+
+    def close(self):
+        if self.handle:
+            lib.dspsr_amd_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------------------------
+# host-side preparation
+# ----------------------------------------------------------------------------------------------
+
+JA98_SPACING_8BIT = 0.02957   # JenetAnderson98::get_optimal_spacing(8) (PSRCHIVE, ext)
+
+
+def eight_bit_scale(spacing: float = JA98_SPACING_8BIT) -> float:
+    return float(np.float32(lib.dspsr_amd_eight_bit_scale(spacing)))
+
+
+def optimal_fft_length(nbadperfft: int, nfft_max: int = 0) -> int:
+    n = lib.dspsr_amd_optimal_fft_length(nbadperfft, nfft_max)
+    return -1 if n == 2 ** 64 - 1 else int(n)
+
+
+class Dedispersion:
+    """dsp::Dedispersion: smearing -> impulse_pos/neg, frequency resolution, chirp (host, double->float)."""
+
+    def __init__(self, centre_frequency, bandwidth, dispersion_measure, input_nchan=1, ndim=1,
+                 dual_sideband=-1, dc_centred=False, swap=False):
+        self.cfg = _lib.DedispersionConfig(centre_frequency, bandwidth, dispersion_measure, input_nchan, input_nchan,
+                                           ndim, dual_sideband, int(dc_centred), int(swap), 0, 0)
+        self.impulse_pos = self.impulse_neg = self.ndat = self.minimum_ndat = 0
+        self.nchan = input_nchan
+        self.kernel = None
+
+    def set_frequency_resolution(self, nfft: int):
+        self.cfg.freq_res = int(nfft)
+
+    def set_maximum_ndat(self, n: int):
+        self.cfg.ndat_max = int(n)
+
+    def match(self, nchan: int):
+        """Dedispersion::match(input, channels): prepare + build + Response::match ordering."""
+        self.cfg.nchan = int(nchan)
+        self.nchan = int(nchan)
+        info = _lib.DedispersionInfo()
+        err = C.create_string_buffer(256)
+        code = lib.dspsr_amd_dedispersion_prepare(C.byref(self.cfg), C.byref(info), err, 256)
+        if code != 0:
+            raise DspsrAmdError(err.value.decode() or "dspsr_amd_dedispersion_prepare failed (%d)" % code)
+        self.impulse_pos, self.impulse_neg = info.impulse_pos, info.impulse_neg
+        self.minimum_ndat, self.ndat = info.minimum_ndat, info.ndat
+        k = np.empty(self.nchan * self.ndat, dtype=np.complex64)
+        code = lib.dspsr_amd_dedispersion_build(C.byref(self.cfg), self.ndat, k.ctypes.data_as(C.c_void_p))
+        if code != 0:
+            raise DspsrAmdError("dspsr_amd_dedispersion_build failed (%d)" % code)
+        self.kernel = k
+        return self
+
+
+def fold_binplan(phi: float, phase_per_sample: float, nbin: int, ndat: int):
+    plan = np.empty(ndat, dtype=np.uint32)
+    hits = np.zeros(nbin, dtype=np.uint32)
+    code = lib.dspsr_amd_fold_binplan(phi, phase_per_sample, nbin, ndat, plan.ctypes.data_as(C.c_void_p),
+                                      hits.ctypes.data_as(C.c_void_p))
+    if code != 0:
+        raise DspsrAmdError("dspsr_amd_fold_binplan failed (%d)" % code)
+    return plan, hits
+
+
+# ----------------------------------------------------------------------------------------------
+# engines
+# ----------------------------------------------------------------------------------------------
+
+def _strides3(t):
+    """(chan_stride, pol_stride) in elements of a [nchan][npol][n] tensor with contiguous last dim."""
+    assert t.dim() == 3 and t.stride(2) == 1, "TimeSeries rows must be contiguous"
+    return t.stride(0), t.stride(1)
+
+
+class FilterbankEngine:
+    """dsp::Filterbank::Engine.  setup() takes what CUDA::FilterbankEngine::setup reads from the
+    Filterbank (FilterbankCUDA.cu:73-168)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.handle = None
+
+    def setup(self, nchan_subband, freq_res, nfilt_pos, nfilt_neg, input_nchan=1, npol=2, real_input=True,
+              kernel: np.ndarray | None = None, max_parts: int = 1):
+        if self.handle:
+            lib.dspsr_amd_filterbank_destroy(self.handle)
+            self.handle = None
+        cfg = _lib.FilterbankConfig(nchan_subband, freq_res, nfilt_pos, nfilt_neg, input_nchan, npol,
+                                    1 if real_input else 0, max_parts)
+        h = C.c_void_p()
+        _check(self.ctx.handle, lib.dspsr_amd_filterbank_create(self.ctx.handle, C.byref(cfg), C.byref(h)),
+               "dspsr_amd_filterbank_create")
+        self.handle = h
+        self.cfg = cfg
+        if kernel is not None:
+            k = np.ascontiguousarray(kernel, dtype=np.complex64)
+            _check(self.ctx.handle, lib.dspsr_amd_filterbank_set_kernel(h, k.ctypes.data_as(C.c_void_p), k.size),
+                   "dspsr_amd_filterbank_set_kernel")
+        else:
+            _check(self.ctx.handle, lib.dspsr_amd_filterbank_set_kernel(h, None, 0), "dspsr_amd_filterbank_set_kernel")
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32()
+        lib.dspsr_amd_filterbank_sizes(h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        self.nsamp_fft, self.nsamp_overlap, self.nsamp_step, self.nkeep = a.value, b.value, c.value, d.value
+        return self
+
+    def perform(self, inp, out, npart, in_step, out_step):
+        ics, ips = _strides3(inp)
+        if out is not None:
+            ocs, ops = _strides3(out)
+            optr = out.data_ptr()
+        else:
+            ocs = ops = 0
+            optr = None
+        _check(self.ctx.handle,
+               lib.dspsr_amd_filterbank_perform(self.handle, inp.data_ptr(), ics, ips, optr, ocs, ops, npart, in_step,
+                                                out_step), "dspsr_amd_filterbank_perform")
+
+    def perform_raw(self, raw, layout, scale, out, npart, out_step=None):
+        ocs, ops = _strides3(out) if out is not None else (0, 0)
+        if out_step is None:
+            out_step = 2 * self.nkeep
+        _check(self.ctx.handle,
+               lib.dspsr_amd_filterbank_perform_raw(self.handle, raw.data_ptr(), layout, scale,
+                                                    out.data_ptr() if out is not None else None, ocs, ops, npart,
+                                                    out_step), "dspsr_amd_filterbank_perform_raw")
+
+    def perform_detect(self, det, npart, state=_lib.COHERENCE, ndim=4, inp=None, in_step=0, raw=None,
+                       layout=_lib.RAW_GENERIC, scale=1.0):
+        dcs, dps = _strides3(det)
+        if inp is not None:
+            ics, ips = _strides3(inp)
+            iptr = inp.data_ptr()
+        else:
+            ics = ips = 0
+            iptr = None
+        _check(self.ctx.handle,
+               lib.dspsr_amd_filterbank_perform_detect(self.handle, iptr, ics, ips, in_step,
+                                                       raw.data_ptr() if raw is not None else None, layout, scale,
+                                                       state, ndim, det.data_ptr(), dcs, dps, npart),
+               "dspsr_amd_filterbank_perform_detect")
+
+    def finish(self):
+        self.ctx.synchronize()
+
+    def close(self):
+        if self.handle:
+            lib.dspsr_amd_filterbank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DetectionEngine:
+    """dsp::Detection::Engine."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def polarimetry(self, ndim, inp, out, state=_lib.COHERENCE):
+        ics, ips = _strides3(inp)
+        ocs, ops = _strides3(out)
+        nchan = inp.shape[0]
+        ndat = inp.shape[2] // 2
+        _check(self.ctx.handle,
+               lib.dspsr_amd_detect_polarimetry(self.ctx.handle, state, ndim, inp.data_ptr(), ics, ips,
+                                                out.data_ptr(), ocs, ops, nchan, ndat),
+               "dspsr_amd_detect_polarimetry")
+
+    def square_law(self, inp, out, intensity=False):
+        ics, ips = _strides3(inp)
+        ocs, ops = _strides3(out)
+        _check(self.ctx.handle,
+               lib.dspsr_amd_detect_square_law(self.ctx.handle, int(intensity), inp.data_ptr(), ics, ips,
+                                               out.data_ptr(), ocs, ops, inp.shape[0], inp.shape[1],
+                                               inp.shape[2] // 2), "dspsr_amd_detect_square_law")
+
+
+class FoldEngine:
+    """dsp::Fold::Engine; owns the device-resident profiles (get_profiles)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        h = C.c_void_p()
+        _check(ctx.handle, lib.dspsr_amd_fold_create(ctx.handle, C.byref(h)), "dspsr_amd_fold_create")
+        self.handle = h
+        self.shape = None
+
+    def set_shape(self, nchan, npol, ndim, nbin):
+        _check(self.ctx.handle, lib.dspsr_amd_fold_set_shape(self.handle, nchan, npol, ndim, nbin),
+               "dspsr_amd_fold_set_shape")
+        self.shape = (nchan, npol, nbin, ndim)
+
+    def set_nbin(self, nbin):
+        _check(self.ctx.handle, lib.dspsr_amd_fold_set_nbin(self.handle, nbin), "dspsr_amd_fold_set_nbin")
+
+    def set_ndat(self, ndat, idat_start):
+        _check(self.ctx.handle, lib.dspsr_amd_fold_set_ndat(self.handle, ndat, idat_start), "dspsr_amd_fold_set_ndat")
+
+    def set_bin(self, idat, ibin, bins_per_samp=0.0):
+        _check(self.ctx.handle, lib.dspsr_amd_fold_set_bin(self.handle, idat, ibin, bins_per_samp),
+               "dspsr_amd_fold_set_bin")
+
+    def set_bins(self, phi, phase_per_sample, ndat, idat_start, hits: np.ndarray | None = None):
+        n = C.c_uint64()
+        hp = hits.ctypes.data_as(C.c_void_p) if hits is not None else None
+        _check(self.ctx.handle,
+               lib.dspsr_amd_fold_set_bins(self.handle, phi, phase_per_sample, ndat, idat_start, hp, C.byref(n)),
+               "dspsr_amd_fold_set_bins")
+        return n.value
+
+    def get_ndat_folded(self):
+        return lib.dspsr_amd_fold_get_ndat_folded(self.handle)
+
+    def fold(self, inp):
+        cs, ps = _strides3(inp)
+        _check(self.ctx.handle, lib.dspsr_amd_fold_fold(self.handle, inp.data_ptr(), cs, ps), "dspsr_amd_fold_fold")
+
+    def get_profiles_ptr(self):
+        return lib.dspsr_amd_fold_profiles_dev(self.handle)
+
+    def zero(self):
+        _check(self.ctx.handle, lib.dspsr_amd_fold_zero(self.handle), "dspsr_amd_fold_zero")
+
+    def synch(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.float32)
+        _check(self.ctx.handle, lib.dspsr_amd_fold_synch(self.handle, out.ctypes.data_as(C.c_void_p)),
+               "dspsr_amd_fold_synch")
+        return out
+
+    def close(self):
+        if self.handle:
+            lib.dspsr_amd_fold_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

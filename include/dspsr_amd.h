@@ -1,0 +1,181 @@
+/* dspsr_amd.h -- C-ABI of the MI355X (gfx950) coherent-dedispersion + detection + fold engine.
+ *
+ * This is the drop-in boundary for DSPSR's GPU hot path.  Each entry point replaces one method of
+ * the reference's Engine plug-in interfaces (citations are relative to the demorest/dspsr tree):
+ *
+ *   dsp::Memory                 Kernel/Classes/dsp/Memory.h:18-34      (CUDA impl MemoryCUDA.C:47-106)
+ *   dsp::Filterbank::Engine     Signal/General/dsp/FilterbankEngine.h:15-44 (CUDA impl FilterbankCUDA.cu:73-304)
+ *   dsp::Detection::Engine      Signal/General/dsp/Detection.h:98-106  (CUDA impl DetectionCUDA.cu:127-322)
+ *   dsp::Fold::Engine           Signal/Pulsar/dsp/Fold.h:249-312       (CUDA impl FoldCUDA.cu:64-697)
+ *   host-side preparation       Dedispersion.C:216-556, Response.C:132-344,649-700, optimize_fft.c:63-127,
+ *                               Filterbank.C:55-263, Fold.C:650-787
+ *
+ * Conventions: plain C, opaque handles, every function returns 0 on success or a negative
+ * DSPSR_AMD_E* code (never throws); dspsr_amd_last_error() gives the text a host wrapper turns
+ * into the reference's `Error` exception.  All device work is enqueued on the context's HIP
+ * stream and is asynchronous unless stated; pointers named *_dev are device pointers.
+ * The host adaptor classes that bind these to the dsp::*::Engine interfaces are in
+ * dspsr_amd/host/ (see INTEGRATION.md).
+ */
+#ifndef DSPSR_AMD_H
+#define DSPSR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSPSR_AMD_OK 0
+#define DSPSR_AMD_EINVAL (-1)   /* invalid argument / unsupported configuration (reference: Error InvalidParam/InvalidState) */
+#define DSPSR_AMD_EHIP (-2)     /* HIP runtime failure (reference: CUFFTError / check_error) */
+#define DSPSR_AMD_ENOMEM (-3)
+#define DSPSR_AMD_ESTATE (-4)   /* called out of order (e.g. perform before set_kernel) */
+
+typedef struct dspsr_amd_ctx dspsr_amd_ctx;
+typedef struct dspsr_amd_filterbank dspsr_amd_filterbank;
+typedef struct dspsr_amd_fold dspsr_amd_fold;
+
+/* ---- context: one per pipeline thread / GPU, bound to one stream (SingleThread.C:213-290) ---- */
+int dspsr_amd_ctx_create(int device, void* hip_stream /* NULL => create own stream */, dspsr_amd_ctx** ctx);
+void dspsr_amd_ctx_destroy(dspsr_amd_ctx* ctx);
+const char* dspsr_amd_last_error(const dspsr_amd_ctx* ctx);
+int dspsr_amd_stream_sync(dspsr_amd_ctx* ctx);            /* FilterbankEngine::finish / check_error_stream */
+const char* dspsr_amd_version(void);
+
+/* ---- dsp::Memory (Memory.h:18-34): do_allocate / do_free / do_zero / do_copy ---- */
+int dspsr_amd_malloc(dspsr_amd_ctx* ctx, size_t nbytes, void** ptr_dev);
+int dspsr_amd_free(dspsr_amd_ctx* ctx, void* ptr_dev);
+int dspsr_amd_zero(dspsr_amd_ctx* ctx, void* ptr_dev, size_t nbytes);
+#define DSPSR_AMD_H2D 1
+#define DSPSR_AMD_D2H 2
+#define DSPSR_AMD_D2D 3
+int dspsr_amd_copy(dspsr_amd_ctx* ctx, void* dst, const void* src, size_t nbytes, int kind);
+
+/* ---- dsp::Filterbank::Engine ------------------------------------------------------------
+ * setup(Filterbank*)  -> dspsr_amd_filterbank_create + dspsr_amd_filterbank_set_kernel
+ *   (FilterbankCUDA.cu:73-168 reads freq_res, nchan_subband, input state, response nchan/ndat/
+ *    impulse_pos/neg and copies the host-built, already swapped kernel to the device) */
+typedef struct {
+  uint32_t nchan_subband;   /* output channels per input channel          Filterbank.C:68  */
+  uint32_t freq_res;        /* response ndat = backward FFT length (>= 2) Filterbank.C:93  */
+  uint32_t nfilt_pos;       /* response impulse_pos                       Filterbank.C:90  */
+  uint32_t nfilt_neg;       /* response impulse_neg                       Filterbank.C:91  */
+  uint32_t input_nchan;     /* input channels (kernel has input_nchan*nchan_subband*freq_res bins) */
+  uint32_t npol;            /* 1 or 2 */
+  uint32_t real_input;      /* 1: Signal::Nyquist (ndim 1), 0: Signal::Analytic (ndim 2) */
+  uint32_t max_parts;       /* parts processed per launch group (scratch is sized for this); 0 => default */
+} dspsr_amd_filterbank_config;
+
+int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_filterbank_config* cfg,
+                                dspsr_amd_filterbank** fb);
+void dspsr_amd_filterbank_destroy(dspsr_amd_filterbank* fb);
+/* host kernel: input_nchan*nchan_subband*freq_res complex floats (response->get_datptr(0,0)); NULL => no response */
+int dspsr_amd_filterbank_set_kernel(dspsr_amd_filterbank* fb, const float* kernel_host, uint64_t ncomplex);
+/* derived sizes, same arithmetic as Filterbank::make_preparations (Filterbank.C:107-155) */
+int dspsr_amd_filterbank_sizes(const dspsr_amd_filterbank* fb, uint64_t* nsamp_fft, uint64_t* nsamp_overlap,
+                               uint64_t* nsamp_step, uint32_t* nkeep);
+
+/* perform(in, out, npart, in_step, out_step)  (FilterbankEngine.h:28-32, FilterbankCUDA.cu:181-304)
+ *   in_dev : unpacked float32 rows, in->get_datptr(ichan,ipol) = in_dev + ichan*in_chan_stride + ipol*in_pol_stride (floats)
+ *   out_dev: complex float rows, out->get_datptr(ochan,ipol) = out_dev + ochan*out_chan_stride + ipol*out_pol_stride (floats);
+ *            NULL => benchmark only (FilterbankCUDA.cu:265)
+ *   in_step: floats between parts (= nsamp_step*ndim), out_step: floats between parts (= 2*nkeep) */
+int dspsr_amd_filterbank_perform(dspsr_amd_filterbank* fb, const float* in_dev, uint64_t in_chan_stride,
+                                 uint64_t in_pol_stride, float* out_dev, uint64_t out_chan_stride,
+                                 uint64_t out_pol_stride, uint64_t npart, uint64_t in_step, uint64_t out_step);
+
+/* Optional side channel (north star: fuse the 8-bit load into FFT pass 1; replaces the separate
+ * unpack kernels GenericEightBitUnpackerCUDA.cu:24-45 / CASPSRUnpackerCUDA.cu:44-82 + perform).
+ * raw_dev points at the first byte of the block (BitSeries::get_rawptr()); value = (int8+0.5)*scale. */
+#define DSPSR_AMD_RAW_GENERIC 0  /* byte ((t*nchan+c)*npol+p)*ndim+d   BitUnpacker.C:48-80 */
+#define DSPSR_AMD_RAW_CASPSR 1   /* 4 B pol0, 4 B pol1 repeating       CASPSRUnpacker.C:132-187 */
+int dspsr_amd_filterbank_perform_raw(dspsr_amd_filterbank* fb, const int8_t* raw_dev, int raw_layout, float scale,
+                                     float* out_dev, uint64_t out_chan_stride, uint64_t out_pol_stride,
+                                     uint64_t npart, uint64_t out_step);
+
+/* Fused filterbank + Detection::polarimetry (npol must be 2): writes the detected TimeSeries directly.
+ *   state: DSPSR_AMD_COHERENCE | DSPSR_AMD_STOKES ; ndim in {1,2,4} (Detection.C:423-474 layouts):
+ *     ndim 4: det_dev + chan*det_chan_stride + 4*idat               (npol 1)
+ *     ndim 2: det_dev + chan*det_chan_stride + plane*det_pol_stride + 2*idat   (plane0 = PP,QQ plane1 = Re,Im)
+ *     ndim 1: det_dev + chan*det_chan_stride + k*det_pol_stride + idat         (k = 0..3)
+ *   exactly one of in_f32_dev / raw_dev is non-NULL. */
+#define DSPSR_AMD_COHERENCE 0
+#define DSPSR_AMD_STOKES 1
+int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, const float* in_f32_dev, uint64_t in_chan_stride,
+                                        uint64_t in_pol_stride, uint64_t in_step, const int8_t* raw_dev,
+                                        int raw_layout, float scale, int state, uint32_t ndim, float* det_dev,
+                                        uint64_t det_chan_stride, uint64_t det_pol_stride, uint64_t npart);
+
+/* ---- dsp::Detection::Engine (Detection.h:98-106) ------------------------------------------
+ * polarimetry(ndim, in, out): in = complex rows [nchan][2][ndat]; in-place allowed for ndim 2
+ * (LoadToFold1.C:545-546 uses input==output).  Layouts as above. */
+int dspsr_amd_detect_polarimetry(dspsr_amd_ctx* ctx, int state, uint32_t ndim, const float* in_dev,
+                                 uint64_t in_chan_stride, uint64_t in_pol_stride, float* out_dev,
+                                 uint64_t out_chan_stride, uint64_t out_pol_stride, uint32_t nchan, uint64_t ndat);
+/* square_law(in,out) (Detection.C:218-320): out[chan][pol][idat] = re^2+im^2 ; intensity!=0 sums the two pols */
+int dspsr_amd_detect_square_law(dspsr_amd_ctx* ctx, int intensity, const float* in_dev, uint64_t in_chan_stride,
+                                uint64_t in_pol_stride, float* out_dev, uint64_t out_chan_stride,
+                                uint64_t out_pol_stride, uint32_t nchan, uint32_t npol, uint64_t ndat);
+
+/* ---- dsp::Fold::Engine (Fold.h:249-312, FoldCUDA.cu) --------------------------------------
+ * The engine owns the device-resident profile (get_profiles()).  Call order per Fold::fold
+ * (Fold.C:724-829): set_nbin, set_ndat, set_bin x ndat (or set_bins), fold.  synch copies to host. */
+int dspsr_amd_fold_create(dspsr_amd_ctx* ctx, dspsr_amd_fold** fold);
+void dspsr_amd_fold_destroy(dspsr_amd_fold* fold);
+/* shape of the input TimeSeries / output PhaseSeries (Fold::Engine::setup, Fold.C:973-1007) */
+int dspsr_amd_fold_set_shape(dspsr_amd_fold* fold, uint32_t nchan, uint32_t npol, uint32_t ndim, uint32_t nbin);
+int dspsr_amd_fold_set_nbin(dspsr_amd_fold* fold, uint32_t nbin);                        /* FoldCUDA.cu:64-70 */
+int dspsr_amd_fold_set_ndat(dspsr_amd_fold* fold, uint64_t ndat, uint64_t idat_start);   /* FoldCUDA.cu:72-82 */
+int dspsr_amd_fold_set_bin(dspsr_amd_fold* fold, uint64_t idat, double ibin, double bins_per_sample); /* :84-113 */
+/* whole plan at once: the double recurrence of Fold.C:744-787 run inside the library;
+ * hits_host[nbin] (may be NULL) is incremented like Fold.C:783; returns ndat folded via *ndat_folded */
+int dspsr_amd_fold_set_bins(dspsr_amd_fold* fold, double phi, double phase_per_sample, uint64_t ndat,
+                            uint64_t idat_start, uint32_t* hits_host, uint64_t* ndat_folded);
+/* fold(): accumulate in_dev rows (get_datptr(ichan,ipol) = in_dev + ichan*in_chan_stride + ipol*in_pol_stride)
+ * into the device profile using the plan built since the last set_nbin (FoldCUDA.cu:586-697) */
+int dspsr_amd_fold_fold(dspsr_amd_fold* fold, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride);
+float* dspsr_amd_fold_profiles_dev(dspsr_amd_fold* fold);   /* device [nchan][npol][nbin][ndim] (get_profiles) */
+uint64_t dspsr_amd_fold_get_ndat_folded(const dspsr_amd_fold* fold);
+int dspsr_amd_fold_zero(dspsr_amd_fold* fold);                                            /* Engine::zero */
+int dspsr_amd_fold_synch(dspsr_amd_fold* fold, float* profile_host);                      /* FoldCUDA.cu:127-152 (blocks) */
+
+/* ---- host-side preparation (stays on the host in the reference as well) --------------------- */
+typedef struct {
+  double centre_frequency;   /* MHz */
+  double bandwidth;          /* MHz, signed */
+  double dispersion_measure;
+  uint32_t input_nchan;
+  uint32_t nchan;            /* output channels */
+  uint32_t ndim;             /* input ndim: 1 Nyquist, 2 Analytic */
+  int32_t dual_sideband;     /* -1 unset (Observation.C:80-87) */
+  uint32_t dc_centred;
+  uint32_t swap;
+  uint32_t freq_res;         /* 0 => optimal (optimize_fft.c) else -x value (checked like Response.C:328-344) */
+  uint32_t ndat_max;         /* Response::ndat_max, 0 => none */
+} dspsr_amd_dedispersion_config;
+
+typedef struct {
+  uint32_t impulse_pos, impulse_neg;   /* Dedispersion.C:216-248 */
+  uint32_t minimum_ndat;               /* Response.C:259-275 */
+  uint32_t ndat;                       /* chosen frequency resolution */
+} dspsr_amd_dedispersion_info;
+
+/* Dedispersion::prepare + resolution choice; error if -x is below the minimum (Response::check_ndat) */
+int dspsr_amd_dedispersion_prepare(const dspsr_amd_dedispersion_config* cfg, dspsr_amd_dedispersion_info* info,
+                                   char* errbuf, size_t errlen);
+/* Dedispersion::build + Response::match ordering (Dedispersion.C:261-331,478-556; Response.C:132-181):
+ * kernel_host receives nchan*ndat complex floats */
+int dspsr_amd_dedispersion_build(const dspsr_amd_dedispersion_config* cfg, uint32_t ndat, float* kernel_host);
+uint64_t dspsr_amd_optimal_fft_length(uint64_t nbadperfft, uint64_t nfft_max);           /* optimize_fft.c:63-127 */
+/* (int8+0.5)*scale constant of the 8-bit LUT (BitTable.C:165-218) for a given JA98 spacing (ext) */
+double dspsr_amd_eight_bit_scale(double ja98_spacing);
+/* bin plan of Fold.C:744-787: binplan[ndat] and hits[nbin] += */
+int dspsr_amd_fold_binplan(double phi, double phase_per_sample, uint32_t nbin, uint64_t ndat,
+                           uint32_t* binplan_host, uint32_t* hits_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSPSR_AMD_H */

@@ -163,6 +163,7 @@ def unpack_8bit(raw: np.ndarray, obs: Observation, scale=S8) -> np.ndarray:
         ndat = raw.size // nskip
         v = raw[: ndat * nskip].reshape(ndat, nchan, npol, ndim).transpose(1, 2, 0, 3)
         v = v.reshape(nchan, npol, ndat * ndim)
+    v = np.ascontiguousarray(v)      # C order: callers hand the buffer to C / the device
     return ((v.astype(np.float32) + np.float32(0.5)) * np.float32(scale)).astype(np.float32)
 
 
@@ -222,7 +223,6 @@ class Dedispersion:
     impulse_neg: int = 0
     whole_swapped: bool = False
     swap_divisions: int = 0
-    response_dc_centred: bool = False
     buffer: np.ndarray | None = None     # complex64 [nchan*ndat]
     supported_channels: list = field(default_factory=list)
 
@@ -361,11 +361,13 @@ class Dedispersion:
             if obs.get_dual_sideband() and not self.whole_swapped:
                 self.doswap()
         else:
-            if obs.dc_centred and not self.response_dc_centred:
+            # Response::dc_centred is the member Dedispersion::prepare already set from the input
+            # (Dedispersion.C:179, Response.h:170), so this branch only fires for other Responses
+            if obs.dc_centred and not self.dc_centred:
                 if self.swap_divisions:
                     self.doswap(self.swap_divisions)
                 self.rotate(-int(self.ndat // 2))
-                self.response_dc_centred = True
+                self.dc_centred = True
             if obs.get_dual_sideband() and self.swap_divisions != obs.nchan:
                 self.doswap(obs.nchan)
             if obs.swap and not self.whole_swapped:

@@ -1,0 +1,292 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (stated per BASELINE.json north_star: folded output within 1e-5 relative of the
+CPU/FFTW reference; integer/index work bit-exact):
+  * raw filterbank output vs the float64 oracle: max |err| <= 2e-6 * sqrt(log2 N) * rms(out) * 8
+    and rms(err)/rms(out) <= 2e-6 * sqrt(log2 N)                     
+  * folded profile vs float64 oracle: max |err| / max |profile| <= 1e-5 per (chan, product)
+  * hits[], bin plan, fold of identical detected samples: bit-exact
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    import dspsr_amd
+    ctx = dspsr_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    yield dspsr_amd, ctx
+    ctx.close()
+
+
+def _raw(ndat, npol=2, ndim=1, nchan=1, seed=1):
+    rng = np.random.default_rng(seed)
+    return np.clip(np.rint(rng.standard_normal(ndat * nchan * npol * ndim) * 24.0), -128, 127).astype(np.int8)
+
+
+def _fb_case(oracle, gpu, C, M, nfilt, npart, npol=2, real=True, input_nchan=1, layout="generic", use_raw=True,
+             max_parts=1, seed=3):
+    dspsr_amd, ctx = gpu
+    o = oracle
+    nchan = C * input_nchan
+    N = C * M
+    nfilt_pos, nfilt_neg = nfilt
+    rng = np.random.default_rng(seed)
+    kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, input_nchan * N)).astype(np.complex64)
+    kernel[0] = 0
+    obs = o.Observation(nchan=input_nchan, npol=npol, ndim=1 if real else 2,
+                        machine="CASPSR" if layout == "caspsr" else "DADA")
+    plan = o.FilterbankPlan(nchan, input_nchan, C, M, N, nfilt_pos, nfilt_neg, nfilt_pos + nfilt_neg,
+                            2 * N if real else N, (2 if real else 1) * (nfilt_pos + nfilt_neg) * C, 0,
+                            M - nfilt_pos - nfilt_neg, float(N) * M, real)
+    plan.nsamp_step = plan.nsamp_fft - plan.nsamp_overlap
+    ndat = npart * plan.nsamp_step + plan.nsamp_overlap
+    raw = _raw(ndat, npol, obs.ndim, input_nchan, seed)
+    scale = float(o.S8)
+    unpacked = o.unpack_8bit(raw, obs)
+    ref = o.filterbank(unpacked, plan, kernel, npart=npart, dtype=np.float64)
+
+    eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt_pos, nfilt_neg, input_nchan, npol, real, kernel,
+                                                max_parts=max_parts)
+    assert (eng.nsamp_fft, eng.nsamp_overlap, eng.nsamp_step, eng.nkeep) == \
+        (plan.nsamp_fft, plan.nsamp_overlap, plan.nsamp_step, plan.nkeep)
+    out = torch.zeros((nchan, npol, 2 * npart * plan.nkeep), dtype=torch.float32, device="cuda")
+    if use_raw:
+        d_raw = torch.from_numpy(raw).cuda()
+        eng.perform_raw(d_raw, dspsr_amd.RAW_CASPSR if layout == "caspsr" else dspsr_amd.RAW_GENERIC, scale, out,
+                        npart)
+    else:
+        d_in = torch.from_numpy(unpacked).cuda()
+        eng.perform(d_in, out, npart, plan.nsamp_step * obs.ndim, 2 * plan.nkeep)
+    eng.finish()
+    got = out.cpu().numpy().view(np.complex64).astype(np.complex128)
+    eng.close()
+    err = got - ref
+    rms_ref = math.sqrt(np.mean(np.abs(ref) ** 2))
+    rms_err = math.sqrt(np.mean(np.abs(err) ** 2))
+    tol = 2e-6 * math.sqrt(math.log2(2 * N))
+    assert rms_err / rms_ref <= tol, (rms_err / rms_ref, tol)
+    assert np.abs(err).max() <= 8 * tol * rms_ref, (np.abs(err).max() / rms_ref, 8 * tol)
+    return got, ref
+
+
+@pytest.mark.parametrize("C,M,nfilt,npart", [
+    (8, 64, (5, 7), 3),          # tiny: one workgroup per pass
+    (4, 16, (1, 2), 2),          # below one wave per workgroup
+    (16, 256, (20, 21), 2),
+    (32, 512, (40, 30), 3),      # radix 16*16*2 / rows 64
+    (64, 1024, (100, 101), 2),
+    (2, 2048, (100, 50), 2),     # few channels, long backward FFT
+    (512, 32, (3, 4), 2),        # many channels, short backward FFT
+])
+def test_filterbank_real_dualpol_raw(oracle, gpu, C, M, nfilt, npart):
+    _fb_case(oracle, gpu, C, M, nfilt, npart)
+
+
+def test_filterbank_cfg2_size(oracle, gpu):
+    # BASELINE cfg2 geometry: -F 256:D -x 4096 (N = 2^20), nfilt 953/956
+    _fb_case(oracle, gpu, 256, 4096, (953, 956), 2, max_parts=2)
+
+
+def test_filterbank_target_size(oracle, gpu):
+    # headline geometry: -F 1024:D -x 4096 (N = 2^22), DM 1000 -> 422/422
+    _fb_case(oracle, gpu, 1024, 4096, (422, 422), 1)
+
+
+def test_filterbank_float_input_equals_raw(oracle, gpu):
+    a, _ = _fb_case(oracle, gpu, 16, 256, (20, 21), 2, use_raw=True)
+    b, _ = _fb_case(oracle, gpu, 16, 256, (20, 21), 2, use_raw=False)
+    assert np.array_equal(a, b)      # same arithmetic after the (int8+0.5)*scale conversion
+
+
+def test_filterbank_caspsr_layout(oracle, gpu):
+    _fb_case(oracle, gpu, 16, 256, (20, 21), 2, layout="caspsr")
+
+
+def test_filterbank_single_pol(oracle, gpu):
+    _fb_case(oracle, gpu, 16, 256, (20, 21), 2, npol=1)
+
+
+@pytest.mark.parametrize("input_nchan,npol", [(1, 2), (4, 2), (2, 1)])
+def test_filterbank_complex_input(oracle, gpu, input_nchan, npol):
+    _fb_case(oracle, gpu, 32, 128, (9, 10), 2, npol=npol, real=False, input_nchan=input_nchan)
+    _fb_case(oracle, gpu, 32, 128, (9, 10), 2, npol=npol, real=False, input_nchan=input_nchan, use_raw=False)
+
+
+def test_filterbank_batched_parts_identical(oracle, gpu):
+    a, _ = _fb_case(oracle, gpu, 16, 256, (20, 21), 5, max_parts=1)
+    b, _ = _fb_case(oracle, gpu, 16, 256, (20, 21), 5, max_parts=4)
+    assert np.array_equal(a, b)
+
+
+def test_filterbank_errors(gpu):
+    dspsr_amd, ctx = gpu
+    with pytest.raises(dspsr_amd.DspsrAmdError):
+        dspsr_amd.FilterbankEngine(ctx).setup(8, 48, 1, 1)            # freq_res not a power of two
+    with pytest.raises(dspsr_amd.DspsrAmdError):
+        dspsr_amd.FilterbankEngine(ctx).setup(8, 64, 40, 30)          # nfilt_tot >= freq_res
+    with pytest.raises(dspsr_amd.DspsrAmdError):
+        dspsr_amd.FilterbankEngine(ctx).setup(8, 64, 1, 1, kernel=np.zeros(5, np.complex64))
+
+
+@pytest.mark.parametrize("state", ["Coherence", "Stokes"])
+@pytest.mark.parametrize("ndim", [1, 2, 4])
+def test_detection_engine(oracle, gpu, state, ndim):
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(5)
+    nchan, ndat = 6, 1000
+    x = rng.standard_normal((nchan, 2, 2 * ndat)).astype(np.float32)
+    fb = x.view(np.complex64)
+    prod = oracle.detect_products(fb, state)                    # float32 arithmetic as the reference
+    want = oracle.detect_layout(prod, ndim)
+    npol_out = 4 // ndim
+    out = torch.zeros((nchan, npol_out, ndat * ndim), dtype=torch.float32, device="cuda")
+    st = dspsr_amd.COHERENCE if state == "Coherence" else dspsr_amd.STOKES
+    dspsr_amd.DetectionEngine(ctx).polarimetry(ndim, torch.from_numpy(x).cuda(), out, st)
+    got = out.cpu().numpy().reshape(want.shape if ndim > 1 else (nchan, 4, ndat))
+    # same float32 operations; allow 1 ulp for fused multiply-add contraction on the device
+    np.testing.assert_allclose(got, want, rtol=3e-7, atol=3e-7 * np.abs(want).max())
+
+
+def test_detection_inplace_ndim2(oracle, gpu):
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((3, 2, 512)).astype(np.float32)
+    want = oracle.detect_layout(oracle.detect_products(x.view(np.complex64), "Coherence"), 2)
+    d = torch.from_numpy(x).cuda()
+    dspsr_amd.DetectionEngine(ctx).polarimetry(2, d, d)          # LoadToFold1.C:545-546 in-place use
+    np.testing.assert_allclose(d.cpu().numpy().reshape(want.shape), want, rtol=3e-7, atol=1e-6)
+
+
+def test_square_law(oracle, gpu):
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((5, 2, 600)).astype(np.float32)
+    fb = x.view(np.complex64)
+    for intensity in (False, True):
+        want = oracle.square_law(fb, "Intensity" if intensity else "PPQQ")
+        out = torch.zeros((5, 1 if intensity else 2, 300), dtype=torch.float32, device="cuda")
+        dspsr_amd.DetectionEngine(ctx).square_law(torch.from_numpy(x).cuda(), out, intensity)
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=3e-7, atol=1e-6)
+
+
+@pytest.mark.parametrize("ndim,npol", [(4, 1), (2, 2), (1, 4)])
+@pytest.mark.parametrize("nbin", [64, 1024, 100])
+def test_fold_engine_bit_exact(oracle, gpu, ndim, npol, nbin):
+    """Fold of identical detected samples is bit-identical to the CPU loop (Fold.C:835-891)."""
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(8)
+    nchan, ndat = 5, 7000
+    det = rng.standard_normal((nchan, npol, ndat, ndim)).astype(np.float32) ** 2
+    phi, pps = 0.37, 1.0 / 333.3
+    idat_start, ndat_fold = 11, ndat - 50
+    eng = dspsr_amd.FoldEngine(ctx)
+    eng.set_shape(nchan, npol, ndim, nbin)
+    d = torch.from_numpy(det.reshape(nchan, npol, ndat * ndim)).cuda()
+    want = np.zeros((nchan, npol, nbin, ndim), np.float32)
+    hits_total = np.zeros(nbin, np.uint32)
+    for rep in range(2):                                   # accumulate twice: += semantics
+        hits = np.zeros(nbin, np.uint32)
+        eng.set_nbin(nbin)
+        eng.set_ndat(ndat_fold, idat_start)
+        n = eng.set_bins(phi, pps, ndat_fold, idat_start, hits)
+        assert n == ndat_fold and eng.get_ndat_folded() == ndat_fold
+        eng.fold(d)
+        plan = oracle.fold_binplan(phi, pps, nbin, ndat_fold)
+        assert np.array_equal(hits, np.bincount(plan, minlength=nbin).astype(np.uint32))
+        hits_total += hits
+        for i in range(ndat_fold):
+            want[:, :, plan[i], :] += det[:, :, idat_start + i, :]
+    got = eng.synch()
+    assert np.array_equal(got, want)
+    eng.zero()
+    assert not eng.synch().any()
+    eng.close()
+
+
+def test_fold_set_bin_equals_set_bins(gpu):
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(9)
+    det = rng.standard_normal((2, 1, 3000 * 4)).astype(np.float32)
+    d = torch.from_numpy(det).cuda()
+    res = []
+    for mode in (0, 1):
+        eng = dspsr_amd.FoldEngine(ctx)
+        eng.set_shape(2, 1, 4, 128)
+        eng.set_nbin(128)
+        eng.set_ndat(3000, 0)
+        phi, pps = 0.9, 0.0123
+        if mode == 0:
+            eng.set_bins(phi, pps, 3000, 0)
+        else:                                             # the per-sample host loop of Fold.C:744-787
+            for i in range(3000):
+                phi -= math.floor(phi)
+                eng.set_bin(i, phi * 128.0, pps * 128.0)
+                phi += pps
+        eng.fold(d)
+        res.append(eng.synch())
+        eng.close()
+    assert np.array_equal(res[0], res[1])
+
+
+def test_end_to_end_folded_profile(oracle, gpu):
+    """raw bytes -> fused filterbank+detect -> fold, against the float64 oracle pipeline (<= 1e-5 relative)."""
+    dspsr_amd, ctx = gpu
+    from dspsr_amd import synth
+    o = oracle
+    freq, bw, tsamp, dm, period, nchan, nbin = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004, 16, 64
+    obs = o.Observation(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, npol=2, ndim=1)
+    resp = dspsr_amd.Dedispersion(freq, bw, dm)
+    resp.match(nchan)
+    oresp = o.Dedispersion()
+    obs.dispersion_measure = dm
+    oresp.match(obs, nchan)
+    assert (resp.impulse_pos, resp.impulse_neg, resp.ndat) == (oresp.impulse_pos, oresp.impulse_neg, oresp.ndat)
+    plan = o.filterbank_plan(obs, nchan, oresp)
+    npart = 6
+    ndat = npart * plan.nsamp_step + plan.nsamp_overlap
+    raw = synth.voltages(ndat, freq, bw, tsamp, dm, period)
+    # oracle (float64 arithmetic, product's own kernel so only the device path differs)
+    unpacked = o.unpack_8bit(raw, obs)
+    fb = o.filterbank(unpacked, plan, resp.kernel, dtype=np.float64)
+    det = o.detect_layout(o.detect_products(fb, "Coherence"), 4)
+    fobs = o.filterbank_output_observation(obs, plan)
+    ps = o.PhaseSeries(nchan, 1, 4, nbin, data=np.zeros((nchan, 1, nbin, 4), np.float64))
+    cfg = o.FoldConfig(nbin=nbin, folding_period=period)
+    o.fold(det, fobs, cfg, ps)
+    # device
+    eng = dspsr_amd.FilterbankEngine(ctx).setup(plan.nchan_subband, plan.freq_res, plan.nfilt_pos, plan.nfilt_neg, 1,
+                                                2, True, resp.kernel, max_parts=4)
+    d_det = torch.zeros((nchan, 1, 4 * npart * plan.nkeep), dtype=torch.float32, device="cuda")
+    eng.perform_detect(d_det, npart, dspsr_amd.COHERENCE, 4, raw=torch.from_numpy(raw).cuda(),
+                       scale=float(o.S8))
+    fold = dspsr_amd.FoldEngine(ctx)
+    fold.set_shape(nchan, 1, 4, nbin)
+    fold.set_nbin(nbin)
+    ndat_out = npart * plan.nkeep
+    phi, pfold = o.fold_phase(cfg, fobs, fobs.start_seconds + 0.5 / fobs.rate)
+    hits = np.zeros(nbin, np.uint32)
+    fold.set_ndat(ndat_out, 0)
+    fold.set_bins(phi, (1.0 / fobs.rate) / pfold, ndat_out, 0, hits)
+    fold.fold(d_det)
+    got = fold.synch().astype(np.float64)
+    assert np.array_equal(hits, ps.hits)
+    for c in range(nchan):
+        for k in range(4):
+            ref = ps.data[c, 0, :, k]
+            err = np.abs(got[c, 0, :, k] - ref).max() / np.abs(ps.data[c, 0, :, :2]).max()
+            assert err <= 1e-5, (c, k, err)
+    # the dedispersed pulse must be sharp: on-pulse bins well above the off-pulse mean
+    # (per channel: inter-channel delays are not removed by the filterbank, Dedispersion.C:524-545 needs -K)
+    prof = got[0, 0, :, 0] / hits
+    assert prof.max() > 1.5 * np.median(prof)
+    eng.close()
+    fold.close()
