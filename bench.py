@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: 8-bit dual-pol voltages -> coherent-dedispersion filterbank (-F N:D)
+-> detection -> fold, on N MI355X GPUs (one process per GPU).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|cfg3|cfg2|cfg4]
+
+A "step" is one pass of the hot path over one block (parts_per_block overlap-save parts) of synthetic
+8-bit input already resident in HBM.  metric = Msamples/s = unique input time samples per polarisation
+consumed per second, summed over all ranks.  With N > 1 every rank holds one
+frequency sub-band of the same geometry (weak scaling) and ONE RCCL reduce of the folded profiles is
+done per sub-integration dump (every --dump-steps steps), inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     : algorithmic bytes of the FFT+chirp launch group / its measured duration (HIP events)
+  cpu_baseline : the numpy oracle timed on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+# name -> (freq MHz, bw MHz, input nchan, ndim, tsamp_us, nchan out, DM, -x freq_res, nbin)
+WORKLOADS = {
+    # north-star headline: -F 1024:D -x 4096, DM 1000 on Benchmark/header.dada (SURVEY Appendix B "target")
+    "target": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=1024, dm=1000.0,
+                   freq_res=4096, nbin=1024, machine="CASPSR",
+                   cmd="dspsr -F 1024:D -x 4096 -D 1000 -b 1024 (header.dada band, 8-bit dual-pol real)"),
+    "cfg3": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=1024, dm=2000.0,
+                 freq_res=4096, nbin=1024, machine="CASPSR",
+                 cmd="dspsr -F 1024:D -x 4096 -D 2000 -b 1024"),
+    "cfg2": dict(freq=2000.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=256, dm=500.0,
+                 freq_res=4096, nbin=1024, machine="CASPSR",
+                 cmd="dspsr -F 256:D -x 4096 -D 500 -b 1024 (band moved to 2000 MHz, SURVEY Appendix B)"),
+    # one 50 MHz complex sub-band per rank of an 8-channel 400 MHz band
+    "cfg4": dict(freq=1382.0, bw=-50.0, in_nchan=1, ndim=2, tsamp_us=0.02, nchan=512, dm=1000.0,
+                 freq_res=512, nbin=1024, machine="DADA",
+                 cmd="dspsr -F 512:D -D 1000 -b 1024 per 50 MHz complex sub-band"),
+}
+
+
+def algorithmic_bytes_per_part(npol, nsamp_fft, nbit, N, nchan_subband, nkeep):
+    """each input byte read once, chirp read once, each kept output written once."""
+    return npol * nsamp_fft * nbit // 8 + 8 * N + npol * nchan_subband * nkeep * 8
+
+
+def cpu_baseline(wl, lt, nparts=1):
+    """Times the numpy oracle (oracle/dspsr_oracle.py, a 'port') on `nparts` parts of the same workload."""
+    import oracle.dspsr_oracle as o
+    obs = o.Observation(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=wl["in_nchan"], npol=2,
+                        ndim=wl["ndim"], tsamp_us=wl["tsamp_us"], machine=wl["machine"],
+                        dispersion_measure=wl["dm"])
+    resp = o.Dedispersion()
+    resp.set_frequency_resolution(wl["freq_res"])
+    resp.match(obs, wl["nchan"])
+    plan = o.filterbank_plan(obs, wl["nchan"], resp)
+    ndat = nparts * plan.nsamp_step + plan.nsamp_overlap
+    rng = np.random.default_rng(1)
+    raw = np.clip(np.rint(rng.standard_normal(ndat * wl["in_nchan"] * 2 * wl["ndim"]) * 24), -128, 127).astype(np.int8)
+    t0 = time.perf_counter()
+    unpacked = o.unpack_8bit(raw, obs)
+    fb = o.filterbank(unpacked, plan, resp.buffer, dtype=np.float32)
+    det = o.detect_layout(o.detect_products(fb, "Coherence"), 4)
+    fobs = o.filterbank_output_observation(obs, plan)
+    # fold with the vectorised equivalent of the sequential loop (np.add.at keeps time order per bin)
+    phi, pfold = o.fold_phase(o.FoldConfig(nbin=wl["nbin"], folding_period=0.089), fobs, fobs.start_seconds)
+    binplan = o.fold_binplan(phi, (1.0 / fobs.rate) / pfold, wl["nbin"], det.shape[2])
+    prof = np.zeros((det.shape[0], wl["nbin"], 4), np.float32)
+    np.add.at(prof, (slice(None), binplan), det[:, 0])
+    dt = time.perf_counter() - t0
+    return {"value": nparts * plan.nsamp_step / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d overlap-save part(s) of the same workload (%.1f Msamples/pol), numpy oracle with "
+                      "pocketfft float32, single thread, %.1f s" % (nparts, nparts * plan.nsamp_step / 1e6, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
+    ap.add_argument("--parts-per-block", type=int, default=16)
+    ap.add_argument("--max-parts", type=int, default=2)
+    ap.add_argument("--dump-steps", type=int, default=8, help="steps per sub-integration dump")
+    ap.add_argument("--ndim", type=int, default=4, choices=[1, 2, 4])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from dspsr_amd import pipeline
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    wl = WORKLOADS[args.workload]
+    # sub-band sharding: rank g holds the g-th band of the same geometry (centre frequencies stacked downwards)
+    freq = wl["freq"] + rank * wl["bw"]
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=wl["bw"], nchan=wl["in_nchan"], npol=2,
+                              ndim=wl["ndim"], tsamp_us=wl["tsamp_us"], machine=wl["machine"])
+    cfg = pipeline.Config(nchan=wl["nchan"], dispersion_measure=wl["dm"], nbin=wl["nbin"],
+                          folding_period=0.0893, freq_res=wl["freq_res"], ndim=args.ndim,
+                          parts_per_block=args.parts_per_block, max_parts=args.max_parts)
+    lt = pipeline.LoadToFold(cfg, info, device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+
+    # synthetic block resident in HBM: seeded Gaussian noise, sigma = 24 LSB (content does not change the work)
+    nbytes = lt.block_bytes()
+    gen = torch.Generator(device="cuda").manual_seed(20100413 + rank)
+    raw = torch.empty(nbytes, dtype=torch.int8, device="cuda")
+    chunk = 1 << 26
+    for s in range(0, nbytes, chunk):
+        e = min(nbytes, s + chunk)
+        raw[s:e] = torch.randn(e - s, generator=gen, device="cuda").mul_(24.0).round_().clamp_(-128, 127).to(torch.int8)
+
+    gather = None
+    if world > 1:
+        gather = torch.zeros(world * cfg.nchan * lt.npol_out * cfg.nbin * cfg.ndim, dtype=torch.float32, device="cuda")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i, ev=None):
+        lt.process_block(raw, events=ev)
+        if (i + 1) % args.dump_steps == 0:
+            lt.finish_subint(dist if world > 1 else None, rank, world, gather)
+            lt.subints.clear()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        step(i, events[i])
+    lt.finish_subint(dist if world > 1 else None, rank, world, gather)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples_per_step = cfg.parts_per_block * lt.nsamp_step            # per rank, per pol
+    value = world * samples_per_step * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        fb_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)      # FFT+chirp(+fused detect) launch group
+        r = lt.response
+        nchan_subband = cfg.nchan // info.nchan
+        N = nchan_subband * r.ndat
+        nsamp_fft = 2 * N if info.ndim == 1 else N
+        b_alg = algorithmic_bytes_per_part(2, nsamp_fft * info.ndim, 8, N, nchan_subband, lt.nkeep)
+        achieved = b_alg * cfg.parts_per_block * info.nchan / (fb_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Msamples/s dedispersed+folded", "value": round(value, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "command": wl["cmd"], "nchan": cfg.nchan, "freq_res": r.ndat,
+                       "n_fft": N, "nfilt_pos": r.impulse_pos, "nfilt_neg": r.impulse_neg, "nkeep": lt.nkeep,
+                       "nsamp_step": lt.nsamp_step, "dm": cfg.dispersion_measure, "nbin": cfg.nbin,
+                       "parts_per_block": cfg.parts_per_block, "input": "8-bit dual-pol, resident in HBM",
+                       "detected_ndim": cfg.ndim, "parallelism": "sub-band per GPU x%d" % world,
+                       "realtime_factor": round(value / world / (info.rate / 1e6), 3)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "filterbank launch group k_fwd_cols+k_fwd_rows+k_inv_chan (FFT+chirp+fused detect)",
+                         "algorithmic_bytes_per_part": b_alg, "group_ms_per_block": round(fb_ms, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(wl, lt)
+            except Exception as e:  # the oracle is only a reported baseline
+                out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    lt.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

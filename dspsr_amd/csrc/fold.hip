@@ -58,6 +58,18 @@ struct RunBin { uint32_t ibin, hits; uint64_t offset; };   // FoldCUDA.h:19-24
 
 using namespace dspsr_amd;
 
+// device plan, double-buffered so that building/uploading the plan of block i+1 never waits for
+// the fold kernel of block i (pinned staging => the H2D copies are truly asynchronous)
+struct PlanSlot {
+  uint32_t* h_bin_start = nullptr;   // pinned
+  Interval* h_iv = nullptr;          // pinned
+  uint32_t* d_bin_start = nullptr;
+  Interval* d_iv = nullptr;
+  size_t bin_cap = 0, iv_cap = 0;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+};
+
 struct dspsr_amd_fold {
   dspsr_amd_ctx* ctx;
   uint32_t nchan = 0, npol = 0, ndim = 0, nbin = 0;
@@ -67,13 +79,43 @@ struct dspsr_amd_fold {
   std::vector<RunBin> binplan;
   uint32_t current_bin = 0, current_hits = 0, folding_nbin = 0;
   uint64_t ndat_fold = 0;
-  // device copies
-  uint32_t* d_bin_start = nullptr;
-  Interval* d_iv = nullptr;
-  size_t d_bin_start_cap = 0, d_iv_cap = 0;
-  std::vector<uint32_t> h_bin_start;
-  std::vector<Interval> h_iv;
+  PlanSlot slot[2];
+  int next_slot = 0;
+  std::vector<uint32_t> cursor;
 };
+
+static void slot_free(PlanSlot& s)
+{
+  if (s.h_bin_start) (void)hipHostFree(s.h_bin_start);
+  if (s.h_iv) (void)hipHostFree(s.h_iv);
+  if (s.d_bin_start) (void)hipFree(s.d_bin_start);
+  if (s.d_iv) (void)hipFree(s.d_iv);
+  if (s.done) (void)hipEventDestroy(s.done);
+  s = PlanSlot();
+}
+
+static bool slot_reserve(PlanSlot& s, size_t nbin1, size_t niv)
+{
+  if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return false;
+  if (nbin1 > s.bin_cap) {
+    if (s.h_bin_start) (void)hipHostFree(s.h_bin_start);
+    if (s.d_bin_start) (void)hipFree(s.d_bin_start);
+    s.h_bin_start = nullptr; s.d_bin_start = nullptr; s.bin_cap = 0;
+    if (hipHostMalloc((void**)&s.h_bin_start, nbin1 * sizeof(uint32_t)) != hipSuccess) return false;
+    if (hipMalloc((void**)&s.d_bin_start, nbin1 * sizeof(uint32_t)) != hipSuccess) return false;
+    s.bin_cap = nbin1;
+  }
+  if (niv > s.iv_cap) {
+    const size_t n = niv + niv / 2 + 16;
+    if (s.h_iv) (void)hipHostFree(s.h_iv);
+    if (s.d_iv) (void)hipFree(s.d_iv);
+    s.h_iv = nullptr; s.d_iv = nullptr; s.iv_cap = 0;
+    if (hipHostMalloc((void**)&s.h_iv, n * sizeof(Interval)) != hipSuccess) return false;
+    if (hipMalloc((void**)&s.d_iv, n * sizeof(Interval)) != hipSuccess) return false;
+    s.iv_cap = n;
+  }
+  return true;
+}
 
 extern "C" int dspsr_amd_fold_create(dspsr_amd_ctx* ctx, dspsr_amd_fold** out)
 {
@@ -89,8 +131,8 @@ extern "C" void dspsr_amd_fold_destroy(dspsr_amd_fold* f)
   if (!f) return;
   (void)hipStreamSynchronize(f->ctx->stream);
   if (f->profile) (void)hipFree(f->profile);
-  if (f->d_bin_start) (void)hipFree(f->d_bin_start);
-  if (f->d_iv) (void)hipFree(f->d_iv);
+  slot_free(f->slot[0]);
+  slot_free(f->slot[1]);
   delete f;
 }
 
@@ -180,17 +222,6 @@ extern "C" int dspsr_amd_fold_zero(dspsr_amd_fold* f)
   return DSPSR_AMD_OK;
 }
 
-template <typename T> static bool grow(T** p, size_t* cap, size_t need)
-{
-  if (need <= *cap) return true;
-  if (*p) (void)hipFree(*p);
-  *p = nullptr;
-  size_t n = need + need / 2;
-  if (hipMalloc((void**)p, n * sizeof(T)) != hipSuccess) { *cap = 0; return false; }
-  *cap = n;
-  return true;
-}
-
 extern "C" int dspsr_amd_fold_fold(dspsr_amd_fold* f, const float* in_dev, uint64_t in_chan_stride,
                                    uint64_t in_pol_stride)
 {
@@ -207,41 +238,45 @@ extern "C" int dspsr_amd_fold_fold(dspsr_amd_fold* f, const float* in_dev, uint6
   // bucket the time-ordered intervals by phase bin (stable => time order kept inside a bin)
   const uint32_t nbin = f->nbin;
   const size_t niv = f->binplan.size();
-  f->h_bin_start.assign(nbin + 1, 0);
-  for (const RunBin& r : f->binplan) f->h_bin_start[r.ibin + 1]++;
-  for (uint32_t b = 0; b < nbin; b++) f->h_bin_start[b + 1] += f->h_bin_start[b];
-  f->h_iv.resize(niv);
-  {
-    std::vector<uint32_t> cursor(f->h_bin_start.begin(), f->h_bin_start.end() - 1);
-    for (const RunBin& r : f->binplan) {
-      Interval v; v.offset = r.offset; v.hits = r.hits; v.pad = 0;
-      f->h_iv[cursor[r.ibin]++] = v;
-    }
+  PlanSlot& sl = f->slot[f->next_slot];
+  f->next_slot ^= 1;
+  hipError_t e = hipSuccess;
+  if (sl.pending) {            // the fold that last used this slot (two calls ago) must have consumed it
+    e = hipEventSynchronize(sl.done);
+    if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: %s", hipGetErrorString(e));
+    sl.pending = false;
   }
-  // a previous fold may still be reading the device plan
-  hipError_t e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: %s", hipGetErrorString(e));
-  if (!grow(&f->d_bin_start, &f->d_bin_start_cap, nbin + 1) || !grow(&f->d_iv, &f->d_iv_cap, niv))
+  if (!slot_reserve(sl, nbin + 1, niv))
     return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_fold_fold: plan allocation failed");
-  e = hipMemcpyAsync(f->d_bin_start, f->h_bin_start.data(), (nbin + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
+  for (uint32_t b = 0; b <= nbin; b++) sl.h_bin_start[b] = 0;
+  for (const RunBin& r : f->binplan) sl.h_bin_start[r.ibin + 1]++;
+  for (uint32_t b = 0; b < nbin; b++) sl.h_bin_start[b + 1] += sl.h_bin_start[b];
+  f->cursor.assign(sl.h_bin_start, sl.h_bin_start + nbin);
+  for (const RunBin& r : f->binplan) {
+    Interval v; v.offset = r.offset; v.hits = r.hits; v.pad = 0;
+    sl.h_iv[f->cursor[r.ibin]++] = v;
+  }
+  e = hipMemcpyAsync(sl.d_bin_start, sl.h_bin_start, (nbin + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
                      ctx->stream);
   if (e == hipSuccess)
-    e = hipMemcpyAsync(f->d_iv, f->h_iv.data(), niv * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);
+    e = hipMemcpyAsync(sl.d_iv, sl.h_iv, niv * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: plan copy: %s", hipGetErrorString(e));
 
   uint32_t threads = nbin < 1024 ? ((nbin + 63) / 64) * 64 : 1024;
   dim3 grid(f->npol, f->nchan);
   if (f->ndim == 4)
     hipLaunchKernelGGL(k_fold<4>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride, in_pol_stride,
-                       f->profile, nbin, f->d_bin_start, f->d_iv);
+                       f->profile, nbin, sl.d_bin_start, sl.d_iv);
   else if (f->ndim == 2)
     hipLaunchKernelGGL(k_fold<2>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride, in_pol_stride,
-                       f->profile, nbin, f->d_bin_start, f->d_iv);
+                       f->profile, nbin, sl.d_bin_start, sl.d_iv);
   else
     hipLaunchKernelGGL(k_fold<1>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride, in_pol_stride,
-                       f->profile, nbin, f->d_bin_start, f->d_iv);
+                       f->profile, nbin, sl.d_bin_start, sl.d_iv);
   e = hipGetLastError();
+  if (e == hipSuccess) e = hipEventRecord(sl.done, ctx->stream);
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: %s", hipGetErrorString(e));
+  sl.pending = true;
   f->binplan.clear();
   return DSPSR_AMD_OK;
 }

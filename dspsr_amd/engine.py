@@ -37,7 +37,9 @@ class Context:
 
     def __init__(self, device: int = 0, stream: int | None = None):
         h = C.c_void_p()
-        code = lib.dspsr_amd_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        # stream: a hipStream_t handle as int (0 = the default stream torch uses), None = context-owned stream
+        sp = C.c_void_p(-1 & (2 ** 64 - 1)) if stream is None else C.c_void_p(int(stream))
+        code = lib.dspsr_amd_ctx_create(int(device), sp, C.byref(h))
         if code != 0:
             raise DspsrAmdError("dspsr_amd_ctx_create(device=%d) failed (%d): no usable HIP device" % (device, code))
         self.handle = h

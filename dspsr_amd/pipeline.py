@@ -1,0 +1,226 @@
+"""Host pipeline for the hot path: the caller of the engines, mirroring what
+dsp::LoadToFold / SingleThread::run do around them (Signal/Pulsar/LoadToFold1.C:117-880,
+Signal/General/SingleThread.C:355-497):
+
+  per block:  Filterbank (+ fused Detection) -> Fold::fold plan + accumulate
+  per sub-integration (Subint<Fold>, Signal/Pulsar/dsp/Subint.h:234-309): emit + zero the profile;
+      with more than one rank this is where the single RCCL reduce of the per-sub-band
+      profiles happens (PhaseSeries::combine semantics, PhaseSeries.C:442-484).
+
+Only plumbing lives here; all arithmetic on samples is done by libdspsr_amd.so.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .engine import Context, Dedispersion, DspsrAmdError, FilterbankEngine, FoldEngine, eight_bit_scale
+
+
+@dataclass
+class Config:
+    """The dspsr command-line options that matter on this path (dspsr.C:207-510)."""
+    nchan: int = 1024                 # -F nchan:D
+    dispersion_measure: float = 1000  # -D
+    nbin: int = 1024                  # -b
+    folding_period: float = 0.0       # -c  (seconds); 0 => polyco
+    freq_res: int = 0                 # -x  (0 => optimal)
+    subint_seconds: float = 0.0       # -L  (0 => single integration)
+    stokes: bool = False              # -4? (default Coherence, LoadToFold1.C:1119-1134)
+    ndim: int = 4                     # detected layout (CPU default 4, CUDA engine 2; LoadToFoldConfig.C:104)
+    parts_per_block: int = 16         # block size in overlap-save parts (LoadToFold1.C:825-835 sizes blocks likewise)
+    max_parts: int = 2                # parts per launch group (scratch resident in the Infinity Cache)
+
+
+@dataclass
+class InputInfo:
+    """What ASCIIObservation.C:82-415 reads from the DADA header."""
+    centre_frequency: float = 1382.0
+    bandwidth: float = -400.0
+    nchan: int = 1
+    npol: int = 2
+    ndim: int = 1
+    tsamp_us: float = 0.00125
+    machine: str = "CASPSR"
+    start_seconds: float = 0.0        # of the first sample, relative to UTC_START
+    mjd_day: int = 55299
+    mjd_sec: float = 7545.0
+
+    @property
+    def rate(self):
+        return 1e6 / self.tsamp_us
+
+
+class Polyco:
+    """TEMPO polyco predictor (the role of Pulsar::Predictor, PSRCHIVE ext): phase and frequency."""
+
+    def __init__(self, text: str):
+        tok = text.replace("D", "E").split()
+        day, frac = tok[3].split(".")
+        ri, rf = tok[7].split(".")
+        self.tmid_day, self.tmid_frac = int(day), float("0." + frac)
+        self.rphase_int, self.rphase_frac = int(ri), float("0." + rf)
+        self.f0 = float(tok[8])
+        ncoef = int(tok[11])
+        self.coef = [float(t) for t in tok[13:13 + ncoef]]
+
+    def _dt(self, day, sec):
+        return ((day - self.tmid_day) + (sec / 86400.0 - self.tmid_frac)) * 1440.0
+
+    def phase_frac(self, day, sec):
+        dt = self._dt(day, sec)
+        poly = 0.0
+        for c in reversed(self.coef):
+            poly = poly * dt + c
+        spin = 60.0 * dt * self.f0
+        ph = (self.rphase_frac + (spin - math.floor(spin))) + poly
+        return ph - math.floor(ph)
+
+    def frequency(self, day, sec):
+        dt = self._dt(day, sec)
+        d = 0.0
+        for k in range(len(self.coef) - 1, 0, -1):
+            d = d * dt + k * self.coef[k]
+        return self.f0 + d / 60.0
+
+
+class LoadToFold:
+    """One pipeline instance = one GPU = one stream (SingleThread).  `raw` blocks are int8 torch
+    tensors already resident on the device (the PCIe copy is the caller's, as TransferCUDA is a
+    separate Operation in the reference)."""
+
+    def __init__(self, cfg: Config, info: InputInfo, device: int = 0, stream: int | None = None,
+                 polyco: Polyco | None = None, reference_phase: float = 0.0):
+        import torch
+        self.torch = torch
+        self.cfg, self.info, self.polyco = cfg, info, polyco
+        self.reference_phase = reference_phase
+        if cfg.folding_period <= 0 and polyco is None:
+            raise DspsrAmdError("dsp::Fold::fold no polynomial and no period specified")   # Fold.C:638-640
+        if info.npol != 2:
+            raise DspsrAmdError("dsp::Detection::polarimetry Cannot detect polarization when npol != 2")
+        self.ctx = Context(device, stream)
+        # kernel (host) --------------------------------------------------------------------
+        self.response = Dedispersion(info.centre_frequency, info.bandwidth, cfg.dispersion_measure,
+                                     input_nchan=info.nchan, ndim=info.ndim)
+        if cfg.freq_res:
+            self.response.set_frequency_resolution(cfg.freq_res)
+        self.response.match(cfg.nchan)
+        r = self.response
+        if cfg.nchan % info.nchan:
+            raise DspsrAmdError("dsp::Filterbank::make_preparations output nchan=%d not a multiple of input nchan=%d"
+                                % (cfg.nchan, info.nchan))
+        # engines --------------------------------------------------------------------------
+        self.fb = FilterbankEngine(self.ctx).setup(cfg.nchan // info.nchan, r.ndat, r.impulse_pos, r.impulse_neg,
+                                                   info.nchan, info.npol, info.ndim == 1, r.kernel,
+                                                   max_parts=cfg.max_parts)
+        self.nkeep, self.nsamp_step, self.nsamp_overlap = self.fb.nkeep, self.fb.nsamp_step, self.fb.nsamp_overlap
+        self.npol_out = 4 // cfg.ndim
+        self.fold = FoldEngine(self.ctx)
+        self.fold.set_shape(cfg.nchan, self.npol_out, cfg.ndim, cfg.nbin)
+        self.scale8 = eight_bit_scale()
+        self.layout = _lib.RAW_CASPSR if info.machine == "CASPSR" else _lib.RAW_GENERIC
+        # output observation (Filterbank::prepare_output, Filterbank.C:265-379)
+        n_fft = (cfg.nchan // info.nchan) * r.ndat
+        nsamp_fft = 2 * n_fft if info.ndim == 1 else n_fft
+        self.out_rate = info.rate * (float(r.ndat) / float(nsamp_fft))
+        self.out_start = info.start_seconds + r.impulse_pos / self.out_rate
+        self.scalefac = float(n_fft) * float(r.ndat)
+        self.detected = torch.empty((cfg.nchan, self.npol_out, cfg.parts_per_block * self.nkeep * cfg.ndim),
+                                    dtype=torch.float32, device="cuda:%d" % device)
+        # fold bookkeeping (PhaseSeries) ---------------------------------------------------
+        self.hits = np.zeros(cfg.nbin, dtype=np.uint32)
+        self.integration_length = 0.0
+        self.ndat_total = 0
+        self.nsamples_in = 0            # unique input samples consumed (per pol)
+        self.ndat_out = 0               # output samples produced so far
+        self.subints = []               # completed sub-integrations (host copies) on the writer rank
+
+    # bytes of one block of `npart` parts
+    def block_bytes(self, npart=None):
+        npart = npart or self.cfg.parts_per_block
+        nsamp = npart * self.nsamp_step + self.nsamp_overlap
+        return nsamp * self.info.nchan * self.info.npol * self.info.ndim
+
+    def _phase(self, t_seconds):
+        """Fold::get_phi / get_pfold (Fold.C:943-958)."""
+        if self.cfg.folding_period > 0:
+            p = self.cfg.folding_period
+            return math.fmod(t_seconds, p) / p - self.reference_phase, p
+        day, sec = self.info.mjd_day, self.info.mjd_sec + t_seconds
+        return self.polyco.phase_frac(day, sec) - self.reference_phase, 1.0 / self.polyco.frequency(day, sec)
+
+    def process_block(self, raw, npart=None, events=None):
+        """raw: device int8 tensor holding npart*nsamp_step + nsamp_overlap samples (the InputBuffering
+        tail of the previous block already prepended, Filterbank.C:443-444)."""
+        cfg = self.cfg
+        npart = npart or cfg.parts_per_block
+        if raw.numel() < self.block_bytes(npart):
+            raise DspsrAmdError("dspsr_amd.LoadToFold.process_block: block holds %d bytes, %d needed"
+                                % (raw.numel(), self.block_bytes(npart)))
+        if events is not None:          # HIP events bracketing the FFT+chirp launch group (bench.py roofline)
+            events[0].record()
+        self.fb.perform_detect(self.detected, npart, _lib.STOKES if cfg.stokes else _lib.COHERENCE, cfg.ndim,
+                               raw=raw, layout=self.layout, scale=self.scale8)
+        if events is not None:
+            events[1].record()
+        ndat = npart * self.nkeep
+        # Fold::fold (Fold.C:650-657,718-803): phase at the midpoint of the first sample of this block
+        t0 = self.out_start + (self.ndat_out + 0.5) / self.out_rate
+        phi, pfold = self._phase(t0)
+        self.fold.set_nbin(cfg.nbin)
+        self.fold.set_ndat(ndat, 0)
+        folded = self.fold.set_bins(phi, (1.0 / self.out_rate) / pfold, ndat, 0, self.hits)
+        self.fold.fold(self.detected)
+        self.integration_length += folded / self.out_rate
+        self.ndat_total += ndat
+        self.ndat_out += ndat
+        self.nsamples_in += npart * self.nsamp_step
+
+    def profiles_tensor(self):
+        """Zero-copy torch view of the device-resident PhaseSeries (Fold::Engine::get_profiles)."""
+        import ctypes as C
+        torch = self.torch
+        n = self.cfg.nchan * self.npol_out * self.cfg.nbin * self.cfg.ndim
+        ptr = self.fold.get_profiles_ptr()
+
+        class _Holder:
+            pass
+        h = _Holder()
+        h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2,
+                                      "strides": None}
+        return torch.as_tensor(h, device="cuda:%d" % self.ctx.device)
+
+    def finish_subint(self, dist=None, rank=0, world=1, gather_buffer=None):
+        """Subint<Fold>: emit the finished sub-integration and zero the profile.  With world>1 each rank
+        holds one frequency sub-band; the full-band buffer [world*nchan][npol][nbin][ndim] is zero outside
+        the rank's slice and ONE reduce(sum, dst=0) over RCCL delivers it to the writer rank."""
+        torch = self.torch
+        prof = self.profiles_tensor()
+        result = None
+        if world > 1:
+            gather_buffer.zero_()
+            gather_buffer.view(world, -1)[rank].copy_(prof)
+            dist.reduce(gather_buffer, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                result = gather_buffer
+        else:
+            result = prof
+        if rank == 0:
+            self.subints.append({"hits": self.hits.copy(), "integration_length": self.integration_length,
+                                 "ndat_total": self.ndat_total, "profile_dev": result.clone()})
+        self.fold.zero()
+        self.hits[:] = 0
+        self.integration_length = 0.0
+        self.ndat_total = 0
+
+    def synchronize(self):
+        self.ctx.synchronize()
+
+    def close(self):
+        self.fb.close()
+        self.fold.close()
+        self.ctx.close()

@@ -38,7 +38,10 @@ typedef struct dspsr_amd_filterbank dspsr_amd_filterbank;
 typedef struct dspsr_amd_fold dspsr_amd_fold;
 
 /* ---- context: one per pipeline thread / GPU, bound to one stream (SingleThread.C:213-290) ---- */
-int dspsr_amd_ctx_create(int device, void* hip_stream /* NULL => create own stream */, dspsr_amd_ctx** ctx);
+/* hip_stream: a hipStream_t to enqueue on (NULL = the legacy default stream), or
+ * DSPSR_AMD_NEW_STREAM to let the context create and own a non-blocking stream */
+#define DSPSR_AMD_NEW_STREAM ((void*)(intptr_t)-1)
+int dspsr_amd_ctx_create(int device, void* hip_stream, dspsr_amd_ctx** ctx);
 void dspsr_amd_ctx_destroy(dspsr_amd_ctx* ctx);
 const char* dspsr_amd_last_error(const dspsr_amd_ctx* ctx);
 int dspsr_amd_stream_sync(dspsr_amd_ctx* ctx);            /* FilterbankEngine::finish / check_error_stream */
