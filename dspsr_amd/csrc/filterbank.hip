@@ -15,6 +15,8 @@
 //   Scratch between passes is stored blocked so every global access is a >=128-byte run:
 //     A[(ka/T2)][nb][ka%T2]   (written by P1 as T1*T2-element runs, read contiguously by P2)
 //     X[(s'/T3)][m][s'%T3]    (written by P2 as T2*T3-element runs, read contiguously by P3)
+#include <stdlib.h>
+
 #include "engine_internal.h"
 
 namespace dspsr_amd {
@@ -23,6 +25,7 @@ struct FbGeom {
   int logM, logR, logT1, logT2, logT3;
   int real_input, npol;
   uint32_t C, nfilt_pos, nkeep;
+  int dbg;   // DSPSR_AMD_DEBUG ablation bits (timing experiments only; results are wrong when set)
 };
 
 struct FbIn {
@@ -44,33 +47,70 @@ struct FbOut {
 
 DEV float cvt8(int v, float scale) { return ((float)v + 0.5f) * scale; }
 
-DEV cf load_sample(const FbGeom& g, const FbIn& in, uint32_t seq, uint64_t t)
+// ---- input: two time-adjacent samples (columns col, col+1 of a tile) per request ---------------
+// The load is split in two so that a persistent workgroup can issue the loads of its NEXT tile
+// before computing the current one and only convert them afterwards:
+//   fetch_pair  : issues the global loads, result = up to 4 raw 32-bit words
+//   decode_pair : raw words -> two complex float samples  ((int8 + 0.5) * scale for 8-bit data,
+//                 GenericEightBitUnpackerCUDA.cu:45)
+struct Raw4 { uint32_t w[4]; };
+
+DEV Raw4 fetch_pair(const FbGeom& g, const FbIn& in, const uint32_t seq, const uint64_t t)
 {
-  if (g.real_input) {
-    if (in.kind == 0) {
-      const float* x = (const float*)in.base;
-      return make_float2(x[t], g.npol == 2 ? x[in.pol_stride + t] : 0.0f);
+  Raw4 r = {{0u, 0u, 0u, 0u}};
+  if (in.kind == 0) {                                   // float32 rows
+    if (g.real_input) {
+      const float* x = (const float*)in.base + t;
+      r.w[0] = __float_as_uint(x[0]); r.w[1] = __float_as_uint(x[1]);
+      if (g.npol == 2) { r.w[2] = __float_as_uint(x[in.pol_stride]); r.w[3] = __float_as_uint(x[in.pol_stride + 1]); }
+    } else {
+      const float* x = (const float*)in.base + seq * in.pol_stride + 2 * t;
+      r.w[0] = __float_as_uint(x[0]); r.w[1] = __float_as_uint(x[1]);
+      r.w[2] = __float_as_uint(x[2]); r.w[3] = __float_as_uint(x[3]);
     }
-    if (in.kind == 1) {
-      const int8_t* r = (const int8_t*)in.base + (t * in.nchan + in.ichan) * g.npol;
-      if (g.npol == 2) {
-        if (((uintptr_t)r & 1) == 0) {
-          const uint16_t u = *(const uint16_t*)r;
-          return make_float2(cvt8((int8_t)(u & 0xff), in.scale), cvt8((int8_t)(u >> 8), in.scale));
-        }
-        return make_float2(cvt8(r[0], in.scale), cvt8(r[1], in.scale));
+  } else if (in.kind == 2) {                            // CASPSR: 4 B pol0, 4 B pol1 (t even)
+    const uint8_t* b = (const uint8_t*)in.base + (t >> 2) * 8 + (t & 3);
+    r.w[0] = *(const uint16_t*)b;
+    r.w[1] = *(const uint16_t*)(b + 4);
+  } else if (g.real_input) {                            // generic 8-bit, byte (t*nchan + c)*npol + p
+    const uint64_t skip = (uint64_t)in.nchan * g.npol;
+    const uint8_t* b = (const uint8_t*)in.base + t * skip + (uint64_t)in.ichan * g.npol;
+    if (g.npol == 2) {
+      if (in.nchan == 1 && (((uintptr_t)b) & 3) == 0) {
+        r.w[0] = *(const uint32_t*)b;                   // (p0,p1)[t], (p0,p1)[t+1]
+      } else {
+        r.w[0] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[skip] << 16) | ((uint32_t)b[skip + 1] << 24);
       }
-      return make_float2(cvt8(r[0], in.scale), 0.0f);
+    } else {
+      r.w[0] = (uint32_t)b[0] | ((uint32_t)b[skip] << 16);
     }
-    const int8_t* r = (const int8_t*)in.base + (t >> 2) * 8 + (t & 3);
-    return make_float2(cvt8(r[0], in.scale), cvt8(r[4], in.scale));
+  } else {                                              // generic 8-bit complex: ((t*nchan+c)*npol+p)*2+d
+    const uint64_t skip = (uint64_t)in.nchan * g.npol * 2;
+    const uint8_t* b = (const uint8_t*)in.base + t * skip + ((uint64_t)in.ichan * g.npol + seq) * 2;
+    r.w[0] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[skip] << 16) | ((uint32_t)b[skip + 1] << 24);
   }
+  return r;
+}
+
+DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw4& r, cf& a, cf& b)
+{
   if (in.kind == 0) {
-    const float2* x = (const float2*)((const float*)in.base + seq * in.pol_stride);
-    return x[t];
+    if (g.real_input) {
+      a = make_float2(__uint_as_float(r.w[0]), g.npol == 2 ? __uint_as_float(r.w[2]) : 0.0f);
+      b = make_float2(__uint_as_float(r.w[1]), g.npol == 2 ? __uint_as_float(r.w[3]) : 0.0f);
+    } else {
+      a = make_float2(__uint_as_float(r.w[0]), __uint_as_float(r.w[1]));
+      b = make_float2(__uint_as_float(r.w[2]), __uint_as_float(r.w[3]));
+    }
+  } else if (in.kind == 2) {
+    a = make_float2(cvt8((int8_t)(r.w[0] & 0xff), in.scale), cvt8((int8_t)(r.w[1] & 0xff), in.scale));
+    b = make_float2(cvt8((int8_t)((r.w[0] >> 8) & 0xff), in.scale), cvt8((int8_t)((r.w[1] >> 8) & 0xff), in.scale));
+  } else {
+    const float v0 = cvt8((int8_t)(r.w[0] & 0xff), in.scale), v1 = cvt8((int8_t)((r.w[0] >> 8) & 0xff), in.scale);
+    const float v2 = cvt8((int8_t)((r.w[0] >> 16) & 0xff), in.scale), v3 = cvt8((int8_t)(r.w[0] >> 24), in.scale);
+    if (g.real_input && g.npol == 1) { a = make_float2(v0, 0.0f); b = make_float2(v2, 0.0f); }
+    else { a = make_float2(v0, v1); b = make_float2(v2, v3); }
   }
-  const int8_t* r = (const int8_t*)in.base + ((t * in.nchan + in.ichan) * g.npol + seq) * 2;
-  return make_float2(cvt8(r[0], in.scale), cvt8(r[1], in.scale));
 }
 
 // exp(-2*pi*i*j/2^logL), j < 2^logL, from exact float arguments
@@ -88,74 +128,166 @@ DEV cf twiddle_big(uint64_t j, int logL)
   return cmul(make_float2(c, s), make_float2(c2, s2));
 }
 
-// ------------------------------------------------------------------------------------ P1
-template <int LOGF>
-__global__ __launch_bounds__(1024) void k_fwd_cols(const FbGeom g, const FbIn in, cf* __restrict__ A,
-                                                   const cf* __restrict__ tw, const uint64_t part0)
+// v[k] *= W_L^{nb*(k*pstride + p)}, k < R : base and the powers 1,2,4,8 of the step from exact phases
+template <int R> DEV void apply_pass_twiddle(cf (&v)[R], const uint32_t nb, const uint32_t p, const uint32_t pstride,
+                                             const int logL)
 {
+  const uint64_t Lm = (1ull << logL) - 1;
+  const uint64_t a = ((uint64_t)nb * p) & Lm, d = ((uint64_t)nb * pstride) & Lm;
+  const cf wa = twiddle_big(a, logL);
+  if constexpr (R > 1) {
+    const cf w1 = twiddle_big(d, logL);
+    const cf w2 = R >= 4 ? twiddle_big((2 * d) & Lm, logL) : w1;
+    const cf w4 = R >= 8 ? twiddle_big((4 * d) & Lm, logL) : w1;
+    const cf w8 = R >= 16 ? twiddle_big((8 * d) & Lm, logL) : w1;
+    apply_powers<R>(v, w1, w2, w4, w8);
+  }
+#pragma unroll
+  for (int k = 0; k < R; k++) v[k] = cmul(v[k], wa);
+}
+
+// ------------------------------------------------------------------------------------ P1
+// M-point forward FFTs down T1 adjacent stride-Rr columns of one sequence of one part.
+//   in : sample n = na*Rr + nb (8-bit or float32, converted on load), nb = tile*T1 + col
+//   out: A[ka/T2][nb][ka%T2] = W_L^{nb*ka} * sum_na w[na*Rr+nb] W_M^{na*ka}
+// Persistent: each workgroup walks its items (tile fastest, then sequence, then part) and
+// prefetches the raw samples of the next item while transforming the current one.
+template <int LOGF>
+__global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in, cf* __restrict__ A,
+                                                  const cf* __restrict__ tw, const uint64_t part0,
+                                                  const uint32_t nparts, const uint32_t nseq, const uint32_t run)
+{
+  typedef FftPlan<LOGF> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  uint32_t tid = threadIdx.x;
   const int logT = g.logT1, logT2 = g.logT2;
   const uint32_t T = 1u << logT, T2 = 1u << logT2;
-  const uint32_t tile = blockIdx.x, seq = blockIdx.y, nseq = gridDim.y;
-  const uint64_t part = blockIdx.z;
   const int logL = g.logM + g.logR;
   const uint64_t L = 1ull << logL;
-  const uint64_t t0 = (part0 + part) * in.part_step;
+  const uint32_t ntile = 1u << (g.logR - logT);
+  const uint64_t total = (uint64_t)ntile * nseq * nparts;
 
-#pragma unroll 4
-  for (int j = 0; j < 16; j++) {
-    const uint32_t q = tid + nt * j;
-    const uint32_t col = q & (T - 1), na = q >> logT;
-    const uint64_t n = ((uint64_t)na << g.logR) + tile * T + col;
-    lds[lds_pad(q)] = load_sample(g, in, seq, t0 + n);
-  }
-  __syncthreads();
-  wgfft<LOGF, -1>(lds, tid, nt, logT, tw);
+  auto fetch = [&](const uint64_t item, Raw4 (&raw)[PTS / 2]) {
+    const uint32_t tile = (uint32_t)(item % ntile);
+    const uint64_t rest = item / ntile;
+    const uint32_t seq = (uint32_t)(rest % nseq);
+    const uint64_t t0 = (part0 + rest / nseq) * in.part_step + tile * T;
+#pragma unroll
+    for (int g2 = 0; g2 < P::G1; g2 += 2)
+#pragma unroll
+      for (int i = 0; i < P::R1; i++) {
+        const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
+        if (g.dbg & 2) { Raw4 z = {{e, 0u, 0u, 0u}}; raw[(g2 / 2) * P::R1 + i] = z; }
+        else raw[(g2 / 2) * P::R1 + i] = fetch_pair(g, in, seq, t0 + (((uint64_t)(e >> logT)) << g.logR) + (e & (T - 1)));
+      }
+  };
 
-  cf* __restrict__ Aseq = A + (part * nseq + seq) * L;
-#pragma unroll 4
-  for (int j = 0; j < 16; j++) {
-    const uint32_t q = tid + nt * j;
-    const uint32_t klo = q & (T2 - 1), col = (q >> logT2) & (T - 1), khi = q >> (logT2 + logT);
-    const uint32_t ka = (khi << logT2) | klo;
-    const uint32_t nb = tile * T + col;
-    cf v = lds[lds_pad((ka << logT) | col)];
-    v = cmul(v, twiddle_big(((uint64_t)nb * ka) & (L - 1), logL));
-    Aseq[(((((uint64_t)khi) << g.logR) + nb) << logT2) | klo] = v;
+  uint64_t item, next;
+  uint32_t j = 0;
+  if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
+  Raw4 raw[PTS / 2];
+  fetch(item, raw);
+  for (;;) {
+    asm volatile("" : "+v"(tid));   // per-tile index math stays inside the loop (see wgfft)
+    cf x[PTS];
+#pragma unroll
+    for (int g2 = 0; g2 < P::G1; g2 += 2)
+#pragma unroll
+      for (int i = 0; i < P::R1; i++)
+        decode_pair(g, in, raw[(g2 / 2) * P::R1 + i], x[g2 * P::R1 + i], x[(g2 + 1) * P::R1 + i]);
+    const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
+    if (more) fetch(next, raw);
+
+    const uint32_t tile = (uint32_t)(item % ntile);
+    const uint64_t rest = item / ntile;
+    cf* __restrict__ Aseq = A + ((rest / nseq) * nseq + rest % nseq) * L;
+    auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& va, auto& vb) {
+      constexpr int R = sizeof(va) / sizeof(va[0]);
+      const uint32_t nb = tile * T + col;
+      if (!(g.dbg & 8)) {
+        apply_pass_twiddle<R>(va, nb, p, pstride, logL);
+        apply_pass_twiddle<R>(vb, nb + 1, p, pstride, logL);
+      }
+      if (g.dbg & 1) { if (va[0].x == 1.2345f && vb[R - 1].y == 3.3f) Aseq[0] = va[0]; return; }
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const uint32_t ka = k * pstride + p;
+        uint64_t o = ((((uint64_t)(ka >> logT2) << g.logR) + nb) << logT2) | (ka & (T2 - 1));
+        uint64_t o2 = o + T2;
+        if (g.dbg & 4) { o = ((uint64_t)tile << (g.logM + logT)) + (((uint64_t)ka << logT) | col); o2 = o + 1; }
+        Aseq[o] = va[k];
+        Aseq[o2] = vb[k];
+      }
+    };
+    wgfft<LOGF, -1>(lds, tid, logT, tw, x, store);
+    if (!more) break;
+    item = next;
   }
 }
 
 // ------------------------------------------------------------------------------------ P2
+// Rr-point forward FFTs along T2 adjacent rows ka of A (one contiguous block) -> spectrum rows
+// s' = kb, bin m = ka, stored as X[s'/T3][m][s'%T3].
 template <int LOGF>
-__global__ __launch_bounds__(1024) void k_fwd_rows(const FbGeom g, const cf* __restrict__ A, cf* __restrict__ X,
-                                                   const cf* __restrict__ tw)
+__global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __restrict__ A, cf* __restrict__ X,
+                                                  const cf* __restrict__ tw, const uint32_t nparts,
+                                                  const uint32_t nseq, const uint32_t run)
 {
+  typedef FftPlan<LOGF> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  uint32_t tid = threadIdx.x;
   const int logT = g.logT2, logT3 = g.logT3;
   const uint32_t T2 = 1u << logT, T3 = 1u << logT3;
-  const uint32_t tile = blockIdx.x, seq = blockIdx.y, nseq = gridDim.y;
-  const uint64_t part = blockIdx.z;
   const uint64_t L = 1ull << (g.logM + g.logR);
-  const cf* __restrict__ Ablk = A + (part * nseq + seq) * L + (((uint64_t)tile << g.logR) << logT);
+  const uint32_t ntile = 1u << (g.logM - logT);
+  const uint64_t total = (uint64_t)ntile * nseq * nparts;
 
-#pragma unroll 4
-  for (int j = 0; j < 16; j++) {
-    const uint32_t q = tid + nt * j;
-    lds[lds_pad(q)] = Ablk[q];
-  }
-  __syncthreads();
-  wgfft<LOGF, -1>(lds, tid, nt, logT, tw);
+  auto fetch = [&](const uint64_t item, cf (&y)[PTS]) {
+    const uint32_t tile = (uint32_t)(item % ntile);
+    const cf* __restrict__ Ablk = A + (item / ntile) * L + (((uint64_t)tile << g.logR) << logT);
+#pragma unroll
+    for (int g2 = 0; g2 < P::G1; g2 += 2)
+#pragma unroll
+      for (int i = 0; i < P::R1; i++) {
+        float4 pr;
+        if (g.dbg & 2) pr = make_float4(tid, i, g2, 1.f);
+        else pr = *(const float4*)&Ablk[first_stage_elem<LOGF>(tid, logT, g2, i)];
+        y[g2 * P::R1 + i] = make_float2(pr.x, pr.y);
+        y[(g2 + 1) * P::R1 + i] = make_float2(pr.z, pr.w);
+      }
+  };
 
-  cf* __restrict__ Xseq = X + (part * nseq + seq) * L;
-#pragma unroll 4
-  for (int j = 0; j < 16; j++) {
-    const uint32_t q = tid + nt * j;
-    const uint32_t slo = q & (T3 - 1), klo = (q >> logT3) & (T2 - 1), shi = q >> (logT3 + logT);
-    const uint32_t srow = (shi << logT3) | slo;
-    const cf v = lds[lds_pad((srow << logT) | klo)];
-    Xseq[(((((uint64_t)shi) << g.logM) + tile * T2 + klo) << logT3) | slo] = v;
+  uint64_t item, next;
+  uint32_t j = 0;
+  if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
+  cf y[PTS];
+  fetch(item, y);
+  for (;;) {
+    asm volatile("" : "+v"(tid));   // per-tile index math stays inside the loop (see wgfft)
+    cf x[PTS];
+#pragma unroll
+    for (int i = 0; i < PTS; i++) x[i] = y[i];
+    const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
+    if (more) fetch(next, y);
+
+    const uint32_t tile = (uint32_t)(item % ntile);
+    cf* __restrict__ Xseq = X + (item / ntile) * L;
+    auto store = [&](const uint32_t klo, const uint32_t p, const uint32_t pstride, auto& va, auto& vb) {
+      constexpr int R = sizeof(va) / sizeof(va[0]);
+      if (g.dbg & 1) { if (va[0].x == 1.2345f && vb[R - 1].y == 3.3f) Xseq[0] = va[0]; return; }
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const uint32_t srow = k * pstride + p;
+        uint64_t o = ((((uint64_t)(srow >> logT3) << g.logM) + tile * T2 + klo) << logT3) | (srow & (T3 - 1));
+        uint64_t o2 = o + T3;
+        if (g.dbg & 4) { o = ((uint64_t)tile << (g.logR + logT)) + (((uint64_t)srow << logT) | klo); o2 = o + 1; }
+        Xseq[o] = va[k];
+        Xseq[o2] = vb[k];
+      }
+    };
+    wgfft<LOGF, -1>(lds, tid, logT, tw, x, store);
+    if (!more) break;
+    item = next;
   }
 }
 
@@ -171,101 +303,133 @@ DEV void detect4(const cf p, const cf q, const int state, float (&r)[4])
   else { r[0] = pp; r[1] = qq; r[2] = re; r[3] = im; }
 }
 
+// T3 output channels (both polarisations) of one part: Hermitian split of spectrum rows s and
+// Rr-1-s into the two polarisations (real input), x chirp, inverse M-point FFT, keep window,
+// complex output or fused detection.  Columns are (channel, pol) pairs: col = 2*slo + pol, so
+// the two butterflies a thread owns are the two polarisations of the same (channel, bin):
+// one (a, b, chirp) load serves both and detection needs no cross-lane traffic.
+// Items: part fastest, so one XCD re-reads a tile's chirp rows from its L2 for every part.
 template <int LOGF>
-__global__ __launch_bounds__(1024) void k_inv_chan(const FbGeom g, const cf* __restrict__ X,
-                                                   const cf* __restrict__ kernel, const FbOut out,
-                                                   const cf* __restrict__ tw, const uint64_t part0)
+__global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __restrict__ X,
+                                                  const cf* __restrict__ kernel, const FbOut out,
+                                                  const cf* __restrict__ tw, const uint64_t part0,
+                                                  const uint32_t nparts, const uint32_t run)
 {
+  typedef FftPlan<LOGF> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  uint32_t tid = threadIdx.x;
   const int logT3 = g.logT3;
-  const int logT = logT3 + (g.npol == 2 ? 1 : 0);
-  const uint32_t T3 = 1u << logT3, M = 1u << g.logM, Rr = 1u << g.logR;
-  const uint32_t tile = blockIdx.x;
-  const uint64_t part = blockIdx.z;
+  const int logT = logT3 + 1;
+  const uint32_t T = 1u << logT, T3 = 1u << logT3, M = 1u << g.logM, Rr = 1u << g.logR;
   const uint64_t L = (uint64_t)M << g.logR;
   const uint32_t nseq = g.real_input ? 1 : g.npol;
-  const cf* __restrict__ X0s = X + part * nseq * L;
   const uint64_t blk = ((uint64_t)M) << logT3;  // elements per X block
+  const uint32_t ntile = g.C >> logT3;
+  const uint64_t total = (uint64_t)ntile * nparts;
+  struct Abk { cf a, b, k; };
 
-  for (uint32_t q = tid; q < (M << logT3); q += nt) {
-    const uint32_t slo = q & (T3 - 1), m = q >> logT3;
-    const uint32_t s = tile * T3 + slo;
-    cf x0, x1;
-    if (g.real_input) {
-      const cf a = X0s[tile * blk + q];
-      cf b;
-      if (m > 0) {
-        const uint32_t mblk = (Rr >> logT3) - 1 - tile;
-        b = X0s[mblk * blk + (((uint64_t)(M - m)) << logT3) + (T3 - 1 - slo)];
-      } else {
-        const uint32_t r = (Rr - s) & (Rr - 1);
-        b = X0s[(r >> logT3) * blk + (r & (T3 - 1))];
-      }
-      // W[k] = X0[k] + i X1[k] ; conj(W[L-k]) = X0[k] - i X1[k]
-      x0 = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
-      x1 = make_float2(0.5f * (a.y + b.y), 0.5f * (b.x - a.x));
-    } else {
-      x0 = X0s[tile * blk + q];
-      x1 = g.npol == 2 ? X0s[L + tile * blk + q] : make_float2(0.f, 0.f);
-    }
-    if (kernel) {
-      const cf k = kernel[((uint64_t)s << g.logM) + m];
-      x0 = cmul(k, x0);
-      x1 = cmul(k, x1);
-    }
-    if (g.npol == 2) {
-      float4* dst = (float4*)&lds[lds_pad((m << logT) | (slo << 1))];
-      *dst = make_float4(x0.x, x0.y, x1.x, x1.y);
-    } else {
-      lds[lds_pad((m << logT) | slo)] = x0;
-    }
-  }
-  __syncthreads();
-  wgfft<LOGF, +1>(lds, tid, nt, logT, tw);
-
-  if (out.kind == 0) return;
-  for (uint32_t slo = 0; slo < T3; slo++) {
-    const uint32_t chan = out.chan0 + tile * T3 + slo;
-    float* __restrict__ row = out.base + chan * out.chan_stride;
-    for (uint32_t t = tid; t < g.nkeep; t += nt) {
-      const uint32_t pos = g.nfilt_pos + t;
-      cf p, q = make_float2(0.f, 0.f);
-      if (g.npol == 2) {
-        const float4 pq = *(const float4*)&lds[lds_pad((pos << logT) | (slo << 1))];
-        p = make_float2(pq.x, pq.y);
-        q = make_float2(pq.z, pq.w);
-      } else {
-        p = lds[lds_pad((pos << logT) | slo)];
-      }
-      if (out.kind == 1) {
-        float2* o = (float2*)(row + (part0 + part) * out.part_step) + t;
-        o[0] = p;
-        if (g.npol == 2) ((float2*)((float*)o + out.pol_stride))[0] = q;
-      } else {
-        float r[4];
-        detect4(p, q, out.state, r);
-        const uint64_t idat = (part0 + part) * g.nkeep + t;
-        if (out.ndim == 4) {
-          ((float4*)row)[idat] = make_float4(r[0], r[1], r[2], r[3]);
-        } else if (out.ndim == 2) {
-          ((float2*)row)[idat] = make_float2(r[0], r[1]);
-          ((float2*)(row + out.pol_stride))[idat] = make_float2(r[2], r[3]);
+  auto fetch = [&](const uint64_t item, Abk (&raw)[PTS / 2]) {
+    const uint32_t tile = (uint32_t)(item / nparts);
+    const cf* __restrict__ X0s = X + (item % nparts) * nseq * L;
+    const uint32_t mblk = (Rr >> logT3) - 1 - tile;
+#pragma unroll
+    for (int g2 = 0; g2 < P::G1; g2 += 2)
+#pragma unroll
+      for (int i = 0; i < P::R1; i++) {
+        const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
+        const uint32_t slo = (e & (T - 1)) >> 1, m = e >> logT;
+        const uint32_t s = tile * T3 + slo;
+        Abk r;
+        if (g.dbg & 2) { r.a = make_float2(m, slo); r.b = r.a; r.k = r.a; raw[(g2 / 2) * P::R1 + i] = r; continue; }
+        r.a = X0s[tile * blk + ((uint64_t)m << logT3) + slo];
+        if (g.real_input) {
+          if (m > 0) {
+            r.b = X0s[mblk * blk + (((uint64_t)(M - m)) << logT3) + (T3 - 1 - slo)];
+          } else {
+            const uint32_t rr = (Rr - s) & (Rr - 1);
+            r.b = X0s[(rr >> logT3) * blk + (rr & (T3 - 1))];
+          }
         } else {
-          row[idat] = r[0];
-          row[out.pol_stride + idat] = r[1];
-          row[2 * out.pol_stride + idat] = r[2];
-          row[3 * out.pol_stride + idat] = r[3];
+          r.b = g.npol == 2 ? X0s[L + tile * blk + ((uint64_t)m << logT3) + slo] : make_float2(0.f, 0.f);
+        }
+        r.k = kernel ? kernel[((uint64_t)s << g.logM) + m] : make_float2(1.f, 0.f);
+        raw[(g2 / 2) * P::R1 + i] = r;
+      }
+  };
+
+  uint64_t item, next;
+  uint32_t j = 0;
+  if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
+  Abk raw[PTS / 2];
+  fetch(item, raw);
+  for (;;) {
+    asm volatile("" : "+v"(tid));   // per-tile index math stays inside the loop (see wgfft)
+    cf x[PTS];
+#pragma unroll
+    for (int g2 = 0; g2 < P::G1; g2 += 2)
+#pragma unroll
+      for (int i = 0; i < P::R1; i++) {
+        const Abk r = raw[(g2 / 2) * P::R1 + i];
+        cf x0, x1;
+        if (g.real_input) {
+          // W[k] = X0[k] + i X1[k] ; conj(W[L-k]) = X0[k] - i X1[k]
+          x0 = make_float2(0.5f * (r.a.x + r.b.x), 0.5f * (r.a.y - r.b.y));
+          x1 = make_float2(0.5f * (r.a.y + r.b.y), 0.5f * (r.b.x - r.a.x));
+        } else {
+          x0 = r.a;
+          x1 = r.b;
+        }
+        x[g2 * P::R1 + i] = cmul(r.k, x0);          // Response::operate, Response.C:429-441
+        x[(g2 + 1) * P::R1 + i] = cmul(r.k, x1);
+      }
+    const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
+    if (more) fetch(next, raw);
+
+    const uint32_t tile = (uint32_t)(item / nparts);
+    const uint64_t part = part0 + item % nparts;
+    auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& va, auto& vb) {
+      constexpr int R = sizeof(va) / sizeof(va[0]);
+      if (out.kind == 0) return;
+      if (g.dbg & 1) { if (va[0].x == 1.2345f && vb[R - 1].y == 3.3f) out.base[0] = va[0].x; return; }
+      const uint32_t chan = out.chan0 + tile * T3 + (col >> 1);
+      float* __restrict__ row = out.base + chan * out.chan_stride;
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const uint32_t pos = k * pstride + p;
+        if (pos < g.nfilt_pos || pos >= g.nfilt_pos + g.nkeep) continue;
+        const uint32_t t = pos - g.nfilt_pos;
+        if (out.kind == 1) {
+          float2* o = (float2*)(row + part * out.part_step) + t;
+          o[0] = va[k];
+          if (g.npol == 2) ((float2*)((float*)o + out.pol_stride))[0] = vb[k];
+        } else {
+          float r[4];
+          detect4(va[k], vb[k], out.state, r);
+          const uint64_t idat = part * g.nkeep + t;
+          if (out.ndim == 4) {
+            ((float4*)row)[idat] = make_float4(r[0], r[1], r[2], r[3]);
+          } else if (out.ndim == 2) {
+            ((float2*)row)[idat] = make_float2(r[0], r[1]);
+            ((float2*)(row + out.pol_stride))[idat] = make_float2(r[2], r[3]);
+          } else {
+            row[idat] = r[0];
+            row[out.pol_stride + idat] = r[1];
+            row[2 * out.pol_stride + idat] = r[2];
+            row[3 * out.pol_stride + idat] = r[3];
+          }
         }
       }
-    }
+    };
+    wgfft<LOGF, +1>(lds, tid, logT, tw, x, store);
+    if (!more) break;
+    item = next;
   }
 }
 
 // ------------------------------------------------------------------------------------ host
-typedef void (*k1_t)(FbGeom, FbIn, cf*, const cf*, uint64_t);
-typedef void (*k2_t)(FbGeom, const cf*, cf*, const cf*);
-typedef void (*k3_t)(FbGeom, const cf*, const cf*, FbOut, const cf*, uint64_t);
+typedef void (*k1_t)(FbGeom, FbIn, cf*, const cf*, uint64_t, uint32_t, uint32_t, uint32_t);
+typedef void (*k2_t)(FbGeom, const cf*, cf*, const cf*, uint32_t, uint32_t, uint32_t);
+typedef void (*k3_t)(FbGeom, const cf*, const cf*, FbOut, const cf*, uint64_t, uint32_t, uint32_t);
 
 template <int... I> struct iseq {};
 template <int N, int... I> struct mkseq : mkseq<N - 1, N - 1, I...> {};
@@ -275,8 +439,8 @@ template <int... I> static k1_t pick1(int logf, iseq<I...>) { static const k1_t 
 template <int... I> static k2_t pick2(int logf, iseq<I...>) { static const k2_t t[] = {k_fwd_rows<I>...}; return t[logf]; }
 template <int... I> static k3_t pick3(int logf, iseq<I...>) { static const k3_t t[] = {k_inv_chan<I>...}; return t[logf]; }
 
-constexpr int MAX_LOGF = 14;
-constexpr int LOG_POINTS = 14;  // points per workgroup (16 per thread, 1024 threads)
+constexpr int MAX_LOGF = 13;    // every pass keeps >= 2 columns per workgroup
+constexpr int LOG_POINTS = 14;  // points per workgroup (32 per thread, 512 threads)
 
 static inline int ilog2(uint64_t v) { int l = 0; while ((1ull << l) < v) l++; return l; }
 static inline bool ispow2(uint64_t v) { return v && !(v & (v - 1)); }
@@ -287,7 +451,7 @@ struct dspsr_amd_filterbank_impl {
   FbGeom g;
   uint64_t N, L;
   uint32_t nseq, max_parts;
-  uint32_t nt1, nt2, nt3;
+  uint32_t nt1, nt2, nt3, ncu;
   size_t lds1, lds2, lds3;
   cf* A = nullptr;
   cf* X = nullptr;
@@ -344,6 +508,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   g.C = (uint32_t)C;
   g.nfilt_pos = cfg->nfilt_pos;
   g.nkeep = cfg->freq_res - cfg->nfilt_pos - cfg->nfilt_neg;
+  g.dbg = getenv("DSPSR_AMD_DEBUG") ? atoi(getenv("DSPSR_AMD_DEBUG")) : 0;
   fb->nseq = cfg->real_input ? 1 : cfg->npol;
   if (g.logM > MAX_LOGF || g.logR > MAX_LOGF) {
     delete fb;
@@ -354,21 +519,24 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   // tiles: every workgroup holds min(2^14, available) points = 16 per thread
   g.logT1 = g.logR < LOG_POINTS - g.logM ? g.logR : LOG_POINTS - g.logM;
   g.logT2 = g.logM < LOG_POINTS - g.logR ? g.logM : LOG_POINTS - g.logR;
-  const int logC = ilog2(C), logPol = cfg->npol == 2 ? 1 : 0;
+  const int logC = ilog2(C), logPol = 1;   // pass 3 always carries (pol0, pol1) column pairs
   int t3 = LOG_POINTS - g.logM - logPol;
   if (t3 < 0) t3 = 0;
   g.logT3 = logC < t3 ? logC : t3;
   const uint64_t p1 = M << g.logT1, p2 = Rr << g.logT2, p3 = (M << g.logT3) << logPol;
-  if (p1 < 16 || p2 < 16 || p3 < 16 || p3 > (1u << LOG_POINTS)) {
+  if (p1 < 32 || p2 < 32 || p3 < 32 || p3 > (1u << LOG_POINTS) || g.logT1 < 1 || g.logT2 < 1) {
     delete fb;
     return fb_fail(ctx, DSPSR_AMD_EINVAL,
                    "dspsr_amd_filterbank_create: problem too small/large for the workgroup tiling "
-                   "(points per pass %llu/%llu/%llu, need 16..16384)",
+                   "(points per pass %llu/%llu/%llu, need 32..16384 and >= 2 columns)",
                    (unsigned long long)p1, (unsigned long long)p2, (unsigned long long)p3);
   }
-  fb->nt1 = (uint32_t)(p1 / 16);
-  fb->nt2 = (uint32_t)(p2 / 16);
-  fb->nt3 = (uint32_t)(p3 / 16);
+  fb->nt1 = (uint32_t)(p1 / PTS);
+  fb->nt2 = (uint32_t)(p2 / PTS);
+  fb->nt3 = (uint32_t)(p3 / PTS);
+  hipDeviceProp_t prop;
+  fb->ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+                ? (uint32_t)prop.multiProcessorCount : 256u;
   fb->lds1 = lds_words_host((uint32_t)p1) * sizeof(cf);
   fb->lds2 = lds_words_host((uint32_t)p2) * sizeof(cf);
   fb->lds3 = lds_words_host((uint32_t)p3) * sizeof(cf);
@@ -431,6 +599,13 @@ extern "C" int dspsr_amd_filterbank_sizes(const dspsr_amd_filterbank* fb, uint64
   return DSPSR_AMD_OK;
 }
 
+static uint32_t grid_for(uint64_t items, uint32_t ncu)
+{
+  uint64_t gsz = items < ncu ? items : ncu;
+  if (gsz >= 8) gsz &= ~7ull;
+  return (uint32_t)gsz;
+}
+
 template <typename K> static hipError_t allow_lds(K kern, size_t bytes)
 {
   return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -463,12 +638,16 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
     const cf* kern = fb->kernel ? fb->kernel + (uint64_t)ichan * fb->N : nullptr;
     for (uint64_t part0 = 0; part0 < npart; part0 += fb->max_parts) {
       const uint32_t nb = (uint32_t)((npart - part0) < fb->max_parts ? (npart - part0) : fb->max_parts);
-      hipLaunchKernelGGL(k1, dim3(Rr >> g.logT1, fb->nseq, nb), dim3(fb->nt1), fb->lds1, ctx->stream, g, ci, fb->A,
-                         ctx->tw, part0);
-      hipLaunchKernelGGL(k2, dim3(M >> g.logT2, fb->nseq, nb), dim3(fb->nt2), fb->lds2, ctx->stream, g, fb->A, fb->X,
-                         ctx->tw);
-      hipLaunchKernelGGL(k3, dim3(g.C >> g.logT3, 1, nb), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern, co,
-                         ctx->tw, part0);
+      // persistent grids: one workgroup per CU (LDS-limited), a multiple of 8 so the XCD-aware item order applies
+      const uint64_t n1 = (uint64_t)(Rr >> g.logT1) * fb->nseq * nb, n2 = (uint64_t)(M >> g.logT2) * fb->nseq * nb,
+                     n3 = (uint64_t)(g.C >> g.logT3) * nb;
+      const uint32_t run1 = 32, run2 = 4, run3 = nb;
+      hipLaunchKernelGGL(k1, dim3(grid_for(n1, fb->ncu)), dim3(fb->nt1), fb->lds1, ctx->stream, g, ci, fb->A, ctx->tw,
+                         part0, nb, fb->nseq, run1);
+      hipLaunchKernelGGL(k2, dim3(grid_for(n2, fb->ncu)), dim3(fb->nt2), fb->lds2, ctx->stream, g, fb->A, fb->X,
+                         ctx->tw, nb, fb->nseq, run2);
+      hipLaunchKernelGGL(k3, dim3(grid_for(n3, fb->ncu)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern, co,
+                         ctx->tw, part0, nb, run3);
     }
   }
   e = hipGetLastError();

@@ -18,10 +18,12 @@ namespace dspsr_amd {
 
 struct Interval { uint64_t offset; uint32_t hits; uint32_t pad; };   // sorted by (bin, time)
 
+// Direct variant: every bin-owner thread reads its samples straight from global memory
+// (used when nbin is too large for the chunked kernel).
 template <int NDIM>
-__global__ void k_fold(const float* __restrict__ in, const uint64_t chan_stride, const uint64_t pol_stride,
-                       float* __restrict__ prof, const uint32_t nbin, const uint32_t* __restrict__ bin_start,
-                       const Interval* __restrict__ iv)
+__global__ void k_fold_direct(const float* __restrict__ in, const uint64_t chan_stride, const uint64_t pol_stride,
+                              float* __restrict__ prof, const uint32_t nbin, const uint32_t* __restrict__ bin_start,
+                              const Interval* __restrict__ iv)
 {
   const uint32_t ipol = blockIdx.x, npol = gridDim.x, ichan = blockIdx.y;
   const float* __restrict__ row = in + ichan * chan_stride + ipol * pol_stride;
@@ -35,20 +37,110 @@ __global__ void k_fold(const float* __restrict__ in, const uint64_t chan_stride,
     for (uint32_t i = i0; i < i1; i++) {
       const Interval v = iv[i];
       const float* __restrict__ x = row + v.offset * NDIM;
-      for (uint32_t h = 0; h < v.hits; h++) {
-        if (NDIM == 4) {
-          const float4 s = ((const float4*)x)[h];
-          acc[0] += s.x; acc[1 % NDIM] += s.y; acc[2 % NDIM] += s.z; acc[3 % NDIM] += s.w;
-        } else if (NDIM == 2) {
-          const float2 s = ((const float2*)x)[h];
-          acc[0] += s.x; acc[1 % NDIM] += s.y;
-        } else {
-          acc[0] += x[h];
-        }
-      }
+      for (uint32_t h = 0; h < v.hits; h++)
+#pragma unroll
+        for (int d = 0; d < NDIM; d++) acc[d] += x[h * NDIM + d];
     }
 #pragma unroll
     for (int d = 0; d < NDIM; d++) out[b * NDIM + d] = acc[d];
+  }
+}
+
+// Chunked variant (the hot one).  One workgroup per (channel, pol) row.  The row is streamed
+// through LDS in chunks of FOLD_CHUNK samples with fully coalesced 16-byte loads (the next
+// chunk is already in flight in registers while the current one is folded); thread b owns phase
+// bins b, b+blockDim, ... and walks each bin's time-ordered interval list with a cursor, adding
+// the samples that fall inside the current chunk one by one.  Per (chan, pol, bin, dim) the adds
+// therefore happen in time order, as in Fold.C:844-852.
+constexpr uint32_t FOLD_CHUNK = 2048;   // samples per chunk
+constexpr int FOLD_BPT = 4;             // bins per thread (nbin <= FOLD_BPT * blockDim)
+
+template <int NDIM>
+__global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__ in, const uint64_t chan_stride,
+                                                       const uint64_t pol_stride, float* __restrict__ prof,
+                                                       const uint32_t nbin, const uint32_t* __restrict__ bin_start,
+                                                       const Interval* __restrict__ iv, const uint64_t first,
+                                                       const uint64_t last /* [first,last): sample span of the plan */)
+{
+  extern __shared__ __attribute__((aligned(16))) float fold_lds[];   // FOLD_CHUNK * NDIM floats
+  const uint32_t ipol = blockIdx.x, npol = gridDim.x, ichan = blockIdx.y;
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const float* __restrict__ row = in + ichan * chan_stride + ipol * pol_stride;
+  float* __restrict__ out = prof + ((uint64_t)ichan * npol + ipol) * nbin * NDIM;
+  constexpr uint32_t NF4 = FOLD_CHUNK * NDIM / 4;        // float4 per chunk
+  constexpr uint32_t MAXR = NF4 / 256;                    // float4 per thread at the minimum block size (256)
+
+  uint32_t cur[FOLD_BPT], end[FOLD_BPT];
+  float acc[FOLD_BPT][NDIM];
+#pragma unroll
+  for (int j = 0; j < FOLD_BPT; j++) {
+    const uint32_t b = tid + j * nt;
+    cur[j] = end[j] = 0;
+    if (b < nbin) { cur[j] = bin_start[b]; end[j] = bin_start[b + 1]; }
+#pragma unroll
+    for (int d = 0; d < NDIM; d++) acc[j][d] = (b < nbin && cur[j] != end[j]) ? out[b * NDIM + d] : 0.f;
+  }
+  const bool touched0 = cur[0] != end[0], touched1 = cur[1] != end[1], touched2 = cur[2] != end[2],
+             touched3 = cur[3] != end[3];
+
+  // chunk c covers samples [first + c*FOLD_CHUNK, ...); rows are 16-byte aligned when first*NDIM % 4 == 0,
+  // the host guarantees it by rounding `first` down
+  const float4* __restrict__ src = (const float4*)(row + first * NDIM);
+  const uint64_t nfl_total = (last - first) * NDIM;      // floats in the span
+  const uint32_t nchunk = (uint32_t)((last - first + FOLD_CHUNK - 1) / FOLD_CHUNK);
+  float4 pre[MAXR];
+  auto fetch = [&](uint32_t c) {
+#pragma unroll
+    for (uint32_t r = 0; r < MAXR; r++) {
+      const uint32_t q = tid + r * nt;
+      const uint64_t k = (uint64_t)c * NF4 + q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < NF4) {
+        if (4 * k + 4 <= nfl_total) {
+          v = src[k];
+        } else if (4 * k < nfl_total) {                  // ragged end of the span: never read past it
+          const float* t = (const float*)(src + k);
+          const uint32_t n = (uint32_t)(nfl_total - 4 * k);
+          v.x = t[0];
+          if (n > 1) v.y = t[1];
+          if (n > 2) v.z = t[2];
+        }
+      }
+      pre[r] = v;
+    }
+  };
+  fetch(0);
+  for (uint32_t c = 0; c < nchunk; c++) {
+    __syncthreads();                                    // previous chunk fully consumed
+#pragma unroll
+    for (uint32_t r = 0; r < MAXR; r++)
+      if (tid + r * nt < NF4) ((float4*)fold_lds)[tid + r * nt] = pre[r];
+    if (c + 1 < nchunk) fetch(c + 1);
+    __syncthreads();
+    const uint64_t c0 = first + (uint64_t)c * FOLD_CHUNK, c1 = c0 + FOLD_CHUNK;
+#pragma unroll
+    for (int j = 0; j < FOLD_BPT; j++) {
+      while (cur[j] < end[j]) {
+        const Interval v = iv[cur[j]];
+        if (v.offset >= c1) break;
+        const uint64_t lo = v.offset > c0 ? v.offset : c0;
+        const uint64_t hi = v.offset + v.hits < c1 ? v.offset + v.hits : c1;
+        const float* x = fold_lds + (lo - c0) * NDIM;
+        for (uint32_t h = 0; h < (uint32_t)(hi - lo); h++)
+#pragma unroll
+          for (int d = 0; d < NDIM; d++) acc[j][d] += x[h * NDIM + d];
+        if (v.offset + v.hits <= c1) cur[j]++;
+        else break;                                      // interval continues in the next chunk
+      }
+    }
+  }
+  const bool touched[FOLD_BPT] = {touched0, touched1, touched2, touched3};
+#pragma unroll
+  for (int j = 0; j < FOLD_BPT; j++) {
+    const uint32_t b = tid + j * nt;
+    if (b < nbin && touched[j])
+#pragma unroll
+      for (int d = 0; d < NDIM; d++) out[b * NDIM + d] = acc[j][d];
   }
 }
 
@@ -262,17 +354,36 @@ extern "C" int dspsr_amd_fold_fold(dspsr_amd_fold* f, const float* in_dev, uint6
     e = hipMemcpyAsync(sl.d_iv, sl.h_iv, niv * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: plan copy: %s", hipGetErrorString(e));
 
-  uint32_t threads = nbin < 1024 ? ((nbin + 63) / 64) * 64 : 1024;
   dim3 grid(f->npol, f->nchan);
-  if (f->ndim == 4)
-    hipLaunchKernelGGL(k_fold<4>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride, in_pol_stride,
-                       f->profile, nbin, sl.d_bin_start, sl.d_iv);
-  else if (f->ndim == 2)
-    hipLaunchKernelGGL(k_fold<2>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride, in_pol_stride,
-                       f->profile, nbin, sl.d_bin_start, sl.d_iv);
-  else
-    hipLaunchKernelGGL(k_fold<1>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride, in_pol_stride,
-                       f->profile, nbin, sl.d_bin_start, sl.d_iv);
+  // sample span covered by the plan (intervals are time ordered)
+  uint64_t first = f->binplan.front().offset, last = f->binplan.back().offset + f->binplan.back().hits;
+  first -= first % 4;                                  // keeps 16-byte alignment of the chunk loads for any ndim
+  const bool aligned = ((uintptr_t)in_dev % 16 == 0) && (in_chan_stride % 4 == 0) && (in_pol_stride % 4 == 0);
+  uint32_t threads = nbin < 1024 ? ((nbin + 63) / 64) * 64 : 1024;
+  if (aligned && nbin <= (uint32_t)FOLD_BPT * threads) {
+    // fewer threads than bins when the pulse period spans few samples would idle most lanes; 256 is the floor
+    if (threads < 256) threads = 256;
+    const size_t lds = (size_t)FOLD_CHUNK * f->ndim * sizeof(float);
+    if (f->ndim == 4)
+      hipLaunchKernelGGL(k_fold_chunked<4>, grid, dim3(threads), lds, ctx->stream, in_dev, in_chan_stride,
+                         in_pol_stride, f->profile, nbin, sl.d_bin_start, sl.d_iv, first, last);
+    else if (f->ndim == 2)
+      hipLaunchKernelGGL(k_fold_chunked<2>, grid, dim3(threads), lds, ctx->stream, in_dev, in_chan_stride,
+                         in_pol_stride, f->profile, nbin, sl.d_bin_start, sl.d_iv, first, last);
+    else
+      hipLaunchKernelGGL(k_fold_chunked<1>, grid, dim3(threads), lds, ctx->stream, in_dev, in_chan_stride,
+                         in_pol_stride, f->profile, nbin, sl.d_bin_start, sl.d_iv, first, last);
+  } else {
+    if (f->ndim == 4)
+      hipLaunchKernelGGL(k_fold_direct<4>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride,
+                         in_pol_stride, f->profile, nbin, sl.d_bin_start, sl.d_iv);
+    else if (f->ndim == 2)
+      hipLaunchKernelGGL(k_fold_direct<2>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride,
+                         in_pol_stride, f->profile, nbin, sl.d_bin_start, sl.d_iv);
+    else
+      hipLaunchKernelGGL(k_fold_direct<1>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride,
+                         in_pol_stride, f->profile, nbin, sl.d_bin_start, sl.d_iv);
+  }
   e = hipGetLastError();
   if (e == hipSuccess) e = hipEventRecord(sl.done, ctx->stream);
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: %s", hipGetErrorString(e));

@@ -1,13 +1,18 @@
-// In-workgroup batched FFT for gfx950 (wave64): F-point FFTs over T interleaved columns,
-// F*T = 16*blockDim.x points resident in LDS, every thread owning 16 points per stage.
+// In-workgroup batched FFT for gfx950 (wave64): F-point FFTs over T interleaved columns
+// (T >= 2), F*T = 32*blockDim.x points, every thread owning PTS = 32 points per stage.
 //
 // Stockham auto-sort, radix-16 stages (4x4 butterflies held in registers) plus one
-// radix-2/4/8 remainder stage.  Element (pos, col) lives at LDS word lds_pad(pos*T + col).
-// Stage with radix R, P = product of earlier radices, Q = F/(P*R):
-//   butterfly u = col + T*(p + P*s)        (p < P, s < Q; consecutive lanes -> consecutive words)
+// radix-2/4/8 remainder stage.  The FIRST stage takes its inputs from a register array the
+// caller filled (prefetched from global memory while the previous tile was computed) and the
+// LAST stage hands its outputs to a caller functor (registers -> global memory); only the
+// exchanges BETWEEN stages go through LDS, element (pos, col) at word lds_pad(pos*T + col).
+// Stage with radix R, G = 32/R butterflies per thread, P = product of earlier radices, Q = F/(P*R):
+//   butterfly u = G*tid + g = col + T*(p + P*s)   (p < P, s < Q)
 //   reads   u + i*(F/R)*T                  i < R
-//   twiddle W_{R*Q}^{k*s}
+//   twiddle W_{R*Q}^{k*s}                  (4 table loads + multiplication ladder per butterfly)
 //   writes  (s*P*R + k*P + p)*T + col      k < R
+// Butterflies 2j and 2j+1 of a thread are columns (col, col+1) of the same position, so every
+// LDS access moves a 16-byte pair (ds_read_b128 / ds_write_b128).
 // (index math validated against numpy in tests/test_wgfft_model.py)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -30,6 +35,9 @@ template <int SIGN> DEV cf mul_si(cf a) { return SIGN < 0 ? make_float2(a.y, -a.
 // and preserve 16-byte alignment of even word indices
 DEV uint32_t lds_pad(uint32_t e) { return e + ((e >> 6) << 2); }
 inline uint32_t lds_words_host(uint32_t points) { return points + ((points >> 6) << 2) + 8; }
+
+constexpr int PTS = 32;      // points per thread
+constexpr int LOG_PTS = 5;
 
 // cos/sin(2*pi*k/16)
 #define C16_1 0.92387953251128674f
@@ -101,70 +109,156 @@ template <int R, int SIGN> DEV void fftR(cf (&v)[R])
   if constexpr (R == 2) fft2<SIGN>(v[0], v[1]);
   else if constexpr (R == 4) fft4<SIGN>(v[0], v[1], v[2], v[3]);
   else if constexpr (R == 8) fft8<SIGN>(v);
-  else fft16<SIGN>(v);
+  else if constexpr (R == 16) fft16<SIGN>(v);
+}
+
+// v[k] *= w1^k for k = 1..R-1 given the exact powers w1, w2, w4, w8 (those that exist for R);
+// the remaining powers are products of at most three exact factors.
+template <int R> DEV void apply_powers(cf (&v)[R], const cf w1, const cf w2, const cf w4, const cf w8)
+{
+  if constexpr (R >= 2) v[1] = cmul(v[1], w1);
+  if constexpr (R >= 4) {
+    const cf w3 = cmul(w2, w1);
+    v[2] = cmul(v[2], w2);
+    v[3] = cmul(v[3], w3);
+    if constexpr (R >= 8) {
+      const cf w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+      v[4] = cmul(v[4], w4); v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7);
+      if constexpr (R >= 16) {
+        v[8] = cmul(v[8], w8);
+        v[9] = cmul(v[9], cmul(w8, w1));
+        v[10] = cmul(v[10], cmul(w8, w2));
+        v[11] = cmul(v[11], cmul(w8, w3));
+        v[12] = cmul(v[12], cmul(w8, w4));
+        v[13] = cmul(v[13], cmul(w8, w5));
+        v[14] = cmul(v[14], cmul(w8, w6));
+        v[15] = cmul(v[15], cmul(w8, w7));
+      }
+    }
+  }
 }
 
 // twiddle table: tw[j] = exp(-2*pi*i*j/TWN), j < TWN
 constexpr int LOG_TWN = 14;
 constexpr int TWN = 1 << LOG_TWN;
 
-template <int LOGR, int SIGN>
-DEV void wgfft_stage(cf* lds, const uint32_t tid, const uint32_t nt, const int logT, const int logF,
-                     const int logP, const cf* __restrict__ tw)
+// radix plan of an F = 2^LOGF transform
+template <int LOGF> struct FftPlan {
+  static constexpr int NQ = LOGF / 4, REM = LOGF % 4;
+  static constexpr int NS = NQ + (REM ? 1 : 0);
+  static constexpr int LOGR1 = NS == 0 ? 0 : (NQ ? 4 : REM);   // first-stage radix
+  static constexpr int R1 = 1 << LOGR1;
+  static constexpr int G1 = PTS / R1;
+};
+
+// logical element index (pos*T + col) held in x[g*R1 + i] of the first-stage register array
+template <int LOGF> DEV uint32_t first_stage_elem(uint32_t tid, int logT, int g, int i)
+{
+  typedef FftPlan<LOGF> P;
+  return P::G1 * tid + g + ((uint32_t)i << (LOGF - P::LOGR1 + logT));
+}
+
+// Out: void operator()(uint32_t col, uint32_t p, uint32_t pstride, cf (&va)[R], cf (&vb)[R])
+//      va[k] / vb[k] are output position k*pstride + p of columns col (even) and col + 1
+template <int LOGR, int SIGN, bool FIRST, bool LAST, class Out>
+DEV void wgfft_stage(cf* lds, const uint32_t tid, const int logT, const int logF, const int logP,
+                     const cf* __restrict__ tw, cf (&x)[PTS], Out& out)
 {
   constexpr int R = 1 << LOGR;
-  constexpr int G = 16 / R;
+  constexpr int G = PTS / R;
   const int logQ = logF - logP - LOGR;
   const uint32_t stride = 1u << (logF - LOGR + logT);
   cf v[G][R];
 #pragma unroll
-  for (int g = 0; g < G; g++) {
-    const uint32_t u = tid + nt * g;
+  for (int g = 0; g < G; g += 2) {
+    const uint32_t u = G * tid + g;
 #pragma unroll
-    for (int i = 0; i < R; i++) v[g][i] = lds[lds_pad(u + i * stride)];
+    for (int i = 0; i < R; i++) {
+      if constexpr (FIRST) {
+        v[g][i] = x[g * R + i];
+        v[g + 1][i] = x[(g + 1) * R + i];
+      } else {
+        const float4 pr = *(const float4*)&lds[lds_pad(u + i * stride)];
+        v[g][i] = make_float2(pr.x, pr.y);
+        v[g + 1][i] = make_float2(pr.z, pr.w);
+      }
+    }
   }
 #pragma unroll
   for (int g = 0; g < G; g++) {
     fftR<R, SIGN>(v[g]);
-    if (logQ > 0) {
-      const uint32_t u = tid + nt * g;
+    if (R > 1 && logQ > 0) {
+      const uint32_t u = G * tid + g;
       const uint32_t s = u >> (logT + logP);
       const int sh = LOG_TWN - LOGR - logQ;
-#pragma unroll
-      for (int k = 1; k < R; k++) {
-        cf w = tw[(k * s) << sh];
-        if (SIGN > 0) w.y = -w.y;
-        v[g][k] = cmul(v[g][k], w);
-      }
+      cf w1 = tw[s << sh], w2 = w1, w4 = w1, w8 = w1;
+      if (R >= 4) w2 = tw[s << (sh + 1)];
+      if (R >= 8) w4 = tw[s << (sh + 2)];
+      if (R >= 16) w8 = tw[s << (sh + 3)];
+      if (SIGN > 0) { w1.y = -w1.y; w2.y = -w2.y; w4.y = -w4.y; w8.y = -w8.y; }
+      apply_powers<R>(v[g], w1, w2, w4, w8);
     }
   }
-  __syncthreads();
+  if (!LAST) __syncthreads();   // every read of the in-place exchange buffer (this or the previous tile) is done
 #pragma unroll
-  for (int g = 0; g < G; g++) {
-    const uint32_t u = tid + nt * g;
+  for (int g = 0; g < G; g += 2) {
+    const uint32_t u = G * tid + g;
     const uint32_t col = u & ((1u << logT) - 1);
     const uint32_t rest = u >> logT;
     const uint32_t p = rest & ((1u << logP) - 1);
     const uint32_t s = rest >> logP;
+    if constexpr (LAST) {
+      out(col, p, 1u << logP, v[g], v[g + 1]);     // Q == 1, s == 0
+    } else {
 #pragma unroll
-    for (int k = 0; k < R; k++) {
-      const uint32_t pos = (s << (logP + LOGR)) + ((uint32_t)k << logP) + p;
-      lds[lds_pad((pos << logT) | col)] = v[g][k];
+      for (int k = 0; k < R; k++) {
+        const uint32_t pos = (s << (logP + LOGR)) + ((uint32_t)k << logP) + p;
+        *(float4*)&lds[lds_pad((pos << logT) | col)] = make_float4(v[g][k].x, v[g][k].y, v[g + 1][k].x, v[g + 1][k].y);
+      }
     }
   }
-  __syncthreads();
+  if (!LAST) __syncthreads();
 }
 
-// Pre : element (n, col) at lds_pad(n*T + col), all threads synchronised.
-// Post: element (k, col) at lds_pad(k*T + col), all threads synchronised.
-template <int LOGF, int SIGN>
-DEV void wgfft(cf* lds, const uint32_t tid, const uint32_t nt, const int logT, const cf* __restrict__ tw)
+// Runs the whole F-point transform of one tile: x feeds the first stage, `out` receives the last.
+// May be called repeatedly (persistent workgroup): the barrier in front of the first LDS write
+// also separates it from the previous tile's last-stage LDS reads.
+template <int LOGF, int SIGN, class Out>
+DEV void wgfft(cf* lds, uint32_t tid, const int logT, const cf* __restrict__ tw, cf (&x)[PTS], Out& out)
 {
-  constexpr int NQ = LOGF / 4, REM = LOGF % 4;
-  int logP = 0;
+  typedef FftPlan<LOGF> P;
+  // opaque copy: LDS addresses and twiddle indices are loop-invariant in a persistent workgroup and
+  // would otherwise be hoisted out of the tile loop and spilled (hundreds of registers)
+  asm volatile("" : "+v"(tid));
+  if constexpr (P::NS <= 1) {
+    wgfft_stage<P::LOGR1, SIGN, true, true>(lds, tid, logT, LOGF, 0, tw, x, out);
+  } else {
+    wgfft_stage<4, SIGN, true, false>(lds, tid, logT, LOGF, 0, tw, x, out);
+    int logP = 4;
 #pragma unroll
-  for (int j = 0; j < NQ; j++) { wgfft_stage<4, SIGN>(lds, tid, nt, logT, LOGF, logP, tw); logP += 4; }
-  if constexpr (REM != 0) wgfft_stage<REM, SIGN>(lds, tid, nt, logT, LOGF, logP, tw);
+    for (int j = 1; j < P::NQ - (P::REM ? 0 : 1); j++) {
+      wgfft_stage<4, SIGN, false, false>(lds, tid, logT, LOGF, logP, tw, x, out);
+      logP += 4;
+    }
+    if constexpr (P::REM != 0) wgfft_stage<P::REM, SIGN, false, true>(lds, tid, logT, LOGF, logP, tw, x, out);
+    else wgfft_stage<4, SIGN, false, true>(lds, tid, logT, LOGF, logP, tw, x, out);
+  }
+}
+
+// Work distribution of a persistent grid.  Items are dealt to the 8 XCDs in runs of `run`
+// consecutive items (blocks b and b+8 share an XCD under the observed round-robin placement;
+// a different placement only changes speed), so neighbouring items -- which share 128-byte
+// input lines (P1) or chirp rows (P3) -- are served by one XCD's L2.
+DEV bool persistent_item(uint32_t b, uint32_t grid, uint32_t j, uint32_t run, uint64_t total, uint64_t& item)
+{
+  if (grid & 7) {
+    item = b + (uint64_t)j * grid;
+  } else {
+    const uint32_t nxl = grid >> 3;
+    const uint64_t q = (uint64_t)j * nxl + (b >> 3);
+    item = (q / run) * (8ull * run) + (uint64_t)(b & 7) * run + (q % run);
+  }
+  return item < total;
 }
 
 }  // namespace dspsr_amd
