@@ -70,18 +70,30 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
   constexpr uint32_t NF4 = FOLD_CHUNK * NDIM / 4;        // float4 per chunk
   constexpr uint32_t MAXR = NF4 / 256;                    // float4 per thread at the minimum block size (256)
 
+  // cursor into each owned bin's interval list; the current and the following interval are kept in
+  // registers (loaded long before they are needed) so the chunk loop never waits on global memory
   uint32_t cur[FOLD_BPT], end[FOLD_BPT];
+  Interval v0[FOLD_BPT], v1[FOLD_BPT];
   float acc[FOLD_BPT][NDIM];
+  bool touched[FOLD_BPT];
+  // "no interval" = offset ~0.  Always load through the global pointer with a clamped index: selecting
+  // between &iv[i] and a local would make the load generic (flat_load + full vmcnt/lgkmcnt drain).
+  auto load_iv = [&](const uint32_t i, const bool valid) -> Interval {
+    Interval t = iv[valid ? i : 0u];
+    if (!valid) { t.offset = ~0ull; t.hits = 0u; }
+    return t;
+  };
 #pragma unroll
   for (int j = 0; j < FOLD_BPT; j++) {
     const uint32_t b = tid + j * nt;
     cur[j] = end[j] = 0;
     if (b < nbin) { cur[j] = bin_start[b]; end[j] = bin_start[b + 1]; }
+    touched[j] = cur[j] != end[j];
+    v0[j] = load_iv(cur[j], cur[j] < end[j]);
+    v1[j] = load_iv(cur[j] + 1, cur[j] + 1 < end[j]);
 #pragma unroll
-    for (int d = 0; d < NDIM; d++) acc[j][d] = (b < nbin && cur[j] != end[j]) ? out[b * NDIM + d] : 0.f;
+    for (int d = 0; d < NDIM; d++) acc[j][d] = (b < nbin && touched[j]) ? out[b * NDIM + d] : 0.f;
   }
-  const bool touched0 = cur[0] != end[0], touched1 = cur[1] != end[1], touched2 = cur[2] != end[2],
-             touched3 = cur[3] != end[3];
 
   // chunk c covers samples [first + c*FOLD_CHUNK, ...); rows are 16-byte aligned when first*NDIM % 4 == 0,
   // the host guarantees it by rounding `first` down
@@ -120,21 +132,25 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
     const uint64_t c0 = first + (uint64_t)c * FOLD_CHUNK, c1 = c0 + FOLD_CHUNK;
 #pragma unroll
     for (int j = 0; j < FOLD_BPT; j++) {
-      while (cur[j] < end[j]) {
-        const Interval v = iv[cur[j]];
-        if (v.offset >= c1) break;
+      while (v0[j].offset < c1) {                        // `none` has offset ~0 and ends the walk
+        const Interval v = v0[j];
         const uint64_t lo = v.offset > c0 ? v.offset : c0;
         const uint64_t hi = v.offset + v.hits < c1 ? v.offset + v.hits : c1;
-        const float* x = fold_lds + (lo - c0) * NDIM;
-        for (uint32_t h = 0; h < (uint32_t)(hi - lo); h++)
+        // index the __shared__ array directly (a generic pointer would turn these into flat loads
+        // whose vmcnt(0) wait also drains the chunk prefetch)
+        const uint32_t x0 = (uint32_t)(lo - c0) * NDIM;
+        const uint32_t n = (uint32_t)(hi - lo);
+#pragma unroll 4
+        for (uint32_t h = 0; h < n; h++)
 #pragma unroll
-          for (int d = 0; d < NDIM; d++) acc[j][d] += x[h * NDIM + d];
-        if (v.offset + v.hits <= c1) cur[j]++;
-        else break;                                      // interval continues in the next chunk
+          for (int d = 0; d < NDIM; d++) acc[j][d] += fold_lds[x0 + h * NDIM + d];
+        if (v.offset + v.hits > c1) break;               // interval continues in the next chunk
+        cur[j]++;
+        v0[j] = v1[j];
+        v1[j] = load_iv(cur[j] + 1, cur[j] + 1 < end[j]);
       }
     }
   }
-  const bool touched[FOLD_BPT] = {touched0, touched1, touched2, touched3};
 #pragma unroll
   for (int j = 0; j < FOLD_BPT; j++) {
     const uint32_t b = tid + j * nt;
@@ -360,9 +376,12 @@ extern "C" int dspsr_amd_fold_fold(dspsr_amd_fold* f, const float* in_dev, uint6
   first -= first % 4;                                  // keeps 16-byte alignment of the chunk loads for any ndim
   const bool aligned = ((uintptr_t)in_dev % 16 == 0) && (in_chan_stride % 4 == 0) && (in_pol_stride % 4 == 0);
   uint32_t threads = nbin < 1024 ? ((nbin + 63) / 64) * 64 : 1024;
-  if (aligned && nbin <= (uint32_t)FOLD_BPT * threads) {
-    // fewer threads than bins when the pulse period spans few samples would idle most lanes; 256 is the floor
+  if (aligned && nbin <= (uint32_t)FOLD_BPT * 1024) {
+    // FOLD_BPT bins per thread: 256-thread workgroups for nbin <= 1024, so that four of them share a CU and
+    // keep 4 x 32 KiB of chunk loads in flight (the kernel is HBM-latency bound per workgroup)
+    threads = ((nbin + FOLD_BPT - 1) / FOLD_BPT + 63) / 64 * 64;
     if (threads < 256) threads = 256;
+    if (threads > 1024) threads = 1024;
     const size_t lds = (size_t)FOLD_CHUNK * f->ndim * sizeof(float);
     if (f->ndim == 4)
       hipLaunchKernelGGL(k_fold_chunked<4>, grid, dim3(threads), lds, ctx->stream, in_dev, in_chan_stride,
