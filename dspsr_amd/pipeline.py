@@ -87,6 +87,25 @@ class Polyco:
         return self.f0 + d / 60.0
 
 
+def reduce_subbands(prof, dist=None, rank=0, world=1, gather_buffer=None):
+    """The ONE collective of the path.  Each rank holds the folded profile of its own frequency sub-band
+    (flat [nchan*npol*nbin*ndim] float32).  The full-band buffer [world][...] is zero outside the rank's
+    slice, so a single reduce(SUM, dst=0) -- RCCL over xGMI on GPUs, gloo in the CPU tests -- delivers
+    the concatenated band to the writer rank with exactly PhaseSeries::combine semantics
+    (PhaseSeries.C:442-484: float add of profiles).  hits / integration_length are identical on all
+    ranks (channel-independent bin plan, Fold.C:744-787) and are taken from rank 0.
+    Returns the full-band tensor on rank 0, None elsewhere; with world == 1 returns `prof` itself."""
+    if world <= 1:
+        return prof
+    if gather_buffer is None or gather_buffer.numel() != world * prof.numel():
+        raise DspsrAmdError("reduce_subbands: gather buffer must hold world*profile = %d floats"
+                            % (world * prof.numel()))
+    gather_buffer.zero_()
+    gather_buffer.view(world, -1)[rank].copy_(prof.reshape(-1))
+    dist.reduce(gather_buffer, dst=0, op=dist.ReduceOp.SUM)
+    return gather_buffer if rank == 0 else None
+
+
 class LoadToFold:
     """One pipeline instance = one GPU = one stream (SingleThread).  `raw` blocks are int8 torch
     tensors already resident on the device (the PCIe copy is the caller's, as TransferCUDA is a
@@ -195,20 +214,9 @@ class LoadToFold:
         return torch.as_tensor(h, device="cuda:%d" % self.ctx.device)
 
     def finish_subint(self, dist=None, rank=0, world=1, gather_buffer=None):
-        """Subint<Fold>: emit the finished sub-integration and zero the profile.  With world>1 each rank
-        holds one frequency sub-band; the full-band buffer [world*nchan][npol][nbin][ndim] is zero outside
-        the rank's slice and ONE reduce(sum, dst=0) over RCCL delivers it to the writer rank."""
-        torch = self.torch
+        """Subint<Fold>: emit the finished sub-integration and zero the profile (Subint.h:291-303)."""
         prof = self.profiles_tensor()
-        result = None
-        if world > 1:
-            gather_buffer.zero_()
-            gather_buffer.view(world, -1)[rank].copy_(prof)
-            dist.reduce(gather_buffer, dst=0, op=dist.ReduceOp.SUM)
-            if rank == 0:
-                result = gather_buffer
-        else:
-            result = prof
+        result = reduce_subbands(prof, dist, rank, world, gather_buffer)
         if rank == 0:
             self.subints.append({"hits": self.hits.copy(), "integration_length": self.integration_length,
                                  "ndat_total": self.ndat_total, "profile_dev": result.clone()})
