@@ -1,0 +1,213 @@
+// Host adaptor classes: bind the C-ABI of include/dspsr_amd.h to DSPSR's Engine plug-in interfaces.
+// A DSPSR maintainer compiles this header inside the dspsr tree (it only needs the dsp headers named
+// below and -ldspsr_amd) and installs the engines where the CUDA ones are installed today
+// (INTEGRATION.md).  Each method mirrors the CUDA twin it replaces:
+//   HIP::DeviceMemory      <- CUDA::DeviceMemory      Kernel/Classes/MemoryCUDA.C:47-106
+//   HIP::FilterbankEngine  <- CUDA::FilterbankEngine  Signal/General/FilterbankCUDA.cu:73-304
+//   HIP::DetectionEngine   <- CUDA::DetectionEngine   Signal/General/DetectionCUDA.cu:127-322
+//   HIP::FoldEngine        <- CUDA::FoldEngine        Signal/Pulsar/FoldCUDA.cu:64-697
+// Errors: every non-zero C-ABI status is rethrown as the reference's `Error` with the library's message.
+#ifndef DSPSR_AMD_ENGINES_H
+#define DSPSR_AMD_ENGINES_H
+
+#include "dsp/Memory.h"
+#include "dsp/FilterbankEngine.h"   // dsp::Filterbank, dsp::Filterbank::Engine, dsp::Response, dsp::TimeSeries
+#include "dsp/Detection.h"          // dsp::Detection::Engine
+#include "dsp/Fold.h"               // dsp::Fold::Engine, dsp::PhaseSeries
+#include "Error.h"
+
+#include "dspsr_amd.h"
+
+namespace HIP
+{
+  inline void check (dspsr_amd_ctx* ctx, int status, const char* method)
+  {
+    if (status != DSPSR_AMD_OK)
+      throw Error (status == DSPSR_AMD_EINVAL ? InvalidParam : InvalidState, method,
+                   dspsr_amd_last_error (ctx));
+  }
+
+  //! dsp::Memory on the MI355X: allocation bound to one context/stream (SingleThread.C:237-244)
+  class DeviceMemory : public dsp::Memory
+  {
+  public:
+    DeviceMemory (dspsr_amd_ctx* _ctx) : ctx (_ctx) { }
+    void* do_allocate (size_t nbytes)
+    { void* p = 0; check (ctx, dspsr_amd_malloc (ctx, nbytes, &p), "HIP::DeviceMemory::do_allocate"); return p; }
+    void do_free (void* ptr) { check (ctx, dspsr_amd_free (ctx, ptr), "HIP::DeviceMemory::do_free"); }
+    void do_zero (void* ptr, size_t nbytes)
+    { check (ctx, dspsr_amd_zero (ctx, ptr, nbytes), "HIP::DeviceMemory::do_zero"); }
+    void do_copy (void* to, const void* from, size_t nbytes)
+    { check (ctx, dspsr_amd_copy (ctx, to, from, nbytes, DSPSR_AMD_D2D), "HIP::DeviceMemory::do_copy"); }
+    bool on_host () const { return false; }
+    dspsr_amd_ctx* get_context () const { return ctx; }
+  protected:
+    dspsr_amd_ctx* ctx;
+  };
+
+  //! dsp::Filterbank::Engine (FilterbankEngine.h:15-44)
+  class FilterbankEngine : public dsp::Filterbank::Engine
+  {
+  public:
+    FilterbankEngine (dspsr_amd_ctx* _ctx) : ctx (_ctx), fb (0) { }
+    ~FilterbankEngine () { dspsr_amd_filterbank_destroy (fb); }
+
+    //! reads exactly what CUDA::FilterbankEngine::setup reads (FilterbankCUDA.cu:73-168)
+    void setup (dsp::Filterbank* filterbank)
+    {
+      filterbank->set_passband (NULL);          // the engine does not maintain the passband
+      dspsr_amd_filterbank_config cfg;
+      cfg.nchan_subband = filterbank->get_nchan_subband ();
+      cfg.freq_res = filterbank->get_freq_res ();
+      cfg.input_nchan = filterbank->get_input()->get_nchan ();
+      cfg.npol = filterbank->get_input()->get_npol ();
+      cfg.real_input = filterbank->get_input()->get_state () == Signal::Nyquist;
+      cfg.nfilt_pos = cfg.nfilt_neg = 0;
+      cfg.max_parts = 0;
+      const float* kernel = 0;
+      uint64_t ncomplex = 0;
+      if (filterbank->has_response ())
+      {
+        const dsp::Response* response = filterbank->get_response ();
+        cfg.nfilt_pos = response->get_impulse_pos ();
+        cfg.nfilt_neg = response->get_impulse_neg ();
+        kernel = response->get_datptr (0, 0);   // host-built, already swapped (Response.C:132-181)
+        ncomplex = uint64_t (response->get_nchan ()) * response->get_ndat ();
+      }
+      dspsr_amd_filterbank_destroy (fb); fb = 0;
+      check (ctx, dspsr_amd_filterbank_create (ctx, &cfg, &fb), "HIP::FilterbankEngine::setup");
+      check (ctx, dspsr_amd_filterbank_set_kernel (fb, kernel, ncomplex), "HIP::FilterbankEngine::setup");
+    }
+
+    void set_scratch (float* _scratch) { scratch = _scratch; }   // unused: the library owns its scratch
+
+    //! FilterbankCUDA.cu:181-304; pointers come from DeviceMemory-backed TimeSeries
+    void perform (const dsp::TimeSeries* in, dsp::TimeSeries* out,
+                  uint64_t npart, const uint64_t in_step, const uint64_t out_step)
+    {
+      const float* ibase = in->get_datptr (0, 0);
+      const uint64_t ics = in->get_nchan () > 1 ? in->get_datptr (1, 0) - ibase : 0;
+      const uint64_t ips = in->get_npol () > 1 ? in->get_datptr (0, 1) - ibase : 0;
+      float* obase = out ? out->get_datptr (0, 0) : 0;      // out == NULL: benchmark only (:265)
+      const uint64_t ocs = out && out->get_nchan () > 1 ? out->get_datptr (1, 0) - obase : 0;
+      const uint64_t ops = out && out->get_npol () > 1 ? out->get_datptr (0, 1) - obase : 0;
+      check (ctx, dspsr_amd_filterbank_perform (fb, ibase, ics, ips, obase, ocs, ops, npart, in_step, out_step),
+             "HIP::FilterbankEngine::perform");
+    }
+
+    void finish () { check (ctx, dspsr_amd_stream_sync (ctx), "HIP::FilterbankEngine::finish"); }
+
+    //! optional side channel: 8-bit input straight from the BitSeries (fused unpack)
+    void perform_raw (const int8_t* raw, int layout, float scale, dsp::TimeSeries* out, uint64_t npart, uint64_t out_step)
+    {
+      float* obase = out->get_datptr (0, 0);
+      const uint64_t ocs = out->get_nchan () > 1 ? out->get_datptr (1, 0) - obase : 0;
+      const uint64_t ops = out->get_npol () > 1 ? out->get_datptr (0, 1) - obase : 0;
+      check (ctx, dspsr_amd_filterbank_perform_raw (fb, raw, layout, scale, obase, ocs, ops, npart, out_step),
+             "HIP::FilterbankEngine::perform_raw");
+    }
+
+  protected:
+    dspsr_amd_ctx* ctx;
+    dspsr_amd_filterbank* fb;
+  };
+
+  //! dsp::Detection::Engine (Detection.h:98-106)
+  class DetectionEngine : public dsp::Detection::Engine
+  {
+  public:
+    DetectionEngine (dspsr_amd_ctx* _ctx) : ctx (_ctx) { }
+
+    void polarimetry (unsigned ndim, const dsp::TimeSeries* in, dsp::TimeSeries* out)
+    {
+      if (in->get_ndat () != out->get_ndat ())
+        throw Error (InvalidParam, "HIP::DetectionEngine::polarimetry", "input ndat != output ndat");
+      const float* ibase = in->get_datptr (0, 0);
+      float* obase = out->get_datptr (0, 0);
+      const int state = out->get_state () == Signal::Stokes ? DSPSR_AMD_STOKES : DSPSR_AMD_COHERENCE;
+      check (ctx, dspsr_amd_detect_polarimetry (ctx, state, ndim, ibase,
+               in->get_nchan () > 1 ? in->get_datptr (1, 0) - ibase : 0, in->get_datptr (0, 1) - ibase,
+               obase, out->get_nchan () > 1 ? out->get_datptr (1, 0) - obase : 0,
+               out->get_npol () > 1 ? out->get_datptr (0, 1) - obase : 0,
+               in->get_nchan (), in->get_ndat ()), "HIP::DetectionEngine::polarimetry");
+    }
+
+    void square_law (const dsp::TimeSeries* in, dsp::TimeSeries* out)
+    {
+      const float* ibase = in->get_datptr (0, 0);
+      float* obase = out->get_datptr (0, 0);
+      check (ctx, dspsr_amd_detect_square_law (ctx, out->get_state () == Signal::Intensity, ibase,
+               in->get_nchan () > 1 ? in->get_datptr (1, 0) - ibase : 0,
+               in->get_npol () > 1 ? in->get_datptr (0, 1) - ibase : 0, obase,
+               out->get_nchan () > 1 ? out->get_datptr (1, 0) - obase : 0,
+               out->get_npol () > 1 ? out->get_datptr (0, 1) - obase : 0,
+               in->get_nchan (), in->get_npol (), in->get_ndat ()), "HIP::DetectionEngine::square_law");
+    }
+
+  protected:
+    dspsr_amd_ctx* ctx;
+  };
+
+  //! dsp::Fold::Engine (Fold.h:249-312).  The device-resident profile lives inside the library;
+  //! get_profiles() exposes it as a PhaseSeries whose Memory is a HIP::DeviceMemory so that
+  //! Fold::get_output()->zero()/resize act on the device (Fold.C:88-94).
+  class FoldEngine : public dsp::Fold::Engine
+  {
+  public:
+    FoldEngine (dspsr_amd_ctx* _ctx) : ctx (_ctx), fold_handle (0)
+    {
+      use_set_bins = true;                       // plan built inside the library (Fold.C:730-740)
+      check (ctx, dspsr_amd_fold_create (ctx, &fold_handle), "HIP::FoldEngine");
+      d_profiles = new dsp::PhaseSeries;
+      d_profiles->set_memory (new DeviceMemory (ctx));
+      synchronized = true;
+    }
+    ~FoldEngine () { dspsr_amd_fold_destroy (fold_handle); }
+
+    void set_nbin (unsigned nbin)
+    { nbin_hits.assign (nbin, 0); check (ctx, dspsr_amd_fold_set_nbin (fold_handle, nbin), "HIP::FoldEngine::set_nbin"); }
+    void set_ndat (uint64_t ndat, uint64_t idat_start)
+    { check (ctx, dspsr_amd_fold_set_ndat (fold_handle, ndat, idat_start), "HIP::FoldEngine::set_ndat"); }
+    void set_bin (uint64_t idat, double ibin, double bins_per_samp)
+    { check (ctx, dspsr_amd_fold_set_bin (fold_handle, idat, ibin, bins_per_samp), "HIP::FoldEngine::set_bin"); }
+    uint64_t set_bins (double phi, double phase_per_sample, uint64_t ndat, uint64_t idat_start)
+    {
+      uint64_t folded = 0;
+      check (ctx, dspsr_amd_fold_set_bins (fold_handle, phi, phase_per_sample, ndat, idat_start,
+                                           &nbin_hits[0], &folded), "HIP::FoldEngine::set_bins");
+      return folded;
+    }
+    uint64_t get_bin_hits (int ibin) { return nbin_hits[ibin]; }
+    uint64_t get_ndat_folded () const { return dspsr_amd_fold_get_ndat_folded (fold_handle); }
+    dsp::PhaseSeries* get_profiles () { return d_profiles; }
+
+    void fold ()
+    {
+      setup ();                                  // Fold::Engine::setup caches input/output pointers (Fold.C:973-1007)
+      check (ctx, dspsr_amd_fold_set_shape (fold_handle, nchan, npol, ndim, d_profiles->get_nbin ()),
+             "HIP::FoldEngine::fold");
+      const dsp::TimeSeries* in = parent->get_input ();
+      const float* ibase = in->get_datptr (0, 0);
+      check (ctx, dspsr_amd_fold_fold (fold_handle, ibase, nchan > 1 ? in->get_datptr (1, 0) - ibase : 0,
+                                       npol > 1 ? in->get_datptr (0, 1) - ibase : 0), "HIP::FoldEngine::fold");
+      synchronized = false;
+    }
+
+    void synch (dsp::PhaseSeries* out)
+    {
+      if (synchronized) return;                  // idempotent (FoldCUDA.cu:132-133)
+      check (ctx, dspsr_amd_fold_synch (fold_handle, out->get_datptr (0, 0)), "HIP::FoldEngine::synch");
+      synchronized = true;
+    }
+
+    void zero () { check (ctx, dspsr_amd_fold_zero (fold_handle), "HIP::FoldEngine::zero"); }
+
+  protected:
+    dspsr_amd_ctx* ctx;
+    dspsr_amd_fold* fold_handle;
+    Reference::To<dsp::PhaseSeries> d_profiles;
+    std::vector<unsigned> nbin_hits;
+  };
+}
+
+#endif
