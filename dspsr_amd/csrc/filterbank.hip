@@ -29,7 +29,7 @@ struct FbGeom {
 };
 
 struct FbIn {
-  int kind;  // 0: float32 rows, 1: int8 generic, 2: int8 caspsr
+  int kind;  // 0: float32 rows, 1: int8 generic, 2: int8 caspsr, 3: (pol0,pol1) byte pairs pre-transposed per tile
   const void* base;
   uint64_t pol_stride;  // float32: floats between pol rows
   uint64_t part_step;   // time samples between parts
@@ -53,11 +53,20 @@ DEV float cvt8(int v, float scale) { return ((float)v + 0.5f) * scale; }
 //   fetch_pair  : issues the global loads, result = up to 4 raw 32-bit words
 //   decode_pair : raw words -> two complex float samples  ((int8 + 0.5) * scale for 8-bit data,
 //                 GenericEightBitUnpackerCUDA.cu:45)
-struct Raw4 { uint32_t w[4]; };
+template <int W> struct RawW { uint32_t w[W]; };
+typedef RawW<4> Raw4;
 
-DEV Raw4 fetch_pair(const FbGeom& g, const FbIn& in, const uint32_t seq, const uint64_t t)
+template <int W> DEV RawW<W> fetch_pair(const FbGeom& g, const FbIn& in, const uint32_t seq, const uint64_t t)
 {
-  Raw4 r = {{0u, 0u, 0u, 0u}};
+  RawW<W> r;
+#pragma unroll
+  for (int i = 0; i < W; i++) r.w[i] = 0u;
+  if constexpr (W == 1) {
+    // one 32-bit word per pair: 8-bit real dual-pol, single input channel, 4-byte aligned (generic order) or
+    // the pre-transposed copy; t is the byte-pair index
+    r.w[0] = *(const uint32_t*)((const uint8_t*)in.base + 2 * t);
+    return r;
+  } else {
   if (in.kind == 0) {                                   // float32 rows
     if (g.real_input) {
       const float* x = (const float*)in.base + t;
@@ -90,10 +99,16 @@ DEV Raw4 fetch_pair(const FbGeom& g, const FbIn& in, const uint32_t seq, const u
     r.w[0] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[skip] << 16) | ((uint32_t)b[skip + 1] << 24);
   }
   return r;
+  }
 }
 
-DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw4& r, cf& a, cf& b)
+template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const RawW<W>& r, cf& a, cf& b)
 {
+  if constexpr (W == 1) {
+    a = make_float2(cvt8((int8_t)(r.w[0] & 0xff), in.scale), cvt8((int8_t)((r.w[0] >> 8) & 0xff), in.scale));
+    b = make_float2(cvt8((int8_t)((r.w[0] >> 16) & 0xff), in.scale), cvt8((int8_t)(r.w[0] >> 24), in.scale));
+    return;
+  } else {
   if (in.kind == 0) {
     if (g.real_input) {
       a = make_float2(__uint_as_float(r.w[0]), g.npol == 2 ? __uint_as_float(r.w[2]) : 0.0f);
@@ -110,6 +125,7 @@ DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw4& r, cf& a, cf& 
     const float v2 = cvt8((int8_t)((r.w[0] >> 16) & 0xff), in.scale), v3 = cvt8((int8_t)(r.w[0] >> 24), in.scale);
     if (g.real_input && g.npol == 1) { a = make_float2(v0, 0.0f); b = make_float2(v2, 0.0f); }
     else { a = make_float2(v0, v1); b = make_float2(v2, v3); }
+  }
   }
 }
 
@@ -146,13 +162,56 @@ template <int R> DEV void apply_pass_twiddle(cf (&v)[R], const uint32_t nb, cons
   for (int k = 0; k < R; k++) v[k] = cmul(v[k], wa);
 }
 
+// ------------------------------------------------------------------------------------ P0
+// 8-bit pre-transposition: P1 needs, for every na (stride Rr samples apart), the T1 adjacent samples of
+// its tile -- 2*T1 bytes per 2*Rr-byte row.  Reading those straight from the block costs one 128-byte line
+// per 8 useful bytes and per lane, so for 8-bit real dual-pol input the window of each part is first
+// regrouped (2 bytes per sample pair, coalesced both ways through LDS) into
+//   Rt[part][tile][na][T1]  (pol0,pol1) byte pairs
+// Both the generic order and the CASPSR 4-sample interleave are accepted.
+__global__ __launch_bounds__(256) void k_raw_transpose(const FbGeom g, const FbIn in, uint16_t* __restrict__ Rt,
+                                                       const uint64_t part0)
+{
+  __shared__ uint16_t sm[32][256 + 2];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t M = 1u << g.logM, Rr = 1u << g.logR, T = 1u << g.logT1;
+  const uint32_t nb0 = blockIdx.x * 256, na0 = blockIdx.y * 32;
+  const uint64_t part = blockIdx.z;
+  const uint64_t t0 = (part0 + part) * in.part_step;
+  const uint32_t ncol = Rr - nb0 < 256 ? Rr - nb0 : 256, nrow = M - na0 < 32 ? M - na0 : 32;
+  for (uint32_t q = tid; q < nrow * (ncol / 4); q += 256) {       // 4 samples (8 bytes) per thread and step
+    const uint32_t r = q / (ncol / 4), c4 = (q % (ncol / 4)) * 4;
+    const uint64_t t = t0 + (((uint64_t)(na0 + r)) << g.logR) + nb0 + c4;   // multiple of 4
+    uint32_t lo, hi;                                                  // samples t,t+1 | t+2,t+3 as byte pairs
+    if (in.kind == 2) {
+      const uint32_t* p = (const uint32_t*)((const uint8_t*)in.base + (t >> 2) * 8);
+      const uint32_t p0 = p[0], p1 = p[1];
+      lo = (p0 & 0xff) | ((p1 & 0xff) << 8) | ((p0 & 0xff00) << 8) | ((p1 & 0xff00) << 16);
+      hi = ((p0 >> 16) & 0xff) | (((p1 >> 16) & 0xff) << 8) | ((p0 >> 24) << 16) | ((p1 >> 24) << 24);
+    } else {
+      const uint32_t* p = (const uint32_t*)((const uint8_t*)in.base + 2 * t);
+      lo = p[0];
+      hi = p[1];
+    }
+    sm[r][c4] = (uint16_t)lo; sm[r][c4 + 1] = (uint16_t)(lo >> 16);
+    sm[r][c4 + 2] = (uint16_t)hi; sm[r][c4 + 3] = (uint16_t)(hi >> 16);
+  }
+  __syncthreads();
+  uint16_t* __restrict__ dst = Rt + part * ((uint64_t)M << g.logR);
+  const uint32_t ntl = ncol >> g.logT1;
+  for (uint32_t q = tid; q < ntl * nrow * T; q += 256) {           // [tile][row][col] runs of nrow*T pairs
+    const uint32_t col = q & (T - 1), r = (q >> g.logT1) % nrow, tl = (q >> g.logT1) / nrow;
+    dst[(((uint64_t)((nb0 >> g.logT1) + tl) << g.logM) + na0 + r) * T + col] = sm[r][tl * T + col];
+  }
+}
+
 // ------------------------------------------------------------------------------------ P1
 // M-point forward FFTs down T1 adjacent stride-Rr columns of one sequence of one part.
 //   in : sample n = na*Rr + nb (8-bit or float32, converted on load), nb = tile*T1 + col
 //   out: A[ka/T2][nb][ka%T2] = W_L^{nb*ka} * sum_na w[na*Rr+nb] W_M^{na*ka}
 // Persistent: each workgroup walks its items (tile fastest, then sequence, then part) and
 // prefetches the raw samples of the next item while transforming the current one.
-template <int LOGF>
+template <int LOGF, int RAWW>
 __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in, cf* __restrict__ A,
                                                   const cf* __restrict__ tw, const uint64_t part0,
                                                   const uint32_t nparts, const uint32_t nseq, const uint32_t run)
@@ -167,25 +226,29 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
   const uint32_t ntile = 1u << (g.logR - logT);
   const uint64_t total = (uint64_t)ntile * nseq * nparts;
 
-  auto fetch = [&](const uint64_t item, Raw4 (&raw)[PTS / 2]) {
+  auto fetch = [&](const uint64_t item, RawW<RAWW> (&raw)[PTS / 2]) {
     const uint32_t tile = (uint32_t)(item % ntile);
     const uint64_t rest = item / ntile;
     const uint32_t seq = (uint32_t)(rest % nseq);
-    const uint64_t t0 = (part0 + rest / nseq) * in.part_step + tile * T;
+    const bool pret = in.kind == 3;   // pre-transposed: [part][tile][na][T] pairs, contiguous per tile
+    const uint64_t t0 = pret ? ((rest / nseq) * ntile + tile) * ((uint64_t)T << g.logM)
+                             : (part0 + rest / nseq) * in.part_step + tile * T;
 #pragma unroll
     for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
       for (int i = 0; i < P::R1; i++) {
         const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
-        if (g.dbg & 2) { Raw4 z = {{e, 0u, 0u, 0u}}; raw[(g2 / 2) * P::R1 + i] = z; }
-        else raw[(g2 / 2) * P::R1 + i] = fetch_pair(g, in, seq, t0 + (((uint64_t)(e >> logT)) << g.logR) + (e & (T - 1)));
+        if (g.dbg & 2) { RawW<RAWW> z; z.w[0] = e; raw[(g2 / 2) * P::R1 + i] = z; }
+        else raw[(g2 / 2) * P::R1 + i] = fetch_pair<RAWW>(g, in, seq, pret ? t0 + e : t0 + (((uint64_t)(e >> logT)) << g.logR) + (e & (T - 1)));
       }
   };
 
+  const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
+  ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
   uint64_t item, next;
   uint32_t j = 0;
   if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
-  Raw4 raw[PTS / 2];
+  RawW<RAWW> raw[PTS / 2];
   fetch(item, raw);
   for (;;) {
     asm volatile("" : "+v"(tid));   // per-tile index math stays inside the loop (see wgfft)
@@ -194,13 +257,15 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
       for (int i = 0; i < P::R1; i++)
-        decode_pair(g, in, raw[(g2 / 2) * P::R1 + i], x[g2 * P::R1 + i], x[(g2 + 1) * P::R1 + i]);
+        decode_pair<RAWW>(g, in, raw[(g2 / 2) * P::R1 + i], x[g2 * P::R1 + i], x[(g2 + 1) * P::R1 + i]);
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
     if (more) fetch(next, raw);
 
     const uint32_t tile = (uint32_t)(item % ntile);
     const uint64_t rest = item / ntile;
     cf* __restrict__ Aseq = A + ((rest / nseq) * nseq + rest % nseq) * L;
+    // last-stage outputs go to LDS in A-layout order [ka/T2][col][ka%T2]; after a barrier the tile is
+    // written out as whole runs of T*T2 elements with 16-byte-per-lane stores
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& va, auto& vb) {
       constexpr int R = sizeof(va) / sizeof(va[0]);
       const uint32_t nb = tile * T + col;
@@ -208,18 +273,26 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
         apply_pass_twiddle<R>(va, nb, p, pstride, logL);
         apply_pass_twiddle<R>(vb, nb + 1, p, pstride, logL);
       }
-      if (g.dbg & 1) { if (va[0].x == 1.2345f && vb[R - 1].y == 3.3f) Aseq[0] = va[0]; return; }
 #pragma unroll
       for (int k = 0; k < R; k++) {
         const uint32_t ka = k * pstride + p;
-        uint64_t o = ((((uint64_t)(ka >> logT2) << g.logR) + nb) << logT2) | (ka & (T2 - 1));
-        uint64_t o2 = o + T2;
-        if (g.dbg & 4) { o = ((uint64_t)tile << (g.logM + logT)) + (((uint64_t)ka << logT) | col); o2 = o + 1; }
-        Aseq[o] = va[k];
-        Aseq[o2] = vb[k];
+        const uint32_t l = ((((ka >> logT2) << logT) + col) << logT2) | (ka & (T2 - 1));
+        lds[lds_pad(l)] = va[k];
+        lds[lds_pad(l + T2)] = vb[k];
       }
     };
-    wgfft<LOGF, -1>(lds, tid, logT, tw, x, store);
+    wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, tw, x, store);
+    __syncthreads();
+    if (!(g.dbg & 1)) {
+      const uint32_t nthr = blockDim.x;
+#pragma unroll 4
+      for (int jj = 0; jj < PTS / 2; jj++) {
+        const uint32_t l = 2 * (tid + jj * nthr);                  // element index inside the staged tile
+        const uint32_t blkA = l >> (logT + logT2), within = l & ((1u << (logT + logT2)) - 1);
+        const float4 pr = *(const float4*)&lds[lds_pad(l)];
+        *(float4*)&Aseq[((((uint64_t)blkA << g.logR) + tile * T) << logT2) + within] = pr;
+      }
+    }
     if (!more) break;
     item = next;
   }
@@ -257,6 +330,8 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
       }
   };
 
+  const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
+  ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
   uint64_t item, next;
   uint32_t j = 0;
   if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
@@ -272,20 +347,30 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
 
     const uint32_t tile = (uint32_t)(item % ntile);
     cf* __restrict__ Xseq = X + (item / ntile) * L;
+    // last-stage outputs go to LDS in X-layout order [s'/T3][klo][s'%T3]; after a barrier the tile is
+    // written out as whole runs of T2*T3 elements with 16-byte-per-lane stores
     auto store = [&](const uint32_t klo, const uint32_t p, const uint32_t pstride, auto& va, auto& vb) {
       constexpr int R = sizeof(va) / sizeof(va[0]);
-      if (g.dbg & 1) { if (va[0].x == 1.2345f && vb[R - 1].y == 3.3f) Xseq[0] = va[0]; return; }
 #pragma unroll
       for (int k = 0; k < R; k++) {
         const uint32_t srow = k * pstride + p;
-        uint64_t o = ((((uint64_t)(srow >> logT3) << g.logM) + tile * T2 + klo) << logT3) | (srow & (T3 - 1));
-        uint64_t o2 = o + T3;
-        if (g.dbg & 4) { o = ((uint64_t)tile << (g.logR + logT)) + (((uint64_t)srow << logT) | klo); o2 = o + 1; }
-        Xseq[o] = va[k];
-        Xseq[o2] = vb[k];
+        const uint32_t l = ((((srow >> logT3) << logT) + klo) << logT3) | (srow & (T3 - 1));
+        lds[lds_pad(l)] = va[k];
+        lds[lds_pad(l + T3)] = vb[k];
       }
     };
-    wgfft<LOGF, -1>(lds, tid, logT, tw, x, store);
+    wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, tw, x, store);
+    __syncthreads();
+    if (!(g.dbg & 1)) {
+      const uint32_t nthr = blockDim.x;
+#pragma unroll 4
+      for (int jj = 0; jj < PTS / 2; jj++) {
+        const uint32_t l = 2 * (tid + jj * nthr);
+        const uint32_t blkX = l >> (logT + logT3), within = l & ((1u << (logT + logT3)) - 1);
+        const float4 pr = *(const float4*)&lds[lds_pad(l)];
+        *(float4*)&Xseq[((((uint64_t)blkX << g.logM) + tile * T2) << logT3) + within] = pr;
+      }
+    }
     if (!more) break;
     item = next;
   }
@@ -326,7 +411,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   const uint64_t blk = ((uint64_t)M) << logT3;  // elements per X block
   const uint32_t ntile = g.C >> logT3;
   const uint64_t total = (uint64_t)ntile * nparts;
-  struct Abk { cf a, b, k; };
+  struct Abk { cf a, b; };   // the chirp is fetched at the start of the item (keeps the prefetch at 64 registers)
 
   auto fetch = [&](const uint64_t item, Abk (&raw)[PTS / 2]) {
     const uint32_t tile = (uint32_t)(item / nparts);
@@ -340,7 +425,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         const uint32_t slo = (e & (T - 1)) >> 1, m = e >> logT;
         const uint32_t s = tile * T3 + slo;
         Abk r;
-        if (g.dbg & 2) { r.a = make_float2(m, slo); r.b = r.a; r.k = r.a; raw[(g2 / 2) * P::R1 + i] = r; continue; }
+        if (g.dbg & 2) { r.a = make_float2(m, slo); r.b = r.a; raw[(g2 / 2) * P::R1 + i] = r; continue; }
         r.a = X0s[tile * blk + ((uint64_t)m << logT3) + slo];
         if (g.real_input) {
           if (m > 0) {
@@ -352,11 +437,12 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         } else {
           r.b = g.npol == 2 ? X0s[L + tile * blk + ((uint64_t)m << logT3) + slo] : make_float2(0.f, 0.f);
         }
-        r.k = kernel ? kernel[((uint64_t)s << g.logM) + m] : make_float2(1.f, 0.f);
         raw[(g2 / 2) * P::R1 + i] = r;
       }
   };
 
+  const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
+  ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
   uint64_t item, next;
   uint32_t j = 0;
   if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
@@ -365,23 +451,36 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   for (;;) {
     asm volatile("" : "+v"(tid));   // per-tile index math stays inside the loop (see wgfft)
     cf x[PTS];
+    {
+      const uint32_t ktile = (uint32_t)(item / nparts);
+      cf kk[PTS / 2];
 #pragma unroll
-    for (int g2 = 0; g2 < P::G1; g2 += 2)
+      for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
-      for (int i = 0; i < P::R1; i++) {
-        const Abk r = raw[(g2 / 2) * P::R1 + i];
-        cf x0, x1;
-        if (g.real_input) {
-          // W[k] = X0[k] + i X1[k] ; conj(W[L-k]) = X0[k] - i X1[k]
-          x0 = make_float2(0.5f * (r.a.x + r.b.x), 0.5f * (r.a.y - r.b.y));
-          x1 = make_float2(0.5f * (r.a.y + r.b.y), 0.5f * (r.b.x - r.a.x));
-        } else {
-          x0 = r.a;
-          x1 = r.b;
+        for (int i = 0; i < P::R1; i++) {
+          const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
+          const uint32_t s = ktile * T3 + ((e & (T - 1)) >> 1), m = e >> logT;
+          kk[(g2 / 2) * P::R1 + i] = (kernel && !(g.dbg & 2)) ? kernel[((uint64_t)s << g.logM) + m] : make_float2(1.f, 0.f);
         }
-        x[g2 * P::R1 + i] = cmul(r.k, x0);          // Response::operate, Response.C:429-441
-        x[(g2 + 1) * P::R1 + i] = cmul(r.k, x1);
-      }
+#pragma unroll
+      for (int g2 = 0; g2 < P::G1; g2 += 2)
+#pragma unroll
+        for (int i = 0; i < P::R1; i++) {
+          const Abk r = raw[(g2 / 2) * P::R1 + i];
+          const cf k = kk[(g2 / 2) * P::R1 + i];
+          cf x0, x1;
+          if (g.real_input) {
+            // W[k] = X0[k] + i X1[k] ; conj(W[L-k]) = X0[k] - i X1[k]
+            x0 = make_float2(0.5f * (r.a.x + r.b.x), 0.5f * (r.a.y - r.b.y));
+            x1 = make_float2(0.5f * (r.a.y + r.b.y), 0.5f * (r.b.x - r.a.x));
+          } else {
+            x0 = r.a;
+            x1 = r.b;
+          }
+          x[g2 * P::R1 + i] = cmul(k, x0);          // Response::operate, Response.C:429-441
+          x[(g2 + 1) * P::R1 + i] = cmul(k, x1);
+        }
+    }
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
     if (more) fetch(next, raw);
 
@@ -420,7 +519,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         }
       }
     };
-    wgfft<LOGF, +1>(lds, tid, logT, tw, x, store);
+    wgfft<LOGF, +1>(lds, ltw_off, tid, logT, tw, x, store);
     if (!more) break;
     item = next;
   }
@@ -435,12 +534,17 @@ template <int... I> struct iseq {};
 template <int N, int... I> struct mkseq : mkseq<N - 1, N - 1, I...> {};
 template <int... I> struct mkseq<0, I...> { typedef iseq<I...> type; };
 
-template <int... I> static k1_t pick1(int logf, iseq<I...>) { static const k1_t t[] = {k_fwd_cols<I>...}; return t[logf]; }
+template <int... I> static k1_t pick1(int logf, int raww, iseq<I...>)
+{
+  static const k1_t t4[] = {k_fwd_cols<I, 4>...};
+  static const k1_t t1[] = {k_fwd_cols<I, 1>...};
+  return raww == 1 ? t1[logf] : t4[logf];
+}
 template <int... I> static k2_t pick2(int logf, iseq<I...>) { static const k2_t t[] = {k_fwd_rows<I>...}; return t[logf]; }
 template <int... I> static k3_t pick3(int logf, iseq<I...>) { static const k3_t t[] = {k_inv_chan<I>...}; return t[logf]; }
 
 constexpr int MAX_LOGF = 13;    // every pass keeps >= 2 columns per workgroup
-constexpr int LOG_POINTS = 14;  // points per workgroup (32 per thread, 512 threads)
+constexpr int LOG_POINTS_DEFAULT = 14;  // points per workgroup (32 per thread, 512 threads)
 
 static inline int ilog2(uint64_t v) { int l = 0; while ((1ull << l) < v) l++; return l; }
 static inline bool ispow2(uint64_t v) { return v && !(v & (v - 1)); }
@@ -451,11 +555,12 @@ struct dspsr_amd_filterbank_impl {
   FbGeom g;
   uint64_t N, L;
   uint32_t nseq, max_parts;
-  uint32_t nt1, nt2, nt3, ncu;
+  uint32_t nt1, nt2, nt3, ncu, wg_per_cu;
   size_t lds1, lds2, lds3;
   cf* A = nullptr;
   cf* X = nullptr;
   cf* kernel = nullptr;
+  uint16_t* Rt = nullptr;   // pre-transposed 8-bit pairs of the parts of one launch group
   bool kernel_set = false;
 };
 
@@ -516,7 +621,9 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
                    "dspsr_amd_filterbank_create: freq_res=%llu / spectrum rows=%llu exceed the single-pass "
                    "limit 2^%d", (unsigned long long)M, (unsigned long long)Rr, MAX_LOGF);
   }
-  // tiles: every workgroup holds min(2^14, available) points = 16 per thread
+  // tiles: every workgroup holds min(2^14, available) points = 32 per thread
+  const int LOG_POINTS = getenv("DSPSR_AMD_LOG_POINTS") ? atoi(getenv("DSPSR_AMD_LOG_POINTS")) : LOG_POINTS_DEFAULT;
+  fb->wg_per_cu = getenv("DSPSR_AMD_WG_PER_CU") ? atoi(getenv("DSPSR_AMD_WG_PER_CU")) : 1;
   g.logT1 = g.logR < LOG_POINTS - g.logM ? g.logR : LOG_POINTS - g.logM;
   g.logT2 = g.logM < LOG_POINTS - g.logR ? g.logM : LOG_POINTS - g.logR;
   const int logC = ilog2(C), logPol = 1;   // pass 3 always carries (pol0, pol1) column pairs
@@ -537,9 +644,9 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   hipDeviceProp_t prop;
   fb->ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
                 ? (uint32_t)prop.multiProcessorCount : 256u;
-  fb->lds1 = lds_words_host((uint32_t)p1) * sizeof(cf);
-  fb->lds2 = lds_words_host((uint32_t)p2) * sizeof(cf);
-  fb->lds3 = lds_words_host((uint32_t)p3) * sizeof(cf);
+  fb->lds1 = lds_total_words_host((uint32_t)p1) * sizeof(cf);
+  fb->lds2 = lds_total_words_host((uint32_t)p2) * sizeof(cf);
+  fb->lds3 = lds_total_words_host((uint32_t)p3) * sizeof(cf);
   fb->max_parts = cfg->max_parts ? cfg->max_parts : 1;
   const size_t scratch = (size_t)fb->max_parts * fb->nseq * fb->L * sizeof(cf);
   if (hipMalloc((void**)&fb->A, scratch) != hipSuccess || hipMalloc((void**)&fb->X, scratch) != hipSuccess) {
@@ -559,6 +666,7 @@ extern "C" void dspsr_amd_filterbank_destroy(dspsr_amd_filterbank* fb)
   if (fb->A) (void)hipFree(fb->A);
   if (fb->X) (void)hipFree(fb->X);
   if (fb->kernel) (void)hipFree(fb->kernel);
+  if (fb->Rt) (void)hipFree(fb->Rt);
   delete fb;
 }
 
@@ -619,7 +727,18 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   if (npart == 0) return DSPSR_AMD_OK;
   const FbGeom& g = fb->g;
   typedef mkseq<MAX_LOGF + 1>::type seq_t;
-  k1_t k1 = pick1(g.logM, seq_t());
+  // 8-bit real dual-pol single-channel input: one 32-bit word per sample pair; regroup it per tile first
+  // (k_raw_transpose) unless the rows are already long enough or the layout preconditions fail
+  const bool fast8 = (in.kind == 1 || in.kind == 2) && g.real_input && g.npol == 2 && fb->cfg.input_nchan == 1 &&
+                     ((uintptr_t)in.base % 4) == 0;
+  bool pret = fast8 && g.logR >= 2 && g.logT1 <= 5 && !getenv("DSPSR_AMD_NO_PRETRANSPOSE");   // rows of >= 128 B need no regrouping
+  if (pret && in.kind == 2 && (in.part_step % 4) != 0) pret = false;
+  if (pret && !fb->Rt) {
+    if (hipMalloc((void**)&fb->Rt, (size_t)fb->max_parts * fb->L * sizeof(uint16_t)) != hipSuccess)
+      return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of the 8-bit regroup buffer failed");
+  }
+  const int raww = (pret || (fast8 && in.kind == 1)) ? 1 : 4;
+  k1_t k1 = pick1(g.logM, raww, seq_t());
   k2_t k2 = pick2(g.logR, seq_t());
   k3_t k3 = pick3(g.logM, seq_t());
   hipError_t e;
@@ -642,11 +761,19 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
       const uint64_t n1 = (uint64_t)(Rr >> g.logT1) * fb->nseq * nb, n2 = (uint64_t)(M >> g.logT2) * fb->nseq * nb,
                      n3 = (uint64_t)(g.C >> g.logT3) * nb;
       const uint32_t run1 = 32, run2 = 4, run3 = nb;
-      hipLaunchKernelGGL(k1, dim3(grid_for(n1, fb->ncu)), dim3(fb->nt1), fb->lds1, ctx->stream, g, ci, fb->A, ctx->tw,
+      if (pret) {
+        hipLaunchKernelGGL(k_raw_transpose, dim3((Rr + 255) / 256, (M + 31) / 32, nb), dim3(256), 0, ctx->stream, g, ci,
+                           fb->Rt, part0);
+        ci.kind = 3;
+        ci.base = fb->Rt;
+      }
+      hipLaunchKernelGGL(k1, dim3(grid_for(n1, fb->ncu * fb->wg_per_cu)), dim3(fb->nt1), fb->lds1, ctx->stream, g, ci, fb->A, ctx->tw,
                          part0, nb, fb->nseq, run1);
-      hipLaunchKernelGGL(k2, dim3(grid_for(n2, fb->ncu)), dim3(fb->nt2), fb->lds2, ctx->stream, g, fb->A, fb->X,
+      ci = in; ci.ichan = ichan; ci.nchan = fb->cfg.input_nchan;
+      if (in.kind == 0) ci.base = in_f32 + ichan * in_chan_stride_bytes_or_floats;
+      hipLaunchKernelGGL(k2, dim3(grid_for(n2, fb->ncu * fb->wg_per_cu)), dim3(fb->nt2), fb->lds2, ctx->stream, g, fb->A, fb->X,
                          ctx->tw, nb, fb->nseq, run2);
-      hipLaunchKernelGGL(k3, dim3(grid_for(n3, fb->ncu)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern, co,
+      hipLaunchKernelGGL(k3, dim3(grid_for(n3, fb->ncu * fb->wg_per_cu)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern, co,
                          ctx->tw, part0, nb, run3);
     }
   }

@@ -34,7 +34,9 @@ template <int SIGN> DEV cf mul_si(cf a) { return SIGN < 0 ? make_float2(a.y, -a.
 // 4 words of padding per 64 keep the strided stage writes spread over the LDS banks
 // and preserve 16-byte alignment of even word indices
 DEV uint32_t lds_pad(uint32_t e) { return e + ((e >> 6) << 2); }
-inline uint32_t lds_words_host(uint32_t points) { return points + ((points >> 6) << 2) + 8; }
+inline uint32_t lds_words_host(uint32_t points) { return points + ((points >> 6) << 2) + 8; }   // exchange buffer
+// total dynamic LDS words of a kernel: exchange buffer followed by the half twiddle table
+inline uint32_t lds_total_words_host(uint32_t points) { return lds_words_host(points) + 2304; }
 
 constexpr int PTS = 32;      // points per thread
 constexpr int LOG_PTS = 5;
@@ -142,6 +144,31 @@ template <int R> DEV void apply_powers(cf (&v)[R], const cf w1, const cf w2, con
 constexpr int LOG_TWN = 14;
 constexpr int TWN = 1 << LOG_TWN;
 
+// Stage twiddles live in LDS behind the exchange buffer, one small table per twiddled (radix-16) stage:
+//   table[st][kk][s] = W_{16 Q}^{(1<<kk) s},  kk < 4, s < Q = F / 16^(st+1)
+// so the transform phase issues no global loads (the in-order vmcnt would otherwise force the next
+// tile's prefetch and the previous tile's stores to drain), and lanes read consecutive or identical
+// entries (conflict-free).  4*(F/16 + F/256 + ...) < 0.27 F entries.
+constexpr int LTW_MAX_ENTRIES = 2304;       // enough for F = 8192
+template <int LOGF> DEV void ltw_fill(cf* lds, const uint32_t ltw_off, const cf* __restrict__ tw, const uint32_t tid,
+                                      const uint32_t nt)
+{
+  constexpr int NQ = LOGF / 4, REM = LOGF % 4;
+  constexpr int NTW = NQ - (REM ? 0 : 1);   // twiddled stages: every radix-16 stage except a final one
+  uint32_t off = 0;
+#pragma unroll
+  for (int st = 0; st < NTW; st++) {
+    const int logQ = LOGF - 4 * (st + 1);
+    const uint32_t Q = 1u << logQ;
+    for (uint32_t i = tid; i < 4 * Q; i += nt) {
+      const uint32_t kk = i >> logQ, sidx = i & (Q - 1);
+      lds[ltw_off + off + i] = tw[((sidx << kk) << (LOG_TWN - 4 - logQ)) & (TWN - 1)];
+    }
+    off += 4 * Q;
+  }
+  __syncthreads();
+}
+
 // radix plan of an F = 2^LOGF transform
 template <int LOGF> struct FftPlan {
   static constexpr int NQ = LOGF / 4, REM = LOGF % 4;
@@ -160,9 +187,9 @@ template <int LOGF> DEV uint32_t first_stage_elem(uint32_t tid, int logT, int g,
 
 // Out: void operator()(uint32_t col, uint32_t p, uint32_t pstride, cf (&va)[R], cf (&vb)[R])
 //      va[k] / vb[k] are output position k*pstride + p of columns col (even) and col + 1
-template <int LOGR, int SIGN, bool FIRST, bool LAST, class Out>
-DEV void wgfft_stage(cf* lds, const uint32_t tid, const int logT, const int logF, const int logP,
-                     const cf* __restrict__ tw, cf (&x)[PTS], Out& out)
+template <int LOGR, int SIGN, bool FIRST, bool LAST, bool STAGED, class Out>
+DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const int logT, const int logF,
+                     const int logP, const cf* __restrict__ tw, cf (&x)[PTS], Out& out)
 {
   constexpr int R = 1 << LOGR;
   constexpr int G = PTS / R;
@@ -190,16 +217,16 @@ DEV void wgfft_stage(cf* lds, const uint32_t tid, const int logT, const int logF
     if (R > 1 && logQ > 0) {
       const uint32_t u = G * tid + g;
       const uint32_t s = u >> (logT + logP);
-      const int sh = LOG_TWN - LOGR - logQ;
-      cf w1 = tw[s << sh], w2 = w1, w4 = w1, w8 = w1;
-      if (R >= 4) w2 = tw[s << (sh + 1)];
-      if (R >= 8) w4 = tw[s << (sh + 2)];
-      if (R >= 16) w8 = tw[s << (sh + 3)];
+      // only radix-16 stages carry twiddles (a remainder stage is always last)
+      const uint32_t tb = ltw_off + s;
+      cf w1 = lds[tb], w2 = lds[tb + (1u << logQ)], w4 = lds[tb + (2u << logQ)], w8 = lds[tb + (3u << logQ)];
       if (SIGN > 0) { w1.y = -w1.y; w2.y = -w2.y; w4.y = -w4.y; w8.y = -w8.y; }
       apply_powers<R>(v[g], w1, w2, w4, w8);
     }
   }
-  if (!LAST) __syncthreads();   // every read of the in-place exchange buffer (this or the previous tile) is done
+  // every read of the in-place exchange buffer (this or the previous tile) is done; a STAGED last stage
+  // re-uses the buffer to reorder its outputs, so it needs the same guarantee
+  if (!LAST || (STAGED && !FIRST)) __syncthreads();
 #pragma unroll
   for (int g = 0; g < G; g += 2) {
     const uint32_t u = G * tid + g;
@@ -223,25 +250,29 @@ DEV void wgfft_stage(cf* lds, const uint32_t tid, const int logT, const int logF
 // Runs the whole F-point transform of one tile: x feeds the first stage, `out` receives the last.
 // May be called repeatedly (persistent workgroup): the barrier in front of the first LDS write
 // also separates it from the previous tile's last-stage LDS reads.
-template <int LOGF, int SIGN, class Out>
-DEV void wgfft(cf* lds, uint32_t tid, const int logT, const cf* __restrict__ tw, cf (&x)[PTS], Out& out)
+// STAGED: `out` writes into the exchange buffer (the caller copies it out after a barrier).
+template <int LOGF, int SIGN, bool STAGED = false, class Out>
+DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, const cf* __restrict__ tw,
+               cf (&x)[PTS], Out& out)
 {
   typedef FftPlan<LOGF> P;
   // opaque copy: LDS addresses and twiddle indices are loop-invariant in a persistent workgroup and
   // would otherwise be hoisted out of the tile loop and spilled (hundreds of registers)
   asm volatile("" : "+v"(tid));
   if constexpr (P::NS <= 1) {
-    wgfft_stage<P::LOGR1, SIGN, true, true>(lds, tid, logT, LOGF, 0, tw, x, out);
+    wgfft_stage<P::LOGR1, SIGN, true, true, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, tw, x, out);
   } else {
-    wgfft_stage<4, SIGN, true, false>(lds, tid, logT, LOGF, 0, tw, x, out);
+    wgfft_stage<4, SIGN, true, false, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, tw, x, out);
     int logP = 4;
+    uint32_t toff = ltw_off + (4u << (LOGF - 4));
 #pragma unroll
     for (int j = 1; j < P::NQ - (P::REM ? 0 : 1); j++) {
-      wgfft_stage<4, SIGN, false, false>(lds, tid, logT, LOGF, logP, tw, x, out);
+      wgfft_stage<4, SIGN, false, false, STAGED>(lds, toff, tid, logT, LOGF, logP, tw, x, out);
       logP += 4;
+      toff += 4u << (LOGF - logP);
     }
-    if constexpr (P::REM != 0) wgfft_stage<P::REM, SIGN, false, true>(lds, tid, logT, LOGF, logP, tw, x, out);
-    else wgfft_stage<4, SIGN, false, true>(lds, tid, logT, LOGF, logP, tw, x, out);
+    if constexpr (P::REM != 0) wgfft_stage<P::REM, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, tw, x, out);
+    else wgfft_stage<4, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, tw, x, out);
   }
 }
 

