@@ -87,6 +87,62 @@ class Polyco:
         return self.f0 + d / 60.0
 
 
+def choose_nbin(folding_period, rate, requested_nbin=0, maximum_nbin=1024, minimum_bin_width=1.2,
+                power_of_two=True, force_sensible_nbin=False):
+    """dsp::Fold::choose_nbin (Fold.C:291-382): largest power of two <= period / (1.2 * tsamp), capped at
+    maximum_nbin, unless -b requested_nbin was given."""
+    if folding_period <= 0.0:
+        raise DspsrAmdError("dsp::Fold::choose_nbin invalid folding period=%f" % folding_period)
+    ratio = folding_period / (minimum_bin_width / rate)
+    sensible = int(2.0 ** math.floor(math.log(ratio) / math.log(2.0))) if power_of_two else int(ratio)
+    sensible = max(sensible, 1)
+    if requested_nbin > 1:
+        return sensible if (force_sensible_nbin and requested_nbin > sensible) else requested_nbin
+    return maximum_nbin if (maximum_nbin and sensible > maximum_nbin) else sensible
+
+
+def subint_bounds(k, division_seconds, rate):
+    """[first, last) output sample of division k, with the two roundings of TimeDivide::set_boundaries
+    (TimeDivide.C:503-540): lower = lrint(k*L*rate); division_ndat = lrint((k+1)*L*rate - lower) evaluated in
+    seconds like the reference.  Python's round() is the same round-half-even as lrint."""
+    lower = int(round(float(k) * division_seconds * rate))
+    ndat = int(round((float(k + 1) * division_seconds - lower / rate) * rate))
+    return lower, lower + ndat
+
+
+def subint_pieces(first_sample, ndat, division_seconds, rate):
+    """Subint<Fold> / TimeDivide in seconds mode (TimeDivide.C:440-459,503-540, Subint.h:234-309), expressed
+    in output samples (the observation start is the start of division 0).  Splits the block
+    [first_sample, first_sample+ndat) into (idat_start, ndat_fold, division, division_complete) pieces."""
+    out = []
+    pos = first_sample
+    end = first_sample + ndat
+    k = max(int(pos / (division_seconds * rate)) - 1, 0)
+    while subint_bounds(k, division_seconds, rate)[1] <= pos:
+        k += 1
+    while pos < end:
+        upper = subint_bounds(k, division_seconds, rate)[1]
+        stop = min(end, upper)
+        out.append((pos - first_sample, stop - pos, k, stop == upper))
+        pos = stop
+        if pos == upper:
+            k += 1
+    return out
+
+
+def normalise_profile(profile, hits, scale):
+    """dsp::Archiver::set (Archiver.C:773-893): amps = sum / (scale * hits); bins without hits take the mean
+    of the others.  profile: [nchan][npol][nbin][ndim] sums, hits: [nbin]."""
+    hits = np.asarray(hits, dtype=np.float64)
+    prof = np.asarray(profile, dtype=np.float64)
+    ok = hits > 0
+    amps = np.zeros_like(prof)
+    amps[:, :, ok, :] = prof[:, :, ok, :] / (scale * hits[ok])[None, None, :, None]
+    if ok.any() and not ok.all():
+        amps[:, :, ~ok, :] = amps[:, :, ok, :].mean(axis=2, keepdims=True)
+    return amps.astype(np.float32)
+
+
 def reduce_subbands(prof, dist=None, rank=0, world=1, gather_buffer=None):
     """The ONE collective of the path.  Each rank holds the folded profile of its own frequency sub-band
     (flat [nchan*npol*nbin*ndim] float32).  The full-band buffer [world][...] is zero outside the rank's
@@ -187,17 +243,34 @@ class LoadToFold:
         if events is not None:
             events[1].record()
         ndat = npart * self.nkeep
-        # Fold::fold (Fold.C:650-657,718-803): phase at the midpoint of the first sample of this block
-        t0 = self.out_start + (self.ndat_out + 0.5) / self.out_rate
-        phi, pfold = self._phase(t0)
-        self.fold.set_nbin(cfg.nbin)
-        self.fold.set_ndat(ndat, 0)
-        folded = self.fold.set_bins(phi, (1.0 / self.out_rate) / pfold, ndat, 0, self.hits)
-        self.fold.fold(self.detected)
-        self.integration_length += folded / self.out_rate
-        self.ndat_total += ndat
+        # Subint<Fold>::transformation: fold piece by piece, emitting a sub-integration at every boundary
+        if self.cfg.subint_seconds > 0:
+            pieces = subint_pieces(self.ndat_out, ndat, self.cfg.subint_seconds, self.out_rate)
+        else:
+            pieces = [(0, ndat, 0, False)]
+        for idat_start, ndat_fold, _division, complete in pieces:
+            self._fold_piece(idat_start, ndat_fold)
+            if complete:
+                self.finish_subint(*self._subint_comm)
         self.ndat_out += ndat
         self.nsamples_in += npart * self.nsamp_step
+
+    _subint_comm = (None, 0, 1, None)     # (dist, rank, world, gather_buffer) used at sub-integration dumps
+
+    def set_communicator(self, dist, rank, world, gather_buffer):
+        self._subint_comm = (dist, rank, world, gather_buffer)
+
+    def _fold_piece(self, idat_start, ndat_fold):
+        """Fold::fold (Fold.C:650-657,718-803) on detected[idat_start : idat_start+ndat_fold]."""
+        cfg = self.cfg
+        t0 = self.out_start + (self.ndat_out + idat_start + 0.5) / self.out_rate     # midpoint of first sample
+        phi, pfold = self._phase(t0)
+        self.fold.set_nbin(cfg.nbin)
+        self.fold.set_ndat(ndat_fold, idat_start)
+        folded = self.fold.set_bins(phi, (1.0 / self.out_rate) / pfold, ndat_fold, idat_start, self.hits)
+        self.fold.fold(self.detected)
+        self.integration_length += folded / self.out_rate
+        self.ndat_total += ndat_fold
 
     def profiles_tensor(self):
         """Zero-copy torch view of the device-resident PhaseSeries (Fold::Engine::get_profiles)."""

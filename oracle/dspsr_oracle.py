@@ -718,6 +718,29 @@ def fold(detected: np.ndarray, obs: Observation, cfg: FoldConfig, out: PhaseSeri
     return plan
 
 
+def choose_nbin(folding_period: float, rate: float, requested_nbin: int = 0, maximum_nbin: int = 1024,
+                minimum_bin_width: float = 1.2, power_of_two: bool = True, force_sensible_nbin: bool = False) -> int:
+    """dsp::Fold::choose_nbin (Fold.C:291-382)."""
+    if folding_period <= 0.0:
+        raise OracleError("dsp::Fold::choose_nbin invalid folding period=%f" % folding_period)
+    sampling_period = 1.0 / rate
+    binwidth = minimum_bin_width * sampling_period
+    sensible = int(folding_period / binwidth)
+    if power_of_two:
+        log2bin = math.log(folding_period / binwidth) / math.log(2.0)
+        sensible = int(math.pow(2.0, math.floor(log2bin)))
+    if sensible == 0:
+        sensible = 1
+    if requested_nbin > 1:
+        nbin = requested_nbin
+        if requested_nbin > sensible and force_sensible_nbin:
+            nbin = sensible
+        return nbin
+    if maximum_nbin and sensible > maximum_nbin:
+        return maximum_nbin
+    return sensible
+
+
 def archive_profile(ps: PhaseSeries, scale: float) -> np.ndarray:
     """dsp::Archiver::set normalisation (Archiver.C:773-893): amp = sum / (scale * hits);
     zero-hit bins take the mean of the others."""
@@ -747,6 +770,15 @@ def subint_boundaries(obs: Observation, division_seconds: float, t_seconds: floa
     lower = start + samples / rate
     division_ndat = int(round((mjd2 - lower) * rate))
     return division, lower, division_ndat
+
+
+def subint_sample_bounds(obs: Observation, division_seconds: float, division: int) -> tuple[int, int]:
+    """[first, last) output sample of a division, following TimeDivide::set_boundaries (TimeDivide.C:503-540):
+    lower = start + lrint(k*L*rate)/rate ; division_ndat = lrint((start + (k+1)*L - lower)*rate)."""
+    rate = obs.rate
+    lower = int(round(float(division) * division_seconds * rate))
+    ndat = int(round((float(division + 1) * division_seconds - lower / rate) * rate))
+    return lower, lower + ndat
 
 
 # --------------------------------------------------------------------------------------

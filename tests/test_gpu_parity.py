@@ -292,3 +292,47 @@ def test_end_to_end_folded_profile(oracle, gpu):
     assert prof.max() > 1.5 * np.median(prof)
     eng.close()
     fold.close()
+
+
+def test_pipeline_subintegrations(oracle, gpu):
+    """LoadToFold driver with -L sub-integrations over several blocks (overlap carried between blocks) against
+    the oracle folding the same pieces: identical hits per sub-integration, profiles <= 1e-5."""
+    dspsr_amd, _ = gpu
+    from dspsr_amd import pipeline, synth
+    o = oracle
+    freq, bw, tsamp, dm, period, nchan, nbin = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004, 16, 64
+    cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=4,
+                          parts_per_block=3, max_parts=2, subint_seconds=0.002)
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
+    lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    nblocks = 4
+    step = cfg.parts_per_block * lt.nsamp_step
+    ndat = nblocks * step + lt.nsamp_overlap
+    raw = synth.voltages(ndat, freq, bw, tsamp, dm, period)
+    d_raw = torch.from_numpy(raw).cuda()
+    for b in range(nblocks):
+        lt.process_block(d_raw[2 * b * step: 2 * (b * step + step + lt.nsamp_overlap)])
+    lt.synchronize()
+    got = [(s["hits"], s["profile_dev"].cpu().numpy().reshape(nchan, 1, nbin, 4)) for s in lt.subints]
+    assert len(got) >= 2
+    # oracle: whole stream in one go, then fold division by division
+    obs = o.Observation(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, dispersion_measure=dm)
+    resp = o.Dedispersion().match(obs, nchan)
+    plan = o.filterbank_plan(obs, nchan, resp)
+    fb = o.filterbank(o.unpack_8bit(raw, obs), plan, lt.response.kernel, dtype=np.float64)
+    det = o.detect_layout(o.detect_products(fb, "Coherence"), 4)
+    fobs = o.filterbank_output_observation(obs, plan)
+    fcfg = o.FoldConfig(nbin=nbin, folding_period=period)
+    block_out = cfg.parts_per_block * plan.nkeep
+    for isub, (hits, prof) in enumerate(got):
+        ps = o.PhaseSeries(nchan, 1, 4, nbin, data=np.zeros((nchan, 1, nbin, 4), np.float64))
+        lo, hi = o.subint_sample_bounds(fobs, cfg.subint_seconds, isub)
+        # the product folds piecewise (block and division boundaries restart the phase recurrence, Fold.C:650-657)
+        pos = lo
+        while pos < hi:
+            stop = min(hi, (pos // block_out + 1) * block_out)
+            o.fold(det, fobs, fcfg, ps, idat_start=pos, ndat_fold=stop - pos)
+            pos = stop
+        assert np.array_equal(hits, ps.hits), isub
+        assert np.abs(prof - ps.data).max() <= 1e-5 * np.abs(ps.data).max(), isub
+    lt.close()
