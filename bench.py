@@ -51,7 +51,19 @@ def algorithmic_bytes_per_part(npol, nsamp_fft, nbit, N, nchan_subband, nkeep):
     return npol * nsamp_fft * nbit // 8 + 8 * N + npol * nchan_subband * nkeep * 8
 
 
-def cpu_baseline(wl, lt, nparts=1):
+def measured_traffic(workload, max_parts):
+    """HBM bytes per launch group from the committed PMC profile (rocprofv3 cannot run inside the bench);
+    None when the profile was taken for another workload / grouping."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01b_traffic.json")))
+        if d["workload"] == workload and d["parts_per_launch_group"] == max_parts:
+            return d["hbm_bytes_per_launch_group"]
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(wl, lt, nparts=24):
     """Times the numpy oracle (oracle/dspsr_oracle.py, a 'port') on `nparts` parts of the same workload."""
     import oracle.dspsr_oracle as o
     obs = o.Observation(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=wl["in_nchan"], npol=2,
@@ -183,7 +195,10 @@ def main():
                        "detected_ndim": cfg.ndim, "parallelism": "sub-band per GPU x%d" % world,
                        "realtime_factor": round(value / world / (info.rate / 1e6), 3)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": measured_traffic(args.workload, cfg.max_parts),
+                         "traffic_unit": "HBM bytes per launch group of %d parts (profiles/r01b_traffic.json); "
+                                         "algorithmic bytes for the same group: %d" % (cfg.max_parts, b_alg * cfg.max_parts),
                          "kernel": "filterbank launch group k_fwd_cols+k_fwd_rows+k_inv_chan (FFT+chirp+fused detect)",
                          "algorithmic_bytes_per_part": b_alg, "group_ms_per_block": round(fb_ms, 4)},
         }
