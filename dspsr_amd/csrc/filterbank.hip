@@ -144,19 +144,21 @@ DEV cf twiddle_big(uint64_t j, int logL)
   return cmul(make_float2(c, s), make_float2(c2, s2));
 }
 
-// v[k] *= W_L^{nb*(k*pstride + p)}, k < R : base and the powers 1,2,4,8 of the step from exact phases
-template <int R> DEV void apply_pass_twiddle(cf (&v)[R], const uint32_t nb, const uint32_t p, const uint32_t pstride,
+// v[k] *= W_L^{nb*(k*pstride + p)} for the column pair (nb, nb+1), k < R : base and the powers 1,2,4,8 of
+// the step from exact phases (sincospif of an exactly representable argument), the rest by the ladder
+template <int R> DEV void apply_pass_twiddle(cx2 (&v)[R], const uint32_t nb, const uint32_t p, const uint32_t pstride,
                                              const int logL)
 {
   const uint64_t Lm = (1ull << logL) - 1;
-  const uint64_t a = ((uint64_t)nb * p) & Lm, d = ((uint64_t)nb * pstride) & Lm;
-  const cf wa = twiddle_big(a, logL);
+  const uint64_t a0 = ((uint64_t)nb * p) & Lm, d0 = ((uint64_t)nb * pstride) & Lm;
+  const uint64_t a1 = (a0 + p) & Lm, d1 = (d0 + pstride) & Lm;             // column nb + 1
+  const cx2 wa = make_cx2(twiddle_big(a0, logL), twiddle_big(a1, logL));
   if constexpr (R > 1) {
-    const cf w1 = twiddle_big(d, logL);
-    const cf w2 = R >= 4 ? twiddle_big((2 * d) & Lm, logL) : w1;
-    const cf w4 = R >= 8 ? twiddle_big((4 * d) & Lm, logL) : w1;
-    const cf w8 = R >= 16 ? twiddle_big((8 * d) & Lm, logL) : w1;
-    apply_powers<R>(v, w1, w2, w4, w8);
+    const cx2 w1 = make_cx2(twiddle_big(d0, logL), twiddle_big(d1, logL));
+    const cx2 w2 = R >= 4 ? make_cx2(twiddle_big((2 * d0) & Lm, logL), twiddle_big((2 * d1) & Lm, logL)) : w1;
+    const cx2 w4 = R >= 8 ? make_cx2(twiddle_big((4 * d0) & Lm, logL), twiddle_big((4 * d1) & Lm, logL)) : w1;
+    const cx2 w8 = R >= 16 ? make_cx2(twiddle_big((8 * d0) & Lm, logL), twiddle_big((8 * d1) & Lm, logL)) : w1;
+    apply_powers2<R>(v, w1, w2, w4, w8);
   }
 #pragma unroll
   for (int k = 0; k < R; k++) v[k] = cmul(v[k], wa);
@@ -233,13 +235,17 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     const bool pret = in.kind == 3;   // pre-transposed: [part][tile][na][T] pairs, contiguous per tile
     const uint64_t t0 = pret ? ((rest / nseq) * ntile + tile) * ((uint64_t)T << g.logM)
                              : (part0 + rest / nseq) * in.part_step + tile * T;
+    if (g.dbg & 2) {     // ablation only; hoisted so that the real path has no per-load branch
+#pragma unroll
+      for (int i = 0; i < NPAIR; i++) { RawW<RAWW> z; z.w[0] = tid + i; raw[i] = z; }
+      return;
+    }
 #pragma unroll
     for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
       for (int i = 0; i < P::R1; i++) {
         const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
-        if (g.dbg & 2) { RawW<RAWW> z; z.w[0] = e; raw[(g2 / 2) * P::R1 + i] = z; }
-        else raw[(g2 / 2) * P::R1 + i] = fetch_pair<RAWW>(g, in, seq, pret ? t0 + e : t0 + (((uint64_t)(e >> logT)) << g.logR) + (e & (T - 1)));
+        raw[(g2 / 2) * P::R1 + i] = fetch_pair<RAWW>(g, in, seq, pret ? t0 + e : t0 + (((uint64_t)(e >> logT)) << g.logR) + (e & (T - 1)));
       }
   };
 
@@ -252,12 +258,13 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
   fetch(item, raw);
   for (;;) {
     asm volatile("" : "+v"(tid));   // per-tile index math stays inside the loop (see wgfft)
-    cf x[PTS];
+    cx2 x[NPAIR];
 #pragma unroll
-    for (int g2 = 0; g2 < P::G1; g2 += 2)
-#pragma unroll
-      for (int i = 0; i < P::R1; i++)
-        decode_pair<RAWW>(g, in, raw[(g2 / 2) * P::R1 + i], x[g2 * P::R1 + i], x[(g2 + 1) * P::R1 + i]);
+    for (int h = 0; h < NPAIR; h++) {
+      cf a, b;
+      decode_pair<RAWW>(g, in, raw[h], a, b);
+      x[h] = make_cx2(a, b);
+    }
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
     if (more) fetch(next, raw);
 
@@ -266,22 +273,19 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     cf* __restrict__ Aseq = A + ((rest / nseq) * nseq + rest % nseq) * L;
     // last-stage outputs go to LDS in A-layout order [ka/T2][col][ka%T2]; after a barrier the tile is
     // written out as whole runs of T*T2 elements with 16-byte-per-lane stores
-    auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& va, auto& vb) {
-      constexpr int R = sizeof(va) / sizeof(va[0]);
+    auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
+      constexpr int R = sizeof(v) / sizeof(v[0]);
       const uint32_t nb = tile * T + col;
-      if (!(g.dbg & 8)) {
-        apply_pass_twiddle<R>(va, nb, p, pstride, logL);
-        apply_pass_twiddle<R>(vb, nb + 1, p, pstride, logL);
-      }
+      if (!(g.dbg & 8)) apply_pass_twiddle<R>(v, nb, p, pstride, logL);
 #pragma unroll
       for (int k = 0; k < R; k++) {
         const uint32_t ka = k * pstride + p;
         const uint32_t l = ((((ka >> logT2) << logT) + col) << logT2) | (ka & (T2 - 1));
-        lds[lds_pad(l)] = va[k];
-        lds[lds_pad(l + T2)] = vb[k];
+        lds[lds_pad(l)] = cx2_lo(v[k]);
+        lds[lds_pad(l + T2)] = cx2_hi(v[k]);
       }
     };
-    wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, tw, x, store);
+    wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
     __syncthreads();
     if (!(g.dbg & 1)) {
       const uint32_t nthr = blockDim.x;
@@ -315,19 +319,21 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
   const uint32_t ntile = 1u << (g.logM - logT);
   const uint64_t total = (uint64_t)ntile * nseq * nparts;
 
-  auto fetch = [&](const uint64_t item, cf (&y)[PTS]) {
+  // the prefetch keeps the loaded 16-byte pairs untouched (any use would wait for the loads at once);
+  // they are rearranged into split form when the tile is started
+  auto fetch = [&](const uint64_t item, float4 (&y)[NPAIR]) {
     const uint32_t tile = (uint32_t)(item % ntile);
     const cf* __restrict__ Ablk = A + (item / ntile) * L + (((uint64_t)tile << g.logR) << logT);
+    if (g.dbg & 2) {     // ablation only; hoisted so that the real path has no per-load branch (and vmcnt(0))
+#pragma unroll
+      for (int i = 0; i < NPAIR; i++) y[i] = make_float4(tid, i, 1.f, 1.f);
+      return;
+    }
 #pragma unroll
     for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
-      for (int i = 0; i < P::R1; i++) {
-        float4 pr;
-        if (g.dbg & 2) pr = make_float4(tid, i, g2, 1.f);
-        else pr = *(const float4*)&Ablk[first_stage_elem<LOGF>(tid, logT, g2, i)];
-        y[g2 * P::R1 + i] = make_float2(pr.x, pr.y);
-        y[(g2 + 1) * P::R1 + i] = make_float2(pr.z, pr.w);
-      }
+      for (int i = 0; i < P::R1; i++)
+        y[(g2 / 2) * P::R1 + i] = *(const float4*)&Ablk[first_stage_elem<LOGF>(tid, logT, g2, i)];
   };
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
@@ -335,13 +341,13 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
   uint64_t item, next;
   uint32_t j = 0;
   if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
-  cf y[PTS];
+  float4 y[NPAIR];
   fetch(item, y);
   for (;;) {
     asm volatile("" : "+v"(tid));   // per-tile index math stays inside the loop (see wgfft)
-    cf x[PTS];
+    cx2 x[NPAIR];
 #pragma unroll
-    for (int i = 0; i < PTS; i++) x[i] = y[i];
+    for (int i = 0; i < NPAIR; i++) x[i] = make_cx2(make_float2(y[i].x, y[i].y), make_float2(y[i].z, y[i].w));
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
     if (more) fetch(next, y);
 
@@ -349,17 +355,17 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
     cf* __restrict__ Xseq = X + (item / ntile) * L;
     // last-stage outputs go to LDS in X-layout order [s'/T3][klo][s'%T3]; after a barrier the tile is
     // written out as whole runs of T2*T3 elements with 16-byte-per-lane stores
-    auto store = [&](const uint32_t klo, const uint32_t p, const uint32_t pstride, auto& va, auto& vb) {
-      constexpr int R = sizeof(va) / sizeof(va[0]);
+    auto store = [&](const uint32_t klo, const uint32_t p, const uint32_t pstride, auto& v) {
+      constexpr int R = sizeof(v) / sizeof(v[0]);
 #pragma unroll
       for (int k = 0; k < R; k++) {
         const uint32_t srow = k * pstride + p;
         const uint32_t l = ((((srow >> logT3) << logT) + klo) << logT3) | (srow & (T3 - 1));
-        lds[lds_pad(l)] = va[k];
-        lds[lds_pad(l + T3)] = vb[k];
+        lds[lds_pad(l)] = cx2_lo(v[k]);
+        lds[lds_pad(l + T3)] = cx2_hi(v[k]);
       }
     };
-    wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, tw, x, store);
+    wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
     __syncthreads();
     if (!(g.dbg & 1)) {
       const uint32_t nthr = blockDim.x;
@@ -417,6 +423,11 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     const uint32_t tile = (uint32_t)(item / nparts);
     const cf* __restrict__ X0s = X + (item % nparts) * nseq * L;
     const uint32_t mblk = (Rr >> logT3) - 1 - tile;
+    if (g.dbg & 2) {     // ablation only; hoisted so that the real path has no per-load branch
+#pragma unroll
+      for (int i = 0; i < NPAIR; i++) { raw[i].a = make_float2(tid, i); raw[i].b = raw[i].a; }
+      return;
+    }
 #pragma unroll
     for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
@@ -424,19 +435,16 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
         const uint32_t slo = (e & (T - 1)) >> 1, m = e >> logT;
         const uint32_t s = tile * T3 + slo;
+        // branch-free addressing: a conditional around a load would make the compiler wait for every
+        // load separately (vmcnt(0) per element)
+        const uint64_t ia = tile * blk + ((uint64_t)m << logT3) + slo;
+        const uint32_t rr = (Rr - s) & (Rr - 1);
+        const uint64_t ib_mirror = m > 0 ? mblk * blk + (((uint64_t)(M - m)) << logT3) + (T3 - 1 - slo)
+                                         : (rr >> logT3) * blk + (rr & (T3 - 1));
+        const uint64_t ib = g.real_input ? ib_mirror : (g.npol == 2 ? L + ia : ia);
         Abk r;
-        if (g.dbg & 2) { r.a = make_float2(m, slo); r.b = r.a; raw[(g2 / 2) * P::R1 + i] = r; continue; }
-        r.a = X0s[tile * blk + ((uint64_t)m << logT3) + slo];
-        if (g.real_input) {
-          if (m > 0) {
-            r.b = X0s[mblk * blk + (((uint64_t)(M - m)) << logT3) + (T3 - 1 - slo)];
-          } else {
-            const uint32_t rr = (Rr - s) & (Rr - 1);
-            r.b = X0s[(rr >> logT3) * blk + (rr & (T3 - 1))];
-          }
-        } else {
-          r.b = g.npol == 2 ? X0s[L + tile * blk + ((uint64_t)m << logT3) + slo] : make_float2(0.f, 0.f);
-        }
+        r.a = X0s[ia];
+        r.b = X0s[ib];
         raw[(g2 / 2) * P::R1 + i] = r;
       }
   };
@@ -450,18 +458,23 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   fetch(item, raw);
   for (;;) {
     asm volatile("" : "+v"(tid));   // per-tile index math stays inside the loop (see wgfft)
-    cf x[PTS];
+    cx2 x[NPAIR];
     {
       const uint32_t ktile = (uint32_t)(item / nparts);
       cf kk[PTS / 2];
+      if (kernel && !(g.dbg & 2)) {      // uniform; outside the unrolled loads (no per-load branch / vmcnt(0))
 #pragma unroll
-      for (int g2 = 0; g2 < P::G1; g2 += 2)
+        for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
-        for (int i = 0; i < P::R1; i++) {
-          const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
-          const uint32_t s = ktile * T3 + ((e & (T - 1)) >> 1), m = e >> logT;
-          kk[(g2 / 2) * P::R1 + i] = (kernel && !(g.dbg & 2)) ? kernel[((uint64_t)s << g.logM) + m] : make_float2(1.f, 0.f);
-        }
+          for (int i = 0; i < P::R1; i++) {
+            const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
+            const uint32_t s = ktile * T3 + ((e & (T - 1)) >> 1), m = e >> logT;
+            kk[(g2 / 2) * P::R1 + i] = kernel[((uint64_t)s << g.logM) + m];
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PTS / 2; i++) kk[i] = make_float2(1.f, 0.f);
+      }
 #pragma unroll
       for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
@@ -475,10 +488,9 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
             x1 = make_float2(0.5f * (r.a.y + r.b.y), 0.5f * (r.b.x - r.a.x));
           } else {
             x0 = r.a;
-            x1 = r.b;
+            x1 = g.npol == 2 ? r.b : make_float2(0.f, 0.f);
           }
-          x[g2 * P::R1 + i] = cmul(k, x0);          // Response::operate, Response.C:429-441
-          x[(g2 + 1) * P::R1 + i] = cmul(k, x1);
+          x[(g2 / 2) * P::R1 + i] = cmuls(make_cx2(x0, x1), k);          // Response::operate, Response.C:429-441
         }
     }
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
@@ -486,10 +498,10 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 
     const uint32_t tile = (uint32_t)(item / nparts);
     const uint64_t part = part0 + item % nparts;
-    auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& va, auto& vb) {
-      constexpr int R = sizeof(va) / sizeof(va[0]);
+    auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
+      constexpr int R = sizeof(v) / sizeof(v[0]);
       if (out.kind == 0) return;
-      if (g.dbg & 1) { if (va[0].x == 1.2345f && vb[R - 1].y == 3.3f) out.base[0] = va[0].x; return; }
+      if (g.dbg & 1) { if (v[0].x[0] == 1.2345f && v[R - 1].y[1] == 3.3f) out.base[0] = v[0].x[0]; return; }
       const uint32_t chan = out.chan0 + tile * T3 + (col >> 1);
       float* __restrict__ row = out.base + chan * out.chan_stride;
 #pragma unroll
@@ -497,13 +509,14 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         const uint32_t pos = k * pstride + p;
         if (pos < g.nfilt_pos || pos >= g.nfilt_pos + g.nkeep) continue;
         const uint32_t t = pos - g.nfilt_pos;
+        const cf va = cx2_lo(v[k]), vb = cx2_hi(v[k]);
         if (out.kind == 1) {
           float2* o = (float2*)(row + part * out.part_step) + t;
-          o[0] = va[k];
-          if (g.npol == 2) ((float2*)((float*)o + out.pol_stride))[0] = vb[k];
+          o[0] = va;
+          if (g.npol == 2) ((float2*)((float*)o + out.pol_stride))[0] = vb;
         } else {
           float r[4];
-          detect4(va[k], vb[k], out.state, r);
+          detect4(va, vb, out.state, r);
           const uint64_t idat = part * g.nkeep + t;
           if (out.ndim == 4) {
             ((float4*)row)[idat] = make_float4(r[0], r[1], r[2], r[3]);
@@ -519,7 +532,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         }
       }
     };
-    wgfft<LOGF, +1>(lds, ltw_off, tid, logT, tw, x, store);
+    wgfft<LOGF, +1>(lds, ltw_off, tid, logT, x, store);
     if (!more) break;
     item = next;
   }

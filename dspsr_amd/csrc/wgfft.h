@@ -24,58 +24,72 @@ typedef float2 cf;
 
 #define DEV __device__ __forceinline__
 
-DEV cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
-DEV cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
 DEV cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-DEV cf cconj(cf a) { return make_float2(a.x, -a.y); }
-// multiply by SIGN*i  (forward SIGN=-1: -i ; inverse SIGN=+1: +i)
-template <int SIGN> DEV cf mul_si(cf a) { return SIGN < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x); }
 
 // 4 words of padding per 64 keep the strided stage writes spread over the LDS banks
 // and preserve 16-byte alignment of even word indices
 DEV uint32_t lds_pad(uint32_t e) { return e + ((e >> 6) << 2); }
 inline uint32_t lds_words_host(uint32_t points) { return points + ((points >> 6) << 2) + 8; }   // exchange buffer
-// total dynamic LDS words of a kernel: exchange buffer followed by the half twiddle table
+// total dynamic LDS words of a kernel: exchange buffer followed by the stage twiddle tables
 inline uint32_t lds_total_words_host(uint32_t points) { return lds_words_host(points) + 2304; }
 
 constexpr int PTS = 32;      // points per thread
 constexpr int LOG_PTS = 5;
+constexpr int NPAIR = PTS / 2;
+
+// A thread's two butterflies (columns col, col+1 of the same position) are carried together in SPLIT
+// form: x = (re_col, re_col+1), y = (im_col, im_col+1).  Every complex operation is then a plain
+// element-wise operation on 2-vectors (v_pk_add/mul/fma_f32) with no operand shuffling, and the pair
+// is also the 16-byte unit moved through LDS.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct cx2 { v2f x, y; };
+
+DEV cx2 make_cx2(cf a, cf b) { cx2 r; r.x = (v2f){a.x, b.x}; r.y = (v2f){a.y, b.y}; return r; }
+DEV cf cx2_lo(cx2 a) { return make_float2(a.x[0], a.y[0]); }
+DEV cf cx2_hi(cx2 a) { return make_float2(a.x[1], a.y[1]); }
+DEV cx2 cadd(cx2 a, cx2 b) { cx2 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
+DEV cx2 csub(cx2 a, cx2 b) { cx2 r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
+DEV cx2 cmul(cx2 a, cx2 b) { cx2 r; r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; return r; }
+// multiply both by the same scalar complex w
+DEV cx2 cmuls(cx2 a, cf w) { cx2 r; r.x = a.x * w.x - a.y * w.y; r.y = a.x * w.y + a.y * w.x; return r; }
+// multiply by SIGN*i  (forward SIGN=-1: -i ; inverse SIGN=+1: +i)
+template <int SIGN> DEV cx2 mul_si(cx2 a) { cx2 r; if (SIGN < 0) { r.x = a.y; r.y = -a.x; } else { r.x = -a.y; r.y = a.x; } return r; }
 
 // cos/sin(2*pi*k/16)
 #define C16_1 0.92387953251128674f
 #define S16_1 0.38268343236508977f
 #define C16_2 0.70710678118654752f
 
-template <int SIGN> DEV void fft2(cf& a, cf& b) { cf t = a; a = cadd(t, b); b = csub(t, b); }
+template <int SIGN> DEV void fft2(cx2& a, cx2& b) { cx2 t = a; a = cadd(t, b); b = csub(t, b); }
 
-template <int SIGN> DEV void fft4(cf& v0, cf& v1, cf& v2, cf& v3)
+template <int SIGN> DEV void fft4(cx2& v0, cx2& v1, cx2& v2, cx2& v3)
 {
-  cf t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3), t3 = mul_si<SIGN>(csub(v1, v3));
+  cx2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3), t3 = mul_si<SIGN>(csub(v1, v3));
   v0 = cadd(t0, t2); v2 = csub(t0, t2);
   v1 = cadd(t1, t3); v3 = csub(t1, t3);
 }
 
 // multiply by W_8^1 = exp(SIGN*i*pi/4) and W_8^3
-template <int SIGN> DEV cf mul_w8_1(cf a)
-{ return SIGN < 0 ? make_float2(C16_2 * (a.x + a.y), C16_2 * (a.y - a.x)) : make_float2(C16_2 * (a.x - a.y), C16_2 * (a.x + a.y)); }
-template <int SIGN> DEV cf mul_w8_3(cf a)
-{ return SIGN < 0 ? make_float2(C16_2 * (a.y - a.x), -C16_2 * (a.x + a.y)) : make_float2(-C16_2 * (a.x + a.y), C16_2 * (a.x - a.y)); }
-template <int SIGN> DEV cf mul_w(cf a, float c, float s) { return cmul(a, make_float2(c, SIGN < 0 ? -s : s)); }
+template <int SIGN> DEV cx2 mul_w8_1(cx2 a)
+{ cx2 r; if (SIGN < 0) { r.x = C16_2 * (a.x + a.y); r.y = C16_2 * (a.y - a.x); } else { r.x = C16_2 * (a.x - a.y); r.y = C16_2 * (a.x + a.y); } return r; }
+template <int SIGN> DEV cx2 mul_w8_3(cx2 a)
+{ cx2 r; if (SIGN < 0) { r.x = C16_2 * (a.y - a.x); r.y = -C16_2 * (a.x + a.y); } else { r.x = -C16_2 * (a.x + a.y); r.y = C16_2 * (a.x - a.y); } return r; }
+template <int SIGN> DEV cx2 mul_w(cx2 a, float c, float s) { return cmuls(a, make_float2(c, SIGN < 0 ? -s : s)); }
 
-template <int SIGN> DEV void fft8(cf (&v)[8])
+template <int SIGN> DEV void fft8(cx2 (&v)[8])
 {
   // DIT: even/odd 4-point transforms then combine
   fft4<SIGN>(v[0], v[2], v[4], v[6]);
   fft4<SIGN>(v[1], v[3], v[5], v[7]);
-  cf o1 = mul_w8_1<SIGN>(v[3]), o2 = mul_si<SIGN>(v[5]), o3 = mul_w8_3<SIGN>(v[7]);
-  cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+  cx2 o1 = mul_w8_1<SIGN>(v[3]), o2 = mul_si<SIGN>(v[5]), o3 = mul_w8_3<SIGN>(v[7]);
+  cx2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
   v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
   v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
   v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
   v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
 }
 
-template <int SIGN> DEV void fft16(cf (&v)[16])
+template <int SIGN> DEV void fft16(cx2 (&v)[16])
 {
   // n = 4*n1 + n2 : 4-point over n1 for each n2, twiddle W_16^{n2*k1}, 4-point over n2 ; k = k1 + 4*k2
   fft4<SIGN>(v[0], v[4], v[8], v[12]);
@@ -97,7 +111,7 @@ template <int SIGN> DEV void fft16(cf (&v)[16])
   fft4<SIGN>(v[8], v[9], v[10], v[11]);
   fft4<SIGN>(v[12], v[13], v[14], v[15]);
   // X[k1 + 4*k2] sits in v[4*k1 + k2] : transpose 4x4 into natural order
-  cf t;
+  cx2 t;
   t = v[1]; v[1] = v[4]; v[4] = t;
   t = v[2]; v[2] = v[8]; v[8] = t;
   t = v[3]; v[3] = v[12]; v[12] = t;
@@ -106,7 +120,7 @@ template <int SIGN> DEV void fft16(cf (&v)[16])
   t = v[11]; v[11] = v[14]; v[14] = t;
 }
 
-template <int R, int SIGN> DEV void fftR(cf (&v)[R])
+template <int R, int SIGN> DEV void fftR(cx2 (&v)[R])
 {
   if constexpr (R == 2) fft2<SIGN>(v[0], v[1]);
   else if constexpr (R == 4) fft4<SIGN>(v[0], v[1], v[2], v[3]);
@@ -114,17 +128,42 @@ template <int R, int SIGN> DEV void fftR(cf (&v)[R])
   else if constexpr (R == 16) fft16<SIGN>(v);
 }
 
-// v[k] *= w1^k for k = 1..R-1 given the exact powers w1, w2, w4, w8 (those that exist for R);
-// the remaining powers are products of at most three exact factors.
-template <int R> DEV void apply_powers(cf (&v)[R], const cf w1, const cf w2, const cf w4, const cf w8)
+// v[k] *= w1^k for k = 1..R-1 given the exact powers w1, w2, w4, w8 (those that exist for R), the same
+// scalar twiddle for both columns of the pair; the remaining powers are products of at most three
+// exact factors.
+template <int R> DEV void apply_powers(cx2 (&v)[R], const cf w1, const cf w2, const cf w4, const cf w8)
+{
+  if constexpr (R >= 2) v[1] = cmuls(v[1], w1);
+  if constexpr (R >= 4) {
+    const cf w3 = cmul(w2, w1);
+    v[2] = cmuls(v[2], w2);
+    v[3] = cmuls(v[3], w3);
+    if constexpr (R >= 8) {
+      const cf w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+      v[4] = cmuls(v[4], w4); v[5] = cmuls(v[5], w5); v[6] = cmuls(v[6], w6); v[7] = cmuls(v[7], w7);
+      if constexpr (R >= 16) {
+        v[8] = cmuls(v[8], w8);
+        v[9] = cmuls(v[9], cmul(w8, w1));
+        v[10] = cmuls(v[10], cmul(w8, w2));
+        v[11] = cmuls(v[11], cmul(w8, w3));
+        v[12] = cmuls(v[12], cmul(w8, w4));
+        v[13] = cmuls(v[13], cmul(w8, w5));
+        v[14] = cmuls(v[14], cmul(w8, w6));
+        v[15] = cmuls(v[15], cmul(w8, w7));
+      }
+    }
+  }
+}
+// same with a different twiddle per column (packed powers)
+template <int R> DEV void apply_powers2(cx2 (&v)[R], const cx2 w1, const cx2 w2, const cx2 w4, const cx2 w8)
 {
   if constexpr (R >= 2) v[1] = cmul(v[1], w1);
   if constexpr (R >= 4) {
-    const cf w3 = cmul(w2, w1);
+    const cx2 w3 = cmul(w2, w1);
     v[2] = cmul(v[2], w2);
     v[3] = cmul(v[3], w3);
     if constexpr (R >= 8) {
-      const cf w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+      const cx2 w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
       v[4] = cmul(v[4], w4); v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7);
       if constexpr (R >= 16) {
         v[8] = cmul(v[8], w8);
@@ -178,69 +217,72 @@ template <int LOGF> struct FftPlan {
   static constexpr int G1 = PTS / R1;
 };
 
-// logical element index (pos*T + col) held in x[g*R1 + i] of the first-stage register array
+// logical element index (pos*T + col) of the FIRST element of pair x[(g/2)*R1 + i] (g even) of the
+// first-stage register array; the second element of the pair is the next column (index + 1)
 template <int LOGF> DEV uint32_t first_stage_elem(uint32_t tid, int logT, int g, int i)
 {
   typedef FftPlan<LOGF> P;
   return P::G1 * tid + g + ((uint32_t)i << (LOGF - P::LOGR1 + logT));
 }
 
-// Out: void operator()(uint32_t col, uint32_t p, uint32_t pstride, cf (&va)[R], cf (&vb)[R])
-//      va[k] / vb[k] are output position k*pstride + p of columns col (even) and col + 1
+// Out: void operator()(uint32_t col, uint32_t p, uint32_t pstride, cx2 (&v)[R])
+//      v[k] holds output position k*pstride + p of columns col (even, .x[0]/.y[0]) and col + 1
 template <int LOGR, int SIGN, bool FIRST, bool LAST, bool STAGED, class Out>
 DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const int logT, const int logF,
-                     const int logP, const cf* __restrict__ tw, cf (&x)[PTS], Out& out)
+                     const int logP, cx2 (&x)[NPAIR], Out& out)
 {
   constexpr int R = 1 << LOGR;
-  constexpr int G = PTS / R;
+  constexpr int G = PTS / R;          // butterflies per thread
+  constexpr int H = G / 2;            // pairs of butterflies
   const int logQ = logF - logP - LOGR;
   const uint32_t stride = 1u << (logF - LOGR + logT);
-  cf v[G][R];
+  cx2 v[H][R];
 #pragma unroll
-  for (int g = 0; g < G; g += 2) {
-    const uint32_t u = G * tid + g;
+  for (int h = 0; h < H; h++) {
+    const uint32_t u = G * tid + 2 * h;
 #pragma unroll
     for (int i = 0; i < R; i++) {
       if constexpr (FIRST) {
-        v[g][i] = x[g * R + i];
-        v[g + 1][i] = x[(g + 1) * R + i];
+        v[h][i] = x[h * R + i];
       } else {
         const float4 pr = *(const float4*)&lds[lds_pad(u + i * stride)];
-        v[g][i] = make_float2(pr.x, pr.y);
-        v[g + 1][i] = make_float2(pr.z, pr.w);
+        v[h][i].x = (v2f){pr.x, pr.y};
+        v[h][i].y = (v2f){pr.z, pr.w};
       }
     }
   }
 #pragma unroll
-  for (int g = 0; g < G; g++) {
-    fftR<R, SIGN>(v[g]);
+  for (int h = 0; h < H; h++) {
+    fftR<R, SIGN>(v[h]);
     if (R > 1 && logQ > 0) {
-      const uint32_t u = G * tid + g;
+      // only radix-16 stages carry twiddles (a remainder stage is always last); both columns of a pair
+      // share s, hence the twiddle
+      const uint32_t u = G * tid + 2 * h;
       const uint32_t s = u >> (logT + logP);
-      // only radix-16 stages carry twiddles (a remainder stage is always last)
       const uint32_t tb = ltw_off + s;
       cf w1 = lds[tb], w2 = lds[tb + (1u << logQ)], w4 = lds[tb + (2u << logQ)], w8 = lds[tb + (3u << logQ)];
       if (SIGN > 0) { w1.y = -w1.y; w2.y = -w2.y; w4.y = -w4.y; w8.y = -w8.y; }
-      apply_powers<R>(v[g], w1, w2, w4, w8);
+      apply_powers<R>(v[h], w1, w2, w4, w8);
     }
   }
   // every read of the in-place exchange buffer (this or the previous tile) is done; a STAGED last stage
   // re-uses the buffer to reorder its outputs, so it needs the same guarantee
   if (!LAST || (STAGED && !FIRST)) __syncthreads();
 #pragma unroll
-  for (int g = 0; g < G; g += 2) {
-    const uint32_t u = G * tid + g;
+  for (int h = 0; h < H; h++) {
+    const uint32_t u = G * tid + 2 * h;
     const uint32_t col = u & ((1u << logT) - 1);
     const uint32_t rest = u >> logT;
     const uint32_t p = rest & ((1u << logP) - 1);
     const uint32_t s = rest >> logP;
     if constexpr (LAST) {
-      out(col, p, 1u << logP, v[g], v[g + 1]);     // Q == 1, s == 0
+      out(col, p, 1u << logP, v[h]);     // Q == 1, s == 0
     } else {
 #pragma unroll
       for (int k = 0; k < R; k++) {
         const uint32_t pos = (s << (logP + LOGR)) + ((uint32_t)k << logP) + p;
-        *(float4*)&lds[lds_pad((pos << logT) | col)] = make_float4(v[g][k].x, v[g][k].y, v[g + 1][k].x, v[g + 1][k].y);
+        *(float4*)&lds[lds_pad((pos << logT) | col)] =
+            make_float4(v[h][k].x[0], v[h][k].x[1], v[h][k].y[0], v[h][k].y[1]);
       }
     }
   }
@@ -252,27 +294,26 @@ DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const 
 // also separates it from the previous tile's last-stage LDS reads.
 // STAGED: `out` writes into the exchange buffer (the caller copies it out after a barrier).
 template <int LOGF, int SIGN, bool STAGED = false, class Out>
-DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, const cf* __restrict__ tw,
-               cf (&x)[PTS], Out& out)
+DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx2 (&x)[NPAIR], Out& out)
 {
   typedef FftPlan<LOGF> P;
   // opaque copy: LDS addresses and twiddle indices are loop-invariant in a persistent workgroup and
   // would otherwise be hoisted out of the tile loop and spilled (hundreds of registers)
   asm volatile("" : "+v"(tid));
   if constexpr (P::NS <= 1) {
-    wgfft_stage<P::LOGR1, SIGN, true, true, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, tw, x, out);
+    wgfft_stage<P::LOGR1, SIGN, true, true, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out);
   } else {
-    wgfft_stage<4, SIGN, true, false, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, tw, x, out);
+    wgfft_stage<4, SIGN, true, false, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out);
     int logP = 4;
     uint32_t toff = ltw_off + (4u << (LOGF - 4));
 #pragma unroll
     for (int j = 1; j < P::NQ - (P::REM ? 0 : 1); j++) {
-      wgfft_stage<4, SIGN, false, false, STAGED>(lds, toff, tid, logT, LOGF, logP, tw, x, out);
+      wgfft_stage<4, SIGN, false, false, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out);
       logP += 4;
       toff += 4u << (LOGF - logP);
     }
-    if constexpr (P::REM != 0) wgfft_stage<P::REM, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, tw, x, out);
-    else wgfft_stage<4, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, tw, x, out);
+    if constexpr (P::REM != 0) wgfft_stage<P::REM, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out);
+    else wgfft_stage<4, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out);
   }
 }
 
