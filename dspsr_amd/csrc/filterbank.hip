@@ -657,9 +657,9 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   hipDeviceProp_t prop;
   fb->ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
                 ? (uint32_t)prop.multiProcessorCount : 256u;
-  fb->lds1 = lds_total_words_host((uint32_t)p1) * sizeof(cf);
-  fb->lds2 = lds_total_words_host((uint32_t)p2) * sizeof(cf);
-  fb->lds3 = lds_total_words_host((uint32_t)p3) * sizeof(cf);
+  fb->lds1 = lds_total_words_host((uint32_t)p1, g.logM) * sizeof(cf);
+  fb->lds2 = lds_total_words_host((uint32_t)p2, g.logR) * sizeof(cf);
+  fb->lds3 = lds_total_words_host((uint32_t)p3, g.logM) * sizeof(cf);
   fb->max_parts = cfg->max_parts ? cfg->max_parts : 1;
   const size_t scratch = (size_t)fb->max_parts * fb->nseq * fb->L * sizeof(cf);
   if (hipMalloc((void**)&fb->A, scratch) != hipSuccess || hipMalloc((void**)&fb->X, scratch) != hipSuccess) {

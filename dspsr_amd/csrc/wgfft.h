@@ -31,7 +31,14 @@ DEV cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + 
 DEV uint32_t lds_pad(uint32_t e) { return e + ((e >> 6) << 2); }
 inline uint32_t lds_words_host(uint32_t points) { return points + ((points >> 6) << 2) + 8; }   // exchange buffer
 // total dynamic LDS words of a kernel: exchange buffer followed by the stage twiddle tables
-inline uint32_t lds_total_words_host(uint32_t points) { return lds_words_host(points) + 2304; }
+inline uint32_t ltw_entries_host(int logF)
+{
+  const int nq = logF / 4, rem = logF % 4, ntw = nq - (rem ? 0 : 1);
+  uint32_t n = 0;
+  for (int st = 0; st < ntw; st++) n += 4u << (logF - 4 * (st + 1));
+  return n;
+}
+inline uint32_t lds_total_words_host(uint32_t points, int logF) { return lds_words_host(points) + ltw_entries_host(logF) + 8; }
 
 constexpr int PTS = 32;      // points per thread
 constexpr int LOG_PTS = 5;
