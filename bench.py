@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--parts-per-block", type=int, default=16)
-    ap.add_argument("--max-parts", type=int, default=4)
+    ap.add_argument("--max-parts", type=int, default=8)
     ap.add_argument("--dump-steps", type=int, default=8, help="steps per sub-integration dump")
     ap.add_argument("--ndim", type=int, default=4, choices=[1, 2, 4])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -15,7 +15,10 @@
 //   Scratch between passes is stored blocked so every global access is a >=128-byte run:
 //     A[(ka/T2)][nb][ka%T2]   (written by P1 as T1*T2-element runs, read contiguously by P2)
 //     X[(s'/T3)][m][s'%T3]    (written by P2 as T2*T3-element runs, read contiguously by P3)
+#include <math.h>
 #include <stdlib.h>
+
+#include <vector>
 
 #include "engine_internal.h"
 
@@ -26,6 +29,7 @@ struct FbGeom {
   int real_input, npol;
   uint32_t C, nfilt_pos, nkeep;
   int dbg;   // DSPSR_AMD_DEBUG ablation bits (timing experiments only; results are wrong when set)
+  const float2* tw_lo;   // exp(-2*pi*i*j/L), j < L/TWN : fine part of the pass-1 twiddle (L > TWN)
 };
 
 struct FbIn {
@@ -129,26 +133,21 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
   }
 }
 
-// exp(-2*pi*i*j/2^logL), j < 2^logL, from exact float arguments
-DEV cf twiddle_big(uint64_t j, int logL)
+// exp(-2*pi*i*j/2^logL), j < 2^logL : coarse table (2*pi/TWN steps, built in double) times fine table
+// (the remaining low bits of j), both correctly rounded -> about 1.2e-7 relative error
+DEV cf twiddle_big(const uint64_t j, const int logL, const cf* __restrict__ tw, const cf* __restrict__ tw_lo)
 {
-  float s, c;
-  if (logL <= 24) {
-    sincospif(-2.0f * (float)(uint32_t)j / (float)(1u << logL), &s, &c);
-    return make_float2(c, s);
-  }
-  const uint32_t hi = (uint32_t)(j >> 12), lo = (uint32_t)(j & 4095);
-  float s2, c2;
-  sincospif(-2.0f * (float)hi / (float)(1ull << (logL - 12)), &s, &c);
-  sincospif(-2.0f * (float)lo / (float)(1ull << logL), &s2, &c2);
-  return cmul(make_float2(c, s), make_float2(c2, s2));
+  if (logL <= LOG_TWN) return tw[j << (LOG_TWN - logL)];
+  const int sh = logL - LOG_TWN;
+  return cmul(tw[j >> sh], tw_lo[j & ((1u << sh) - 1)]);
 }
 
 // v[k] *= W_L^{nb*(k*pstride + p)} for the column pair (nb, nb+1), k < R : base and the powers 1,2,4,8 of
 // the step from exact phases (sincospif of an exactly representable argument), the rest by the ladder
 template <int R> DEV void apply_pass_twiddle(cx2 (&v)[R], const uint32_t nb, const uint32_t p, const uint32_t pstride,
-                                             const int logL)
+                                             const int logL, const cf* __restrict__ tw, const cf* __restrict__ tw_lo)
 {
+#define twiddle_big(j, l) twiddle_big((j), (l), tw, tw_lo)
   const uint64_t Lm = (1ull << logL) - 1;
   const uint64_t a0 = ((uint64_t)nb * p) & Lm, d0 = ((uint64_t)nb * pstride) & Lm;
   const uint64_t a1 = (a0 + p) & Lm, d1 = (d0 + pstride) & Lm;             // column nb + 1
@@ -162,6 +161,7 @@ template <int R> DEV void apply_pass_twiddle(cx2 (&v)[R], const uint32_t nb, con
   }
 #pragma unroll
   for (int k = 0; k < R; k++) v[k] = cmul(v[k], wa);
+#undef twiddle_big
 }
 
 // ------------------------------------------------------------------------------------ P0
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
       const uint32_t nb = tile * T + col;
-      if (!(g.dbg & 8)) apply_pass_twiddle<R>(v, nb, p, pstride, logL);
+      if (!(g.dbg & 8)) apply_pass_twiddle<R>(v, nb, p, pstride, logL, tw, g.tw_lo);
 #pragma unroll
       for (int k = 0; k < R; k++) {
         const uint32_t ka = k * pstride + p;
@@ -573,6 +573,7 @@ struct dspsr_amd_filterbank_impl {
   cf* A = nullptr;
   cf* X = nullptr;
   cf* kernel = nullptr;
+  cf* tw_lo = nullptr;
   uint16_t* Rt = nullptr;   // pre-transposed 8-bit pairs of the parts of one launch group
   bool kernel_set = false;
 };
@@ -668,6 +669,21 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_create: hipMalloc of 2 x %zu scratch bytes failed",
                    scratch);
   }
+  g.tw_lo = nullptr;
+  if (g.logM + g.logR > LOG_TWN) {            // fine twiddle table of pass 1, built in double
+    const int sh = g.logM + g.logR - LOG_TWN;
+    std::vector<cf> lo(1u << sh);
+    for (uint32_t j = 0; j < (1u << sh); j++) {
+      const double a = -2.0 * M_PI * (double)j / (double)fb->L;
+      lo[j] = make_float2((float)cos(a), (float)sin(a));
+    }
+    if (hipMalloc((void**)&fb->tw_lo, lo.size() * sizeof(cf)) != hipSuccess ||
+        hipMemcpy(fb->tw_lo, lo.data(), lo.size() * sizeof(cf), hipMemcpyHostToDevice) != hipSuccess) {
+      dspsr_amd_filterbank_destroy(fb);
+      return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_create: twiddle table allocation failed");
+    }
+    g.tw_lo = fb->tw_lo;
+  }
   *out = fb;
   return DSPSR_AMD_OK;
 }
@@ -680,6 +696,7 @@ extern "C" void dspsr_amd_filterbank_destroy(dspsr_amd_filterbank* fb)
   if (fb->X) (void)hipFree(fb->X);
   if (fb->kernel) (void)hipFree(fb->kernel);
   if (fb->Rt) (void)hipFree(fb->Rt);
+  if (fb->tw_lo) (void)hipFree(fb->tw_lo);
   delete fb;
 }
 

@@ -32,7 +32,7 @@ class Config:
     stokes: bool = False              # -4? (default Coherence, LoadToFold1.C:1119-1134)
     ndim: int = 4                     # detected layout (CPU default 4, CUDA engine 2; LoadToFoldConfig.C:104)
     parts_per_block: int = 16         # block size in overlap-save parts (LoadToFold1.C:825-835 sizes blocks likewise)
-    max_parts: int = 4                # parts per launch group
+    max_parts: int = 8                # parts per launch group
 
 
 @dataclass
