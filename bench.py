@@ -43,7 +43,62 @@ WORKLOADS = {
     "cfg4": dict(freq=1382.0, bw=-50.0, in_nchan=1, ndim=2, tsamp_us=0.02, nchan=512, dm=1000.0,
                  freq_res=512, nbin=1024, machine="DADA",
                  cmd="dspsr -F 512:D -D 1000 -b 1024 per 50 MHz complex sub-band"),
+    # SURVEY 8f-1 / BASELINE config 5: search-mode front end, detect only (no fold)
+    "cfg5": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=4096, dm=0.0, freq_res=1,
+                 nbin=0, machine="DADA", tscrunch=16, nparts=4096,
+                 cmd="digifil -F 4096 -t 16 (TFP filterbank + square law + pscrunch + tscrunch, no fold)"),
 }
+
+
+def bench_search_mode(args, wl, torch):
+    """cfg5: one step = one block of nparts FFT blocks (2*nchan samples each) through the fused search-mode kernel."""
+    import dspsr_amd
+    nchan, sf, npart = wl["nchan"], wl["tscrunch"], wl["nparts"]
+    ctx = dspsr_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    nbytes = npart * 2 * nchan * 2
+    gen = torch.Generator(device="cuda").manual_seed(20100413)
+    raw = torch.randn(nbytes, generator=gen, device="cuda").mul_(24.0).round_().clamp_(-128, 127).to(torch.int8)
+    out = torch.empty((npart // sf, nchan, 1), dtype=torch.float32, device="cuda")
+    scale = dspsr_amd.eight_bit_scale()
+
+    def step():
+        dspsr_amd.tfp_filterbank(ctx, raw, nchan, npart, out, True, sf, scale=scale)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    samples = npart * 2 * nchan
+    b_alg = nbytes + out.numel() * 4
+    achieved = b_alg / (k_ms * 1e-3) / 1e9
+    res = {"metric": "Msamples/s dedispersed+folded", "value": round(samples * args.steps / elapsed / 1e6, 2),
+           "unit": "Msamples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "cfg5", "command": wl["cmd"], "nchan": nchan, "tscrunch": sf,
+                      "parts_per_block": npart, "input": "8-bit dual-pol, resident in HBM",
+                      "note": "search mode: detected + scrunched, NOT folded"},
+           "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_tfp<13>",
+                        "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(k_ms, 4)}}
+    if not args.no_cpu_baseline:
+        import oracle.dspsr_oracle as o
+        n = 512
+        rr = raw[: n * 4 * nchan].cpu().numpy()
+        t1 = time.perf_counter()
+        o.tscrunch_tfp(o.tfp_filterbank(o.unpack_8bit(rr, o.Observation()), nchan, True), sf)
+        dt = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": n * 2 * nchan / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                               "sample": "%d FFT blocks of the same workload, numpy oracle, %.1f s" % (n, dt)}
+    print(json.dumps(res), flush=True)
+    ctx.close()
 
 
 def algorithmic_bytes_per_part(npol, nsamp_fft, nbit, N, nchan_subband, nkeep):
@@ -124,6 +179,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
+    if args.workload == "cfg5":
+        if world > 1:
+            sys.exit("bench.py: the search-mode workload runs as independent replicas; use --gpus 1")
+        return bench_search_mode(args, wl, torch)
     # sub-band sharding: rank g holds the g-th band of the same geometry (centre frequencies stacked downwards)
     freq = wl["freq"] + rank * wl["bw"]
     info = pipeline.InputInfo(centre_frequency=freq, bandwidth=wl["bw"], nchan=wl["in_nchan"], npol=2,

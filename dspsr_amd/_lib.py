@@ -22,6 +22,10 @@ class FilterbankConfig(C.Structure):
                 ("real_input", C.c_uint32), ("max_parts", C.c_uint32)]
 
 
+class TfpConfig(C.Structure):
+    _fields_ = [("nchan", C.c_uint32), ("npol", C.c_uint32), ("pscrunch", C.c_uint32), ("tscrunch", C.c_uint32)]
+
+
 class DedispersionConfig(C.Structure):
     _fields_ = [("centre_frequency", C.c_double), ("bandwidth", C.c_double), ("dispersion_measure", C.c_double),
                 ("input_nchan", C.c_uint32), ("nchan", C.c_uint32), ("ndim", C.c_uint32),
@@ -58,6 +62,7 @@ SYMBOLS = {
                                                  _u64]),
     "dspsr_amd_detect_polarimetry": (_i, [_vp, _i, _u32, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u64]),
     "dspsr_amd_detect_square_law": (_i, [_vp, _i, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u32, _u64]),
+    "dspsr_amd_tfp_filterbank": (_i, [_vp, C.POINTER(TfpConfig), _vp, _i, _f, _vp, _u64]),
     "dspsr_amd_fold_create": (_i, [_vp, _pp]),
     "dspsr_amd_fold_destroy": (None, [_vp]),
     "dspsr_amd_fold_set_shape": (_i, [_vp, _u32, _u32, _u32, _u32]),

@@ -1,0 +1,180 @@
+// Search-mode front end (digifil): non-convolving filterbank + square-law detection + time scrunch,
+// fused into one launch.
+//
+// Reference chain (Signal/General/LoadToFil.C:195-315):
+//   dsp::TFPFilterbank::filterbank   TFPFilterbank.C:27-101   forward FFT of nsamp_fft = 2*nchan real samples
+//                                    per pol and part, power Re^2 + Im^2 of bins 0..nchan-1, TFP order,
+//                                    optional pol sum (pscrunch)
+//   dsp::TScrunch::tfp_tscrunch      TScrunch.C:180-206       out = in[0]; out += in[1] ... in[sfactor-1]
+// Here: both polarisations of one part form one complex sequence w = x0 + i*x1 of L = 2*nchan points
+// (the interleaved 8-bit bytes are w), T = 16384/L consecutive parts are the columns of one workgroup
+// transform, the Hermitian split + |.|^2 is applied while reading the transform back from LDS, and each
+// thread keeps the running time-scrunch sums of the bins it owns in registers (added in time order).
+#include "engine_internal.h"
+
+namespace dspsr_amd {
+
+struct TfpParams {
+  const uint8_t* raw;      // generic 8-bit order, real, 2 pols, 1 channel: byte 2*t + p
+  float* out;              // [nout][nchan][npol_out]
+  uint64_t npart;          // parts available
+  uint32_t sfactor;        // time scrunch factor (>= 1)
+  uint32_t pscrunch;       // 1: sum the two polarisations (Intensity), 0: PPQQ
+  float scale;
+  int logT;
+  int caspsr;
+};
+
+DEV uint32_t tfp_fetch(const TfpParams& p, const uint64_t t)   // (pol0, pol1) bytes of sample t
+{
+  if (p.caspsr) {
+    const uint8_t* b = p.raw + (t >> 2) * 8 + (t & 3);
+    return (uint32_t)b[0] | ((uint32_t)b[4] << 8);
+  }
+  return *(const uint16_t*)(p.raw + 2 * t);
+}
+
+template <int LOGF>
+__global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __restrict__ tw)
+{
+  typedef FftPlan<LOGF> P;
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  uint32_t tid = threadIdx.x;
+  const uint32_t nt = blockDim.x;
+  const int logT = p.logT;
+  const uint32_t T = 1u << logT, L = 1u << LOGF, nchan = L >> 1;
+  const uint32_t npol_out = p.pscrunch ? 1 : 2;
+  // one item = the parts of one output sample, rounded up to whole column groups
+  const uint64_t nout = p.npart / p.sfactor;
+  const uint32_t ltw_off = lds_pad(PTS * nt) + 8;
+  ltw_fill<LOGF>(lds, ltw_off, tw, tid, nt);
+  constexpr int NB = (LOGF - 1 > 9) ? (1 << (LOGF - 1 - 9)) : 1;   // bins per thread at 512 threads
+
+  // work items: groups of T consecutive parts, dealt in order so that a workgroup owns whole output samples
+  // when sfactor >= T, or several whole output samples when sfactor < T (host guarantees sfactor % T == 0
+  // or T % sfactor == 0)
+  const uint32_t groups_per_out = p.sfactor > T ? p.sfactor >> logT : 1;
+  const uint64_t nitem = p.sfactor > T ? nout : (nout * p.sfactor + T - 1) >> logT;
+
+  auto fetch = [&](const uint64_t group, uint32_t (&raw)[NPAIR]) {
+    const uint64_t part0 = group << logT;
+#pragma unroll
+    for (int g2 = 0; g2 < P::G1; g2 += 2)
+#pragma unroll
+      for (int i = 0; i < P::R1; i++) {
+        const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
+        const uint32_t col = e & (T - 1), n = e >> logT;
+        const uint64_t pa = part0 + col, pb = pa + 1;
+        const uint32_t wa = pa < p.npart ? tfp_fetch(p, pa * L + n) : 0x80808080u;
+        const uint32_t wb = pb < p.npart ? tfp_fetch(p, pb * L + n) : 0x80808080u;
+        raw[(g2 / 2) * P::R1 + i] = (wa & 0xffffu) | (wb << 16);
+      }
+  };
+
+  for (uint64_t item = blockIdx.x; item < nitem; item += gridDim.x) {
+    float acc[NB][2];
+#pragma unroll
+    for (int j = 0; j < NB; j++) acc[j][0] = acc[j][1] = 0.f;
+    for (uint32_t gi = 0; gi < groups_per_out; gi++) {
+      const uint64_t group = item * groups_per_out + gi;
+      asm volatile("" : "+v"(tid));
+      uint32_t raw[NPAIR];
+      fetch(group, raw);
+      cx2 x[NPAIR];
+#pragma unroll
+      for (int h = 0; h < NPAIR; h++) {
+        const uint32_t w = raw[h];
+        x[h] = make_cx2(make_float2(((float)(int8_t)(w & 0xff) + 0.5f) * p.scale, ((float)(int8_t)((w >> 8) & 0xff) + 0.5f) * p.scale),
+                        make_float2(((float)(int8_t)((w >> 16) & 0xff) + 0.5f) * p.scale, ((float)(int8_t)(w >> 24) + 0.5f) * p.scale));
+      }
+      auto store = [&](const uint32_t col, const uint32_t pp, const uint32_t pstride, auto& v) {
+        constexpr int R = sizeof(v) / sizeof(v[0]);
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          const uint32_t pos = k * pstride + pp;
+          *(float4*)&lds[lds_pad((pos << logT) | col)] = make_float4(v[k].x[0], v[k].y[0], v[k].x[1], v[k].y[1]);
+        }
+      };
+      wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
+      __syncthreads();
+      // Hermitian split, power, time scrunch (columns = consecutive parts, added in time order)
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        const uint32_t k = tid + j * nt;
+        if (k < nchan) {
+          const uint32_t km = (L - k) & (L - 1);
+          for (uint32_t c = 0; c < T; c++) {
+            const uint64_t part = (group << logT) + c;
+            if (part >= nout * p.sfactor) break;
+            const cf a = lds[lds_pad((k << logT) | c)], b = lds[lds_pad((km << logT) | c)];
+            const float x0r = 0.5f * (a.x + b.x), x0i = 0.5f * (a.y - b.y);
+            const float x1r = 0.5f * (a.y + b.y), x1i = 0.5f * (b.x - a.x);
+            float p0 = x0r * x0r; p0 += x0i * x0i;            // TFPFilterbank.C:56-59
+            float p1 = x1r * x1r; p1 += x1i * x1i;
+            if (p.pscrunch) { p0 += p1; p1 = 0.f; }                 // TFPFilterbank.C:79-80: pol sum BEFORE the time sum
+            const uint32_t phase = (uint32_t)(part % p.sfactor);
+            if (phase == 0) { acc[j][0] = p0; acc[j][1] = p1; }     // TScrunch.C:193-194
+            else { acc[j][0] += p0; acc[j][1] += p1; }               // TScrunch.C:199-200
+            if (phase == p.sfactor - 1) {
+              float* o = p.out + ((part / p.sfactor) * nchan + k) * npol_out;
+              o[0] = acc[j][0];
+              if (!p.pscrunch) o[1] = acc[j][1];
+            }
+          }
+        }
+      }
+      __syncthreads();    // LDS is overwritten by the next group's exchanges
+    }
+  }
+}
+
+typedef void (*ktfp_t)(TfpParams, const cf*);
+template <int... I> struct iseq_t {};
+template <int N, int... I> struct mkseq_t : mkseq_t<N - 1, N - 1, I...> {};
+template <int... I> struct mkseq_t<0, I...> { typedef iseq_t<I...> type; };
+template <int... I> static ktfp_t pick_tfp(int logf, iseq_t<I...>) { static const ktfp_t t[] = {k_tfp<I>...}; return t[logf]; }
+
+}  // namespace dspsr_amd
+
+using namespace dspsr_amd;
+
+extern "C" int dspsr_amd_tfp_filterbank(dspsr_amd_ctx* ctx, const dspsr_amd_tfp_config* cfg, const int8_t* raw_dev,
+                                        int raw_layout, float scale, float* out_dev, uint64_t npart)
+{
+  if (!ctx || !cfg || !raw_dev || !out_dev) return DSPSR_AMD_EINVAL;
+  const uint32_t nchan = cfg->nchan;
+  if (nchan < 16 || (nchan & (nchan - 1)) || nchan > 4096)
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_tfp_filterbank: nchan=%u must be a power of two in [16, 4096]", nchan);
+  if (cfg->npol != 2)
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_tfp_filterbank: only real dual-polarisation 8-bit input is built (npol=%u)", cfg->npol);
+  const uint32_t sf = cfg->tscrunch ? cfg->tscrunch : 1;
+  int logF = 0;
+  while ((1u << logF) < 2 * nchan) logF++;
+  const int logT = 14 - logF;
+  const uint32_t T = 1u << logT;
+  if (!((sf % T) == 0 || (T % sf) == 0))
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL,
+                    "dspsr_amd_tfp_filterbank: tscrunch=%u must divide or be a multiple of %u parts per workgroup", sf, T);
+  if (raw_layout != DSPSR_AMD_RAW_GENERIC && raw_layout != DSPSR_AMD_RAW_CASPSR)
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_tfp_filterbank: unknown raw layout %d", raw_layout);
+  if (raw_layout == DSPSR_AMD_RAW_GENERIC && ((uintptr_t)raw_dev & 1))
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_tfp_filterbank: raw pointer must be 2-byte aligned");
+  const uint64_t nout = npart / sf;
+  if (nout == 0) return DSPSR_AMD_OK;
+  TfpParams p;
+  p.raw = (const uint8_t*)raw_dev; p.out = out_dev; p.npart = npart; p.sfactor = sf; p.pscrunch = cfg->pscrunch ? 1 : 0;
+  p.scale = scale; p.logT = logT; p.caspsr = raw_layout == DSPSR_AMD_RAW_CASPSR;
+  ktfp_t k = pick_tfp(logF, mkseq_t<14>::type());
+  const size_t lds = lds_total_words_host(16384, logF) * sizeof(cf);
+  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_tfp_filterbank: %s", hipGetErrorString(e));
+  const uint64_t nitem = sf > T ? nout : (nout * sf + T - 1) >> logT;
+  hipDeviceProp_t prop;
+  uint32_t ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+                     ? (uint32_t)prop.multiProcessorCount : 256u;
+  const uint32_t grid = (uint32_t)(nitem < ncu ? nitem : ncu);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, ctx->stream, p, ctx->tw);
+  e = hipGetLastError();
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_tfp_filterbank: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}

@@ -214,6 +214,16 @@ class FilterbankEngine:
             pass
 
 
+def tfp_filterbank(ctx: Context, raw, nchan, npart, out, pscrunch=False, tscrunch=1, layout=_lib.RAW_GENERIC,
+                   scale=1.0):
+    """digifil front end: dsp::TFPFilterbank (+pscrunch) + dsp::TScrunch fused (TFPFilterbank.C:27-101,
+    TScrunch.C:180-206).  raw: device int8 block (real, 2 pols); out: device float32
+    [npart // tscrunch][nchan][1 or 2]."""
+    cfg = _lib.TfpConfig(nchan, 2, int(bool(pscrunch)), int(tscrunch))
+    _check(ctx.handle, lib.dspsr_amd_tfp_filterbank(ctx.handle, C.byref(cfg), raw.data_ptr(), layout, scale,
+                                                    out.data_ptr(), npart), "dspsr_amd_tfp_filterbank")
+
+
 class DetectionEngine:
     """dsp::Detection::Engine."""
 

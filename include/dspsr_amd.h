@@ -122,6 +122,19 @@ int dspsr_amd_detect_square_law(dspsr_amd_ctx* ctx, int intensity, const float* 
                                 uint64_t in_pol_stride, float* out_dev, uint64_t out_chan_stride,
                                 uint64_t out_pol_stride, uint32_t nchan, uint32_t npol, uint64_t ndat);
 
+/* ---- search mode (digifil): dsp::TFPFilterbank (TFPFilterbank.C:27-101: forward FFT of 2*nchan real
+ * samples per pol and part, Re^2+Im^2 of bins 0..nchan-1, TFP order) + optional pol sum + dsp::TScrunch
+ * (TScrunch.C:180-206) fused in one launch.  Real dual-pol 8-bit input, raw_dev = first byte of the block.
+ *   out_dev: [npart/tscrunch][nchan][pscrunch ? 1 : 2] floats (PPQQ or Intensity, TimeSeries::OrderTFP) */
+typedef struct {
+  uint32_t nchan;      /* -F nchan (power of two, 16..4096) */
+  uint32_t npol;       /* input polarisations (2) */
+  uint32_t pscrunch;   /* 1: Intensity (p0+p1), 0: PPQQ */
+  uint32_t tscrunch;   /* -t factor, 0/1 = none */
+} dspsr_amd_tfp_config;
+int dspsr_amd_tfp_filterbank(dspsr_amd_ctx* ctx, const dspsr_amd_tfp_config* cfg, const int8_t* raw_dev, int raw_layout,
+                             float scale, float* out_dev, uint64_t npart);
+
 /* ---- dsp::Fold::Engine (Fold.h:249-312, FoldCUDA.cu) --------------------------------------
  * The engine owns the device-resident profile (get_profiles()).  Call order per Fold::fold
  * (Fold.C:724-829): set_nbin, set_ndat, set_bin x ndat (or set_bins), fold.  synch copies to host. */

@@ -556,6 +556,39 @@ def square_law(fb: np.ndarray, state: str = "PPQQ") -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------
+# Search mode front end: TFPFilterbank + pscrunch + TScrunch
+# --------------------------------------------------------------------------------------
+
+def tfp_filterbank(unpacked: np.ndarray, nchan: int, pscrunch: bool, dtype=np.float32) -> np.ndarray:
+    """dsp::TFPFilterbank::filterbank (TFPFilterbank.C:27-101), real input: per pol and part forward FFT of
+    nsamp_fft = 2*nchan samples, Re^2 then += Im^2 of bins 0..nchan-1.  -> [npart][nchan][npol_out]."""
+    _, npol, ndat = unpacked.shape
+    nsamp_fft = 2 * nchan
+    npart = ndat // nsamp_fft
+    x = unpacked[0, :, :npart * nsamp_fft].astype(dtype).reshape(npol, npart, nsamp_fft)
+    spec = np.fft.rfft(x, axis=2)[:, :, :nchan]
+    f = np.float32 if dtype == np.float32 else np.float64
+    re, im = spec.real.astype(f), spec.imag.astype(f)
+    out = re * re
+    out = out + im * im                                   # [npol][npart][nchan]
+    if npol == 2 and pscrunch:
+        return (out[0] + out[1])[:, :, None]              # :79-80  outdat[i] += outdat[i+nfloat]
+    return np.ascontiguousarray(out.transpose(1, 2, 0))
+
+
+def tscrunch_tfp(x: np.ndarray, sfactor: int) -> np.ndarray:
+    """dsp::TScrunch::tfp_tscrunch (TScrunch.C:180-206): out = in[0]; out += in[1]; ... (sequential)."""
+    nout = x.shape[0] // sfactor
+    out = np.empty((nout,) + x.shape[1:], dtype=x.dtype)
+    for o in range(nout):
+        acc = x[o * sfactor].copy()
+        for j in range(1, sfactor):
+            acc = acc + x[o * sfactor + j]
+        out[o] = acc
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # Fold (a9 - a13)
 # --------------------------------------------------------------------------------------
 

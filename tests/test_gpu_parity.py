@@ -336,3 +336,25 @@ def test_pipeline_subintegrations(oracle, gpu):
         assert np.array_equal(hits, ps.hits), isub
         assert np.abs(prof - ps.data).max() <= 1e-5 * np.abs(ps.data).max(), isub
     lt.close()
+
+
+@pytest.mark.parametrize("nchan,tscrunch,pscrunch,npart", [(4096, 16, True, 64), (4096, 16, False, 35), (256, 4, True, 130),
+                                                           (64, 1, False, 300), (1024, 32, True, 96), (16, 2, False, 1024)])
+def test_tfp_filterbank_search_mode(oracle, gpu, nchan, tscrunch, pscrunch, npart):
+    """digifil front end: TFPFilterbank + pscrunch + TScrunch fused, against the float32 oracle
+    (same operation order); tolerance 2e-5 of the rms power (FFT rounding differs from pocketfft)."""
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(12)
+    ndat = npart * 2 * nchan
+    raw = np.clip(np.rint(rng.standard_normal(ndat * 2) * 24.0), -128, 127).astype(np.int8)
+    obs = oracle.Observation()
+    want = oracle.tscrunch_tfp(oracle.tfp_filterbank(oracle.unpack_8bit(raw, obs), nchan, pscrunch), tscrunch)
+    nout = npart // tscrunch
+    out = torch.zeros((nout, nchan, 1 if pscrunch else 2), dtype=torch.float32, device="cuda")
+    dspsr_amd.tfp_filterbank(ctx, torch.from_numpy(raw).cuda(), nchan, npart, out, pscrunch, tscrunch,
+                             scale=float(oracle.S8))
+    got = out.cpu().numpy()
+    assert got.shape == want.shape
+    rms = np.sqrt(np.mean(want.astype(np.float64) ** 2))
+    assert np.abs(got - want).max() <= 2e-5 * rms * 8
+    assert np.sqrt(np.mean((got - want).astype(np.float64) ** 2)) <= 2e-6 * rms
