@@ -173,10 +173,18 @@ def main():
                      % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (the product has no CPU path)")
+    # test hook: DSPSR_AMD_SINGLE_DEVICE=1 maps every rank to GPU 0 with the gloo backend, so the N>1 code path
+    # can be exercised on a one-GPU box (the real run is one rank per GPU over RCCL)
+    single = os.environ.get("DSPSR_AMD_SINGLE_DEVICE") == "1"
+    if single:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if single:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
     if args.workload == "cfg5":
