@@ -174,36 +174,58 @@ template <int R> DEV void apply_pass_twiddle(cx2 (&v)[R], const uint32_t nb, con
 __global__ __launch_bounds__(256) void k_raw_transpose(const FbGeom g, const FbIn in, uint16_t* __restrict__ Rt,
                                                        const uint64_t part0)
 {
-  __shared__ uint16_t sm[32][256 + 2];
+  // block: 64 rows (na) x 256 columns (nb) of byte pairs; rows are read as 16-byte pieces (8 samples),
+  // written as T-sample (2T-byte) pieces of 64 consecutive rows = 128*T contiguous bytes per tile
+  constexpr uint32_t ROWS = 64, COLS = 256, PITCH = COLS / 2 + 1;       // 32-bit words per LDS row (+1: bank skew)
+  __shared__ uint32_t sm[ROWS * PITCH];
   const uint32_t tid = threadIdx.x;
-  const uint32_t M = 1u << g.logM, Rr = 1u << g.logR, T = 1u << g.logT1;
-  const uint32_t nb0 = blockIdx.x * 256, na0 = blockIdx.y * 32;
+  const uint32_t M = 1u << g.logM, Rr = 1u << g.logR;
+  const int logT = g.logT1;
+  const uint32_t nb0 = blockIdx.x * COLS, na0 = blockIdx.y * ROWS;
   const uint64_t part = blockIdx.z;
   const uint64_t t0 = (part0 + part) * in.part_step;
-  const uint32_t ncol = Rr - nb0 < 256 ? Rr - nb0 : 256, nrow = M - na0 < 32 ? M - na0 : 32;
-  for (uint32_t q = tid; q < nrow * (ncol / 4); q += 256) {       // 4 samples (8 bytes) per thread and step
-    const uint32_t r = q / (ncol / 4), c4 = (q % (ncol / 4)) * 4;
-    const uint64_t t = t0 + (((uint64_t)(na0 + r)) << g.logR) + nb0 + c4;   // multiple of 4
-    uint32_t lo, hi;                                                  // samples t,t+1 | t+2,t+3 as byte pairs
-    if (in.kind == 2) {
-      const uint32_t* p = (const uint32_t*)((const uint8_t*)in.base + (t >> 2) * 8);
-      const uint32_t p0 = p[0], p1 = p[1];
-      lo = (p0 & 0xff) | ((p1 & 0xff) << 8) | ((p0 & 0xff00) << 8) | ((p1 & 0xff00) << 16);
-      hi = ((p0 >> 16) & 0xff) | (((p1 >> 16) & 0xff) << 8) | ((p0 >> 24) << 16) | ((p1 >> 24) << 24);
-    } else {
-      const uint32_t* p = (const uint32_t*)((const uint8_t*)in.base + 2 * t);
-      lo = p[0];
-      hi = p[1];
+  const uint32_t ncol = Rr - nb0 < COLS ? Rr - nb0 : COLS, nrow = M - na0 < ROWS ? M - na0 : ROWS;
+  if (ncol % 8 == 0) {
+    for (uint32_t q = tid; q < nrow * (ncol / 8); q += 256) {       // 8 samples (16 bytes) per thread and step
+      const uint32_t r = q / (ncol / 8), c8 = (q % (ncol / 8)) * 8;
+      const uint64_t t = t0 + (((uint64_t)(na0 + r)) << g.logR) + nb0 + c8;   // multiple of 4 (8 unless t0 is odd*4)
+      uint32_t w[4];
+      if (in.kind == 2) {                                              // CASPSR: 4 B pol0 | 4 B pol1
+        const uint32_t* p = (const uint32_t*)((const uint8_t*)in.base + (t >> 2) * 8);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const uint32_t p0 = p[2 * h], p1 = p[2 * h + 1];
+          w[2 * h] = (p0 & 0xff) | ((p1 & 0xff) << 8) | ((p0 & 0xff00) << 8) | ((p1 & 0xff00) << 16);
+          w[2 * h + 1] = ((p0 >> 16) & 0xff) | (((p1 >> 16) & 0xff) << 8) | ((p0 >> 24) << 16) | ((p1 >> 24) << 24);
+        }
+      } else {
+        const uint32_t* p = (const uint32_t*)((const uint8_t*)in.base + 2 * t);
+        w[0] = p[0]; w[1] = p[1]; w[2] = p[2]; w[3] = p[3];
+      }
+#pragma unroll
+      for (int h = 0; h < 4; h++) sm[r * PITCH + c8 / 2 + h] = w[h];
     }
-    sm[r][c4] = (uint16_t)lo; sm[r][c4 + 1] = (uint16_t)(lo >> 16);
-    sm[r][c4 + 2] = (uint16_t)hi; sm[r][c4 + 3] = (uint16_t)(hi >> 16);
+  } else {                                                              // narrow problems: 2 samples per step
+    for (uint32_t q = tid; q < nrow * (ncol / 2); q += 256) {
+      const uint32_t r = q / (ncol / 2), c2 = (q % (ncol / 2)) * 2;
+      const uint64_t t = t0 + (((uint64_t)(na0 + r)) << g.logR) + nb0 + c2;
+      uint32_t w;
+      if (in.kind == 2) {
+        const uint8_t* b = (const uint8_t*)in.base + (t >> 2) * 8 + (t & 3);
+        w = (uint32_t)b[0] | ((uint32_t)b[4] << 8) | ((uint32_t)b[1] << 16) | ((uint32_t)b[5] << 24);
+      } else {
+        w = *(const uint32_t*)((const uint8_t*)in.base + 2 * t);
+      }
+      sm[r * PITCH + c2 / 2] = w;
+    }
   }
   __syncthreads();
-  uint16_t* __restrict__ dst = Rt + part * ((uint64_t)M << g.logR);
-  const uint32_t ntl = ncol >> g.logT1;
-  for (uint32_t q = tid; q < ntl * nrow * T; q += 256) {           // [tile][row][col] runs of nrow*T pairs
-    const uint32_t col = q & (T - 1), r = (q >> g.logT1) % nrow, tl = (q >> g.logT1) / nrow;
-    dst[(((uint64_t)((nb0 >> g.logT1) + tl) << g.logM) + na0 + r) * T + col] = sm[r][tl * T + col];
+  uint32_t* __restrict__ dst = (uint32_t*)(Rt + part * ((uint64_t)M << g.logR));
+  const int logW = logT - 1;                        // 32-bit words per (row, tile) piece
+  const uint32_t ntl = ncol >> logT, W = 1u << logW;
+  for (uint32_t q = tid; q < ntl * nrow * W; q += 256) {           // [tile][row][word]: runs of nrow*T pairs
+    const uint32_t wd = q & (W - 1), r = (q >> logW) % nrow, tl = (q >> logW) / nrow;
+    dst[((((uint64_t)((nb0 >> logT) + tl) << g.logM) + na0 + r) << logW) + wd] = sm[r * PITCH + (tl << logW) + wd];
   }
 }
 
@@ -792,7 +814,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
                      n3 = (uint64_t)(g.C >> g.logT3) * nb;
       const uint32_t run1 = 32, run2 = 4, run3 = nb;
       if (pret) {
-        hipLaunchKernelGGL(k_raw_transpose, dim3((Rr + 255) / 256, (M + 31) / 32, nb), dim3(256), 0, ctx->stream, g, ci,
+        hipLaunchKernelGGL(k_raw_transpose, dim3((Rr + 255) / 256, (M + 63) / 64, nb), dim3(256), 0, ctx->stream, g, ci,
                            fb->Rt, part0);
         ci.kind = 3;
         ci.base = fb->Rt;
