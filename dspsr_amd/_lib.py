@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdspsr_amd.so")
+# DSPSR_AMD_LIB: alternative build of the same library (kernel experiments); there is still no fallback
+LIB_PATH = os.environ.get("DSPSR_AMD_LIB") or os.path.join(_HERE, "libdspsr_amd.so")
 
 OK, EINVAL, EHIP, ENOMEM, ESTATE = 0, -1, -2, -3, -4
 H2D, D2H, D2D = 1, 2, 3

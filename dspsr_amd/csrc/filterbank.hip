@@ -51,6 +51,53 @@ struct FbOut {
 
 DEV float cvt8(int v, float scale) { return ((float)v + 0.5f) * scale; }
 
+// streaming accesses: scratch and output data are written once and read once by another pass, so the
+// stores/loads may carry the non-temporal hint (build-time experiment switches FB_NT_STORE / FB_NT_LOAD)
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+#ifndef FB_NT_STORE
+#define FB_NT_STORE 0
+#endif
+#ifndef FB_NT_LOAD
+#define FB_NT_LOAD 1     // measured: P2 -7 %, P3 -6 % (profiles/r01c_experiments.txt)
+#endif
+DEV void st_stream(float4* p, const float4 v)
+{
+#if FB_NT_STORE
+  const f4v t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, (f4v*)p);
+#else
+  *p = v;
+#endif
+}
+DEV void st_stream(float2* p, const float2 v)
+{
+#if FB_NT_STORE
+  const f2v t = {v.x, v.y};
+  __builtin_nontemporal_store(t, (f2v*)p);
+#else
+  *p = v;
+#endif
+}
+DEV float4 ld_stream(const float4* p)
+{
+#if FB_NT_LOAD
+  const f4v t = __builtin_nontemporal_load((const f4v*)p);
+  return make_float4(t[0], t[1], t[2], t[3]);
+#else
+  return *p;
+#endif
+}
+DEV float2 ld_stream(const float2* p)
+{
+#if FB_NT_LOAD
+  const f2v t = __builtin_nontemporal_load((const f2v*)p);
+  return make_float2(t[0], t[1]);
+#else
+  return *p;
+#endif
+}
+
 // ---- input: two time-adjacent samples (columns col, col+1 of a tile) per request ---------------
 // The load is split in two so that a persistent workgroup can issue the loads of its NEXT tile
 // before computing the current one and only convert them afterwards:
@@ -307,7 +354,8 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
         lds[lds_pad(l + T2)] = cx2_hi(v[k]);
       }
     };
-    wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
+    if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
+    else wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
     __syncthreads();
     if (!(g.dbg & 1)) {
       const uint32_t nthr = blockDim.x;
@@ -316,7 +364,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
         const uint32_t l = 2 * (tid + jj * nthr);                  // element index inside the staged tile
         const uint32_t blkA = l >> (logT + logT2), within = l & ((1u << (logT + logT2)) - 1);
         const float4 pr = *(const float4*)&lds[lds_pad(l)];
-        *(float4*)&Aseq[((((uint64_t)blkA << g.logR) + tile * T) << logT2) + within] = pr;
+        st_stream((float4*)&Aseq[((((uint64_t)blkA << g.logR) + tile * T) << logT2) + within], pr);
       }
     }
     if (!more) break;
@@ -355,7 +403,7 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
     for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
       for (int i = 0; i < P::R1; i++)
-        y[(g2 / 2) * P::R1 + i] = *(const float4*)&Ablk[first_stage_elem<LOGF>(tid, logT, g2, i)];
+        y[(g2 / 2) * P::R1 + i] = ld_stream((const float4*)&Ablk[first_stage_elem<LOGF>(tid, logT, g2, i)]);
   };
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
@@ -387,7 +435,8 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
         lds[lds_pad(l + T3)] = cx2_hi(v[k]);
       }
     };
-    wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
+    if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
+    else wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
     __syncthreads();
     if (!(g.dbg & 1)) {
       const uint32_t nthr = blockDim.x;
@@ -396,7 +445,7 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
         const uint32_t l = 2 * (tid + jj * nthr);
         const uint32_t blkX = l >> (logT + logT3), within = l & ((1u << (logT + logT3)) - 1);
         const float4 pr = *(const float4*)&lds[lds_pad(l)];
-        *(float4*)&Xseq[((((uint64_t)blkX << g.logM) + tile * T2) << logT3) + within] = pr;
+        st_stream((float4*)&Xseq[((((uint64_t)blkX << g.logM) + tile * T2) << logT3) + within], pr);
       }
     }
     if (!more) break;
@@ -465,8 +514,8 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
                                          : (rr >> logT3) * blk + (rr & (T3 - 1));
         const uint64_t ib = g.real_input ? ib_mirror : (g.npol == 2 ? L + ia : ia);
         Abk r;
-        r.a = X0s[ia];
-        r.b = X0s[ib];
+        r.a = ld_stream(&X0s[ia]);
+        r.b = ld_stream(&X0s[ib]);
         raw[(g2 / 2) * P::R1 + i] = r;
       }
   };
@@ -534,17 +583,17 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         const cf va = cx2_lo(v[k]), vb = cx2_hi(v[k]);
         if (out.kind == 1) {
           float2* o = (float2*)(row + part * out.part_step) + t;
-          o[0] = va;
-          if (g.npol == 2) ((float2*)((float*)o + out.pol_stride))[0] = vb;
+          st_stream(o, va);
+          if (g.npol == 2) st_stream((float2*)((float*)o + out.pol_stride), vb);
         } else {
           float r[4];
           detect4(va, vb, out.state, r);
           const uint64_t idat = part * g.nkeep + t;
           if (out.ndim == 4) {
-            ((float4*)row)[idat] = make_float4(r[0], r[1], r[2], r[3]);
+            st_stream(&((float4*)row)[idat], make_float4(r[0], r[1], r[2], r[3]));
           } else if (out.ndim == 2) {
-            ((float2*)row)[idat] = make_float2(r[0], r[1]);
-            ((float2*)(row + out.pol_stride))[idat] = make_float2(r[2], r[3]);
+            st_stream(&((float2*)row)[idat], make_float2(r[0], r[1]));
+            st_stream(&((float2*)(row + out.pol_stride))[idat], make_float2(r[2], r[3]));
           } else {
             row[idat] = r[0];
             row[out.pol_stride + idat] = r[1];
@@ -554,7 +603,8 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         }
       }
     };
-    wgfft<LOGF, +1>(lds, ltw_off, tid, logT, x, store);
+    if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
+    else wgfft<LOGF, +1>(lds, ltw_off, tid, logT, x, store);
     if (!more) break;
     item = next;
   }
@@ -569,6 +619,11 @@ template <int... I> struct iseq {};
 template <int N, int... I> struct mkseq : mkseq<N - 1, N - 1, I...> {};
 template <int... I> struct mkseq<0, I...> { typedef iseq<I...> type; };
 
+#ifdef FB_ONLY_HEADLINE   // experiment builds: only the kernels of the headline geometry (M = 4096, Rr = 2048, 8-bit)
+template <int... I> static k1_t pick1(int logf, int raww, iseq<I...>) { return logf == 12 && raww == 1 ? k_fwd_cols<12, 1> : nullptr; }
+template <int... I> static k2_t pick2(int logf, iseq<I...>) { return logf == 11 ? k_fwd_rows<11> : nullptr; }
+template <int... I> static k3_t pick3(int logf, iseq<I...>) { return logf == 12 ? k_inv_chan<12> : nullptr; }
+#else
 template <int... I> static k1_t pick1(int logf, int raww, iseq<I...>)
 {
   static const k1_t t4[] = {k_fwd_cols<I, 4>...};
@@ -577,6 +632,7 @@ template <int... I> static k1_t pick1(int logf, int raww, iseq<I...>)
 }
 template <int... I> static k2_t pick2(int logf, iseq<I...>) { static const k2_t t[] = {k_fwd_rows<I>...}; return t[logf]; }
 template <int... I> static k3_t pick3(int logf, iseq<I...>) { static const k3_t t[] = {k_inv_chan<I>...}; return t[logf]; }
+#endif
 
 constexpr int MAX_LOGF = 13;    // every pass keeps >= 2 columns per workgroup
 constexpr int LOG_POINTS_DEFAULT = 14;  // points per workgroup (32 per thread, 512 threads)
@@ -793,6 +849,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   k1_t k1 = pick1(g.logM, raww, seq_t());
   k2_t k2 = pick2(g.logR, seq_t());
   k3_t k3 = pick3(g.logM, seq_t());
+  if (!k1 || !k2 || !k3) return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: geometry not in this (experiment) build");
   hipError_t e;
   if ((e = allow_lds(k1, fb->lds1)) != hipSuccess || (e = allow_lds(k2, fb->lds2)) != hipSuccess ||
       (e = allow_lds(k3, fb->lds3)) != hipSuccess)

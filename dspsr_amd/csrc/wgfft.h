@@ -324,6 +324,25 @@ DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx
   }
 }
 
+// Ablation only (DSPSR_AMD_DEBUG bit 4): hands the first-stage registers straight to `out` in the shape
+// of the last stage, i.e. a tile with its global loads and stores but without the transform.
+template <int LOGF, class Out>
+DEV void wgfft_passthrough(uint32_t tid, const int logT, cx2 (&x)[NPAIR], Out& out)
+{
+  typedef FftPlan<LOGF> P;
+  constexpr int LOGRL = P::NS <= 1 ? P::LOGR1 : (P::REM ? P::REM : 4);
+  constexpr int R = 1 << LOGRL, G = PTS / R, H = G / 2;
+  const int logP = LOGF - LOGRL;
+#pragma unroll
+  for (int h = 0; h < H; h++) {
+    const uint32_t u = G * tid + 2 * h;
+    cx2 v[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) v[k] = x[h * R + k];
+    out(u & ((1u << logT) - 1), (u >> logT) & ((1u << logP) - 1), 1u << logP, v);
+  }
+}
+
 // Work distribution of a persistent grid.  Items are dealt to the 8 XCDs in runs of `run`
 // consecutive items (blocks b and b+8 share an XCD under the observed round-robin placement;
 // a different placement only changes speed), so neighbouring items -- which share 128-byte
