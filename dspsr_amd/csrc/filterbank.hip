@@ -25,11 +25,14 @@
 namespace dspsr_amd {
 
 struct FbGeom {
-  int logM, logR, logT1, logT2, logT3;
+  int logM, logR, logT1, logT2, logT3;   // four-pass mode: logM/logR are the forward factors Fa/Fb (L = Fa*Fb), logT3 = 0
+  int four_pass;                         // freq_res handled by a two-pass inverse (k_inv_a + k_inv_b)
+  int logMf, logMa, logMb, logTm, logTt; // freq_res = Ma*Mb ; m2 columns per k_inv_a tile ; t1 columns per k_inv_b tile
   int real_input, npol;
   uint32_t C, nfilt_pos, nkeep;
   int dbg;   // DSPSR_AMD_DEBUG ablation bits (timing experiments only; results are wrong when set)
   const float2* tw_lo;   // exp(-2*pi*i*j/L), j < L/TWN : fine part of the pass-1 twiddle (L > TWN)
+  const float2* tw_lo_m; // exp(-2*pi*i*j/freq_res), j < freq_res/TWN : same for the inverse twiddle (four-pass mode)
 };
 
 struct FbIn {
@@ -209,6 +212,24 @@ template <int R> DEV void apply_pass_twiddle(cx2 (&v)[R], const uint32_t nb, con
 #pragma unroll
   for (int k = 0; k < R; k++) v[k] = cmul(v[k], wa);
 #undef twiddle_big
+}
+
+// v[k] *= conj(W_L^{nb*(k*pstride + p)}) for BOTH columns of the pair (the two polarisations of one column
+// nb), k < R : the inter-pass twiddle of the two-pass inverse transform
+template <int R> DEV void apply_pass_twiddle_inv(cx2 (&v)[R], const uint32_t nb, const uint32_t p, const uint32_t pstride,
+                                                 const int logL, const cf* __restrict__ tw, const cf* __restrict__ tw_lo)
+{
+  const uint64_t Lm = (1ull << logL) - 1;
+  const uint64_t a0 = ((uint64_t)nb * p) & Lm, d0 = ((uint64_t)nb * pstride) & Lm;
+  auto W = [&](const uint64_t j) { cf w = twiddle_big(j & Lm, logL, tw, tw_lo); w.y = -w.y; return w; };
+  const cf wa = W(a0);
+  if constexpr (R > 1) {
+    const cf w1 = W(d0);
+    const cf w2 = R >= 4 ? W(2 * d0) : w1, w4 = R >= 8 ? W(4 * d0) : w1, w8 = R >= 16 ? W(8 * d0) : w1;
+    apply_powers<R>(v, w1, w2, w4, w8);
+  }
+#pragma unroll
+  for (int k = 0; k < R; k++) v[k] = cmuls(v[k], wa);
 }
 
 // ------------------------------------------------------------------------------------ P0
@@ -610,10 +631,223 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   }
 }
 
+// ------------------------------------------------------------------------------------ P3a / P3b
+// Two-pass inverse transform for freq_res = Ma*Mb beyond one workgroup tile (and for nchan_subband = 1,
+// i.e. dsp::Convolution): bin m = m1*Mb + m2, output sample t = t1 + Ma*t2.
+//   P3a k_inv_a : spectrum X in natural order (k = c*freq_res + m) -> Hermitian split / pol select -> x chirp
+//                 -> inverse Ma-point FFTs over m1 for Tm adjacent m2 -> x conj(W_M^{m2*t1})
+//                 -> U[c][t1/Tt][m2][t1%Tt][pol]
+//   P3b k_inv_b : inverse Mb-point FFTs over m2 for Tt adjacent t1 (one contiguous block of U)
+//                 -> keep window on t = t1 + Ma*t2 -> complex output or fused detection
+// Columns of both tiles are (column, pol) pairs, so the thread's two butterflies are the two polarisations.
+template <int LOGF>
+__global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restrict__ X, const cf* __restrict__ kernel,
+                                               cf* __restrict__ U, const cf* __restrict__ tw, const uint32_t nparts,
+                                               const uint32_t run)
+{
+  typedef FftPlan<LOGF> P;
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  uint32_t tid = threadIdx.x;
+  const int logTm = g.logTm, logT = logTm + 1, logTt = g.logTt;
+  const uint32_t Tm = 1u << logTm, Tt = 1u << logTt;
+  const uint64_t L = 1ull << (g.logM + g.logR);
+  const uint32_t nseq = g.real_input ? 1 : g.npol;
+  const uint32_t ntile = 1u << (g.logMb - logTm);          // m2 tiles per channel
+  const uint64_t per_part = (uint64_t)ntile * g.C;
+  const uint64_t total = per_part * nparts;
+  struct Abk { cf a, b; };
+
+  auto fetch = [&](const uint64_t item, Abk (&raw)[PTS / 2]) {
+    const uint64_t part = item / per_part, r = item % per_part;
+    const uint32_t c = (uint32_t)(r / ntile), tile = (uint32_t)(r % ntile);
+    const cf* __restrict__ X0s = X + part * nseq * L;
+    if (g.dbg & 2) {
+#pragma unroll
+      for (int i = 0; i < NPAIR; i++) { raw[i].a = make_float2(tid, i); raw[i].b = raw[i].a; }
+      return;
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < P::G1; g2 += 2)
+#pragma unroll
+      for (int i = 0; i < P::R1; i++) {
+        const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
+        const uint32_t j = (e & ((1u << logT) - 1)) >> 1, m1 = e >> logT;
+        const uint64_t k = ((uint64_t)c << g.logMf) + ((uint64_t)m1 << g.logMb) + tile * Tm + j;
+        const uint64_t kb = g.real_input ? ((L - k) & (L - 1)) : (g.npol == 2 ? L + k : k);
+        Abk q;
+        q.a = ld_stream(&X0s[k]);
+        q.b = ld_stream(&X0s[kb]);
+        raw[(g2 / 2) * P::R1 + i] = q;
+      }
+  };
+
+  const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;
+  ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
+  uint64_t item, next;
+  uint32_t jn = 0;
+  if (!persistent_item(blockIdx.x, gridDim.x, jn, run, total, item)) return;
+  Abk raw[PTS / 2];
+  fetch(item, raw);
+  for (;;) {
+    asm volatile("" : "+v"(tid));
+    const uint64_t part = item / per_part, r = item % per_part;
+    const uint32_t c = (uint32_t)(r / ntile), tile = (uint32_t)(r % ntile);
+    cx2 x[NPAIR];
+    {
+      cf kk[PTS / 2];
+      if (kernel && !(g.dbg & 2)) {
+#pragma unroll
+        for (int g2 = 0; g2 < P::G1; g2 += 2)
+#pragma unroll
+          for (int i = 0; i < P::R1; i++) {
+            const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
+            const uint32_t j = (e & ((1u << logT) - 1)) >> 1, m1 = e >> logT;
+            kk[(g2 / 2) * P::R1 + i] = kernel[((uint64_t)c << g.logMf) + ((uint64_t)m1 << g.logMb) + tile * Tm + j];
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PTS / 2; i++) kk[i] = make_float2(1.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < PTS / 2; i++) {
+        const Abk q = raw[i];
+        cf x0, x1;
+        if (g.real_input) {
+          x0 = make_float2(0.5f * (q.a.x + q.b.x), 0.5f * (q.a.y - q.b.y));
+          x1 = make_float2(0.5f * (q.a.y + q.b.y), 0.5f * (q.b.x - q.a.x));
+        } else {
+          x0 = q.a;
+          x1 = g.npol == 2 ? q.b : make_float2(0.f, 0.f);
+        }
+        x[i] = cmuls(make_cx2(x0, x1), kk[i]);
+      }
+    }
+    const bool more = persistent_item(blockIdx.x, gridDim.x, ++jn, run, total, next);
+    if (more) fetch(next, raw);
+
+    cf* __restrict__ Uc = U + (part * g.C + c) * (2ull << g.logMf);
+    // staged image order [t1/Tt][j][t1%Tt][pol]: whole runs of Tm*Tt*2 elements go out with 16-byte stores
+    auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
+      constexpr int R = sizeof(v) / sizeof(v[0]);
+      const uint32_t j = col >> 1;
+      apply_pass_twiddle_inv<R>(v, tile * Tm + j, p, pstride, g.logMf, tw, g.tw_lo_m);
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const uint32_t t1 = k * pstride + p;
+        const uint32_t l = (((((t1 >> logTt) << logTm) + j) << logTt) | (t1 & (Tt - 1))) << 1;
+        *(float4*)&lds[lds_pad(l)] = make_float4(v[k].x[0], v[k].y[0], v[k].x[1], v[k].y[1]);
+      }
+    };
+    wgfft<LOGF, +1, true>(lds, ltw_off, tid, logT, x, store);
+    __syncthreads();
+    {
+      const uint32_t nthr = blockDim.x;
+      const int logRun = logTm + logTt + 1;
+#pragma unroll 4
+      for (int jj = 0; jj < PTS / 2; jj++) {
+        const uint32_t l = 2 * (tid + jj * nthr);
+        const uint32_t tb = l >> logRun, within = l & ((1u << logRun) - 1);
+        const float4 pr = *(const float4*)&lds[lds_pad(l)];
+        st_stream((float4*)&Uc[((((uint64_t)tb << g.logMb) + tile * Tm) << (logTt + 1)) + within], pr);
+      }
+    }
+    if (!more) break;
+    item = next;
+  }
+}
+
+template <int LOGF>
+__global__ __launch_bounds__(512) void k_inv_b(const FbGeom g, const cf* __restrict__ U, const FbOut out,
+                                               const cf* __restrict__ tw, const uint64_t part0, const uint32_t nparts,
+                                               const uint32_t run)
+{
+  typedef FftPlan<LOGF> P;
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  uint32_t tid = threadIdx.x;
+  const int logTt = g.logTt, logT = logTt + 1;
+  const uint32_t ntile = 1u << (g.logMa - logTt);          // t1 blocks per channel
+  const uint64_t per_part = (uint64_t)ntile * g.C;
+  const uint64_t total = per_part * nparts;
+
+  auto fetch = [&](const uint64_t item, float4 (&y)[NPAIR]) {
+    const uint64_t part = item / per_part, r = item % per_part;
+    const uint32_t c = (uint32_t)(r / ntile), tile = (uint32_t)(r % ntile);
+    const cf* __restrict__ blk = U + (part * g.C + c) * (2ull << g.logMf) + (((uint64_t)tile << g.logMb) << logT);
+    if (g.dbg & 2) {
+#pragma unroll
+      for (int i = 0; i < NPAIR; i++) y[i] = make_float4(tid, i, 1.f, 1.f);
+      return;
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < P::G1; g2 += 2)
+#pragma unroll
+      for (int i = 0; i < P::R1; i++)
+        y[(g2 / 2) * P::R1 + i] = ld_stream((const float4*)&blk[first_stage_elem<LOGF>(tid, logT, g2, i)]);
+  };
+
+  const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;
+  ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
+  uint64_t item, next;
+  uint32_t jn = 0;
+  if (!persistent_item(blockIdx.x, gridDim.x, jn, run, total, item)) return;
+  float4 y[NPAIR];
+  fetch(item, y);
+  for (;;) {
+    asm volatile("" : "+v"(tid));
+    cx2 x[NPAIR];
+#pragma unroll
+    for (int i = 0; i < NPAIR; i++) x[i] = make_cx2(make_float2(y[i].x, y[i].y), make_float2(y[i].z, y[i].w));
+    const uint64_t part = part0 + item / per_part, r = item % per_part;
+    const uint32_t c = (uint32_t)(r / ntile), tile = (uint32_t)(r % ntile);
+    const bool more = persistent_item(blockIdx.x, gridDim.x, ++jn, run, total, next);
+    if (more) fetch(next, y);
+
+    auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
+      constexpr int R = sizeof(v) / sizeof(v[0]);
+      if (out.kind == 0) return;
+      const uint32_t chan = out.chan0 + c;
+      const uint32_t t1 = (tile << logTt) + (col >> 1);
+      float* __restrict__ row = out.base + chan * out.chan_stride;
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const uint32_t pos = ((k * pstride + p) << g.logMa) + t1;
+        if (pos < g.nfilt_pos || pos >= g.nfilt_pos + g.nkeep) continue;
+        const uint32_t t = pos - g.nfilt_pos;
+        const cf va = cx2_lo(v[k]), vb = cx2_hi(v[k]);
+        if (out.kind == 1) {
+          float2* o = (float2*)(row + part * out.part_step) + t;
+          st_stream(o, va);
+          if (g.npol == 2) st_stream((float2*)((float*)o + out.pol_stride), vb);
+        } else {
+          float q[4];
+          detect4(va, vb, out.state, q);
+          const uint64_t idat = part * g.nkeep + t;
+          if (out.ndim == 4) {
+            st_stream(&((float4*)row)[idat], make_float4(q[0], q[1], q[2], q[3]));
+          } else if (out.ndim == 2) {
+            st_stream(&((float2*)row)[idat], make_float2(q[0], q[1]));
+            st_stream(&((float2*)(row + out.pol_stride))[idat], make_float2(q[2], q[3]));
+          } else {
+            row[idat] = q[0];
+            row[out.pol_stride + idat] = q[1];
+            row[2 * out.pol_stride + idat] = q[2];
+            row[3 * out.pol_stride + idat] = q[3];
+          }
+        }
+      }
+    };
+    wgfft<LOGF, +1>(lds, ltw_off, tid, logT, x, store);
+    if (!more) break;
+    item = next;
+  }
+}
+
 // ------------------------------------------------------------------------------------ host
 typedef void (*k1_t)(FbGeom, FbIn, cf*, const cf*, uint64_t, uint32_t, uint32_t, uint32_t);
 typedef void (*k2_t)(FbGeom, const cf*, cf*, const cf*, uint32_t, uint32_t, uint32_t);
 typedef void (*k3_t)(FbGeom, const cf*, const cf*, FbOut, const cf*, uint64_t, uint32_t, uint32_t);
+typedef void (*k3a_t)(FbGeom, const cf*, const cf*, cf*, const cf*, uint32_t, uint32_t);
+typedef void (*k3b_t)(FbGeom, const cf*, FbOut, const cf*, uint64_t, uint32_t, uint32_t);
 
 template <int... I> struct iseq {};
 template <int N, int... I> struct mkseq : mkseq<N - 1, N - 1, I...> {};
@@ -623,6 +857,8 @@ template <int... I> struct mkseq<0, I...> { typedef iseq<I...> type; };
 template <int... I> static k1_t pick1(int logf, int raww, iseq<I...>) { return logf == 12 && raww == 1 ? k_fwd_cols<12, 1> : nullptr; }
 template <int... I> static k2_t pick2(int logf, iseq<I...>) { return logf == 11 ? k_fwd_rows<11> : nullptr; }
 template <int... I> static k3_t pick3(int logf, iseq<I...>) { return logf == 12 ? k_inv_chan<12> : nullptr; }
+template <int... I> static k3a_t pick3a(int, iseq<I...>) { return nullptr; }
+template <int... I> static k3b_t pick3b(int, iseq<I...>) { return nullptr; }
 #else
 template <int... I> static k1_t pick1(int logf, int raww, iseq<I...>)
 {
@@ -632,6 +868,8 @@ template <int... I> static k1_t pick1(int logf, int raww, iseq<I...>)
 }
 template <int... I> static k2_t pick2(int logf, iseq<I...>) { static const k2_t t[] = {k_fwd_rows<I>...}; return t[logf]; }
 template <int... I> static k3_t pick3(int logf, iseq<I...>) { static const k3_t t[] = {k_inv_chan<I>...}; return t[logf]; }
+template <int... I> static k3a_t pick3a(int logf, iseq<I...>) { static const k3a_t t[] = {k_inv_a<I>...}; return t[logf]; }
+template <int... I> static k3b_t pick3b(int logf, iseq<I...>) { static const k3b_t t[] = {k_inv_b<I>...}; return t[logf]; }
 #endif
 
 constexpr int MAX_LOGF = 13;    // every pass keeps >= 2 columns per workgroup
@@ -646,12 +884,14 @@ struct dspsr_amd_filterbank_impl {
   FbGeom g;
   uint64_t N, L;
   uint32_t nseq, max_parts;
-  uint32_t nt1, nt2, nt3, ncu, wg_per_cu;
-  size_t lds1, lds2, lds3;
+  uint32_t nt1, nt2, nt3, nt4 = 0, ncu, wg_per_cu;
+  size_t lds1, lds2, lds3, lds4 = 0;
+  uint64_t part_elems = 0;    // scratch elements per part
   cf* A = nullptr;
   cf* X = nullptr;
   cf* kernel = nullptr;
   cf* tw_lo = nullptr;
+  cf* tw_lo_m = nullptr;
   uint16_t* Rt = nullptr;   // pre-transposed 8-bit pairs of the parts of one launch group
   bool kernel_set = false;
 };
@@ -698,8 +938,13 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   fb->N = C * M;
   fb->L = cfg->real_input ? 2 * fb->N : fb->N;
   const uint64_t Rr = fb->L / M;
-  g.logM = ilog2(M);
+  const int logMf = ilog2(M), logL = ilog2(fb->L), logC = ilog2(C);
+  g.logM = logMf;
   g.logR = ilog2(Rr);
+  g.logMf = logMf;
+  g.four_pass = 0;
+  g.logMa = g.logMb = g.logTm = g.logTt = 0;
+  g.tw_lo = g.tw_lo_m = nullptr;
   g.real_input = cfg->real_input ? 1 : 0;
   g.npol = cfg->npol;
   g.C = (uint32_t)C;
@@ -707,47 +952,88 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   g.nkeep = cfg->freq_res - cfg->nfilt_pos - cfg->nfilt_neg;
   g.dbg = getenv("DSPSR_AMD_DEBUG") ? atoi(getenv("DSPSR_AMD_DEBUG")) : 0;
   fb->nseq = cfg->real_input ? 1 : cfg->npol;
-  if (g.logM > MAX_LOGF || g.logR > MAX_LOGF) {
-    delete fb;
-    return fb_fail(ctx, DSPSR_AMD_EINVAL,
-                   "dspsr_amd_filterbank_create: freq_res=%llu / spectrum rows=%llu exceed the single-pass "
-                   "limit 2^%d", (unsigned long long)M, (unsigned long long)Rr, MAX_LOGF);
-  }
   // tiles: every workgroup holds min(2^14, available) points = 32 per thread
   const int LOG_POINTS = getenv("DSPSR_AMD_LOG_POINTS") ? atoi(getenv("DSPSR_AMD_LOG_POINTS")) : LOG_POINTS_DEFAULT;
   fb->wg_per_cu = getenv("DSPSR_AMD_WG_PER_CU") ? atoi(getenv("DSPSR_AMD_WG_PER_CU")) : 1;
-  g.logT1 = g.logR < LOG_POINTS - g.logM ? g.logR : LOG_POINTS - g.logM;
-  g.logT2 = g.logM < LOG_POINTS - g.logR ? g.logM : LOG_POINTS - g.logR;
-  const int logC = ilog2(C), logPol = 1;   // pass 3 always carries (pol0, pol1) column pairs
-  int t3 = LOG_POINTS - g.logM - logPol;
-  if (t3 < 0) t3 = 0;
-  g.logT3 = logC < t3 ? logC : t3;
-  const uint64_t p1 = M << g.logT1, p2 = Rr << g.logT2, p3 = (M << g.logT3) << logPol;
-  if (p1 < 32 || p2 < 32 || p3 < 32 || p3 > (1u << LOG_POINTS) || g.logT1 < 1 || g.logT2 < 1) {
-    delete fb;
-    return fb_fail(ctx, DSPSR_AMD_EINVAL,
-                   "dspsr_amd_filterbank_create: problem too small/large for the workgroup tiling "
-                   "(points per pass %llu/%llu/%llu, need 32..16384 and >= 2 columns)",
-                   (unsigned long long)p1, (unsigned long long)p2, (unsigned long long)p3);
+  auto imin = [](int a, int b) { return a < b ? a : b; };
+  const int logPol = 1;   // the inverse passes always carry (pol0, pol1) column pairs
+  // three passes (freq_res and the spectrum rows each fit one workgroup tile) when possible ...
+  uint64_t p1 = 0, p2 = 0, p3 = 0, p4 = 0;
+  bool three_ok = g.logM <= MAX_LOGF && g.logR <= MAX_LOGF;
+  if (three_ok) {
+    g.logT1 = imin(g.logR, LOG_POINTS - g.logM);
+    g.logT2 = imin(g.logM, LOG_POINTS - g.logR);
+    int t3 = LOG_POINTS - g.logM - logPol;
+    if (t3 < 0) t3 = 0;
+    g.logT3 = imin(logC, t3);
+    p1 = M << g.logT1; p2 = Rr << g.logT2; p3 = (M << g.logT3) << logPol;
+    three_ok = !(p1 < 32 || p2 < 32 || p3 < 32 || p3 > (1u << LOG_POINTS) || g.logT1 < 1 || g.logT2 < 1);
+  }
+  // ... otherwise four: L = Fa*Fb forward (spectrum in natural order), freq_res = Ma*Mb inverse in two passes.
+  // This also covers nchan_subband = 1 (dsp::Convolution) and freq_res up to 2^26.
+  const char* force = getenv("DSPSR_AMD_FOUR_PASS");
+  if ((force && atoi(force) == 1) || !three_ok) {
+    int la = (logL + 1) / 2;
+    if (la > MAX_LOGF) la = MAX_LOGF;
+    const int lb = logL - la;
+    int lma = (logMf + 1) / 2;
+    if (lma > MAX_LOGF) lma = MAX_LOGF;
+    const int lmb = logMf - lma;
+    g.logM = la; g.logR = lb; g.logT3 = 0;
+    g.logT1 = imin(lb, LOG_POINTS - la);
+    g.logT2 = imin(la, LOG_POINTS - lb);
+    g.logMa = lma; g.logMb = lmb;
+    g.logTm = imin(lmb, LOG_POINTS - logPol - lma);
+    g.logTt = imin(lma, LOG_POINTS - logPol - lmb);
+    p1 = (1ull << la) << g.logT1; p2 = (1ull << lb) << g.logT2;
+    p3 = ((1ull << lma) << g.logTm) << logPol; p4 = ((1ull << lmb) << g.logTt) << logPol;
+    const bool ok = lb >= 1 && lb <= MAX_LOGF && lmb >= 1 && lmb <= MAX_LOGF && g.logT1 >= 1 && g.logT2 >= 1 &&
+                    g.logTm >= 0 && g.logTt >= 0 && p1 >= 32 && p2 >= 32 && p3 >= 32 && p4 >= 32;
+    if (!ok) {
+      delete fb;
+      return fb_fail(ctx, DSPSR_AMD_EINVAL,
+                     "dspsr_amd_filterbank_create: nchan_subband=%llu freq_res=%llu cannot be tiled "
+                     "(forward 2^%d x 2^%d, inverse 2^%d x 2^%d; every pass needs 32..16384 points per workgroup "
+                     "and factors <= 2^%d)", (unsigned long long)C, (unsigned long long)M, la, lb, lma, lmb, MAX_LOGF);
+    }
+    g.four_pass = 1;
   }
   fb->nt1 = (uint32_t)(p1 / PTS);
   fb->nt2 = (uint32_t)(p2 / PTS);
   fb->nt3 = (uint32_t)(p3 / PTS);
+  fb->nt4 = (uint32_t)(p4 / PTS);
   hipDeviceProp_t prop;
   fb->ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
                 ? (uint32_t)prop.multiProcessorCount : 256u;
   fb->lds1 = lds_total_words_host((uint32_t)p1, g.logM) * sizeof(cf);
   fb->lds2 = lds_total_words_host((uint32_t)p2, g.logR) * sizeof(cf);
-  fb->lds3 = lds_total_words_host((uint32_t)p3, g.logM) * sizeof(cf);
+  fb->lds3 = lds_total_words_host((uint32_t)p3, g.four_pass ? g.logMa : g.logM) * sizeof(cf);
+  fb->lds4 = g.four_pass ? lds_total_words_host((uint32_t)p4, g.logMb) * sizeof(cf) : 0;
   fb->max_parts = cfg->max_parts ? cfg->max_parts : 1;
-  const size_t scratch = (size_t)fb->max_parts * fb->nseq * fb->L * sizeof(cf);
+  // per part: nseq sequences of L points; the two-pass inverse re-uses A for 2 polarisations x N bins
+  fb->part_elems = fb->nseq * fb->L;
+  if (g.four_pass && fb->part_elems < 2 * fb->N) fb->part_elems = 2 * fb->N;
+  const size_t scratch = (size_t)fb->max_parts * fb->part_elems * sizeof(cf);
   if (hipMalloc((void**)&fb->A, scratch) != hipSuccess || hipMalloc((void**)&fb->X, scratch) != hipSuccess) {
     if (fb->A) (void)hipFree(fb->A);
     delete fb;
     return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_create: hipMalloc of 2 x %zu scratch bytes failed",
                    scratch);
   }
-  g.tw_lo = nullptr;
+  if (g.four_pass && g.logMf > LOG_TWN) {     // fine twiddle table of the two-pass inverse, built in double
+    const int sh = g.logMf - LOG_TWN;
+    std::vector<cf> lo(1u << sh);
+    for (uint32_t j = 0; j < (1u << sh); j++) {
+      const double a = -2.0 * M_PI * (double)j / (double)M;
+      lo[j] = make_float2((float)cos(a), (float)sin(a));
+    }
+    if (hipMalloc((void**)&fb->tw_lo_m, lo.size() * sizeof(cf)) != hipSuccess ||
+        hipMemcpy(fb->tw_lo_m, lo.data(), lo.size() * sizeof(cf), hipMemcpyHostToDevice) != hipSuccess) {
+      dspsr_amd_filterbank_destroy(fb);
+      return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_create: twiddle table allocation failed");
+    }
+    g.tw_lo_m = fb->tw_lo_m;
+  }
   if (g.logM + g.logR > LOG_TWN) {            // fine twiddle table of pass 1, built in double
     const int sh = g.logM + g.logR - LOG_TWN;
     std::vector<cf> lo(1u << sh);
@@ -775,6 +1061,7 @@ extern "C" void dspsr_amd_filterbank_destroy(dspsr_amd_filterbank* fb)
   if (fb->kernel) (void)hipFree(fb->kernel);
   if (fb->Rt) (void)hipFree(fb->Rt);
   if (fb->tw_lo) (void)hipFree(fb->tw_lo);
+  if (fb->tw_lo_m) (void)hipFree(fb->tw_lo_m);
   delete fb;
 }
 
@@ -848,11 +1135,15 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   const int raww = (pret || (fast8 && in.kind == 1)) ? 1 : 4;
   k1_t k1 = pick1(g.logM, raww, seq_t());
   k2_t k2 = pick2(g.logR, seq_t());
-  k3_t k3 = pick3(g.logM, seq_t());
-  if (!k1 || !k2 || !k3) return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: geometry not in this (experiment) build");
+  k3_t k3 = g.four_pass ? nullptr : pick3(g.logM, seq_t());
+  k3a_t k3a = g.four_pass ? pick3a(g.logMa, seq_t()) : nullptr;
+  k3b_t k3b = g.four_pass ? pick3b(g.logMb, seq_t()) : nullptr;
+  if (!k1 || !k2 || (g.four_pass ? (!k3a || !k3b) : !k3))
+    return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: geometry not in this (experiment) build");
   hipError_t e;
   if ((e = allow_lds(k1, fb->lds1)) != hipSuccess || (e = allow_lds(k2, fb->lds2)) != hipSuccess ||
-      (e = allow_lds(k3, fb->lds3)) != hipSuccess)
+      (k3 && (e = allow_lds(k3, fb->lds3)) != hipSuccess) || (k3a && (e = allow_lds(k3a, fb->lds3)) != hipSuccess) ||
+      (k3b && (e = allow_lds(k3b, fb->lds4)) != hipSuccess))
     return fb_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_filterbank_perform: hipFuncSetAttribute: %s", hipGetErrorString(e));
   const uint32_t Rr = 1u << g.logR, M = 1u << g.logM;
   const float* in_f32 = (const float*)in.base;
@@ -868,7 +1159,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
       const uint32_t nb = (uint32_t)((npart - part0) < fb->max_parts ? (npart - part0) : fb->max_parts);
       // persistent grids: one workgroup per CU (LDS-limited), a multiple of 8 so the XCD-aware item order applies
       const uint64_t n1 = (uint64_t)(Rr >> g.logT1) * fb->nseq * nb, n2 = (uint64_t)(M >> g.logT2) * fb->nseq * nb,
-                     n3 = (uint64_t)(g.C >> g.logT3) * nb;
+                     n3 = g.four_pass ? 0 : (uint64_t)(g.C >> g.logT3) * nb;
       const uint32_t run1 = 32, run2 = 4, run3 = nb;
       if (pret) {
         hipLaunchKernelGGL(k_raw_transpose, dim3((Rr + 255) / 256, (M + 63) / 64, nb), dim3(256), 0, ctx->stream, g, ci,
@@ -882,8 +1173,17 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
       if (in.kind == 0) ci.base = in_f32 + ichan * in_chan_stride_bytes_or_floats;
       hipLaunchKernelGGL(k2, dim3(grid_for(n2, fb->ncu * fb->wg_per_cu)), dim3(fb->nt2), fb->lds2, ctx->stream, g, fb->A, fb->X,
                          ctx->tw, nb, fb->nseq, run2);
-      hipLaunchKernelGGL(k3, dim3(grid_for(n3, fb->ncu * fb->wg_per_cu)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern, co,
-                         ctx->tw, part0, nb, run3);
+      if (!g.four_pass) {
+        hipLaunchKernelGGL(k3, dim3(grid_for(n3, fb->ncu * fb->wg_per_cu)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern, co,
+                           ctx->tw, part0, nb, run3);
+      } else {
+        // two-pass inverse: X (natural order) -> U (in the A buffer, dead after pass 2) -> output
+        const uint64_t n3a = ((uint64_t)g.C << (g.logMb - g.logTm)) * nb, n3b = ((uint64_t)g.C << (g.logMa - g.logTt)) * nb;
+        hipLaunchKernelGGL(k3a, dim3(grid_for(n3a, fb->ncu * fb->wg_per_cu)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern,
+                           fb->A, ctx->tw, nb, 8u);
+        hipLaunchKernelGGL(k3b, dim3(grid_for(n3b, fb->ncu * fb->wg_per_cu)), dim3(fb->nt4), fb->lds4, ctx->stream, g, fb->A, co,
+                           ctx->tw, part0, nb, 8u);
+      }
     }
   }
   e = hipGetLastError();

@@ -129,6 +129,55 @@ def test_filterbank_batched_parts_identical(oracle, gpu):
     assert np.array_equal(a, b)
 
 
+@pytest.fixture
+def four_pass(monkeypatch):
+    """Forces the two-pass inverse (k_inv_a + k_inv_b) also where three passes would do."""
+    monkeypatch.setenv("DSPSR_AMD_FOUR_PASS", "1")
+
+
+@pytest.mark.parametrize("C,M,nfilt,npart", [
+    (8, 64, (5, 7), 3),
+    (16, 256, (20, 21), 2),
+    (64, 1024, (100, 101), 2),
+    (2, 2048, (100, 50), 2),
+    (512, 32, (3, 4), 2),
+])
+def test_filterbank_four_pass_forced(oracle, gpu, four_pass, C, M, nfilt, npart):
+    _fb_case(oracle, gpu, C, M, nfilt, npart)
+
+
+def test_filterbank_four_pass_other_inputs(oracle, gpu, four_pass):
+    _fb_case(oracle, gpu, 16, 256, (20, 21), 2, layout="caspsr")
+    _fb_case(oracle, gpu, 16, 256, (20, 21), 2, npol=1)
+    _fb_case(oracle, gpu, 16, 256, (20, 21), 3, use_raw=False, max_parts=2)
+    for input_nchan, npol in [(1, 2), (4, 2), (2, 1)]:
+        _fb_case(oracle, gpu, 32, 128, (9, 10), 2, npol=npol, real=False, input_nchan=input_nchan)
+
+
+@pytest.mark.parametrize("C,M,nfilt,real", [
+    (4, 16384, (900, 1100), True),       # freq_res beyond one workgroup tile: BASELINE cfg 1 (-F 64:D) class
+    (2, 65536, (7226, 7341), True),
+    (8, 16384, (900, 1100), False),
+])
+def test_filterbank_large_freq_res(oracle, gpu, C, M, nfilt, real):
+    _fb_case(oracle, gpu, C, M, nfilt, 2, real=real, max_parts=2)
+
+
+def test_filterbank_cfg1_size(oracle, gpu):
+    # BASELINE cfg 1: -F 64:D on the header.dada band with the minimum response length 16384 (N = 2^20)
+    _fb_case(oracle, gpu, 64, 16384, (7226, 7341), 1)
+
+
+@pytest.mark.parametrize("M,nfilt,real,input_nchan,npol", [
+    (4096, (300, 320), False, 8, 2),     # dsp::Convolution after a filterbank: nchan_subband = 1 per input channel
+    (1024, (100, 90), False, 3, 1),
+    (32768, (3000, 2000), True, 1, 2),   # single-channel coherent dedispersion of real dual-pol data
+    (131072, (10000, 11000), False, 1, 2),
+])
+def test_convolution_nchan_subband_1(oracle, gpu, M, nfilt, real, input_nchan, npol):
+    _fb_case(oracle, gpu, 1, M, nfilt, 2, npol=npol, real=real, input_nchan=input_nchan, max_parts=2)
+
+
 def test_filterbank_errors(gpu):
     dspsr_amd, ctx = gpu
     with pytest.raises(dspsr_amd.DspsrAmdError):
