@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DSPSR_AMD_LIB") or os.path.join(_HERE, "libdspsr_amd.
 
 OK, EINVAL, EHIP, ENOMEM, ESTATE = 0, -1, -2, -3, -4
 H2D, D2H, D2D = 1, 2, 3
-RAW_GENERIC, RAW_CASPSR = 0, 1
+RAW_GENERIC, RAW_CASPSR, RAW_UWB16 = 0, 1, 2
 COHERENCE, STOKES = 0, 1
 
 

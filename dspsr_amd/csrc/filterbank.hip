@@ -36,7 +36,8 @@ struct FbGeom {
 };
 
 struct FbIn {
-  int kind;  // 0: float32 rows, 1: int8 generic, 2: int8 caspsr, 3: (pol0,pol1) byte pairs pre-transposed per tile
+  int kind;  // 0: float32 rows, 1: int8 generic, 2: int8 caspsr, 3: (pol0,pol1) byte pairs pre-transposed per tile,
+             // 4: 16-bit offset-binary complex in 2048-sample blocks per polarisation (UWB)
   const void* base;
   uint64_t pol_stride;  // float32: floats between pol rows
   uint64_t part_step;   // time samples between parts
@@ -135,6 +136,11 @@ template <int W> DEV RawW<W> fetch_pair(const FbGeom& g, const FbIn& in, const u
     const uint8_t* b = (const uint8_t*)in.base + (t >> 2) * 8 + (t & 3);
     r.w[0] = *(const uint16_t*)b;
     r.w[1] = *(const uint16_t*)(b + 4);
+  } else if (in.kind == 4) {                            // UWB: word (block*npol + pol)*2048 + t%2048 = (re, im) int16
+    const uint32_t* b = (const uint32_t*)in.base;
+    const uint64_t t1 = t + 1;
+    r.w[0] = b[((t >> 11) * g.npol + seq) * 2048 + (t & 2047)];
+    r.w[1] = b[((t1 >> 11) * g.npol + seq) * 2048 + (t1 & 2047)];
   } else if (g.real_input) {                            // generic 8-bit, byte (t*nchan + c)*npol + p
     const uint64_t skip = (uint64_t)in.nchan * g.npol;
     const uint8_t* b = (const uint8_t*)in.base + t * skip + (uint64_t)in.ichan * g.npol;
@@ -171,6 +177,9 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
       a = make_float2(__uint_as_float(r.w[0]), __uint_as_float(r.w[1]));
       b = make_float2(__uint_as_float(r.w[2]), __uint_as_float(r.w[3]));
     }
+  } else if (in.kind == 4) {                            // convert_offset_binary, UWBUnpackerCUDA.cu:24
+    a = make_float2((float)(int16_t)((r.w[0] & 0xffff) ^ 0x8000) * in.scale, (float)(int16_t)((r.w[0] >> 16) ^ 0x8000) * in.scale);
+    b = make_float2((float)(int16_t)((r.w[1] & 0xffff) ^ 0x8000) * in.scale, (float)(int16_t)((r.w[1] >> 16) ^ 0x8000) * in.scale);
   } else if (in.kind == 2) {
     a = make_float2(cvt8((int8_t)(r.w[0] & 0xff), in.scale), cvt8((int8_t)(r.w[1] & 0xff), in.scale));
     b = make_float2(cvt8((int8_t)((r.w[0] >> 8) & 0xff), in.scale), cvt8((int8_t)((r.w[1] >> 8) & 0xff), in.scale));
@@ -1102,6 +1111,8 @@ extern "C" int dspsr_amd_filterbank_sizes(const dspsr_amd_filterbank* fb, uint64
   return DSPSR_AMD_OK;
 }
 
+static int raw_kind(int raw_layout) { return raw_layout == DSPSR_AMD_RAW_CASPSR ? 2 : raw_layout == DSPSR_AMD_RAW_UWB16 ? 4 : 1; }
+
 static uint32_t grid_for(uint64_t items, uint32_t ncu)
 {
   uint64_t gsz = items < ncu ? items : ncu;
@@ -1219,11 +1230,14 @@ extern "C" int dspsr_amd_filterbank_perform_raw(dspsr_amd_filterbank* fb, const 
       !(fb->cfg.real_input && fb->cfg.npol == 2 && fb->cfg.input_nchan == 1))
     return fb_fail(fb->ctx, DSPSR_AMD_EINVAL,
                    "dspsr_amd_filterbank_perform_raw: CASPSR layout needs real dual-pol single-channel input");
-  if (raw_layout != DSPSR_AMD_RAW_CASPSR && raw_layout != DSPSR_AMD_RAW_GENERIC)
+  if (raw_layout == DSPSR_AMD_RAW_UWB16 && (fb->cfg.real_input || fb->cfg.input_nchan != 1))
+    return fb_fail(fb->ctx, DSPSR_AMD_EINVAL,
+                   "dspsr_amd_filterbank_perform_raw: UWB 16-bit layout needs complex single-channel input");
+  if (raw_layout != DSPSR_AMD_RAW_CASPSR && raw_layout != DSPSR_AMD_RAW_GENERIC && raw_layout != DSPSR_AMD_RAW_UWB16)
     return fb_fail(fb->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_raw: unknown raw layout %d", raw_layout);
   uint64_t step;
   dspsr_amd_filterbank_sizes(fb, nullptr, nullptr, &step, nullptr);
-  FbIn in = {raw_layout == DSPSR_AMD_RAW_CASPSR ? 2 : 1, raw_dev, 0, step, fb->cfg.input_nchan, 0, scale};
+  FbIn in = {raw_kind(raw_layout), raw_dev, 0, step, fb->cfg.input_nchan, 0, scale};
   FbOut out = {out_dev ? 1 : 0, out_dev, out_chan_stride, out_pol_stride, out_step, 0, 2, 0};
   return fb_run(fb, in, out, npart, 0);
 }
@@ -1253,7 +1267,12 @@ extern "C" int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, con
         !(fb->cfg.real_input && fb->cfg.npol == 2 && fb->cfg.input_nchan == 1))
       return fb_fail(fb->ctx, DSPSR_AMD_EINVAL,
                      "dspsr_amd_filterbank_perform_detect: CASPSR layout needs real dual-pol single-channel input");
-    in = {raw_layout == DSPSR_AMD_RAW_CASPSR ? 2 : 1, raw_dev, 0, step, fb->cfg.input_nchan, 0, scale};
+    if (raw_layout == DSPSR_AMD_RAW_UWB16 && (fb->cfg.real_input || fb->cfg.input_nchan != 1))
+      return fb_fail(fb->ctx, DSPSR_AMD_EINVAL,
+                     "dspsr_amd_filterbank_perform_detect: UWB 16-bit layout needs complex single-channel input");
+    if (raw_layout != DSPSR_AMD_RAW_CASPSR && raw_layout != DSPSR_AMD_RAW_GENERIC && raw_layout != DSPSR_AMD_RAW_UWB16)
+      return fb_fail(fb->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_detect: unknown raw layout %d", raw_layout);
+    in = {raw_kind(raw_layout), raw_dev, 0, step, fb->cfg.input_nchan, 0, scale};
   }
   FbOut out = {2, det_dev, det_chan_stride, det_pol_stride, 0, state, ndim, 0};
   return fb_run(fb, in, out, npart, in_chan_stride);

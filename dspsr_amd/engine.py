@@ -214,6 +214,16 @@ class FilterbankEngine:
             pass
 
 
+class ConvolutionEngine(FilterbankEngine):
+    """Mirror of dsp::Convolution::Engine (Signal/General/dsp/Convolution.h:158-167; CUDA twin
+    ConvolutionCUDA.cu:202-800): coherent dedispersion of already-channelised (or single-channel) voltages.
+    One forward FFT, response multiply and backward FFT of `ndat` points per (channel, pol, part) -- the
+    filterbank object with nchan_subband = 1."""
+
+    def prepare(self, ndat, nfilt_pos, nfilt_neg, nchan=1, npol=2, real_input=False, kernel=None, max_parts=1):
+        return self.setup(1, ndat, nfilt_pos, nfilt_neg, nchan, npol, real_input, kernel, max_parts=max_parts)
+
+
 def tfp_filterbank(ctx: Context, raw, nchan, npart, out, pscrunch=False, tscrunch=1, layout=_lib.RAW_GENERIC,
                    scale=1.0):
     """digifil front end: dsp::TFPFilterbank (+pscrunch) + dsp::TScrunch fused (TFPFilterbank.C:27-101,

@@ -4,6 +4,7 @@
 // (INTEGRATION.md).  Each method mirrors the CUDA twin it replaces:
 //   HIP::DeviceMemory      <- CUDA::DeviceMemory      Kernel/Classes/MemoryCUDA.C:47-106
 //   HIP::FilterbankEngine  <- CUDA::FilterbankEngine  Signal/General/FilterbankCUDA.cu:73-304
+//   HIP::ConvolutionEngine <- CUDA::ConvolutionEngine Signal/General/ConvolutionCUDA.cu:202-800
 //   HIP::DetectionEngine   <- CUDA::DetectionEngine   Signal/General/DetectionCUDA.cu:127-322
 //   HIP::FoldEngine        <- CUDA::FoldEngine        Signal/Pulsar/FoldCUDA.cu:64-697
 // Errors: every non-zero C-ABI status is rethrown as the reference's `Error` with the library's message.
@@ -12,6 +13,7 @@
 
 #include "dsp/Memory.h"
 #include "dsp/FilterbankEngine.h"   // dsp::Filterbank, dsp::Filterbank::Engine, dsp::Response, dsp::TimeSeries
+#include "dsp/Convolution.h"        // dsp::Convolution, dsp::Convolution::Engine
 #include "dsp/Detection.h"          // dsp::Detection::Engine
 #include "dsp/Fold.h"               // dsp::Fold::Engine, dsp::PhaseSeries
 #include "Error.h"
@@ -110,6 +112,62 @@ namespace HIP
   protected:
     dspsr_amd_ctx* ctx;
     dspsr_amd_filterbank* fb;
+  };
+
+  //! dsp::Convolution::Engine (Convolution.h:158-167): the same library object with nchan_subband = 1,
+  //! i.e. one forward FFT, response multiply and backward FFT of response->get_ndat() points per
+  //! (channel, polarisation, part), all channels and parts batched in one launch group
+  class ConvolutionEngine : public dsp::Convolution::Engine
+  {
+  public:
+    ConvolutionEngine (dspsr_amd_ctx* _ctx) : ctx (_ctx), fb (0), in_step (0), out_step (0) { }
+    ~ConvolutionEngine () { dspsr_amd_filterbank_destroy (fb); }
+
+    void set_scratch (void*) { }                 // the library owns its scratch
+
+    //! reads what CUDA::ConvolutionEngine::prepare reads (ConvolutionCUDA.cu:208-244)
+    void prepare (dsp::Convolution* convolution)
+    {
+      if (!convolution->has_response ())
+        throw Error (InvalidState, "HIP::ConvolutionEngine::prepare", "no response");
+      const dsp::Response* response = convolution->get_response ();
+      const dsp::TimeSeries* input = convolution->get_input ();
+      dspsr_amd_filterbank_config cfg;
+      cfg.nchan_subband = 1;
+      cfg.freq_res = response->get_ndat ();                       // npt_bwd
+      cfg.nfilt_pos = response->get_impulse_pos ();
+      cfg.nfilt_neg = response->get_impulse_neg ();
+      cfg.input_nchan = input->get_nchan ();
+      cfg.npol = input->get_npol ();
+      cfg.real_input = input->get_state () == Signal::Nyquist;    // CUFFT_R2C vs C2C (:219-222)
+      cfg.max_parts = 0;
+      const uint64_t nsamp_step = convolution->get_minimum_samples () - convolution->get_minimum_samples_lost ();
+      in_step = nsamp_step * (cfg.real_input ? 1 : 2);             // floats between parts (Convolution.C:386)
+      out_step = in_step;                                          // the output is written at the same float offset (:441)
+      dspsr_amd_filterbank_destroy (fb); fb = 0;
+      check (ctx, dspsr_amd_filterbank_create (ctx, &cfg, &fb), "HIP::ConvolutionEngine::prepare");
+      check (ctx, dspsr_amd_filterbank_set_kernel (fb, response->get_datptr (0, 0),
+               uint64_t (response->get_nchan ()) * response->get_ndat ()), "HIP::ConvolutionEngine::prepare");
+    }
+
+    //! ConvolutionCUDA.cu:552-800
+    void perform (const dsp::TimeSeries* in, dsp::TimeSeries* out, unsigned npart)
+    {
+      if (npart == 0) return;
+      const float* ibase = in->get_datptr (0, 0);
+      const uint64_t ics = in->get_nchan () > 1 ? in->get_datptr (1, 0) - ibase : 0;
+      const uint64_t ips = in->get_npol () > 1 ? in->get_datptr (0, 1) - ibase : 0;
+      float* obase = out->get_datptr (0, 0);
+      const uint64_t ocs = out->get_nchan () > 1 ? out->get_datptr (1, 0) - obase : 0;
+      const uint64_t ops = out->get_npol () > 1 ? out->get_datptr (0, 1) - obase : 0;
+      check (ctx, dspsr_amd_filterbank_perform (fb, ibase, ics, ips, obase, ocs, ops, npart, in_step, out_step),
+             "HIP::ConvolutionEngine::perform");
+    }
+
+  protected:
+    dspsr_amd_ctx* ctx;
+    dspsr_amd_filterbank* fb;
+    uint64_t in_step, out_step;
   };
 
   //! dsp::Detection::Engine (Detection.h:98-106)

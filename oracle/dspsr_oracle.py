@@ -171,6 +171,15 @@ def unpack_8bit(raw: np.ndarray, obs: Observation, scale=S8) -> np.ndarray:
 # optimal FFT length (a5)   Signal/General/optimize_fft.c:63-127
 # --------------------------------------------------------------------------------------
 
+def unpack_uwb16(raw: np.ndarray, npol: int = 2) -> np.ndarray:
+    """dsp::UWBUnpacker::unpack (Kernel/Formats/uwb/UWBUnpacker.C:180-215; GPU twin UWBUnpackerCUDA.cu:24-75):
+    16-bit offset-binary complex samples in blocks of 2048 per polarisation, value = float(int16(x ^ 0x8000)),
+    no scale.  raw: uint16/int16 [nblock][npol][2048][2] flattened -> float32 [1][npol][ndat*2]."""
+    w = np.ascontiguousarray(raw).view(np.uint16).reshape(-1, npol, 2048, 2)
+    v = (w ^ np.uint16(0x8000)).view(np.int16).astype(np.float32)
+    return np.ascontiguousarray(v.transpose(1, 0, 2, 3).reshape(1, npol, -1))
+
+
 def optimal_fft_length(nbadperfft: int, nfft_max: int = 0) -> int:
     if not nbadperfft:
         return -1
@@ -503,6 +512,42 @@ def filterbank(unpacked: np.ndarray, plan: FilterbankPlan, kernel: np.ndarray | 
                 t = (np.fft.ifft(spec.reshape(C, M), axis=1) * M).astype(cdt)
                 out[ichan * C:(ichan + 1) * C, ipol, ipart * plan.nkeep:(ipart + 1) * plan.nkeep] = \
                     t[:, plan.nfilt_pos: plan.nfilt_pos + plan.nkeep]
+    return out
+
+
+def convolution(unpacked: np.ndarray, response_ndat: int, nfilt_pos: int, nfilt_neg: int, kernel: np.ndarray,
+                real_input: bool, npart: int | None = None, dtype=np.float32) -> np.ndarray:
+    """dsp::Convolution::transformation, scalar (non-matrix) response, no apodization
+    (Convolution.C:105-283 prepare, :338-461 transformation).
+
+    unpacked: float [nchan][npol][ndat*ndim] -> complex [nchan][npol][npart*nsamp_good], where for every
+    (chan, pol, part): forward FFT of nsamp_fft samples (frc1d for Nyquist input, n_fft = nsamp_fft/2 bins used;
+    fcc1d for Analytic), response->operate (kernel of channel ichan, Response.C:385-444), unnormalised
+    backward FFT of n_fft points, copy of nsamp_step*ndim floats from complex sample nfilt_pos (:441-446)."""
+    cdt = np.complex64 if dtype == np.float32 else np.complex128
+    nchan, npol, nfloat = unpacked.shape
+    ndim = 1 if real_input else 2
+    n_fft = response_ndat                                    # :187
+    nfilt_tot = nfilt_pos + nfilt_neg
+    if real_input:                                           # :190-199
+        nsamp_fft, nsamp_overlap = 2 * n_fft, 2 * nfilt_tot
+    else:
+        nsamp_fft, nsamp_overlap = n_fft, nfilt_tot
+    nsamp_step = nsamp_fft - nsamp_overlap                   # :207
+    ngood = nsamp_step * ndim // 2                           # complex samples written per part
+    ndat = nfloat // ndim
+    if npart is None:
+        npart = (ndat - nsamp_overlap) // nsamp_step if ndat > nsamp_overlap else 0     # :304-306
+    out = np.zeros((nchan, npol, npart * ngood), dtype=cdt)
+    step = nsamp_step * ndim                                 # :386
+    for ichan in range(nchan):
+        for ipol in range(npol):
+            for ipart in range(npart):
+                x = unpacked[ichan, ipol, ipart * step: ipart * step + nsamp_fft * ndim].astype(dtype)
+                spec = (np.fft.rfft(x)[:n_fft] if real_input else np.fft.fft(x.view(cdt))).astype(cdt)   # :412-416
+                spec = (spec * kernel[ichan * n_fft:(ichan + 1) * n_fft].astype(cdt)).astype(cdt)        # :432
+                t = (np.fft.ifft(spec) * n_fft).astype(cdt)                                               # :446
+                out[ichan, ipol, ipart * ngood:(ipart + 1) * ngood] = t[nfilt_pos: nfilt_pos + ngood]    # :451
     return out
 
 

@@ -178,6 +178,63 @@ def test_convolution_nchan_subband_1(oracle, gpu, M, nfilt, real, input_nchan, n
     _fb_case(oracle, gpu, 1, M, nfilt, 2, npol=npol, real=real, input_nchan=input_nchan, max_parts=2)
 
 
+@pytest.mark.parametrize("ndat,nfilt,real,nchan,npol", [(2048, (200, 150), False, 16, 2), (8192, (700, 800), True, 2, 2)])
+def test_convolution_engine(oracle, gpu, ndat, nfilt, real, nchan, npol):
+    """HIP ConvolutionEngine (dsp::Convolution::Engine mirror) against the oracle's restatement of Convolution.C."""
+    dspsr_amd, ctx = gpu
+    o = oracle
+    npart = 3
+    rng = np.random.default_rng(11)
+    kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, nchan * ndat)).astype(np.complex64)
+    ndim = 1 if real else 2
+    nfilt_tot = sum(nfilt)
+    nsamp_fft, nsamp_overlap = (2 * ndat, 2 * nfilt_tot) if real else (ndat, nfilt_tot)
+    nsamp_step = nsamp_fft - nsamp_overlap
+    x = rng.standard_normal((nchan, npol, (npart * nsamp_step + nsamp_overlap) * ndim)).astype(np.float32)
+    ref = o.convolution(x, ndat, nfilt[0], nfilt[1], kernel, real, npart=npart, dtype=np.float64)
+    eng = dspsr_amd.ConvolutionEngine(ctx).prepare(ndat, nfilt[0], nfilt[1], nchan, npol, real, kernel, max_parts=2)
+    assert (eng.nsamp_fft, eng.nsamp_overlap, eng.nsamp_step) == (nsamp_fft, nsamp_overlap, nsamp_step)
+    ngood = ndat - nfilt_tot
+    out = torch.zeros((nchan, npol, 2 * npart * ngood), dtype=torch.float32, device="cuda")
+    eng.perform(torch.from_numpy(x).cuda(), out, npart, nsamp_step * ndim, 2 * ngood)
+    eng.finish()
+    got = out.cpu().numpy().view(np.complex64).astype(np.complex128)
+    eng.close()
+    rms_ref = math.sqrt(np.mean(np.abs(ref) ** 2))
+    tol = 2e-6 * math.sqrt(math.log2(2 * ndat))
+    assert math.sqrt(np.mean(np.abs(got - ref) ** 2)) / rms_ref <= tol
+    assert np.abs(got - ref).max() <= 8 * tol * rms_ref
+
+
+@pytest.mark.parametrize("npol,C,M,nfilt", [(2, 8, 256, (30, 31)), (1, 1, 4096, (300, 301))])
+def test_filterbank_uwb_16bit_input(oracle, gpu, npol, C, M, nfilt):
+    """16-bit offset-binary complex input (UWB layout) decoded in pass 1 vs the oracle's unpacker + filterbank."""
+    dspsr_amd, ctx = gpu
+    o = oracle
+    N = C * M
+    ovl = sum(nfilt) * C
+    step = N - ovl
+    npart = 3
+    ndat = -(-(npart * step + ovl) // 2048) * 2048
+    rng = np.random.default_rng(17)
+    raw = np.clip(np.rint(rng.standard_normal(ndat * npol * 2) * 3000.0), -32768, 32767).astype(np.int16)
+    raw = (raw.view(np.uint16) ^ np.uint16(0x8000))                       # offset binary
+    kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, N)).astype(np.complex64)
+    unpacked = o.unpack_uwb16(raw, npol)
+    plan = o.FilterbankPlan(C, 1, C, M, N, nfilt[0], nfilt[1], sum(nfilt), N, ovl, step, M - sum(nfilt), float(N) * M, False)
+    ref = o.filterbank(unpacked, plan, kernel, npart=npart, dtype=np.float64)
+    eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, npol, False, kernel, max_parts=2)
+    out = torch.zeros((C, npol, 2 * npart * plan.nkeep), dtype=torch.float32, device="cuda")
+    eng.perform_raw(torch.from_numpy(raw.view(np.int8)).cuda(), dspsr_amd.RAW_UWB16, 1.0, out, npart)
+    eng.finish()
+    got = out.cpu().numpy().view(np.complex64).astype(np.complex128)
+    eng.close()
+    rms_ref = math.sqrt(np.mean(np.abs(ref) ** 2))
+    tol = 2e-6 * math.sqrt(math.log2(2 * N))
+    assert math.sqrt(np.mean(np.abs(got - ref) ** 2)) / rms_ref <= tol
+    assert np.abs(got - ref).max() <= 8 * tol * rms_ref
+
+
 def test_filterbank_errors(gpu):
     dspsr_amd, ctx = gpu
     with pytest.raises(dspsr_amd.DspsrAmdError):
