@@ -109,12 +109,13 @@ def algorithmic_bytes_per_part(npol, nsamp_fft, nbit, N, nchan_subband, nkeep):
 def measured_traffic(workload, max_parts):
     """HBM bytes per launch group from the committed PMC profile (rocprofv3 cannot run inside the bench);
     None when the profile was taken for another workload / grouping."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01b_traffic.json")))
-        if d["workload"] == workload and d["parts_per_launch_group"] == max_parts:
-            return d["hbm_bytes_per_launch_group"]
-    except Exception:
-        pass
+    for name in ("r01c_traffic.json", "r01b_traffic.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if d["workload"] == workload and d["parts_per_launch_group"] == max_parts:
+                return d["hbm_bytes_per_launch_group"]
+        except Exception:
+            pass
     return None
 
 
@@ -264,7 +265,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic(args.workload, cfg.max_parts),
-                         "traffic_unit": "HBM bytes per launch group of %d parts (profiles/r01b_traffic.json); "
+                         "traffic_unit": "HBM bytes per launch group of %d parts (PMC, profiles/r01c_traffic.json); "
                                          "algorithmic bytes for the same group: %d" % (cfg.max_parts, b_alg * cfg.max_parts),
                          "kernel": "filterbank launch group k_fwd_cols+k_fwd_rows+k_inv_chan (FFT+chirp+fused detect)",
                          "algorithmic_bytes_per_part": b_alg, "group_ms_per_block": round(fb_ms, 4)},

@@ -1,8 +1,10 @@
 # HBM traffic per kernel from PMC counters (separate passes, as MI355X_MICROARCH.md prescribes)
+# usage: bash tools/pmc.sh [max_parts]   -> prints mean KB per dispatch and kernel
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+MP=${1:-8}
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --max-parts 4 > /dev/null 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --max-parts $MP > /dev/null 2>&1
   f=$(find gpurun_out/pmc_$c -name "*counter_collection.csv" | head -1)
   python3 - "$f" "$c" <<'PY'
 import csv,sys,collections
