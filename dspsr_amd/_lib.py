@@ -53,6 +53,7 @@ SYMBOLS = {
     "dspsr_amd_free": (_i, [_vp, _vp]),
     "dspsr_amd_zero": (_i, [_vp, _vp, _sz]),
     "dspsr_amd_copy": (_i, [_vp, _vp, _vp, _sz, _i]),
+    "dspsr_amd_copy_fpt": (_i, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u32, _u64]),
     "dspsr_amd_filterbank_create": (_i, [_vp, C.POINTER(FilterbankConfig), _pp]),
     "dspsr_amd_filterbank_destroy": (None, [_vp]),
     "dspsr_amd_filterbank_set_kernel": (_i, [_vp, _vp, _u64]),

@@ -3,6 +3,7 @@
 // below and -ldspsr_amd) and installs the engines where the CUDA ones are installed today
 // (INTEGRATION.md).  Each method mirrors the CUDA twin it replaces:
 //   HIP::DeviceMemory      <- CUDA::DeviceMemory      Kernel/Classes/MemoryCUDA.C:47-106
+//   HIP::TimeSeriesEngine  <- CUDA::TimeSeriesEngine  Kernel/Classes/TimeSeriesCUDA.cu:31-200
 //   HIP::FilterbankEngine  <- CUDA::FilterbankEngine  Signal/General/FilterbankCUDA.cu:73-304
 //   HIP::ConvolutionEngine <- CUDA::ConvolutionEngine Signal/General/ConvolutionCUDA.cu:202-800
 //   HIP::DetectionEngine   <- CUDA::DetectionEngine   Signal/General/DetectionCUDA.cu:127-322
@@ -45,6 +46,31 @@ namespace HIP
     dspsr_amd_ctx* get_context () const { return ctx; }
   protected:
     dspsr_amd_ctx* ctx;
+  };
+
+  //! dsp::TimeSeries::Engine (TimeSeries.h:211-223): device-side row copies for InputBuffering / prepend
+  class TimeSeriesEngine : public dsp::TimeSeries::Engine
+  {
+  public:
+    TimeSeriesEngine (dspsr_amd_ctx* _ctx) : ctx (_ctx), to (0) { }
+    void prepare (dsp::TimeSeries* parent) { to = parent; }
+    void prepare_buffer (unsigned) { }           // no staging buffer: rows are copied directly
+
+    //! TimeSeriesCUDA.cu:75-200 (same-device case); copies ndat samples of every (chan, pol) row of
+    //! `from`, starting at idat_start, to the start of the rows of the parent
+    void copy_data_fpt (const dsp::TimeSeries* from, uint64_t idat_start = 0, uint64_t ndat = 0)
+    {
+      const unsigned nchan = to->get_nchan (), npol = to->get_npol (), ndim = to->get_ndim ();
+      float* obase = to->get_datptr (0, 0);
+      const float* ibase = from->get_datptr (0, 0);
+      check (ctx, dspsr_amd_copy_fpt (ctx, obase, nchan > 1 ? to->get_datptr (1, 0) - obase : 0,
+               npol > 1 ? to->get_datptr (0, 1) - obase : 0, ibase + idat_start * ndim,
+               nchan > 1 ? from->get_datptr (1, 0) - ibase : 0, npol > 1 ? from->get_datptr (0, 1) - ibase : 0,
+               nchan, npol, ndat * ndim), "HIP::TimeSeriesEngine::copy_data_fpt");
+    }
+  protected:
+    dspsr_amd_ctx* ctx;
+    dsp::TimeSeries* to;
   };
 
   //! dsp::Filterbank::Engine (FilterbankEngine.h:15-44)

@@ -56,6 +56,15 @@ int dspsr_amd_zero(dspsr_amd_ctx* ctx, void* ptr_dev, size_t nbytes);
 #define DSPSR_AMD_D2D 3
 int dspsr_amd_copy(dspsr_amd_ctx* ctx, void* dst, const void* src, size_t nbytes, int kind);
 
+/* ---- dsp::TimeSeries::Engine::copy_data_fpt (Kernel/Classes/dsp/TimeSeries.h:211-223; CUDA twin
+ * Kernel/Classes/TimeSeriesCUDA.cu:20-29,75-200): device-to-device copy of `nfloat` floats of every
+ * (channel, polarisation) row -- the overlap carry-over of dsp::InputBuffering (InputBuffering.C:35-126) and
+ * TimeSeries::prepend.  Strides in floats between channel rows / polarisation rows; the row pointers already
+ * include the start sample.  Rows of `to` and `from` must not overlap. */
+int dspsr_amd_copy_fpt(dspsr_amd_ctx* ctx, float* to_dev, uint64_t to_chan_stride, uint64_t to_pol_stride,
+                       const float* from_dev, uint64_t from_chan_stride, uint64_t from_pol_stride,
+                       uint32_t nchan, uint32_t npol, uint64_t nfloat);
+
 /* ---- dsp::Filterbank::Engine ------------------------------------------------------------
  * setup(Filterbank*)  -> dspsr_amd_filterbank_create + dspsr_amd_filterbank_set_kernel
  *   (FilterbankCUDA.cu:73-168 reads freq_res, nchan_subband, input state, response nchan/ndat/

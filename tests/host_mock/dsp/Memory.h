@@ -20,9 +20,16 @@ namespace dsp {
   };
   class TimeSeries : public Observation {
   public:
+    class Engine;
     float* get_datptr (unsigned = 0, unsigned = 0) { return 0; }
     const float* get_datptr (unsigned = 0, unsigned = 0) const { return 0; }
     void set_memory (Memory*) {}
+  };
+  class TimeSeries::Engine : public Reference::Able {      // Kernel/Classes/dsp/TimeSeries.h:211-223
+  public:
+    virtual void prepare (dsp::TimeSeries* to) = 0;
+    virtual void prepare_buffer (unsigned nbytes) = 0;
+    virtual void copy_data_fpt (const dsp::TimeSeries* copy, uint64_t idat_start = 0, uint64_t ndat = 0) = 0;
   };
   class PhaseSeries : public TimeSeries {
   public:

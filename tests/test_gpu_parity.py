@@ -235,6 +235,22 @@ def test_filterbank_uwb_16bit_input(oracle, gpu, npol, C, M, nfilt):
     assert np.abs(got - ref).max() <= 8 * tol * rms_ref
 
 
+def test_copy_data_fpt(gpu):
+    """dsp::TimeSeries::Engine::copy_data_fpt twin: row copies with independent strides (bit-exact)."""
+    dspsr_amd, ctx = gpu
+    nchan, npol, n = 5, 2, 1003
+    src = torch.randn((nchan, npol, 1500), device="cuda")
+    dst = torch.zeros((nchan, npol, 1200), device="cuda")
+    for off in (0, 3, 4):                                   # aligned and unaligned start samples
+        dst.zero_()
+        lib = dspsr_amd.lib
+        rc = lib.dspsr_amd_copy_fpt(ctx.handle, dst.data_ptr(), dst.stride(0), dst.stride(1),
+                                    src.data_ptr() + 4 * off, src.stride(0), src.stride(1), nchan, npol, n)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(dst[:, :, :n], src[:, :, off:off + n]) and float(dst[:, :, n:].abs().max()) == 0.0
+
+
 def test_filterbank_errors(gpu):
     dspsr_amd, ctx = gpu
     with pytest.raises(dspsr_amd.DspsrAmdError):

@@ -13,7 +13,7 @@ def test_adaptor_header_compiles_and_instantiates(tmp_path):
                    "int main () {\n"
                    "  dspsr_amd_ctx* ctx = 0;\n"
                    "  if (dspsr_amd_ctx_create (0, DSPSR_AMD_NEW_STREAM, &ctx) != DSPSR_AMD_OK) return 0; // no GPU here\n"
-                   "  HIP::DeviceMemory mem (ctx); HIP::FilterbankEngine fb (ctx); HIP::ConvolutionEngine conv (ctx);\n"
+                   "  HIP::DeviceMemory mem (ctx); HIP::FilterbankEngine fb (ctx); HIP::ConvolutionEngine conv (ctx); HIP::TimeSeriesEngine tse (ctx);\n"
                    "  HIP::DetectionEngine det (ctx); HIP::FoldEngine fold (ctx);\n"
                    "  return 0;\n}\n")
     exe = tmp_path / "t"
