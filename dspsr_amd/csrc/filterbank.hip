@@ -21,11 +21,13 @@
 #include <vector>
 
 #include "engine_internal.h"
+#include "fold_internal.h"
 
 namespace dspsr_amd {
 
 struct FbGeom {
   int logM, logR, logT1, logT2, logT3;   // four-pass mode: logM/logR are the forward factors Fa/Fb (L = Fa*Fb), logT3 = 0
+  int logX3;                             // channels per block of the X layout (>= tile channels 2^logT3 of pass 3)
   int four_pass;                         // freq_res handled by a two-pass inverse (k_inv_a + k_inv_b)
   int logMf, logMa, logMb, logTm, logTt; // freq_res = Ma*Mb ; m2 columns per k_inv_a tile ; t1 columns per k_inv_b tile
   int real_input, npol;
@@ -46,11 +48,15 @@ struct FbIn {
 };
 
 struct FbOut {
-  int kind;  // 0: none (benchmark), 1: complex filterbank rows, 2: detected
+  int kind;  // 0: none (benchmark), 1: complex filterbank rows, 2: detected, 3: detected and folded in the same
+             //    kernel (base = device profile [chan][nbin] float4, ndim 4; plan per part, see fold_internal.h)
   float* base;
   uint64_t chan_stride, pol_stride, part_step;  // floats
   int state;                                    // detected: coherence / stokes
   uint32_t ndim, chan0;
+  uint32_t nbin;                                // kind 3
+  const uint32_t* pstart;                       // kind 3: [part][nbin + 1] offsets into piv
+  const Interval* piv;                          // kind 3: intervals (offset within the part, hits), time ordered per bin
 };
 
 DEV float cvt8(int v, float scale) { return ((float)v + 0.5f) * scale; }
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
   typedef FftPlan<LOGF> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
-  const int logT = g.logT2, logT3 = g.logT3;
+  const int logT = g.logT2, logT3 = g.logX3;     // X layout block factor
   const uint32_t T2 = 1u << logT, T3 = 1u << logT3;
   const uint64_t L = 1ull << (g.logM + g.logR);
   const uint32_t ntile = 1u << (g.logM - logT);
@@ -501,7 +507,14 @@ DEV void detect4(const cf p, const cf q, const int state, float (&r)[4])
 // the two butterflies a thread owns are the two polarisations of the same (channel, bin):
 // one (a, b, chirp) load serves both and detection needs no cross-lane traffic.
 // Items: part fastest, so one XCD re-reads a tile's chirp rows from its L2 for every part.
-template <int LOGF>
+// FOLD: the detected samples of the tile (T3 channels x nkeep samples, one float4 each) are staged in the
+// exchange buffer instead of being written out, and folded at once: thread b owns phase bins b, b + blockDim, ...
+// of the tile's channels, loads each touched accumulator from the device profile, adds the samples of the
+// bin's intervals one by one in time order and stores it back.  A workgroup processes ALL parts of a tile in
+// order and launches are stream ordered, so every (chan, bin) sum has the association order of the CPU loop
+// Fold.C:844-852, exactly as the stand-alone fold kernel (fold.hip) -- bit-identical results, without the
+// 16 B/sample round trip of the detected time series through HBM.
+template <int LOGF, bool FOLD>
 __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __restrict__ X,
                                                   const cf* __restrict__ kernel, const FbOut out,
                                                   const cf* __restrict__ tw, const uint64_t part0,
@@ -515,15 +528,18 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   const uint32_t T = 1u << logT, T3 = 1u << logT3, M = 1u << g.logM, Rr = 1u << g.logR;
   const uint64_t L = (uint64_t)M << g.logR;
   const uint32_t nseq = g.real_input ? 1 : g.npol;
-  const uint64_t blk = ((uint64_t)M) << logT3;  // elements per X block
+  const int logX3 = g.logX3;                    // X layout: element (row, m) at ((row >> logX3)*M + m) << logX3 | row % X3
+  const uint32_t X3 = 1u << logX3;
   const uint32_t ntile = g.C >> logT3;
+  auto xi = [&](const uint32_t row, const uint32_t m) -> uint64_t {
+    return ((((uint64_t)(row >> logX3) << g.logM) + m) << logX3) | (row & (X3 - 1));
+  };
   const uint64_t total = (uint64_t)ntile * nparts;
   struct Abk { cf a, b; };   // the chirp is fetched at the start of the item (keeps the prefetch at 64 registers)
 
   auto fetch = [&](const uint64_t item, Abk (&raw)[PTS / 2]) {
     const uint32_t tile = (uint32_t)(item / nparts);
     const cf* __restrict__ X0s = X + (item % nparts) * nseq * L;
-    const uint32_t mblk = (Rr >> logT3) - 1 - tile;
     if (g.dbg & 2) {     // ablation only; hoisted so that the real path has no per-load branch
 #pragma unroll
       for (int i = 0; i < NPAIR; i++) { raw[i].a = make_float2(tid, i); raw[i].b = raw[i].a; }
@@ -538,10 +554,8 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         const uint32_t s = tile * T3 + slo;
         // branch-free addressing: a conditional around a load would make the compiler wait for every
         // load separately (vmcnt(0) per element)
-        const uint64_t ia = tile * blk + ((uint64_t)m << logT3) + slo;
-        const uint32_t rr = (Rr - s) & (Rr - 1);
-        const uint64_t ib_mirror = m > 0 ? mblk * blk + (((uint64_t)(M - m)) << logT3) + (T3 - 1 - slo)
-                                         : (rr >> logT3) * blk + (rr & (T3 - 1));
+        const uint64_t ia = xi(s, m);
+        const uint64_t ib_mirror = m > 0 ? xi(Rr - 1 - s, M - m) : xi((Rr - s) & (Rr - 1), 0);
         const uint64_t ib = g.real_input ? ib_mirror : (g.npol == 2 ? L + ia : ia);
         Abk r;
         r.a = ld_stream(&X0s[ia]);
@@ -554,7 +568,23 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
   uint64_t item, next;
   uint32_t j = 0;
-  if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
+  // FOLD: workgroup b takes tiles b, b + grid, ... and walks the parts of each in order
+  auto next_item = [&](const uint32_t jj, uint64_t& it) -> bool {
+    if constexpr (FOLD) {
+      // tiles that share an X layout block (2^(logX3-logT3) of them) go to blocks b, b+8, ... : one XCD under the
+      // observed round-robin placement, at the same time, so the block's lines are fetched once (speed only)
+      const int lr = logX3 - logT3;
+      uint32_t b = blockIdx.x;
+      if (lr > 0 && (gridDim.x & ((8u << lr) - 1)) == 0)
+        b = ((((b >> (3 + lr)) << 3) | (b & 7)) << lr) | ((b >> 3) & ((1u << lr) - 1));
+      const uint64_t tl = b + (uint64_t)(jj / nparts) * gridDim.x;
+      it = tl * nparts + jj % nparts;
+      return tl < ntile;
+    } else {
+      return persistent_item(blockIdx.x, gridDim.x, jj, run, total, it);
+    }
+  };
+  if (!next_item(j, item)) return;
   Abk raw[PTS / 2];
   fetch(item, raw);
   for (;;) {
@@ -563,7 +593,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     {
       const uint32_t ktile = (uint32_t)(item / nparts);
       cf kk[PTS / 2];
-      if (kernel && !(g.dbg & 2)) {      // uniform; outside the unrolled loads (no per-load branch / vmcnt(0))
+      if (kernel && !(g.dbg & (2 | 32))) {      // uniform; outside the unrolled loads (no per-load branch / vmcnt(0))
 #pragma unroll
         for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
@@ -594,13 +624,25 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
           x[(g2 / 2) * P::R1 + i] = cmuls(make_cx2(x0, x1), k);          // Response::operate, Response.C:429-441
         }
     }
-    const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
+    const bool more = next_item(++j, next);
     if (more) fetch(next, raw);
 
     const uint32_t tile = (uint32_t)(item / nparts);
     const uint64_t part = part0 + item % nparts;
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
+      if constexpr (FOLD) {
+        const uint32_t slo = col >> 1;
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          const uint32_t pos = k * pstride + p;
+          if (pos < g.nfilt_pos || pos >= g.nfilt_pos + g.nkeep) continue;
+          float r[4];
+          detect4(cx2_lo(v[k]), cx2_hi(v[k]), out.state, r);
+          *(float4*)&lds[lds_pad(2 * (slo * g.nkeep + pos - g.nfilt_pos))] = make_float4(r[0], r[1], r[2], r[3]);
+        }
+        return;
+      }
       if (out.kind == 0) return;
       if (g.dbg & 1) { if (v[0].x[0] == 1.2345f && v[R - 1].y[1] == 3.3f) out.base[0] = v[0].x[0]; return; }
       const uint32_t chan = out.chan0 + tile * T3 + (col >> 1);
@@ -634,7 +676,38 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       }
     };
     if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
-    else wgfft<LOGF, +1>(lds, ltw_off, tid, logT, x, store);
+    else wgfft<LOGF, +1, FOLD>(lds, ltw_off, tid, logT, x, store);
+    if constexpr (FOLD) {
+      __syncthreads();                       // the tile's detected samples are staged
+      const uint32_t* __restrict__ ps = out.pstart + part * (out.nbin + 1);
+      // one (bin, channel) accumulator per work item; the samples of an interval are fetched from LDS eight at a
+      // time (independent loads) and then added one after the other, so the sum keeps the time order
+      for (uint32_t w = tid; w < ((g.dbg & 16) ? 0u : (out.nbin << logT3)); w += blockDim.x) {
+        const uint32_t b = w >> logT3, slo = w & (T3 - 1);
+        const uint32_t i0 = ps[b], i1 = ps[b + 1];
+        if (i0 == i1) continue;
+        float4* __restrict__ pp = (float4*)out.base + (uint64_t)(out.chan0 + tile * T3 + slo) * out.nbin + b;
+        float4 acc = *pp;
+        for (uint32_t i = i0; i < i1; i++) {
+          const Interval iv = out.piv[i];
+          const uint32_t l0 = slo * g.nkeep + (uint32_t)iv.offset;
+          uint32_t h = 0;
+          for (; h + 8 <= iv.hits; h += 8) {
+            float4 sm[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) sm[q] = *(const float4*)&lds[lds_pad(2 * (l0 + h + q))];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { acc.x += sm[q].x; acc.y += sm[q].y; acc.z += sm[q].z; acc.w += sm[q].w; }
+          }
+          for (; h < iv.hits; h++) {
+            const float4 sm = *(const float4*)&lds[lds_pad(2 * (l0 + h))];
+            acc.x += sm.x; acc.y += sm.y; acc.z += sm.z; acc.w += sm.w;
+          }
+        }
+        *pp = acc;
+      }
+      // the barrier in front of the next tile's first exchange write also ends this read phase
+    }
     if (!more) break;
     item = next;
   }
@@ -865,7 +938,8 @@ template <int... I> struct mkseq<0, I...> { typedef iseq<I...> type; };
 #ifdef FB_ONLY_HEADLINE   // experiment builds: only the kernels of the headline geometry (M = 4096, Rr = 2048, 8-bit)
 template <int... I> static k1_t pick1(int logf, int raww, iseq<I...>) { return logf == 12 && raww == 1 ? k_fwd_cols<12, 1> : nullptr; }
 template <int... I> static k2_t pick2(int logf, iseq<I...>) { return logf == 11 ? k_fwd_rows<11> : nullptr; }
-template <int... I> static k3_t pick3(int logf, iseq<I...>) { return logf == 12 ? k_inv_chan<12> : nullptr; }
+template <int... I> static k3_t pick3(int logf, iseq<I...>) { return logf == 12 ? k_inv_chan<12, false> : nullptr; }
+template <int... I> static k3_t pick3f(int logf, iseq<I...>) { return logf == 12 ? k_inv_chan<12, true> : nullptr; }
 template <int... I> static k3a_t pick3a(int, iseq<I...>) { return nullptr; }
 template <int... I> static k3b_t pick3b(int, iseq<I...>) { return nullptr; }
 #else
@@ -876,7 +950,8 @@ template <int... I> static k1_t pick1(int logf, int raww, iseq<I...>)
   return raww == 1 ? t1[logf] : t4[logf];
 }
 template <int... I> static k2_t pick2(int logf, iseq<I...>) { static const k2_t t[] = {k_fwd_rows<I>...}; return t[logf]; }
-template <int... I> static k3_t pick3(int logf, iseq<I...>) { static const k3_t t[] = {k_inv_chan<I>...}; return t[logf]; }
+template <int... I> static k3_t pick3(int logf, iseq<I...>) { static const k3_t t[] = {k_inv_chan<I, false>...}; return t[logf]; }
+template <int... I> static k3_t pick3f(int logf, iseq<I...>) { static const k3_t t[] = {k_inv_chan<I, true>...}; return t[logf]; }
 template <int... I> static k3a_t pick3a(int logf, iseq<I...>) { static const k3a_t t[] = {k_inv_a<I>...}; return t[logf]; }
 template <int... I> static k3b_t pick3b(int logf, iseq<I...>) { static const k3b_t t[] = {k_inv_b<I>...}; return t[logf]; }
 #endif
@@ -893,7 +968,7 @@ struct dspsr_amd_filterbank_impl {
   FbGeom g;
   uint64_t N, L;
   uint32_t nseq, max_parts;
-  uint32_t nt1, nt2, nt3, nt4 = 0, ncu, wg_per_cu;
+  uint32_t nt1, nt2, nt3, nt4 = 0, ncu, wg_per_cu, wg3 = 1;
   size_t lds1, lds2, lds3, lds4 = 0;
   uint64_t part_elems = 0;    // scratch elements per part
   cf* A = nullptr;
@@ -974,7 +1049,12 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     g.logT2 = imin(g.logM, LOG_POINTS - g.logR);
     int t3 = LOG_POINTS - g.logM - logPol;
     if (t3 < 0) t3 = 0;
-    g.logT3 = imin(logC, t3);
+    g.logX3 = imin(logC, t3);                    // X layout: keeps the pass-2 store runs at T2*X3 elements
+    // pass-3 tile: may be smaller than a layout block (DSPSR_AMD_P3_LOG_POINTS), two workgroups then share a CU
+    const int LOG_POINTS3 = getenv("DSPSR_AMD_P3_LOG_POINTS") ? atoi(getenv("DSPSR_AMD_P3_LOG_POINTS")) : LOG_POINTS;
+    int t3t = LOG_POINTS3 - g.logM - logPol;
+    if (t3t < 0) t3t = 0;
+    g.logT3 = imin(g.logX3, t3t);
     p1 = M << g.logT1; p2 = Rr << g.logT2; p3 = (M << g.logT3) << logPol;
     three_ok = !(p1 < 32 || p2 < 32 || p3 < 32 || p3 > (1u << LOG_POINTS) || g.logT1 < 1 || g.logT2 < 1);
   }
@@ -988,7 +1068,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     int lma = (logMf + 1) / 2;
     if (lma > MAX_LOGF) lma = MAX_LOGF;
     const int lmb = logMf - lma;
-    g.logM = la; g.logR = lb; g.logT3 = 0;
+    g.logM = la; g.logR = lb; g.logT3 = g.logX3 = 0;
     g.logT1 = imin(lb, LOG_POINTS - la);
     g.logT2 = imin(la, LOG_POINTS - lb);
     g.logMa = lma; g.logMb = lmb;
@@ -1018,6 +1098,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   fb->lds2 = lds_total_words_host((uint32_t)p2, g.logR) * sizeof(cf);
   fb->lds3 = lds_total_words_host((uint32_t)p3, g.four_pass ? g.logMa : g.logM) * sizeof(cf);
   fb->lds4 = g.four_pass ? lds_total_words_host((uint32_t)p4, g.logMb) * sizeof(cf) : 0;
+  fb->wg3 = (!g.four_pass && 2 * fb->lds3 + 1024 <= 160 * 1024) ? 2 * fb->wg_per_cu : fb->wg_per_cu;
   fb->max_parts = cfg->max_parts ? cfg->max_parts : 1;
   // per part: nseq sequences of L points; the two-pass inverse re-uses A for 2 polarisations x N bins
   fb->part_elems = fb->nseq * fb->L;
@@ -1146,7 +1227,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   const int raww = (pret || (fast8 && in.kind == 1)) ? 1 : 4;
   k1_t k1 = pick1(g.logM, raww, seq_t());
   k2_t k2 = pick2(g.logR, seq_t());
-  k3_t k3 = g.four_pass ? nullptr : pick3(g.logM, seq_t());
+  k3_t k3 = g.four_pass ? nullptr : (out.kind == 3 ? pick3f(g.logM, seq_t()) : pick3(g.logM, seq_t()));
   k3a_t k3a = g.four_pass ? pick3a(g.logMa, seq_t()) : nullptr;
   k3b_t k3b = g.four_pass ? pick3b(g.logMb, seq_t()) : nullptr;
   if (!k1 || !k2 || (g.four_pass ? (!k3a || !k3b) : !k3))
@@ -1185,7 +1266,9 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
       hipLaunchKernelGGL(k2, dim3(grid_for(n2, fb->ncu * fb->wg_per_cu)), dim3(fb->nt2), fb->lds2, ctx->stream, g, fb->A, fb->X,
                          ctx->tw, nb, fb->nseq, run2);
       if (!g.four_pass) {
-        hipLaunchKernelGGL(k3, dim3(grid_for(n3, fb->ncu * fb->wg_per_cu)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern, co,
+        // fused fold: one workgroup owns a tile (T3 channels) for all parts of the launch
+        const uint64_t items3 = co.kind == 3 ? (uint64_t)(g.C >> g.logT3) : n3;
+        hipLaunchKernelGGL(k3, dim3(grid_for(items3, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern, co,
                            ctx->tw, part0, nb, run3);
       } else {
         // two-pass inverse: X (natural order) -> U (in the A buffer, dead after pass 2) -> output
@@ -1276,4 +1359,54 @@ extern "C" int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, con
   }
   FbOut out = {2, det_dev, det_chan_stride, det_pol_stride, 0, state, ndim, 0};
   return fb_run(fb, in, out, npart, in_chan_stride);
+}
+
+extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const float* in_f32_dev,
+                                                 uint64_t in_chan_stride, uint64_t in_pol_stride, uint64_t in_step,
+                                                 const int8_t* raw_dev, int raw_layout, float scale, int state,
+                                                 dspsr_amd_fold* fold, uint64_t npart)
+{
+  if (!fb || !fold || (!in_f32_dev == !raw_dev)) return DSPSR_AMD_EINVAL;
+  dspsr_amd_ctx* ctx = fb->ctx;
+  if (fb->cfg.npol != 2)
+    return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_fold: Cannot detect polarization when npol != 2");
+  if (state != DSPSR_AMD_COHERENCE && state != DSPSR_AMD_STOKES)
+    return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_fold: invalid state=%d", state);
+  if (fb->g.four_pass)
+    return fb_fail(ctx, DSPSR_AMD_EINVAL,
+                   "dspsr_amd_filterbank_perform_fold: the fused fold needs the three-pass geometry (freq_res <= 8192); "
+                   "use perform_detect + dspsr_amd_fold_fold");
+  const uint32_t nchan = fb->cfg.input_nchan * fb->g.C;
+  if (!fold->profile || fold->nchan != nchan || fold->npol != 1 || fold->ndim != 4)
+    return fb_fail(ctx, DSPSR_AMD_EINVAL,
+                   "dspsr_amd_filterbank_perform_fold: fold shape must be nchan=%u npol=1 ndim=4 (is %u/%u/%u)", nchan,
+                   fold->nchan, fold->npol, fold->ndim);
+  if (fold->folding_nbin != fold->nbin)
+    return fb_fail(ctx, DSPSR_AMD_EINVAL, "dsp::Fold::fold folding_nbin != output->nbin (%u != %u)",
+                   fold->folding_nbin, fold->nbin);
+  if (npart > 0xffffffffull) return DSPSR_AMD_EINVAL;
+  uint64_t step;
+  dspsr_amd_filterbank_sizes(fb, nullptr, nullptr, &step, nullptr);
+  FbIn in;
+  if (in_f32_dev) {
+    const uint32_t idim = fb->cfg.real_input ? 1 : 2;
+    in = {0, in_f32_dev, in_pol_stride, in_step / idim, fb->cfg.input_nchan, 0, 1.0f};
+  } else {
+    if (raw_layout == DSPSR_AMD_RAW_CASPSR && !(fb->cfg.real_input && fb->cfg.npol == 2 && fb->cfg.input_nchan == 1))
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_fold: CASPSR layout needs real dual-pol single-channel input");
+    if (raw_layout == DSPSR_AMD_RAW_UWB16 && (fb->cfg.real_input || fb->cfg.input_nchan != 1))
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_fold: UWB 16-bit layout needs complex single-channel input");
+    if (raw_layout != DSPSR_AMD_RAW_CASPSR && raw_layout != DSPSR_AMD_RAW_GENERIC && raw_layout != DSPSR_AMD_RAW_UWB16)
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_fold: unknown raw layout %d", raw_layout);
+    in = {raw_kind(raw_layout), raw_dev, 0, step, fb->cfg.input_nchan, 0, scale};
+  }
+  const uint32_t* d_start = nullptr;
+  const Interval* d_iv = nullptr;
+  PlanSlot* slot = nullptr;
+  int rc = fold_build_part_plan(fold, fb->g.nkeep, (uint32_t)npart, &d_start, &d_iv, &slot);
+  if (rc != DSPSR_AMD_OK) return rc;
+  FbOut out = {3, fold->profile, 0, 0, 0, state, 4, 0, fold->nbin, d_start, d_iv};
+  rc = fb_run(fb, in, out, npart, in_chan_stride);
+  const int rc2 = fold_part_plan_submitted(fold, slot);
+  return rc != DSPSR_AMD_OK ? rc : rc2;
 }

@@ -13,10 +13,10 @@
 #include <vector>
 
 #include "engine_internal.h"
+#include "fold_internal.h"
 
 namespace dspsr_amd {
 
-struct Interval { uint64_t offset; uint32_t hits; uint32_t pad; };   // sorted by (bin, time)
 
 // Direct variant: every bin-owner thread reads its samples straight from global memory
 // (used when nbin is too large for the chunked kernel).
@@ -160,37 +160,9 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
   }
 }
 
-struct RunBin { uint32_t ibin, hits; uint64_t offset; };   // FoldCUDA.h:19-24
-
 }  // namespace dspsr_amd
 
 using namespace dspsr_amd;
-
-// device plan, double-buffered so that building/uploading the plan of block i+1 never waits for
-// the fold kernel of block i (pinned staging => the H2D copies are truly asynchronous)
-struct PlanSlot {
-  uint32_t* h_bin_start = nullptr;   // pinned
-  Interval* h_iv = nullptr;          // pinned
-  uint32_t* d_bin_start = nullptr;
-  Interval* d_iv = nullptr;
-  size_t bin_cap = 0, iv_cap = 0;
-  hipEvent_t done = nullptr;
-  bool pending = false;
-};
-
-struct dspsr_amd_fold {
-  dspsr_amd_ctx* ctx;
-  uint32_t nchan = 0, npol = 0, ndim = 0, nbin = 0;
-  float* profile = nullptr;
-  size_t profile_floats = 0;
-  // run-length plan, as CUDA::FoldEngine (FoldCUDA.cu:64-113)
-  std::vector<RunBin> binplan;
-  uint32_t current_bin = 0, current_hits = 0, folding_nbin = 0;
-  uint64_t ndat_fold = 0;
-  PlanSlot slot[2];
-  int next_slot = 0;
-  std::vector<uint32_t> cursor;
-};
 
 static void slot_free(PlanSlot& s)
 {
@@ -419,5 +391,78 @@ extern "C" int dspsr_amd_fold_synch(dspsr_amd_fold* f, float* profile_host)   //
                                 f->ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(f->ctx->stream);
   if (e != hipSuccess) return ctx_fail(f->ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_synch: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}
+
+int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, const uint32_t** d_start,
+                         const Interval** d_iv, PlanSlot** slot)
+{
+  dspsr_amd_ctx* ctx = f->ctx;
+  if (f->current_hits && !f->binplan.empty()) f->binplan.back().hits = f->current_hits;   // FoldCUDA.cu:163-164
+  f->current_hits = 0;
+  const uint32_t nbin = f->nbin;
+  const size_t nb1 = (size_t)npart * (nbin + 1);
+  // count the pieces: a run is cut at every multiple of nkeep
+  size_t npiece = 0;
+  for (const RunBin& r : f->binplan) {
+    if (!r.hits) continue;
+    const uint64_t p0 = r.offset / nkeep, p1 = (r.offset + r.hits - 1) / nkeep;
+    if (p1 >= npart)
+      return ctx_fail(ctx, DSPSR_AMD_EINVAL, "fused fold: plan sample %llu lies beyond the %u parts of this call",
+                      (unsigned long long)(r.offset + r.hits - 1), npart);
+    npiece += (size_t)(p1 - p0 + 1);
+  }
+  PlanSlot& sl = f->slot[f->next_slot];
+  f->next_slot ^= 1;
+  if (sl.pending) {
+    hipError_t e = hipEventSynchronize(sl.done);
+    if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "fused fold: %s", hipGetErrorString(e));
+    sl.pending = false;
+  }
+  if (!slot_reserve(sl, nb1 + 1, npiece ? npiece : 1))
+    return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "fused fold: plan allocation failed");
+  for (size_t i = 0; i <= nb1; i++) sl.h_bin_start[i] = 0;
+  auto for_each_piece = [&](auto&& fn) {
+    for (const RunBin& r : f->binplan) {
+      uint64_t off = r.offset, left = r.hits;
+      while (left) {
+        const uint64_t part = off / nkeep, within = off % nkeep;
+        const uint64_t n = left < nkeep - within ? left : nkeep - within;
+        fn((uint32_t)part, r.ibin, within, (uint32_t)n);
+        off += n; left -= n;
+      }
+    }
+  };
+  for_each_piece([&](uint32_t part, uint32_t ibin, uint64_t, uint32_t) { sl.h_bin_start[(size_t)part * (nbin + 1) + ibin + 1]++; });
+  // prefix sums over the flattened (part, bin) buckets; entry part*(nbin+1) is the start of the part
+  uint32_t run = 0;
+  for (uint32_t part = 0; part < npart; part++) {
+    uint32_t* st = sl.h_bin_start + (size_t)part * (nbin + 1);
+    st[0] = run;
+    for (uint32_t b = 0; b < nbin; b++) { const uint32_t c = st[b + 1]; st[b + 1] = st[b] + c; }
+    run = st[nbin];
+  }
+  f->cursor.resize(nb1);
+  for (size_t i = 0; i < nb1; i++) f->cursor[i] = sl.h_bin_start[i];
+  for_each_piece([&](uint32_t part, uint32_t ibin, uint64_t within, uint32_t n) {
+    Interval v; v.offset = within; v.hits = n; v.pad = 0;
+    sl.h_iv[f->cursor[(size_t)part * (nbin + 1) + ibin]++] = v;
+  });
+  hipError_t e = hipMemcpyAsync(sl.d_bin_start, sl.h_bin_start, nb1 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && npiece)
+    e = hipMemcpyAsync(sl.d_iv, sl.h_iv, npiece * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "fused fold: plan copy: %s", hipGetErrorString(e));
+  f->binplan.clear();
+  *d_start = sl.d_bin_start;
+  *d_iv = sl.d_iv;
+  *slot = &sl;
+  return DSPSR_AMD_OK;
+}
+
+int fold_part_plan_submitted(dspsr_amd_fold* f, PlanSlot* slot)
+{
+  hipError_t e = hipEventRecord(slot->done, f->ctx->stream);
+  if (e != hipSuccess) return ctx_fail(f->ctx, DSPSR_AMD_EHIP, "fused fold: %s", hipGetErrorString(e));
+  slot->pending = true;
   return DSPSR_AMD_OK;
 }

@@ -1,0 +1,45 @@
+// Internals of the fold engine shared with the fused filterbank+detect+fold path (not installed).
+#pragma once
+#include <vector>
+
+#include "engine_internal.h"
+
+namespace dspsr_amd {
+struct Interval { uint64_t offset; uint32_t hits; uint32_t pad; };   // sorted by (bin, time)
+struct RunBin { uint32_t ibin, hits; uint64_t offset; };             // FoldCUDA.h:19-24
+}  // namespace dspsr_amd
+
+// device plan, double-buffered so that building/uploading the plan of block i+1 never waits for
+// the fold kernel of block i (pinned staging => the H2D copies are truly asynchronous)
+struct PlanSlot {
+  uint32_t* h_bin_start = nullptr;   // pinned
+  dspsr_amd::Interval* h_iv = nullptr;          // pinned
+  uint32_t* d_bin_start = nullptr;
+  dspsr_amd::Interval* d_iv = nullptr;
+  size_t bin_cap = 0, iv_cap = 0;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+};
+
+struct dspsr_amd_fold {
+  dspsr_amd_ctx* ctx;
+  uint32_t nchan = 0, npol = 0, ndim = 0, nbin = 0;
+  float* profile = nullptr;
+  size_t profile_floats = 0;
+  // run-length plan, as CUDA::FoldEngine (FoldCUDA.cu:64-113)
+  std::vector<dspsr_amd::RunBin> binplan;
+  uint32_t current_bin = 0, current_hits = 0, folding_nbin = 0;
+  uint64_t ndat_fold = 0;
+  PlanSlot slot[2];
+  int next_slot = 0;
+  std::vector<uint32_t> cursor;
+};
+
+
+// Fused path (filterbank.hip): turns the pending run-length plan into a per-part plan on the device --
+// runs split at multiples of `nkeep`, bucketed by (part, bin), offsets relative to the start of the part;
+// start[part*(nbin+1) + b] .. start[part*(nbin+1) + b + 1] index `iv`.  The plan is consumed (cleared).
+// fold_part_plan_submitted() must be called after the kernels that read the plan have been enqueued.
+int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, const uint32_t** d_start,
+                         const dspsr_amd::Interval** d_iv, PlanSlot** slot);
+int fold_part_plan_submitted(dspsr_amd_fold* f, PlanSlot* slot);

@@ -273,8 +273,9 @@ DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const 
     }
   }
   // every read of the in-place exchange buffer (this or the previous tile) is done; a STAGED last stage
-  // re-uses the buffer to reorder its outputs, so it needs the same guarantee
-  if (!LAST || (STAGED && !FIRST)) __syncthreads();
+  // re-uses the buffer to reorder its outputs, so it needs the same guarantee (also when it is the only stage:
+  // the previous tile's staged image may still be being read)
+  if (!LAST || STAGED) __syncthreads();
 #pragma unroll
   for (int h = 0; h < H; h++) {
     const uint32_t u = G * tid + 2 * h;

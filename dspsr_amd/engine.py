@@ -199,6 +199,22 @@ class FilterbankEngine:
                                                        state, ndim, det.data_ptr(), dcs, dps, npart),
                "dspsr_amd_filterbank_perform_detect")
 
+    def perform_fold(self, fold, npart, state=_lib.COHERENCE, inp=None, in_step=0, raw=None,
+                     layout=_lib.RAW_GENERIC, scale=1.0):
+        """Fused filterbank -> detection (ndim 4) -> fold into `fold`'s device profile; the bin plan of the
+        npart*nkeep output samples must already have been given to `fold` (set_nbin/set_ndat/set_bins)."""
+        if inp is not None:
+            ics, ips = _strides3(inp)
+            iptr = inp.data_ptr()
+        else:
+            ics = ips = 0
+            iptr = None
+        _check(self.ctx.handle,
+               lib.dspsr_amd_filterbank_perform_fold(self.handle, iptr, ics, ips, in_step,
+                                                     raw.data_ptr() if raw is not None else None, layout, scale,
+                                                     state, fold.handle, npart),
+               "dspsr_amd_filterbank_perform_fold")
+
     def finish(self):
         self.ctx.synchronize()
 

@@ -33,6 +33,8 @@ class Config:
     ndim: int = 4                     # detected layout (CPU default 4, CUDA engine 2; LoadToFoldConfig.C:104)
     parts_per_block: int = 16         # block size in overlap-save parts (LoadToFold1.C:825-835 sizes blocks likewise)
     max_parts: int = 8                # parts per launch group
+    fused_fold: bool = True           # fold inside the last filterbank pass when possible (identical sums, no
+                                      # detected time series in HBM); False = Detection and Fold as separate ops
 
 
 @dataclass
@@ -206,6 +208,9 @@ class LoadToFold:
         self.scalefac = float(n_fft) * float(r.ndat)
         self.detected = torch.empty((cfg.nchan, self.npol_out, cfg.parts_per_block * self.nkeep * cfg.ndim),
                                     dtype=torch.float32, device="cuda:%d" % device)
+        # fused filterbank+detect+fold (no detected time series in HBM): ndim 4, three-pass geometries
+        self.fused_fold = bool(cfg.fused_fold) and cfg.ndim == 4 and r.ndat <= 8192 and \
+            (cfg.nchan // info.nchan) * (2 if info.ndim == 1 else 1) >= 2
         # fold bookkeeping (PhaseSeries) ---------------------------------------------------
         self.hits = np.zeros(cfg.nbin, dtype=np.uint32)
         self.integration_length = 0.0
@@ -236,18 +241,35 @@ class LoadToFold:
         if raw.numel() < self.block_bytes(npart):
             raise DspsrAmdError("dspsr_amd.LoadToFold.process_block: block holds %d bytes, %d needed"
                                 % (raw.numel(), self.block_bytes(npart)))
-        if events is not None:          # HIP events bracketing the FFT+chirp launch group (bench.py roofline)
-            events[0].record()
-        self.fb.perform_detect(self.detected, npart, _lib.STOKES if cfg.stokes else _lib.COHERENCE, cfg.ndim,
-                               raw=raw, layout=self.layout, scale=self.scale8)
-        if events is not None:
-            events[1].record()
         ndat = npart * self.nkeep
         # Subint<Fold>::transformation: fold piece by piece, emitting a sub-integration at every boundary
         if self.cfg.subint_seconds > 0:
             pieces = subint_pieces(self.ndat_out, ndat, self.cfg.subint_seconds, self.out_rate)
         else:
             pieces = [(0, ndat, 0, False)]
+        state = _lib.STOKES if cfg.stokes else _lib.COHERENCE
+        if self.fused_fold and len(pieces) == 1:
+            # one fold call covers the block: filterbank, detection and fold in one launch group.  Same sums in the
+            # same order as the unfused chain below (blocks holding a sub-integration boundary take that chain).
+            idat_start, ndat_fold, _division, complete = pieces[0]
+            folded = self._set_plan(idat_start, ndat_fold)
+            if events is not None:
+                events[0].record()
+            self.fb.perform_fold(self.fold, npart, state, raw=raw, layout=self.layout, scale=self.scale8)
+            if events is not None:
+                events[1].record()
+            self.integration_length += folded / self.out_rate
+            self.ndat_total += ndat_fold
+            if complete:
+                self.finish_subint(*self._subint_comm)
+            self.ndat_out += ndat
+            self.nsamples_in += npart * self.nsamp_step
+            return
+        if events is not None:          # HIP events bracketing the FFT+chirp launch group (bench.py roofline)
+            events[0].record()
+        self.fb.perform_detect(self.detected, npart, state, cfg.ndim, raw=raw, layout=self.layout, scale=self.scale8)
+        if events is not None:
+            events[1].record()
         for idat_start, ndat_fold, _division, complete in pieces:
             self._fold_piece(idat_start, ndat_fold)
             if complete:
@@ -260,14 +282,18 @@ class LoadToFold:
     def set_communicator(self, dist, rank, world, gather_buffer):
         self._subint_comm = (dist, rank, world, gather_buffer)
 
-    def _fold_piece(self, idat_start, ndat_fold):
-        """Fold::fold (Fold.C:650-657,718-803) on detected[idat_start : idat_start+ndat_fold]."""
+    def _set_plan(self, idat_start, ndat_fold):
+        """The host plan loop of Fold::fold (Fold.C:650-657,718-787): phase of the first sample, then the bins."""
         cfg = self.cfg
         t0 = self.out_start + (self.ndat_out + idat_start + 0.5) / self.out_rate     # midpoint of first sample
         phi, pfold = self._phase(t0)
         self.fold.set_nbin(cfg.nbin)
         self.fold.set_ndat(ndat_fold, idat_start)
-        folded = self.fold.set_bins(phi, (1.0 / self.out_rate) / pfold, ndat_fold, idat_start, self.hits)
+        return self.fold.set_bins(phi, (1.0 / self.out_rate) / pfold, ndat_fold, idat_start, self.hits)
+
+    def _fold_piece(self, idat_start, ndat_fold):
+        """Fold::fold (Fold.C:650-657,718-803) on detected[idat_start : idat_start+ndat_fold]."""
+        folded = self._set_plan(idat_start, ndat_fold)
         self.fold.fold(self.detected)
         self.integration_length += folded / self.out_rate
         self.ndat_total += ndat_fold

@@ -123,6 +123,18 @@ int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, const float* i
                                         int raw_layout, float scale, int state, uint32_t ndim, float* det_dev,
                                         uint64_t det_chan_stride, uint64_t det_pol_stride, uint64_t npart);
 
+/* Fused Filterbank -> Detection -> Fold (ndim 4, npol 1 profile): the detected time series never leaves the
+ * chip.  Replaces the chain Filterbank::Engine::perform (FilterbankCUDA.cu:181-304) + Detection::Engine::polarimetry
+ * (DetectionCUDA.cu:127-177) + Fold::Engine::fold (FoldCUDA.cu:586-697) for one block of `npart` parts.
+ * The bin plan of the npart*nkeep output samples of this call must have been handed to `fold` beforehand
+ * (dspsr_amd_fold_set_nbin / set_ndat / set_bin(s) with sample indices counted from the first output sample of
+ * this call); it is consumed.  Sums are accumulated into the device profile of `fold` in time order per
+ * (chan, bin), bit-identical to perform_detect followed by dspsr_amd_fold_fold.  Three-pass geometries only
+ * (freq_res <= 8192); otherwise DSPSR_AMD_EINVAL and the caller uses the unfused chain. */
+int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const float* in_f32_dev, uint64_t in_chan_stride,
+                                      uint64_t in_pol_stride, uint64_t in_step, const int8_t* raw_dev, int raw_layout,
+                                      float scale, int state, dspsr_amd_fold* fold, uint64_t npart);
+
 /* ---- dsp::Detection::Engine (Detection.h:98-106) ------------------------------------------
  * polarimetry(ndim, in, out): in = complex rows [nchan][2][ndat]; in-place allowed for ndim 2
  * (LoadToFold1.C:545-546 uses input==output).  Layouts as above. */

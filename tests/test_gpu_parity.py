@@ -416,6 +416,77 @@ def test_end_to_end_folded_profile(oracle, gpu):
     fold.close()
 
 
+@pytest.mark.parametrize("C,M,nfilt,nbin,period_samples,state", [
+    (16, 256, (20, 21), 64, 97.3, "Coherence"),       # ~1.5 samples per bin: every bin touched in every part
+    (8, 1024, (100, 101), 1024, 34766.4, "Coherence"),  # long period: ~34 samples per bin, few bins per part
+    (64, 128, (9, 10), 100, 1234.5, "Stokes"),          # nbin not a power of two
+    (2, 2048, (100, 50), 1500, 333.3, "Coherence"),     # nbin beyond the workgroup size
+])
+def test_fused_fold_bit_identical(oracle, gpu, C, M, nfilt, nbin, period_samples, state):
+    """perform_fold (fold inside the last filterbank pass) == perform_detect + FoldEngine.fold, bit for bit,
+    over several calls and launch groups (accumulators re-loaded from the device profile)."""
+    dspsr_amd, ctx = gpu
+    o = oracle
+    N = C * M
+    nkeep = M - sum(nfilt)
+    step, ovl = 2 * (N - sum(nfilt) * C), 2 * sum(nfilt) * C
+    npart, ncall = 5, 3
+    rng = np.random.default_rng(23)
+    kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, N)).astype(np.complex64)
+    st = dspsr_amd.STOKES if state == "Stokes" else dspsr_amd.COHERENCE
+    eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, 2, True, kernel, max_parts=2)
+    folds = [dspsr_amd.FoldEngine(ctx), dspsr_amd.FoldEngine(ctx)]
+    hits = [np.zeros(nbin, np.uint32), np.zeros(nbin, np.uint32)]
+    for f in folds:
+        f.set_shape(C, 1, 4, nbin)
+    det = torch.zeros((C, 1, 4 * npart * nkeep), dtype=torch.float32, device="cuda")
+    pps = 1.0 / period_samples
+    for call in range(ncall):
+        raw = torch.from_numpy(_raw(npart * step + ovl, seed=100 + call)).cuda()
+        ndat = npart * nkeep
+        phi = (0.37 + call * ndat * pps) % 1.0
+        for k, f in enumerate(folds):
+            f.set_nbin(nbin)
+            f.set_ndat(ndat, 0)
+            f.set_bins(phi, pps, ndat, 0, hits[k])
+        eng.perform_detect(det, npart, st, 4, raw=raw, scale=float(o.S8))
+        folds[0].fold(det)
+        eng.perform_fold(folds[1], npart, st, raw=raw, scale=float(o.S8))
+    a, b = folds[0].synch(), folds[1].synch()
+    assert np.array_equal(hits[0], hits[1])
+    assert np.abs(a).max() > 0 and np.array_equal(a, b)
+    eng.close()
+    for f in folds:
+        f.close()
+
+
+def test_pipeline_fused_equals_unfused(oracle, gpu):
+    """LoadToFold with and without the fused fold over blocks with sub-integration boundaries: identical dumps."""
+    dspsr_amd, _ = gpu
+    from dspsr_amd import pipeline, synth
+    freq, bw, tsamp, dm, period, nchan, nbin = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004, 16, 64
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
+    dumps = []
+    for fused in (True, False):
+        cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=4,
+                              parts_per_block=3, max_parts=2, subint_seconds=0.004, fused_fold=fused)
+        lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+        assert lt.fused_fold == fused
+        nblocks = 5
+        step = cfg.parts_per_block * lt.nsamp_step
+        raw = synth.voltages(nblocks * step + lt.nsamp_overlap, freq, bw, tsamp, dm, period)
+        d_raw = torch.from_numpy(raw).cuda()
+        for b in range(nblocks):
+            lt.process_block(d_raw[2 * b * step: 2 * (b * step + step + lt.nsamp_overlap)])
+        lt.finish_subint()
+        lt.synchronize()
+        dumps.append([(s["hits"].copy(), s["profile_dev"].cpu().numpy(), s["integration_length"]) for s in lt.subints])
+        lt.close()
+    assert len(dumps[0]) == len(dumps[1]) >= 2
+    for (h0, p0, t0), (h1, p1, t1) in zip(*dumps):
+        assert np.array_equal(h0, h1) and np.array_equal(p0, p1) and t0 == t1
+
+
 def test_pipeline_subintegrations(oracle, gpu):
     """LoadToFold driver with -L sub-integrations over several blocks (overlap carried between blocks) against
     the oracle folding the same pieces: identical hits per sub-integration, profiles <= 1e-5."""
