@@ -490,6 +490,15 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
 }
 
 // ------------------------------------------------------------------------------------ P3
+#ifdef FB_STAMPS   // diagnostic build only: where a pass-3 tile spends its cycles (s_memtime per phase, lane 0 of wave 0)
+__device__ unsigned long long g_stamps[1024][8];
+#define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int dspsr_amd_debug_stamps(unsigned long long* out_host, int zero)
+{
+  if (zero) { static unsigned long long z[1024][8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#endif
 DEV void detect4(const cf p, const cf q, const int state, float (&r)[4])
 {
   // cross_detect.ic:23-43 / stokes_detect.ic:21-44
@@ -537,31 +546,59 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   const uint64_t total = (uint64_t)ntile * nparts;
   struct Abk { cf a, b; };   // the chirp is fetched at the start of the item (keeps the prefetch at 64 registers)
 
-  auto fetch = [&](const uint64_t item, Abk (&raw)[PTS / 2]) {
+  // chunk < 0: all elements; otherwise the elements i with i % NCHUNK == chunk (the prefetch of the next tile is
+  // issued in NCHUNK groups spread over the transform, see wgfft_stage)
+  constexpr int NCHUNK = P::NS + 1;
+  auto fetch = [&](const uint64_t item, Abk (&raw)[PTS / 2], const int chunk) {
     const uint32_t tile = (uint32_t)(item / nparts);
     const cf* __restrict__ X0s = X + (item % nparts) * nseq * L;
     if (g.dbg & 2) {     // ablation only; hoisted so that the real path has no per-load branch
+      if (chunk <= 0) {
 #pragma unroll
-      for (int i = 0; i < NPAIR; i++) { raw[i].a = make_float2(tid, i); raw[i].b = raw[i].a; }
+        for (int i = 0; i < NPAIR; i++) { raw[i].a = make_float2(tid, i); raw[i].b = raw[i].a; }
+      }
       return;
     }
+    // element i of a thread's first-stage butterfly is bin m = mb + i*MS of one (channel, pol pair) column, so
+    // every address is a base plus a multiple of a wave-uniform step: no per-element index arithmetic, no
+    // divergent code between the loads (the m = 0 mirror element, the only irregular one, can only be i = 0)
+    constexpr uint32_t MS = 1u << (LOGF - P::LOGR1);
+    const int64_t step = (int64_t)MS << logX3;
 #pragma unroll
-    for (int g2 = 0; g2 < P::G1; g2 += 2)
+    for (int g2 = 0; g2 < P::G1; g2 += 2) {
+      const uint32_t eb = P::G1 * tid + g2;
+      const uint32_t slo = (eb & (T - 1)) >> 1, mb = eb >> logT;
+      const uint32_t s = tile * T3 + slo;
+      const cf* __restrict__ pa = X0s + xi(s, mb);
+      const cf* __restrict__ pb = g.real_input ? X0s + xi(Rr - 1 - s, M - mb) : pa + (g.npol == 2 ? L : 0);
+      const int64_t stepb = g.real_input ? -step : step;
+      const cf* __restrict__ pb0 = (g.real_input && mb == 0) ? X0s + xi((Rr - s) & (Rr - 1), 0) : pb;
 #pragma unroll
       for (int i = 0; i < P::R1; i++) {
-        const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
-        const uint32_t slo = (e & (T - 1)) >> 1, m = e >> logT;
-        const uint32_t s = tile * T3 + slo;
-        // branch-free addressing: a conditional around a load would make the compiler wait for every
-        // load separately (vmcnt(0) per element)
-        const uint64_t ia = xi(s, m);
-        const uint64_t ib_mirror = m > 0 ? xi(Rr - 1 - s, M - m) : xi((Rr - s) & (Rr - 1), 0);
-        const uint64_t ib = g.real_input ? ib_mirror : (g.npol == 2 ? L + ia : ia);
+        if (chunk >= 0 && i % NCHUNK != chunk) continue;
         Abk r;
-        r.a = ld_stream(&X0s[ia]);
-        r.b = ld_stream(&X0s[ib]);
+        r.a = ld_stream(pa + i * step);
+        r.b = ld_stream(i == 0 ? pb0 : pb + i * stepb);
         raw[(g2 / 2) * P::R1 + i] = r;
       }
+    }
+  };
+  // chirp of a tile (fetched at the start of the item: keeps the prefetch at 64 registers)
+  auto load_chirp = [&](const uint64_t item, cf (&kk)[PTS / 2]) {
+    const uint32_t ktile = (uint32_t)(item / nparts);
+    if (kernel && !(g.dbg & (2 | 32))) {      // uniform; outside the unrolled loads (no per-load branch / vmcnt(0))
+      constexpr uint32_t MS = 1u << (LOGF - P::LOGR1);
+#pragma unroll
+      for (int g2 = 0; g2 < P::G1; g2 += 2) {
+        const uint32_t eb = P::G1 * tid + g2;
+        const cf* __restrict__ pk = kernel + ((uint64_t)(ktile * T3 + ((eb & (T - 1)) >> 1)) << g.logM) + (eb >> logT);
+#pragma unroll
+        for (int i = 0; i < P::R1; i++) kk[(g2 / 2) * P::R1 + i] = pk[i * MS];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PTS / 2; i++) kk[i] = make_float2(1.f, 0.f);
+    }
   };
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
@@ -586,26 +623,22 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   };
   if (!next_item(j, item)) return;
   Abk raw[PTS / 2];
-  fetch(item, raw);
+  fetch(item, raw, -1);
+#ifdef FB_STAMPS
+  unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, acc_s[6] = {0, 0, 0, 0, 0, 0};
+  STAMP(ts5);
+#endif
   for (;;) {
     asm volatile("" : "+v"(tid));   // per-tile index math stays inside the loop (see wgfft)
     cx2 x[NPAIR];
+#ifdef FB_STAMPS
+    // wait for the prefetched tile explicitly so that the wait is timed separately
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(ts0);
+#endif
     {
-      const uint32_t ktile = (uint32_t)(item / nparts);
       cf kk[PTS / 2];
-      if (kernel && !(g.dbg & (2 | 32))) {      // uniform; outside the unrolled loads (no per-load branch / vmcnt(0))
-#pragma unroll
-        for (int g2 = 0; g2 < P::G1; g2 += 2)
-#pragma unroll
-          for (int i = 0; i < P::R1; i++) {
-            const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
-            const uint32_t s = ktile * T3 + ((e & (T - 1)) >> 1), m = e >> logT;
-            kk[(g2 / 2) * P::R1 + i] = kernel[((uint64_t)s << g.logM) + m];
-          }
-      } else {
-#pragma unroll
-        for (int i = 0; i < PTS / 2; i++) kk[i] = make_float2(1.f, 0.f);
-      }
+      load_chirp(item, kk);
 #pragma unroll
       for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
@@ -624,8 +657,17 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
           x[(g2 / 2) * P::R1 + i] = cmuls(make_cx2(x0, x1), k);          // Response::operate, Response.C:429-441
         }
     }
+#ifdef FB_STAMPS
+    STAMP(ts1);
+#endif
     const bool more = next_item(++j, next);
-    if (more) fetch(next, raw);
+    // One burst: spreading the loads over the transform (wgfft's `mid` hook) or loading the chirp one tile early
+    // was measured and does not pay -- the wave time goes to ISSUING the 8-byte loads (about 6k cycles per tile,
+    // profiles/r01d_p3_phase_stamps.txt), wherever they are placed.
+    if (more) fetch(next, raw, -1);
+#ifdef FB_STAMPS
+    STAMP(ts2);
+#endif
 
     const uint32_t tile = (uint32_t)(item / nparts);
     const uint64_t part = part0 + item % nparts;
@@ -633,13 +675,14 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       constexpr int R = sizeof(v) / sizeof(v[0]);
       if constexpr (FOLD) {
         const uint32_t slo = col >> 1;
+        const int32_t t0 = (int32_t)p - (int32_t)g.nfilt_pos;
 #pragma unroll
         for (int k = 0; k < R; k++) {
-          const uint32_t pos = k * pstride + p;
-          if (pos < g.nfilt_pos || pos >= g.nfilt_pos + g.nkeep) continue;
+          const int32_t t = t0 + (int32_t)(k * pstride);
+          if ((uint32_t)t >= g.nkeep) continue;           // outside the kept window (negative t wraps)
           float r[4];
           detect4(cx2_lo(v[k]), cx2_hi(v[k]), out.state, r);
-          *(float4*)&lds[lds_pad(2 * (slo * g.nkeep + pos - g.nfilt_pos))] = make_float4(r[0], r[1], r[2], r[3]);
+          *(float4*)&lds[lds_pad(2 * (slo * g.nkeep + (uint32_t)t))] = make_float4(r[0], r[1], r[2], r[3]);
         }
         return;
       }
@@ -647,14 +690,19 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       if (g.dbg & 1) { if (v[0].x[0] == 1.2345f && v[R - 1].y[1] == 3.3f) out.base[0] = v[0].x[0]; return; }
       const uint32_t chan = out.chan0 + tile * T3 + (col >> 1);
       float* __restrict__ row = out.base + chan * out.chan_stride;
+      // output sample of element k: t0 + k*pstride (kept when 0 <= t < nkeep); the addresses are a base plus a
+      // multiple of a wave-uniform step
+      const int32_t t0 = (int32_t)p - (int32_t)g.nfilt_pos;
+      float2* __restrict__ o2 = (float2*)(row + part * out.part_step) + t0;
+      float4* __restrict__ o4 = (float4*)row + ((int64_t)(part * g.nkeep) + t0);
 #pragma unroll
       for (int k = 0; k < R; k++) {
-        const uint32_t pos = k * pstride + p;
-        if (pos < g.nfilt_pos || pos >= g.nfilt_pos + g.nkeep) continue;
-        const uint32_t t = pos - g.nfilt_pos;
+        const int32_t ts = t0 + (int32_t)(k * pstride);
+        if ((uint32_t)ts >= g.nkeep) continue;
+        const uint32_t t = (uint32_t)ts;
         const cf va = cx2_lo(v[k]), vb = cx2_hi(v[k]);
         if (out.kind == 1) {
-          float2* o = (float2*)(row + part * out.part_step) + t;
+          float2* o = o2 + k * pstride;
           st_stream(o, va);
           if (g.npol == 2) st_stream((float2*)((float*)o + out.pol_stride), vb);
         } else {
@@ -662,7 +710,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
           detect4(va, vb, out.state, r);
           const uint64_t idat = part * g.nkeep + t;
           if (out.ndim == 4) {
-            st_stream(&((float4*)row)[idat], make_float4(r[0], r[1], r[2], r[3]));
+            st_stream(o4 + k * pstride, make_float4(r[0], r[1], r[2], r[3]));
           } else if (out.ndim == 2) {
             st_stream(&((float2*)row)[idat], make_float2(r[0], r[1]));
             st_stream(&((float2*)(row + out.pol_stride))[idat], make_float2(r[2], r[3]));
@@ -677,6 +725,9 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     };
     if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
     else wgfft<LOGF, +1, FOLD>(lds, ltw_off, tid, logT, x, store);
+#ifdef FB_STAMPS
+    STAMP(ts3);
+#endif
     if constexpr (FOLD) {
       __syncthreads();                       // the tile's detected samples are staged
       const uint32_t* __restrict__ ps = out.pstart + part * (out.nbin + 1);
@@ -708,9 +759,18 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       }
       // the barrier in front of the next tile's first exchange write also ends this read phase
     }
+#ifdef FB_STAMPS
+    STAMP(ts4);
+    acc_s[0] += ts0 - ts5; acc_s[1] += ts1 - ts0; acc_s[2] += ts2 - ts1; acc_s[3] += ts3 - ts2; acc_s[4] += ts4 - ts3; acc_s[5] += 1;
+    ts5 = ts4;
+#endif
     if (!more) break;
     item = next;
   }
+#ifdef FB_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 1024)
+    for (int q = 0; q < 6; q++) atomicAdd(&g_stamps[blockIdx.x][q], acc_s[q]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------ P3a / P3b

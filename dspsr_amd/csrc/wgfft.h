@@ -234,9 +234,15 @@ template <int LOGF> DEV uint32_t first_stage_elem(uint32_t tid, int logT, int g,
 
 // Out: void operator()(uint32_t col, uint32_t p, uint32_t pstride, cx2 (&v)[R])
 //      v[k] holds output position k*pstride + p of columns col (even, .x[0]/.y[0]) and col + 1
-template <int LOGR, int SIGN, bool FIRST, bool LAST, bool STAGED, class Out>
+struct NoMid { DEV void operator()(int) const {} };
+
+// Mid: called once per stage between the butterflies and the exchange (`mid(stage + 1)`; the driver calls
+// `mid(0)` before the first stage).  The passes use it to issue the global loads of their NEXT tile in
+// NS + 1 small groups spread over the transform instead of one burst that blocks the wave while the
+// memory pipeline accepts it.
+template <int LOGR, int SIGN, bool FIRST, bool LAST, bool STAGED, class Out, class Mid>
 DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const int logT, const int logF,
-                     const int logP, cx2 (&x)[NPAIR], Out& out)
+                     const int logP, cx2 (&x)[NPAIR], Out& out, Mid& mid, const int phase)
 {
   constexpr int R = 1 << LOGR;
   constexpr int G = PTS / R;          // butterflies per thread
@@ -272,6 +278,7 @@ DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const 
       apply_powers<R>(v[h], w1, w2, w4, w8);
     }
   }
+  mid(phase);
   // every read of the in-place exchange buffer (this or the previous tile) is done; a STAGED last stage
   // re-uses the buffer to reorder its outputs, so it needs the same guarantee (also when it is the only stage:
   // the previous tile's staged image may still be being read)
@@ -301,28 +308,35 @@ DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const 
 // May be called repeatedly (persistent workgroup): the barrier in front of the first LDS write
 // also separates it from the previous tile's last-stage LDS reads.
 // STAGED: `out` writes into the exchange buffer (the caller copies it out after a barrier).
-template <int LOGF, int SIGN, bool STAGED = false, class Out>
-DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx2 (&x)[NPAIR], Out& out)
+template <int LOGF, int SIGN, bool STAGED = false, class Out, class Mid>
+DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx2 (&x)[NPAIR], Out& out, Mid& mid)
 {
   typedef FftPlan<LOGF> P;
   // opaque copy: LDS addresses and twiddle indices are loop-invariant in a persistent workgroup and
   // would otherwise be hoisted out of the tile loop and spilled (hundreds of registers)
   asm volatile("" : "+v"(tid));
+  mid(0);
   if constexpr (P::NS <= 1) {
-    wgfft_stage<P::LOGR1, SIGN, true, true, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out);
+    wgfft_stage<P::LOGR1, SIGN, true, true, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out, mid, 1);
   } else {
-    wgfft_stage<4, SIGN, true, false, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out);
+    wgfft_stage<4, SIGN, true, false, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out, mid, 1);
     int logP = 4;
     uint32_t toff = ltw_off + (4u << (LOGF - 4));
 #pragma unroll
     for (int j = 1; j < P::NQ - (P::REM ? 0 : 1); j++) {
-      wgfft_stage<4, SIGN, false, false, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out);
+      wgfft_stage<4, SIGN, false, false, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out, mid, j + 1);
       logP += 4;
       toff += 4u << (LOGF - logP);
     }
-    if constexpr (P::REM != 0) wgfft_stage<P::REM, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out);
-    else wgfft_stage<4, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out);
+    if constexpr (P::REM != 0) wgfft_stage<P::REM, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out, mid, P::NS);
+    else wgfft_stage<4, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out, mid, P::NS);
   }
+}
+template <int LOGF, int SIGN, bool STAGED = false, class Out>
+DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx2 (&x)[NPAIR], Out& out)
+{
+  NoMid mid;
+  wgfft<LOGF, SIGN, STAGED>(lds, ltw_off, tid, logT, x, out, mid);
 }
 
 // Ablation only (DSPSR_AMD_DEBUG bit 4): hands the first-stage registers straight to `out` in the shape
