@@ -55,7 +55,8 @@ struct FbOut {
   int state;                                    // detected: coherence / stokes
   uint32_t ndim, chan0;
   uint32_t nbin;                                // kind 3
-  const uint32_t* pstart;                       // kind 3: [part][nbin + 1] offsets into piv
+  const uint32_t* pstart;                       // kind 3: per-part active-bin plan (fold_internal.h), nparts_plan parts
+  uint32_t nparts_plan;
   const Interval* piv;                          // kind 3: intervals (offset within the part, hits), time ordered per bin
 };
 
@@ -730,13 +731,15 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 #endif
     if constexpr (FOLD) {
       __syncthreads();                       // the tile's detected samples are staged
-      const uint32_t* __restrict__ ps = out.pstart + part * (out.nbin + 1);
-      // one (bin, channel) accumulator per work item; the samples of an interval are fetched from LDS eight at a
-      // time (independent loads) and then added one after the other, so the sum keeps the time order
-      for (uint32_t w = tid; w < ((g.dbg & 16) ? 0u : (out.nbin << logT3)); w += blockDim.x) {
-        const uint32_t b = w >> logT3, slo = w & (T3 - 1);
-        const uint32_t i0 = ps[b], i1 = ps[b + 1];
-        if (i0 == i1) continue;
+      // active phase bins of this part: entries {bin, first interval, count} (fold_internal.h); one (entry, channel)
+      // accumulator per work item; the samples of an interval are fetched from LDS eight at a time (independent
+      // loads) and then added one after the other, so the sum keeps the time order
+      const uint32_t e0 = out.pstart[part], e1 = out.pstart[part + 1];
+      const uint32_t* __restrict__ ent = out.pstart + out.nparts_plan + 1;
+      for (uint32_t w = tid; w < ((g.dbg & 16) ? 0u : ((e1 - e0) << logT3)); w += blockDim.x) {
+        const uint32_t slo = w & (T3 - 1);
+        const uint32_t* __restrict__ en = ent + 3 * (e0 + (w >> logT3));
+        const uint32_t b = en[0], i0 = en[1], i1 = i0 + en[2];
         float4* __restrict__ pp = (float4*)out.base + (uint64_t)(out.chan0 + tile * T3 + slo) * out.nbin + b;
         float4 acc = *pp;
         for (uint32_t i = i0; i < i1; i++) {
@@ -1465,7 +1468,7 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
   PlanSlot* slot = nullptr;
   int rc = fold_build_part_plan(fold, fb->g.nkeep, (uint32_t)npart, &d_start, &d_iv, &slot);
   if (rc != DSPSR_AMD_OK) return rc;
-  FbOut out = {3, fold->profile, 0, 0, 0, state, 4, 0, fold->nbin, d_start, d_iv};
+  FbOut out = {3, fold->profile, 0, 0, 0, state, 4, 0, fold->nbin, d_start, (uint32_t)npart, d_iv};
   rc = fb_run(fb, in, out, npart, in_chan_stride);
   const int rc2 = fold_part_plan_submitted(fold, slot);
   return rc != DSPSR_AMD_OK ? rc : rc2;

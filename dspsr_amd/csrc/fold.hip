@@ -397,11 +397,15 @@ extern "C" int dspsr_amd_fold_synch(dspsr_amd_fold* f, float* profile_host)   //
 int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, const uint32_t** d_start,
                          const Interval** d_iv, PlanSlot** slot)
 {
+  // Layout on the device (one uint32 array + the interval array):
+  //   start[0 .. npart]            : first active-bin entry of every part (start[npart] = total)
+  //   start[npart+1 + 3*e + 0..2]  : entry e = { bin, first interval, number of intervals }
+  // Only the phase bins that receive samples in a part are listed, so a workgroup finds its work with two
+  // dependent loads (entry, then interval + accumulator) instead of walking all nbin bins.
   dspsr_amd_ctx* ctx = f->ctx;
   if (f->current_hits && !f->binplan.empty()) f->binplan.back().hits = f->current_hits;   // FoldCUDA.cu:163-164
   f->current_hits = 0;
   const uint32_t nbin = f->nbin;
-  const size_t nb1 = (size_t)npart * (nbin + 1);
   // count the pieces: a run is cut at every multiple of nkeep
   size_t npiece = 0;
   for (const RunBin& r : f->binplan) {
@@ -412,16 +416,6 @@ int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, cons
                       (unsigned long long)(r.offset + r.hits - 1), npart);
     npiece += (size_t)(p1 - p0 + 1);
   }
-  PlanSlot& sl = f->slot[f->next_slot];
-  f->next_slot ^= 1;
-  if (sl.pending) {
-    hipError_t e = hipEventSynchronize(sl.done);
-    if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "fused fold: %s", hipGetErrorString(e));
-    sl.pending = false;
-  }
-  if (!slot_reserve(sl, nb1 + 1, npiece ? npiece : 1))
-    return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "fused fold: plan allocation failed");
-  for (size_t i = 0; i <= nb1; i++) sl.h_bin_start[i] = 0;
   auto for_each_piece = [&](auto&& fn) {
     for (const RunBin& r : f->binplan) {
       uint64_t off = r.offset, left = r.hits;
@@ -433,25 +427,46 @@ int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, cons
       }
     }
   };
-  for_each_piece([&](uint32_t part, uint32_t ibin, uint64_t, uint32_t) { sl.h_bin_start[(size_t)part * (nbin + 1) + ibin + 1]++; });
-  // prefix sums over the flattened (part, bin) buckets; entry part*(nbin+1) is the start of the part
-  uint32_t run = 0;
-  for (uint32_t part = 0; part < npart; part++) {
-    uint32_t* st = sl.h_bin_start + (size_t)part * (nbin + 1);
-    st[0] = run;
-    for (uint32_t b = 0; b < nbin; b++) { const uint32_t c = st[b + 1]; st[b + 1] = st[b] + c; }
-    run = st[nbin];
+  // bucket the pieces by (part, bin), time order kept inside a bucket
+  const size_t nb1 = (size_t)npart * nbin;
+  std::vector<uint32_t>& cnt = f->cursor;
+  cnt.assign(nb1 + 1, 0u);
+  for_each_piece([&](uint32_t part, uint32_t ibin, uint64_t, uint32_t) { cnt[(size_t)part * nbin + ibin + 1]++; });
+  size_t nentry = 0;
+  for (size_t i = 0; i < nb1; i++) { if (cnt[i + 1]) nentry++; cnt[i + 1] += cnt[i]; }     // cnt[i] = first interval of bucket i
+  PlanSlot& sl = f->slot[f->next_slot];
+  f->next_slot ^= 1;
+  if (sl.pending) {
+    hipError_t e = hipEventSynchronize(sl.done);
+    if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "fused fold: %s", hipGetErrorString(e));
+    sl.pending = false;
   }
-  f->cursor.resize(nb1);
-  for (size_t i = 0; i < nb1; i++) f->cursor[i] = sl.h_bin_start[i];
+  const size_t nwords = (size_t)npart + 1 + 3 * nentry;
+  if (!slot_reserve(sl, nwords, npiece ? npiece : 1))
+    return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "fused fold: plan allocation failed");
+  uint32_t* st = sl.h_bin_start;
+  uint32_t* ent = st + npart + 1;
+  size_t e = 0;
+  for (uint32_t part = 0; part < npart; part++) {
+    st[part] = (uint32_t)e;
+    for (uint32_t b = 0; b < nbin; b++) {
+      const size_t i = (size_t)part * nbin + b;
+      const uint32_t n = cnt[i + 1] - cnt[i];
+      if (!n) continue;
+      ent[3 * e] = b; ent[3 * e + 1] = cnt[i]; ent[3 * e + 2] = n;
+      e++;
+    }
+  }
+  st[npart] = (uint32_t)e;
+  std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
   for_each_piece([&](uint32_t part, uint32_t ibin, uint64_t within, uint32_t n) {
     Interval v; v.offset = within; v.hits = n; v.pad = 0;
-    sl.h_iv[f->cursor[(size_t)part * (nbin + 1) + ibin]++] = v;
+    sl.h_iv[fill[(size_t)part * nbin + ibin]++] = v;
   });
-  hipError_t e = hipMemcpyAsync(sl.d_bin_start, sl.h_bin_start, nb1 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && npiece)
-    e = hipMemcpyAsync(sl.d_iv, sl.h_iv, npiece * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);
-  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "fused fold: plan copy: %s", hipGetErrorString(e));
+  hipError_t er = hipMemcpyAsync(sl.d_bin_start, sl.h_bin_start, nwords * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+  if (er == hipSuccess && npiece)
+    er = hipMemcpyAsync(sl.d_iv, sl.h_iv, npiece * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);
+  if (er != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "fused fold: plan copy: %s", hipGetErrorString(er));
   f->binplan.clear();
   *d_start = sl.d_bin_start;
   *d_iv = sl.d_iv;
