@@ -319,7 +319,9 @@ __global__ __launch_bounds__(256) void k_raw_transpose(const FbGeom g, const FbI
 //   out: A[ka/T2][nb][ka%T2] = W_L^{nb*ka} * sum_na w[na*Rr+nb] W_M^{na*ka}
 // Persistent: each workgroup walks its items (tile fastest, then sequence, then part) and
 // prefetches the raw samples of the next item while transforming the current one.
-template <int LOGF, int RAWW>
+// LOGT >= 0: the number of columns per tile (2^LOGT) is a compile-time constant (the usual full-size tile,
+// LOGT = 14 - LOGF), so every LDS address and stride folds into immediates; LOGT = -1: taken from the geometry.
+template <int LOGF, int RAWW, int LOGT>
 __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in, cf* __restrict__ A,
                                                   const cf* __restrict__ tw, const uint64_t part0,
                                                   const uint32_t nparts, const uint32_t nseq, const uint32_t run)
@@ -327,9 +329,9 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
   typedef FftPlan<LOGF> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
-  const int logT = g.logT1, logT2 = g.logT2;
+  const int logT = LOGT >= 0 ? LOGT : g.logT1, logT2 = g.logT2;
   const uint32_t T = 1u << logT, T2 = 1u << logT2;
-  const int logL = g.logM + g.logR;
+  const int logL = LOGF + g.logR;          // g.logM == LOGF
   const uint64_t L = 1ull << logL;
   const uint32_t ntile = 1u << (g.logR - logT);
   const uint64_t total = (uint64_t)ntile * nseq * nparts;
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     const uint64_t rest = item / ntile;
     const uint32_t seq = (uint32_t)(rest % nseq);
     const bool pret = in.kind == 3;   // pre-transposed: [part][tile][na][T] pairs, contiguous per tile
-    const uint64_t t0 = pret ? ((rest / nseq) * ntile + tile) * ((uint64_t)T << g.logM)
+    const uint64_t t0 = pret ? ((rest / nseq) * ntile + tile) * ((uint64_t)T << LOGF)
                              : (part0 + rest / nseq) * in.part_step + tile * T;
     if (g.dbg & 2) {     // ablation only; hoisted so that the real path has no per-load branch
 #pragma unroll
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
 // ------------------------------------------------------------------------------------ P2
 // Rr-point forward FFTs along T2 adjacent rows ka of A (one contiguous block) -> spectrum rows
 // s' = kb, bin m = ka, stored as X[s'/T3][m][s'%T3].
-template <int LOGF>
+template <int LOGF, int LOGT>
 __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __restrict__ A, cf* __restrict__ X,
                                                   const cf* __restrict__ tw, const uint32_t nparts,
                                                   const uint32_t nseq, const uint32_t run)
@@ -420,9 +422,9 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
   typedef FftPlan<LOGF> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
-  const int logT = g.logT2, logT3 = g.logX3;     // X layout block factor
+  const int logT = LOGT >= 0 ? LOGT : g.logT2, logT3 = g.logX3;     // X layout block factor
   const uint32_t T2 = 1u << logT, T3 = 1u << logT3;
-  const uint64_t L = 1ull << (g.logM + g.logR);
+  const uint64_t L = 1ull << (g.logM + LOGF);
   const uint32_t ntile = 1u << (g.logM - logT);
   const uint64_t total = (uint64_t)ntile * nseq * nparts;
 
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
   // they are rearranged into split form when the tile is started
   auto fetch = [&](const uint64_t item, float4 (&y)[NPAIR]) {
     const uint32_t tile = (uint32_t)(item % ntile);
-    const cf* __restrict__ Ablk = A + (item / ntile) * L + (((uint64_t)tile << g.logR) << logT);
+    const cf* __restrict__ Ablk = A + (item / ntile) * L + (((uint64_t)tile << LOGF) << logT);     // g.logR == LOGF
     if (g.dbg & 2) {     // ablation only; hoisted so that the real path has no per-load branch (and vmcnt(0))
 #pragma unroll
       for (int i = 0; i < NPAIR; i++) y[i] = make_float4(tid, i, 1.f, 1.f);
@@ -524,7 +526,7 @@ DEV void detect4(const cf p, const cf q, const int state, float (&r)[4])
 // order and launches are stream ordered, so every (chan, bin) sum has the association order of the CPU loop
 // Fold.C:844-852, exactly as the stand-alone fold kernel (fold.hip) -- bit-identical results, without the
 // 16 B/sample round trip of the detected time series through HBM.
-template <int LOGF, bool FOLD>
+template <int LOGF, bool FOLD, int LOGT>
 __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __restrict__ X,
                                                   const cf* __restrict__ kernel, const FbOut out,
                                                   const cf* __restrict__ tw, const uint64_t part0,
@@ -533,16 +535,16 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   typedef FftPlan<LOGF> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
-  const int logT3 = g.logT3;
+  const int logT3 = LOGT >= 1 ? LOGT - 1 : g.logT3;
   const int logT = logT3 + 1;
-  const uint32_t T = 1u << logT, T3 = 1u << logT3, M = 1u << g.logM, Rr = 1u << g.logR;
+  const uint32_t T = 1u << logT, T3 = 1u << logT3, M = 1u << LOGF, Rr = 1u << g.logR;
   const uint64_t L = (uint64_t)M << g.logR;
   const uint32_t nseq = g.real_input ? 1 : g.npol;
   const int logX3 = g.logX3;                    // X layout: element (row, m) at ((row >> logX3)*M + m) << logX3 | row % X3
   const uint32_t X3 = 1u << logX3;
   const uint32_t ntile = g.C >> logT3;
   auto xi = [&](const uint32_t row, const uint32_t m) -> uint64_t {
-    return ((((uint64_t)(row >> logX3) << g.logM) + m) << logX3) | (row & (X3 - 1));
+    return ((((uint64_t)(row >> logX3) << LOGF) + m) << logX3) | (row & (X3 - 1));
   };
   const uint64_t total = (uint64_t)ntile * nparts;
   struct Abk { cf a, b; };   // the chirp is fetched at the start of the item (keeps the prefetch at 64 registers)
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 #pragma unroll
       for (int g2 = 0; g2 < P::G1; g2 += 2) {
         const uint32_t eb = P::G1 * tid + g2;
-        const cf* __restrict__ pk = kernel + ((uint64_t)(ktile * T3 + ((eb & (T - 1)) >> 1)) << g.logM) + (eb >> logT);
+        const cf* __restrict__ pk = kernel + ((uint64_t)(ktile * T3 + ((eb & (T - 1)) >> 1)) << LOGF) + (eb >> logT);
 #pragma unroll
         for (int i = 0; i < P::R1; i++) kk[(g2 / 2) * P::R1 + i] = pk[i * MS];
       }
@@ -998,23 +1000,43 @@ template <int... I> struct iseq {};
 template <int N, int... I> struct mkseq : mkseq<N - 1, N - 1, I...> {};
 template <int... I> struct mkseq<0, I...> { typedef iseq<I...> type; };
 
+// full-size tiles (2^14 points) have 2^(14 - LOGF) columns: instantiated with that as a compile-time constant
+constexpr int full_logt(int logf) { return 14 - logf >= 1 ? 14 - logf : -1; }
 #ifdef FB_ONLY_HEADLINE   // experiment builds: only the kernels of the headline geometry (M = 4096, Rr = 2048, 8-bit)
-template <int... I> static k1_t pick1(int logf, int raww, iseq<I...>) { return logf == 12 && raww == 1 ? k_fwd_cols<12, 1> : nullptr; }
-template <int... I> static k2_t pick2(int logf, iseq<I...>) { return logf == 11 ? k_fwd_rows<11> : nullptr; }
-template <int... I> static k3_t pick3(int logf, iseq<I...>) { return logf == 12 ? k_inv_chan<12, false> : nullptr; }
-template <int... I> static k3_t pick3f(int logf, iseq<I...>) { return logf == 12 ? k_inv_chan<12, true> : nullptr; }
+template <int... I> static k1_t pick1(int logf, int raww, bool full, iseq<I...>)
+{ return logf == 12 && raww == 1 ? (full ? k_fwd_cols<12, 1, 2> : k_fwd_cols<12, 1, -1>) : nullptr; }
+template <int... I> static k2_t pick2(int logf, bool full, iseq<I...>) { return logf == 11 ? (full ? k_fwd_rows<11, 3> : k_fwd_rows<11, -1>) : nullptr; }
+template <int... I> static k3_t pick3(int logf, bool full, iseq<I...>) { return logf == 12 ? (full ? k_inv_chan<12, false, 2> : k_inv_chan<12, false, -1>) : nullptr; }
+template <int... I> static k3_t pick3f(int logf, bool full, iseq<I...>) { return logf == 12 ? (full ? k_inv_chan<12, true, 2> : k_inv_chan<12, true, -1>) : nullptr; }
 template <int... I> static k3a_t pick3a(int, iseq<I...>) { return nullptr; }
 template <int... I> static k3b_t pick3b(int, iseq<I...>) { return nullptr; }
 #else
-template <int... I> static k1_t pick1(int logf, int raww, iseq<I...>)
+template <int... I> static k1_t pick1(int logf, int raww, bool full, iseq<I...>)
 {
-  static const k1_t t4[] = {k_fwd_cols<I, 4>...};
-  static const k1_t t1[] = {k_fwd_cols<I, 1>...};
-  return raww == 1 ? t1[logf] : t4[logf];
+  static const k1_t t4[] = {k_fwd_cols<I, 4, -1>...};
+  static const k1_t t1[] = {k_fwd_cols<I, 1, -1>...};
+  static const k1_t f4[] = {k_fwd_cols<I, 4, full_logt(I)>...};
+  static const k1_t f1[] = {k_fwd_cols<I, 1, full_logt(I)>...};
+  return full ? (raww == 1 ? f1[logf] : f4[logf]) : (raww == 1 ? t1[logf] : t4[logf]);
 }
-template <int... I> static k2_t pick2(int logf, iseq<I...>) { static const k2_t t[] = {k_fwd_rows<I>...}; return t[logf]; }
-template <int... I> static k3_t pick3(int logf, iseq<I...>) { static const k3_t t[] = {k_inv_chan<I, false>...}; return t[logf]; }
-template <int... I> static k3_t pick3f(int logf, iseq<I...>) { static const k3_t t[] = {k_inv_chan<I, true>...}; return t[logf]; }
+template <int... I> static k2_t pick2(int logf, bool full, iseq<I...>)
+{
+  static const k2_t t[] = {k_fwd_rows<I, -1>...};
+  static const k2_t f[] = {k_fwd_rows<I, full_logt(I)>...};
+  return full ? f[logf] : t[logf];
+}
+template <int... I> static k3_t pick3(int logf, bool full, iseq<I...>)
+{
+  static const k3_t t[] = {k_inv_chan<I, false, -1>...};
+  static const k3_t f[] = {k_inv_chan<I, false, full_logt(I)>...};
+  return full ? f[logf] : t[logf];
+}
+template <int... I> static k3_t pick3f(int logf, bool full, iseq<I...>)
+{
+  static const k3_t t[] = {k_inv_chan<I, true, -1>...};
+  static const k3_t f[] = {k_inv_chan<I, true, full_logt(I)>...};
+  return full ? f[logf] : t[logf];
+}
 template <int... I> static k3a_t pick3a(int logf, iseq<I...>) { static const k3a_t t[] = {k_inv_a<I>...}; return t[logf]; }
 template <int... I> static k3b_t pick3b(int logf, iseq<I...>) { static const k3b_t t[] = {k_inv_b<I>...}; return t[logf]; }
 #endif
@@ -1288,9 +1310,12 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
       return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of the 8-bit regroup buffer failed");
   }
   const int raww = (pret || (fast8 && in.kind == 1)) ? 1 : 4;
-  k1_t k1 = pick1(g.logM, raww, seq_t());
-  k2_t k2 = pick2(g.logR, seq_t());
-  k3_t k3 = g.four_pass ? nullptr : (out.kind == 3 ? pick3f(g.logM, seq_t()) : pick3(g.logM, seq_t()));
+  const bool notfixed = getenv("DSPSR_AMD_RUNTIME_LOGT") != nullptr;    // experiments: force the generic kernels
+  const bool full1 = !notfixed && g.logT1 == full_logt(g.logM), full2 = !notfixed && g.logT2 == full_logt(g.logR),
+             full3 = !notfixed && !g.four_pass && g.logT3 + 1 == full_logt(g.logM);
+  k1_t k1 = pick1(g.logM, raww, full1, seq_t());
+  k2_t k2 = pick2(g.logR, full2, seq_t());
+  k3_t k3 = g.four_pass ? nullptr : (out.kind == 3 ? pick3f(g.logM, full3, seq_t()) : pick3(g.logM, full3, seq_t()));
   k3a_t k3a = g.four_pass ? pick3a(g.logMa, seq_t()) : nullptr;
   k3b_t k3b = g.four_pass ? pick3b(g.logMb, seq_t()) : nullptr;
   if (!k1 || !k2 || (g.four_pass ? (!k3a || !k3b) : !k3))
