@@ -60,6 +60,17 @@ struct FbOut {
   const Interval* piv;                          // kind 3: intervals (offset within the part, hits), time ordered per bin
 };
 
+#ifdef FB_STAMPS   // diagnostic build only (-DFB_STAMPS=1|2|3: pass to instrument): where a tile spends its cycles
+                   // (s_memtime per phase, lane 0 of wave 0 of every workgroup)
+__device__ unsigned long long g_stamps[1024][8];
+#define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int dspsr_amd_debug_stamps(unsigned long long* out_host, int zero)
+{
+  if (zero) { static unsigned long long z[1024][8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#endif
+
 DEV float cvt8(int v, float scale) { return ((float)v + 0.5f) * scale; }
 
 // streaming accesses: scratch and output data are written once and read once by another pass, so the
@@ -208,26 +219,49 @@ DEV cf twiddle_big(const uint64_t j, const int logL, const cf* __restrict__ tw, 
   return cmul(tw[j >> sh], tw_lo[j & ((1u << sh) - 1)]);
 }
 
+// NT twiddles exp(-2*pi*i*j[q]/2^logL) at once: all table loads are issued back to back (one memory round trip)
+// and only then combined -- evaluating them one by one costs a dependent L1/L2 round trip each
+template <int NT> DEV void twiddles_big(cf (&t)[NT], const uint64_t (&j)[NT], const int logL, const cf* __restrict__ tw,
+                                        const cf* __restrict__ tw_lo)
+{
+  if (logL <= LOG_TWN) {                       // uniform
+#pragma unroll
+    for (int q = 0; q < NT; q++) t[q] = tw[j[q] << (LOG_TWN - logL)];
+  } else {
+    const int sh = logL - LOG_TWN;
+    cf lo[NT];
+#pragma unroll
+    for (int q = 0; q < NT; q++) { t[q] = tw[j[q] >> sh]; lo[q] = tw_lo[j[q] & ((1u << sh) - 1)]; }
+#pragma unroll
+    for (int q = 0; q < NT; q++) t[q] = cmul(t[q], lo[q]);
+  }
+}
+
 // v[k] *= W_L^{nb*(k*pstride + p)} for the column pair (nb, nb+1), k < R : base and the powers 1,2,4,8 of
-// the step from exact phases (sincospif of an exactly representable argument), the rest by the ladder
+// the step from the (coarse x fine) tables, the rest by the ladder
 template <int R> DEV void apply_pass_twiddle(cx2 (&v)[R], const uint32_t nb, const uint32_t p, const uint32_t pstride,
                                              const int logL, const cf* __restrict__ tw, const cf* __restrict__ tw_lo)
 {
-#define twiddle_big(j, l) twiddle_big((j), (l), tw, tw_lo)
   const uint64_t Lm = (1ull << logL) - 1;
   const uint64_t a0 = ((uint64_t)nb * p) & Lm, d0 = ((uint64_t)nb * pstride) & Lm;
   const uint64_t a1 = (a0 + p) & Lm, d1 = (d0 + pstride) & Lm;             // column nb + 1
-  const cx2 wa = make_cx2(twiddle_big(a0, logL), twiddle_big(a1, logL));
+  constexpr int NP = R >= 16 ? 4 : R >= 8 ? 3 : R >= 4 ? 2 : R >= 2 ? 1 : 0;   // powers 1, 2, 4, 8 of the step
+  uint64_t j[2 + 2 * (NP ? NP : 1)];
+  cf t[2 + 2 * (NP ? NP : 1)];
+  j[0] = a0; j[1] = a1;
+#pragma unroll
+  for (int q = 0; q < (NP ? NP : 1); q++) { j[2 + 2 * q] = (d0 << q) & Lm; j[3 + 2 * q] = (d1 << q) & Lm; }
+  twiddles_big(t, j, logL, tw, tw_lo);
+  const cx2 wa = make_cx2(t[0], t[1]);
   if constexpr (R > 1) {
-    const cx2 w1 = make_cx2(twiddle_big(d0, logL), twiddle_big(d1, logL));
-    const cx2 w2 = R >= 4 ? make_cx2(twiddle_big((2 * d0) & Lm, logL), twiddle_big((2 * d1) & Lm, logL)) : w1;
-    const cx2 w4 = R >= 8 ? make_cx2(twiddle_big((4 * d0) & Lm, logL), twiddle_big((4 * d1) & Lm, logL)) : w1;
-    const cx2 w8 = R >= 16 ? make_cx2(twiddle_big((8 * d0) & Lm, logL), twiddle_big((8 * d1) & Lm, logL)) : w1;
+    const cx2 w1 = make_cx2(t[2], t[3]);
+    const cx2 w2 = NP >= 2 ? make_cx2(t[2 + 2 * (NP >= 2 ? 1 : 0)], t[3 + 2 * (NP >= 2 ? 1 : 0)]) : w1;
+    const cx2 w4 = NP >= 3 ? make_cx2(t[2 + 2 * (NP >= 3 ? 2 : 0)], t[3 + 2 * (NP >= 3 ? 2 : 0)]) : w1;
+    const cx2 w8 = NP >= 4 ? make_cx2(t[2 + 2 * (NP >= 4 ? 3 : 0)], t[3 + 2 * (NP >= 4 ? 3 : 0)]) : w1;
     apply_powers2<R>(v, w1, w2, w4, w8);
   }
 #pragma unroll
   for (int k = 0; k < R; k++) v[k] = cmul(v[k], wa);
-#undef twiddle_big
 }
 
 // v[k] *= conj(W_L^{nb*(k*pstride + p)}) for BOTH columns of the pair (the two polarisations of one column
@@ -237,15 +271,23 @@ template <int R> DEV void apply_pass_twiddle_inv(cx2 (&v)[R], const uint32_t nb,
 {
   const uint64_t Lm = (1ull << logL) - 1;
   const uint64_t a0 = ((uint64_t)nb * p) & Lm, d0 = ((uint64_t)nb * pstride) & Lm;
-  auto W = [&](const uint64_t j) { cf w = twiddle_big(j & Lm, logL, tw, tw_lo); w.y = -w.y; return w; };
-  const cf wa = W(a0);
+  constexpr int NP = R >= 16 ? 4 : R >= 8 ? 3 : R >= 4 ? 2 : R >= 2 ? 1 : 0;
+  uint64_t j[1 + (NP ? NP : 1)];
+  cf t[1 + (NP ? NP : 1)];
+  j[0] = a0;
+#pragma unroll
+  for (int q = 0; q < (NP ? NP : 1); q++) j[1 + q] = (d0 << q) & Lm;
+  twiddles_big(t, j, logL, tw, tw_lo);
+#pragma unroll
+  for (int q = 0; q < 1 + (NP ? NP : 1); q++) t[q].y = -t[q].y;          // conjugate: inverse transform
   if constexpr (R > 1) {
-    const cf w1 = W(d0);
-    const cf w2 = R >= 4 ? W(2 * d0) : w1, w4 = R >= 8 ? W(4 * d0) : w1, w8 = R >= 16 ? W(8 * d0) : w1;
+    const cf w1 = t[1];
+    const cf w2 = NP >= 2 ? t[1 + (NP >= 2 ? 1 : 0)] : w1, w4 = NP >= 3 ? t[1 + (NP >= 3 ? 2 : 0)] : w1,
+             w8 = NP >= 4 ? t[1 + (NP >= 4 ? 3 : 0)] : w1;
     apply_powers<R>(v, w1, w2, w4, w8);
   }
 #pragma unroll
-  for (int k = 0; k < R; k++) v[k] = cmuls(v[k], wa);
+  for (int k = 0; k < R; k++) v[k] = cmuls(v[k], t[0]);
 }
 
 // ------------------------------------------------------------------------------------ P0
@@ -348,13 +390,17 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
       for (int i = 0; i < NPAIR; i++) { RawW<RAWW> z; z.w[0] = tid + i; raw[i] = z; }
       return;
     }
+    // element i of a thread's first-stage butterfly is row na = nab + i*MS of one column pair: sample index =
+    // base + i*step with a wave-uniform step (no per-element index arithmetic or branches between the loads)
+    constexpr uint32_t MS = 1u << (LOGF - P::LOGR1);
+    const uint64_t step = pret ? ((uint64_t)MS << logT) : ((uint64_t)MS << g.logR);
 #pragma unroll
-    for (int g2 = 0; g2 < P::G1; g2 += 2)
+    for (int g2 = 0; g2 < P::G1; g2 += 2) {
+      const uint32_t eb = P::G1 * tid + g2;
+      const uint64_t tb = t0 + (pret ? (uint64_t)eb : ((((uint64_t)(eb >> logT)) << g.logR) + (eb & (T - 1))));
 #pragma unroll
-      for (int i = 0; i < P::R1; i++) {
-        const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
-        raw[(g2 / 2) * P::R1 + i] = fetch_pair<RAWW>(g, in, seq, pret ? t0 + e : t0 + (((uint64_t)(e >> logT)) << g.logR) + (e & (T - 1)));
-      }
+      for (int i = 0; i < P::R1; i++) raw[(g2 / 2) * P::R1 + i] = fetch_pair<RAWW>(g, in, seq, tb + i * step);
+    }
   };
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
@@ -364,23 +410,40 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
   if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
   RawW<RAWW> raw[PTS / 2];
   fetch(item, raw);
+#if defined(FB_STAMPS) && FB_STAMPS == 1
+  unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, acc_s[6] = {0, 0, 0, 0, 0, 0};
+  STAMP(ts5);
+#endif
   for (;;) {
     asm volatile("" : "+v"(tid));   // per-tile index math stays inside the loop (see wgfft)
     cx2 x[NPAIR];
+#if defined(FB_STAMPS) && FB_STAMPS == 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(ts0);
+#endif
 #pragma unroll
     for (int h = 0; h < NPAIR; h++) {
       cf a, b;
       decode_pair<RAWW>(g, in, raw[h], a, b);
       x[h] = make_cx2(a, b);
     }
+#if defined(FB_STAMPS) && FB_STAMPS == 1
+    STAMP(ts1);
+#endif
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
     if (more) fetch(next, raw);
+#if defined(FB_STAMPS) && FB_STAMPS == 1
+    STAMP(ts2);
+#endif
 
     const uint32_t tile = (uint32_t)(item % ntile);
     const uint64_t rest = item / ntile;
     cf* __restrict__ Aseq = A + ((rest / nseq) * nseq + rest % nseq) * L;
     // last-stage outputs go to LDS in A-layout order [ka/T2][col][ka%T2]; after a barrier the tile is
-    // written out as whole runs of T*T2 elements with 16-byte-per-lane stores
+    // written out as whole runs of T*T2 elements with 16-byte-per-lane stores.  The image is XOR-swizzled
+    // (bit 3 ^= bit 4; pairs of elements stay together) so that the 8-byte scatter of a wave spreads over all
+    // banks (17 % of this pass's LDS cycles were bank conflicts, profiles/r01d_lds_conflicts.txt)
+    const uint32_t swz = (PTS * blockDim.x) >= 256 ? 1u : 0u;
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
       const uint32_t nb = tile * T + col;
@@ -389,26 +452,38 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
       for (int k = 0; k < R; k++) {
         const uint32_t ka = k * pstride + p;
         const uint32_t l = ((((ka >> logT2) << logT) + col) << logT2) | (ka & (T2 - 1));
-        lds[lds_pad(l)] = cx2_lo(v[k]);
-        lds[lds_pad(l + T2)] = cx2_hi(v[k]);
+        lds[lds_pad(l ^ (((l >> 4) & swz) << 3))] = cx2_lo(v[k]);
+        lds[lds_pad((l + T2) ^ ((((l + T2) >> 4) & swz) << 3))] = cx2_hi(v[k]);
       }
     };
     if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
     else wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
     __syncthreads();
+#if defined(FB_STAMPS) && FB_STAMPS == 1
+    STAMP(ts3);
+#endif
     if (!(g.dbg & 1)) {
       const uint32_t nthr = blockDim.x;
 #pragma unroll 4
       for (int jj = 0; jj < PTS / 2; jj++) {
         const uint32_t l = 2 * (tid + jj * nthr);                  // element index inside the staged tile
         const uint32_t blkA = l >> (logT + logT2), within = l & ((1u << (logT + logT2)) - 1);
-        const float4 pr = *(const float4*)&lds[lds_pad(l)];
+        const float4 pr = *(const float4*)&lds[lds_pad(l ^ (((l >> 4) & swz) << 3))];
         st_stream((float4*)&Aseq[((((uint64_t)blkA << g.logR) + tile * T) << logT2) + within], pr);
       }
     }
+#if defined(FB_STAMPS) && FB_STAMPS == 1
+    STAMP(ts4);
+    acc_s[0] += ts0 - ts5; acc_s[1] += ts1 - ts0; acc_s[2] += ts2 - ts1; acc_s[3] += ts3 - ts2; acc_s[4] += ts4 - ts3; acc_s[5] += 1;
+    ts5 = ts4;
+#endif
     if (!more) break;
     item = next;
   }
+#if defined(FB_STAMPS) && FB_STAMPS == 1
+  if (threadIdx.x == 0 && blockIdx.x < 1024)
+    for (int q = 0; q < 6; q++) atomicAdd(&g_stamps[blockIdx.x][q], acc_s[q]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------ P2
@@ -452,56 +527,75 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
   if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
   float4 y[NPAIR];
   fetch(item, y);
+#if defined(FB_STAMPS) && FB_STAMPS == 2
+  unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, acc_s[6] = {0, 0, 0, 0, 0, 0};
+  STAMP(ts5);
+#endif
   for (;;) {
     asm volatile("" : "+v"(tid));   // per-tile index math stays inside the loop (see wgfft)
     cx2 x[NPAIR];
+#if defined(FB_STAMPS) && FB_STAMPS == 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(ts0);
+#endif
 #pragma unroll
     for (int i = 0; i < NPAIR; i++) x[i] = make_cx2(make_float2(y[i].x, y[i].y), make_float2(y[i].z, y[i].w));
+#if defined(FB_STAMPS) && FB_STAMPS == 2
+    STAMP(ts1);
+#endif
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
     if (more) fetch(next, y);
+#if defined(FB_STAMPS) && FB_STAMPS == 2
+    STAMP(ts2);
+#endif
 
     const uint32_t tile = (uint32_t)(item % ntile);
     cf* __restrict__ Xseq = X + (item / ntile) * L;
     // last-stage outputs go to LDS in X-layout order [s'/T3][klo][s'%T3]; after a barrier the tile is
-    // written out as whole runs of T2*T3 elements with 16-byte-per-lane stores
+    // written out as whole runs of T2*T3 elements with 16-byte-per-lane stores.  XOR swizzle of the image
+    // (bits 1,2 ^= bits 4,5) against bank conflicts of the 8-byte scatter (42 % of this pass's LDS cycles)
+    const uint32_t swz = (PTS * blockDim.x) >= 256 ? 3u : 0u;
     auto store = [&](const uint32_t klo, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
 #pragma unroll
       for (int k = 0; k < R; k++) {
         const uint32_t srow = k * pstride + p;
         const uint32_t l = ((((srow >> logT3) << logT) + klo) << logT3) | (srow & (T3 - 1));
-        lds[lds_pad(l)] = cx2_lo(v[k]);
-        lds[lds_pad(l + T3)] = cx2_hi(v[k]);
+        lds[lds_pad(l ^ (((l >> 4) & swz) << 1))] = cx2_lo(v[k]);
+        lds[lds_pad((l + T3) ^ ((((l + T3) >> 4) & swz) << 1))] = cx2_hi(v[k]);
       }
     };
     if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
     else wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
     __syncthreads();
+#if defined(FB_STAMPS) && FB_STAMPS == 2
+    STAMP(ts3);
+#endif
     if (!(g.dbg & 1)) {
       const uint32_t nthr = blockDim.x;
 #pragma unroll 4
       for (int jj = 0; jj < PTS / 2; jj++) {
         const uint32_t l = 2 * (tid + jj * nthr);
         const uint32_t blkX = l >> (logT + logT3), within = l & ((1u << (logT + logT3)) - 1);
-        const float4 pr = *(const float4*)&lds[lds_pad(l)];
+        const float4 pr = *(const float4*)&lds[lds_pad(l ^ (((l >> 4) & swz) << 1))];
         st_stream((float4*)&Xseq[((((uint64_t)blkX << g.logM) + tile * T2) << logT3) + within], pr);
       }
     }
+#if defined(FB_STAMPS) && FB_STAMPS == 2
+    STAMP(ts4);
+    acc_s[0] += ts0 - ts5; acc_s[1] += ts1 - ts0; acc_s[2] += ts2 - ts1; acc_s[3] += ts3 - ts2; acc_s[4] += ts4 - ts3; acc_s[5] += 1;
+    ts5 = ts4;
+#endif
     if (!more) break;
     item = next;
   }
+#if defined(FB_STAMPS) && FB_STAMPS == 2
+  if (threadIdx.x == 0 && blockIdx.x < 1024)
+    for (int q = 0; q < 6; q++) atomicAdd(&g_stamps[blockIdx.x][q], acc_s[q]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------ P3
-#ifdef FB_STAMPS   // diagnostic build only: where a pass-3 tile spends its cycles (s_memtime per phase, lane 0 of wave 0)
-__device__ unsigned long long g_stamps[1024][8];
-#define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-extern "C" int dspsr_amd_debug_stamps(unsigned long long* out_host, int zero)
-{
-  if (zero) { static unsigned long long z[1024][8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
-  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
-}
-#endif
 DEV void detect4(const cf p, const cf q, const int state, float (&r)[4])
 {
   // cross_detect.ic:23-43 / stokes_detect.ic:21-44
@@ -627,14 +721,14 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   if (!next_item(j, item)) return;
   Abk raw[PTS / 2];
   fetch(item, raw, -1);
-#ifdef FB_STAMPS
+#if defined(FB_STAMPS) && FB_STAMPS == 3
   unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, acc_s[6] = {0, 0, 0, 0, 0, 0};
   STAMP(ts5);
 #endif
   for (;;) {
     asm volatile("" : "+v"(tid));   // per-tile index math stays inside the loop (see wgfft)
     cx2 x[NPAIR];
-#ifdef FB_STAMPS
+#if defined(FB_STAMPS) && FB_STAMPS == 3
     // wait for the prefetched tile explicitly so that the wait is timed separately
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(ts0);
@@ -660,7 +754,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
           x[(g2 / 2) * P::R1 + i] = cmuls(make_cx2(x0, x1), k);          // Response::operate, Response.C:429-441
         }
     }
-#ifdef FB_STAMPS
+#if defined(FB_STAMPS) && FB_STAMPS == 3
     STAMP(ts1);
 #endif
     const bool more = next_item(++j, next);
@@ -668,7 +762,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     // was measured and does not pay -- the wave time goes to ISSUING the 8-byte loads (about 6k cycles per tile,
     // profiles/r01d_p3_phase_stamps.txt), wherever they are placed.
     if (more) fetch(next, raw, -1);
-#ifdef FB_STAMPS
+#if defined(FB_STAMPS) && FB_STAMPS == 3
     STAMP(ts2);
 #endif
 
@@ -728,7 +822,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     };
     if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
     else wgfft<LOGF, +1, FOLD>(lds, ltw_off, tid, logT, x, store);
-#ifdef FB_STAMPS
+#if defined(FB_STAMPS) && FB_STAMPS == 3
     STAMP(ts3);
 #endif
     if constexpr (FOLD) {
@@ -764,7 +858,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       }
       // the barrier in front of the next tile's first exchange write also ends this read phase
     }
-#ifdef FB_STAMPS
+#if defined(FB_STAMPS) && FB_STAMPS == 3
     STAMP(ts4);
     acc_s[0] += ts0 - ts5; acc_s[1] += ts1 - ts0; acc_s[2] += ts2 - ts1; acc_s[3] += ts3 - ts2; acc_s[4] += ts4 - ts3; acc_s[5] += 1;
     ts5 = ts4;
@@ -772,7 +866,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     if (!more) break;
     item = next;
   }
-#ifdef FB_STAMPS
+#if defined(FB_STAMPS) && FB_STAMPS == 3
   if (threadIdx.x == 0 && blockIdx.x < 1024)
     for (int q = 0; q < 6; q++) atomicAdd(&g_stamps[blockIdx.x][q], acc_s[q]);
 #endif

@@ -25,7 +25,9 @@ buf = np.zeros((1024, 8), np.uint64)
 lib.dspsr_amd_debug_stamps(buf.ctypes.data_as(C.c_void_p), 0)
 b = buf[buf[:, 5] > 0].astype(np.float64)
 tiles = b[:, 5]
-names = ["wait prefetched tile", "chirp load+convert", "issue next prefetch", "transform+staging", "fold phase"]
+names = {"3": ["wait prefetched tile", "chirp load+convert", "issue next prefetch", "transform+staging", "fold phase"],
+         "1": ["wait prefetched tile", "decode", "issue next prefetch", "transform+twiddle+staging", "copy-out stores"],
+         "2": ["wait prefetched tile", "regroup", "issue next prefetch", "transform+staging", "copy-out stores"]}[os.environ.get("PASS", "3")]
 tot = b[:, :5].sum(axis=1) / tiles
 print("workgroups %d, tiles per workgroup %.1f, cycles per tile %.0f (100 MHz ticks? no: shader cycles)" % (len(b), tiles.mean(), tot.mean()))
 for q, nm in enumerate(names):
