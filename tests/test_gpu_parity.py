@@ -251,6 +251,67 @@ def test_copy_data_fpt(gpu):
         assert torch.equal(dst[:, :, :n], src[:, :, off:off + n]) and float(dst[:, :, n:].abs().max()) == 0.0
 
 
+def test_edge_cases_empty_and_ragged(oracle, gpu):
+    """npart = 0 is a no-op, an empty fold plan leaves the profile untouched, a ragged last block (fewer parts
+    than the block size) folds like the oracle, and the fused fold refuses the four-pass geometry loudly."""
+    dspsr_amd, ctx = gpu
+    o = oracle
+    C, M, nfilt = 8, 64, (5, 7)
+    kernel = np.ones(C * M, np.complex64)
+    eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, 2, True, kernel, max_parts=2)
+    out = torch.full((C, 2, 8), 7.0, dtype=torch.float32, device="cuda")
+    raw = torch.zeros(4096, dtype=torch.int8, device="cuda")
+    eng.perform_raw(raw, dspsr_amd.RAW_GENERIC, 1.0, out, 0)                       # zero parts
+    eng.finish()
+    assert float(out.min()) == 7.0 and float(out.max()) == 7.0
+    fold = dspsr_amd.FoldEngine(ctx)
+    fold.set_shape(C, 1, 4, 16)
+    fold.set_nbin(16)
+    fold.set_ndat(0, 0)
+    fold.fold(torch.zeros((C, 1, 16), device="cuda"))                             # empty plan
+    eng.perform_fold(fold, 0, dspsr_amd.COHERENCE, raw=raw, scale=1.0)             # zero parts, empty plan
+    assert float(np.abs(fold.synch()).max()) == 0.0
+    eng.close()
+    # fused fold on a four-pass geometry: EINVAL, the caller falls back to detect + fold
+    big = dspsr_amd.FilterbankEngine(ctx).setup(2, 16384, 100, 100, 1, 2, True, None, max_parts=1)
+    f2 = dspsr_amd.FoldEngine(ctx)
+    f2.set_shape(2, 1, 4, 16)
+    f2.set_nbin(16)
+    with pytest.raises(dspsr_amd.DspsrAmdError):
+        big.perform_fold(f2, 1, dspsr_amd.COHERENCE, raw=torch.zeros(1 << 17, dtype=torch.int8, device="cuda"), scale=1.0)
+    big.close()
+    f2.close()
+    fold.close()
+    # ragged block through the pipeline driver: 3 parts, then 1 part
+    from dspsr_amd import pipeline, synth
+    freq, bw, tsamp, dm, period, nchan, nbin = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004, 16, 64
+    cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=4,
+                          parts_per_block=3, max_parts=2)
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
+    lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    step = lt.nsamp_step
+    rawh = synth.voltages(4 * step + lt.nsamp_overlap, freq, bw, tsamp, dm, period)
+    d_raw = torch.from_numpy(rawh).cuda()
+    lt.process_block(d_raw[: 2 * (3 * step + lt.nsamp_overlap)], npart=3)
+    lt.process_block(d_raw[2 * 3 * step:], npart=1)
+    lt.finish_subint()
+    lt.synchronize()
+    got = lt.subints[0]["profile_dev"].cpu().numpy().reshape(nchan, 1, nbin, 4)
+    obs = o.Observation(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, dispersion_measure=dm)
+    resp = o.Dedispersion().match(obs, nchan)
+    plan = o.filterbank_plan(obs, nchan, resp)
+    fb = o.filterbank(o.unpack_8bit(rawh, obs), plan, lt.response.kernel, dtype=np.float64)
+    det = o.detect_layout(o.detect_products(fb, "Coherence"), 4)
+    fobs = o.filterbank_output_observation(obs, plan)
+    ps = o.PhaseSeries(nchan, 1, 4, nbin, data=np.zeros((nchan, 1, nbin, 4), np.float64))
+    fcfg = o.FoldConfig(nbin=nbin, folding_period=period)
+    o.fold(det, fobs, fcfg, ps, idat_start=0, ndat_fold=3 * plan.nkeep)
+    o.fold(det, fobs, fcfg, ps, idat_start=3 * plan.nkeep, ndat_fold=plan.nkeep)
+    assert np.array_equal(lt.subints[0]["hits"], ps.hits)
+    assert np.abs(got - ps.data).max() <= 1e-5 * np.abs(ps.data).max()
+    lt.close()
+
+
 def test_filterbank_errors(gpu):
     dspsr_amd, ctx = gpu
     with pytest.raises(dspsr_amd.DspsrAmdError):
