@@ -31,7 +31,7 @@ class DedispersionConfig(C.Structure):
     _fields_ = [("centre_frequency", C.c_double), ("bandwidth", C.c_double), ("dispersion_measure", C.c_double),
                 ("input_nchan", C.c_uint32), ("nchan", C.c_uint32), ("ndim", C.c_uint32),
                 ("dual_sideband", C.c_int32), ("dc_centred", C.c_uint32), ("swap", C.c_uint32),
-                ("freq_res", C.c_uint32), ("ndat_max", C.c_uint32)]
+                ("freq_res", C.c_uint32), ("ndat_max", C.c_uint32), ("fractional_delay", C.c_uint32)]
 
 
 class DedispersionInfo(C.Structure):

@@ -153,7 +153,7 @@ extern "C" int dspsr_amd_dedispersion_build(const dspsr_amd_dedispersion_config*
   const unsigned nchan = cfg->nchan;
   std::complex<float>* phasors = reinterpret_cast<std::complex<float>*>(kernel_host);
 
-  // Dedispersion::build(vector<float>&, ndat, nchan)  :478-556  (Doppler_shift = 1, no fractional delay)
+  // Dedispersion::build(vector<float>&, ndat, nchan)  :478-556  (Doppler_shift = 1)
   const double centrefreq = cfg->centre_frequency, bw = cfg->bandwidth;
   const double sign = bw / fabs(bw);
   const double chanwidth = bw / double(nchan);
@@ -161,13 +161,21 @@ extern "C" int dspsr_amd_dedispersion_build(const dspsr_amd_dedispersion_config*
   double lower_cfreq = centrefreq - 0.5 * bw;
   if (!cfg->dc_centred) lower_cfreq += 0.5 * chanwidth;
   const double dispersion_per_MHz = 1e6 * cfg->dispersion_measure / dm_dispersion;
+  const double highest_freq = centrefreq + 0.5 * fabs(bw - chanwidth);            // :504
+  const double samp_int = 1.0 / chanwidth;                                         // :506 (microseconds, signed like bw)
   for (unsigned ichan = 0; ichan < nchan; ichan++) {
     const double chan_cfreq = lower_cfreq + double(ichan) * chanwidth;
+    double delay = 0.0;
+    if (cfg->fractional_delay) {                                                   // :524-533
+      delay = dispersion_per_MHz * (1.0 / (chan_cfreq * chan_cfreq) - 1.0 / (highest_freq * highest_freq));
+      delay = -fmod(delay, samp_int);
+    }
     const double coeff = -sign * 2 * M_PI * dispersion_per_MHz / (chan_cfreq * chan_cfreq);
     const uint64_t spt = (uint64_t)ichan * ndat;
     for (unsigned ipt = 0; ipt < ndat; ipt++) {
       const double freq = double(ipt) * binwidth - 0.5 * chanwidth;
-      const float phase = float(coeff * (freq * freq) / (chan_cfreq + freq));   // stored as float :545
+      const double delay_phase = -2.0 * M_PI * freq * delay;                       // :543
+      const float phase = float(coeff * (freq * freq) / (chan_cfreq + freq) + delay_phase);   // stored as float :545
       phasors[spt + ipt] = std::polar(float(1.0), phase);                       // :320
     }
   }

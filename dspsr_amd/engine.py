@@ -80,9 +80,9 @@ class Dedispersion:
     """dsp::Dedispersion: smearing -> impulse_pos/neg, frequency resolution, chirp (host, double->float)."""
 
     def __init__(self, centre_frequency, bandwidth, dispersion_measure, input_nchan=1, ndim=1,
-                 dual_sideband=-1, dc_centred=False, swap=False):
+                 dual_sideband=-1, dc_centred=False, swap=False, fractional_delay=False):
         self.cfg = _lib.DedispersionConfig(centre_frequency, bandwidth, dispersion_measure, input_nchan, input_nchan,
-                                           ndim, dual_sideband, int(dc_centred), int(swap), 0, 0)
+                                           ndim, dual_sideband, int(dc_centred), int(swap), 0, 0, int(fractional_delay))
         self.impulse_pos = self.impulse_neg = self.ndat = self.minimum_ndat = 0
         self.nchan = input_nchan
         self.kernel = None

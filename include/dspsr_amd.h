@@ -194,6 +194,8 @@ typedef struct {
   uint32_t swap;
   uint32_t freq_res;         /* 0 => optimal (optimize_fft.c) else -x value (checked like Response.C:328-344) */
   uint32_t ndat_max;         /* Response::ndat_max, 0 => none */
+  uint32_t fractional_delay; /* -K: add the fractional-sample inter-channel delay phase (Dedispersion.C:524-545,
+                                set by LoadToFold1.C:605-624); the integer part is dsp::SampleDelay's job */
 } dspsr_amd_dedispersion_config;
 
 typedef struct {

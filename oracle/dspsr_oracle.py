@@ -322,13 +322,19 @@ class Dedispersion:
         if not self.dc_centred:
             lower_cfreq += 0.5 * chanwidth
         dispersion_per_mhz = 1e6 * self.dispersion_measure / DM_DISPERSION
+        highest_freq = centrefreq + 0.5 * abs(bw - chanwidth)            # :504
+        samp_int = 1.0 / chanwidth                                       # :506
         phases = np.empty(ndat * nchan, dtype=np.float32)
         ipt = np.arange(ndat, dtype=np.float64)
         freq = ipt * binwidth - 0.5 * chanwidth
         for ichan in range(nchan):
             chan_cfreq = lower_cfreq + float(ichan) * chanwidth
+            delay = 0.0
+            if getattr(self, "fractional_delay", False):                  # -K  :524-533
+                delay = dispersion_per_mhz * (1.0 / (chan_cfreq * chan_cfreq) - 1.0 / (highest_freq * highest_freq))
+                delay = -math.fmod(delay, samp_int)
             coeff = -sign * 2 * math.pi * dispersion_per_mhz / (chan_cfreq * chan_cfreq)
-            ph = coeff * (freq * freq) / (chan_cfreq + freq)      # + delay_phase (=0, no -K)
+            ph = coeff * (freq * freq) / (chan_cfreq + freq) + (-2.0 * math.pi * freq * delay)   # :543-545
             phases[ichan * ndat:(ichan + 1) * ndat] = ph.astype(np.float32)
         return phases
 

@@ -116,3 +116,28 @@ def test_golden_ref_kat_through_product_host_code(oracle):
     fb = np.stack([fx["p"].view(np.complex64), fx["q"].view(np.complex64)])[None]
     assert np.array_equal(oracle.detect_products(fb, "Coherence")[0], fx["cross"])
     assert np.array_equal(oracle.detect_products(fb, "Stokes")[0], fx["stokes"])
+
+
+def test_fractional_delay_kernel_matches_oracle(oracle):
+    """-K: the fractional inter-channel delay phase of Dedispersion::build (Dedispersion.C:524-545) in the product's
+    host code against the oracle, and a sanity check that it is a pure linear phase per channel."""
+    import dspsr_amd
+    o = oracle
+    f0, bw, dm, nchan = 1382.0, -64.0, 10.0, 16
+    d = dspsr_amd.Dedispersion(f0, bw, dm, fractional_delay=True)
+    d.set_frequency_resolution(1024)
+    d.match(nchan)
+    obs = o.Observation(centre_frequency=f0, bandwidth=bw, dispersion_measure=dm)
+    od = o.Dedispersion()
+    od.fractional_delay = True
+    od.set_frequency_resolution(1024)
+    od.match(obs, nchan)
+    assert np.array_equal(d.kernel, od.buffer)
+    plain = dspsr_amd.Dedispersion(f0, bw, dm)
+    plain.set_frequency_resolution(1024)
+    plain.match(nchan)
+    ratio = (d.kernel.reshape(nchan, -1)[:, 1:] * np.conj(plain.kernel.reshape(nchan, -1)[:, 1:]))
+    ph = np.unwrap(np.angle(ratio.astype(np.complex128)), axis=1)
+    slope = np.diff(ph, axis=1)
+    assert np.abs(slope - slope.mean(axis=1, keepdims=True)).max() < 2e-3       # float-phase quantisation only
+    assert np.abs(slope.mean(axis=1)).max() > 0                                  # and it is not the identity
