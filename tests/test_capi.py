@@ -132,7 +132,7 @@ def test_fractional_delay_kernel_matches_oracle(oracle):
     od.fractional_delay = True
     od.set_frequency_resolution(1024)
     od.match(obs, nchan)
-    assert np.array_equal(d.kernel, od.buffer)
+    assert np.abs(d.kernel - od.buffer).max() <= 1.2e-7          # cosf/sinf vs rounded double cos/sin: 1 ulp
     plain = dspsr_amd.Dedispersion(f0, bw, dm)
     plain.set_frequency_resolution(1024)
     plain.match(nchan)
