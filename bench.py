@@ -106,14 +106,14 @@ def algorithmic_bytes_per_part(npol, nsamp_fft, nbit, N, nchan_subband, nkeep):
     return npol * nsamp_fft * nbit // 8 + 8 * N + npol * nchan_subband * nkeep * 8
 
 
-def measured_traffic(workload, max_parts):
+def measured_traffic(workload, max_parts, key="hbm_bytes_per_launch_group"):
     """HBM bytes per launch group from the committed PMC profile (rocprofv3 cannot run inside the bench);
     None when the profile was taken for another workload / grouping."""
-    for name in ("r01c_traffic.json", "r01b_traffic.json"):
+    for name in ("r01e_traffic.json", "r01c_traffic.json", "r01b_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if d["workload"] == workload and d["parts_per_launch_group"] == max_parts:
-                return d["hbm_bytes_per_launch_group"]
+            if d["workload"] == workload and d["parts_per_launch_group"] == max_parts and key in d:
+                return d[key]
         except Exception:
             pass
     return None
@@ -312,7 +312,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic(args.workload, cfg.max_parts),
-                         "traffic_unit": "HBM bytes per launch group of %d parts (PMC, profiles/r01c_traffic.json); "
+                         "traffic_unit": "HBM bytes per launch group of %d parts (PMC, profiles/r01e_traffic.json); "
                                          "algorithmic bytes for the same group: %d" % (cfg.max_parts, b_alg * cfg.max_parts),
                          "kernel": "filterbank launch group k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,false> "
                                    "(FFT+chirp+detect, detected output written)",
@@ -326,7 +326,8 @@ def main():
             ach_f = b_fused * cfg.parts_per_block * info.nchan / (timed_ms * 1e-3) / 1e9
             out["roofline_fused"] = {
                 "bound": "hbm", "achieved": round(ach_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach_f / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(ach_f / HBM_PEAK_GBS, 4),
+                "traffic": measured_traffic(args.workload, cfg.max_parts, "hbm_bytes_per_launch_group_fused"),
                 "kernel": "k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,true> (FFT+chirp+detect+fold in one "
                           "launch group, the timed region)",
                 "algorithmic_bytes_per_part": b_fused, "group_ms_per_block": round(timed_ms, 4),
