@@ -185,6 +185,9 @@ def main():
     ap.add_argument("--dump-steps", type=int, default=8, help="steps per sub-integration dump")
     ap.add_argument("--ndim", type=int, default=4, choices=[1, 2, 4])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--h2d", action="store_true",
+                    help="also measure the PCIe-inclusive rate: every block copied from pinned host memory on a second "
+                         "stream, double buffered, overlapped with the kernels (reported as config.pcie_inclusive)")
     ap.add_argument("--no-fused-fold", action="store_true",
                     help="Detection and Fold as separate operations (detected time series through HBM)")
     args = ap.parse_args()
@@ -333,6 +336,39 @@ def main():
                 "algorithmic_bytes_per_part": b_fused, "group_ms_per_block": round(timed_ms, 4),
                 "note": "the fused group also does the fold; its algorithmic bytes have no output term "
                         "(SURVEY 8(d)), so this fraction is not comparable with roofline.frac"}
+        if args.h2d:
+            # host-buffer hand-over: block i+1 is copied H2D on a side stream while block i is processed
+            host = raw.cpu().pin_memory()
+            bufs = [torch.empty_like(raw), torch.empty_like(raw)]
+            copy_stream = torch.cuda.Stream()
+            ready = [torch.cuda.Event(), torch.cuda.Event()]
+            done = [torch.cuda.Event(), torch.cuda.Event()]
+            main = torch.cuda.current_stream()
+
+            def h2d_run(nsteps):
+                with torch.cuda.stream(copy_stream):
+                    bufs[0].copy_(host, non_blocking=True)
+                    ready[0].record(copy_stream)
+                for i in range(nsteps):
+                    b = i & 1
+                    if i + 1 < nsteps:
+                        with torch.cuda.stream(copy_stream):
+                            if i >= 1:
+                                copy_stream.wait_event(done[b ^ 1])     # the kernels of block i-1 are finished with it
+                            bufs[b ^ 1].copy_(host, non_blocking=True)
+                            ready[b ^ 1].record(copy_stream)
+                    main.wait_event(ready[b])
+                    lt.process_block(bufs[b])
+                    done[b].record(main)
+                torch.cuda.synchronize()
+            h2d_run(3)
+            t1 = time.perf_counter()
+            h2d_run(args.steps)
+            dt = time.perf_counter() - t1
+            out["config"]["pcie_inclusive"] = {
+                "value": round(samples_per_step * args.steps / dt / 1e6, 1), "unit": "Msamples/s",
+                "note": "blocks copied from pinned host memory (%.1f MB each) on a second stream, double buffered"
+                        % (raw.numel() / 1e6)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(wl, lt)
