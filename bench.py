@@ -33,6 +33,14 @@ WORKLOADS = {
     "target": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=1024, dm=1000.0,
                    freq_res=4096, nbin=1024, machine="CASPSR",
                    cmd="dspsr -F 1024:D -x 4096 -D 1000 -b 1024 (header.dada band, 8-bit dual-pol real)"),
+    # BASELINE cfg 1 (the reference's CPU-runnable case): -F 64:D on header.dada, vela.par DM, minimum response
+    # length 16384 -> the four-pass path (two-pass inverse), no fused fold
+    "cfg1": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=64, dm=67.99,
+                 freq_res=16384, nbin=512, machine="CASPSR",
+                 cmd="dspsr -F 64:D -x 16384 -D 67.99 -b 512 (header.dada band, vela.par DM)"),
+    "cfg1opt": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=64, dm=67.99,
+                    freq_res=262144, nbin=512, machine="CASPSR",
+                    cmd="dspsr -F 64:D -D 67.99 -b 512 with the optimal response length 262144 (N = 2^24)"),
     "cfg3": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=1024, dm=2000.0,
                  freq_res=4096, nbin=1024, machine="CASPSR",
                  cmd="dspsr -F 1024:D -x 4096 -D 2000 -b 1024"),

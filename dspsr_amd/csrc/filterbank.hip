@@ -448,12 +448,29 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
       constexpr int R = sizeof(v) / sizeof(v[0]);
       const uint32_t nb = tile * T + col;
       if (!(g.dbg & 8)) apply_pass_twiddle<R>(v, nb, p, pstride, logL, tw, g.tw_lo);
+      // image index of element k: l0 + k*(pstride << logT) (pstride is a multiple of T2), so when that step is a
+      // multiple of 64 the swizzle and the padding of l0 carry over: one address per column, constant offsets
+      auto img = [&](const uint32_t l) { return lds_pad(l ^ (((l >> 4) & swz) << 3)); };
+      const uint32_t l0 = ((((p >> logT2) << logT) + col) << logT2) | (p & (T2 - 1));
+      const uint32_t step = pstride << logT;
+      const bool aff = (step & 63) == 0 && (pstride & (T2 - 1)) == 0;
+      const uint32_t b0 = img(l0), b1 = img(l0 + T2), sp = step + (step >> 4);
+      if (aff) {                                       // uniform
 #pragma unroll
-      for (int k = 0; k < R; k++) {
-        const uint32_t ka = k * pstride + p;
-        const uint32_t l = ((((ka >> logT2) << logT) + col) << logT2) | (ka & (T2 - 1));
-        lds[lds_pad(l ^ (((l >> 4) & swz) << 3))] = cx2_lo(v[k]);
-        lds[lds_pad((l + T2) ^ ((((l + T2) >> 4) & swz) << 3))] = cx2_hi(v[k]);
+        for (int k = 0; k < R; k++) {
+          float* __restrict__ d0 = (float*)&lds[b0 + k * sp];
+          float* __restrict__ d1 = (float*)&lds[b1 + k * sp];
+          d0[0] = v[k].x[0]; d0[1] = v[k].y[0];       // (re, im) of column col   (two dwords: no register shuffling)
+          d1[0] = v[k].x[1]; d1[1] = v[k].y[1];       // column col + 1
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          const uint32_t ka = k * pstride + p;
+          const uint32_t l = ((((ka >> logT2) << logT) + col) << logT2) | (ka & (T2 - 1));
+          lds[img(l)] = cx2_lo(v[k]);
+          lds[img(l + T2)] = cx2_hi(v[k]);
+        }
       }
     };
     if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
@@ -557,12 +574,27 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
     const uint32_t swz = (PTS * blockDim.x) >= 256 ? 3u : 0u;
     auto store = [&](const uint32_t klo, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
+      auto img = [&](const uint32_t l) { return lds_pad(l ^ (((l >> 4) & swz) << 1)); };
+      const uint32_t l0 = ((((p >> logT3) << logT) + klo) << logT3) | (p & (T3 - 1));
+      const uint32_t step = pstride << logT;            // image index step per k (pstride is a multiple of T3)
+      const bool aff = (step & 63) == 0 && (pstride & (T3 - 1)) == 0;
+      const uint32_t b0 = img(l0), b1 = img(l0 + T3), sp = step + (step >> 4);
+      if (aff) {                                       // uniform
 #pragma unroll
-      for (int k = 0; k < R; k++) {
-        const uint32_t srow = k * pstride + p;
-        const uint32_t l = ((((srow >> logT3) << logT) + klo) << logT3) | (srow & (T3 - 1));
-        lds[lds_pad(l ^ (((l >> 4) & swz) << 1))] = cx2_lo(v[k]);
-        lds[lds_pad((l + T3) ^ ((((l + T3) >> 4) & swz) << 1))] = cx2_hi(v[k]);
+        for (int k = 0; k < R; k++) {
+          float* __restrict__ d0 = (float*)&lds[b0 + k * sp];
+          float* __restrict__ d1 = (float*)&lds[b1 + k * sp];
+          d0[0] = v[k].x[0]; d0[1] = v[k].y[0];
+          d1[0] = v[k].x[1]; d1[1] = v[k].y[1];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          const uint32_t srow = k * pstride + p;
+          const uint32_t l = ((((srow >> logT3) << logT) + klo) << logT3) | (srow & (T3 - 1));
+          lds[img(l)] = cx2_lo(v[k]);
+          lds[img(l + T3)] = cx2_hi(v[k]);
+        }
       }
     };
     if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
@@ -1147,7 +1179,7 @@ struct dspsr_amd_filterbank_impl {
   FbGeom g;
   uint64_t N, L;
   uint32_t nseq, max_parts;
-  uint32_t nt1, nt2, nt3, nt4 = 0, ncu, wg_per_cu, wg3 = 1;
+  uint32_t nt1, nt2, nt3, nt4 = 0, ncu, wg_per_cu, wg3 = 1, wg1 = 1;
   size_t lds1, lds2, lds3, lds4 = 0;
   uint64_t part_elems = 0;    // scratch elements per part
   cf* A = nullptr;
@@ -1223,8 +1255,9 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   // three passes (freq_res and the spectrum rows each fit one workgroup tile) when possible ...
   uint64_t p1 = 0, p2 = 0, p3 = 0, p4 = 0;
   bool three_ok = g.logM <= MAX_LOGF && g.logR <= MAX_LOGF;
+  const int LOG_POINTS1 = getenv("DSPSR_AMD_P1_LOG_POINTS") ? atoi(getenv("DSPSR_AMD_P1_LOG_POINTS")) : LOG_POINTS;
   if (three_ok) {
-    g.logT1 = imin(g.logR, LOG_POINTS - g.logM);
+    g.logT1 = imin(g.logR, LOG_POINTS1 - g.logM);
     g.logT2 = imin(g.logM, LOG_POINTS - g.logR);
     int t3 = LOG_POINTS - g.logM - logPol;
     if (t3 < 0) t3 = 0;
@@ -1278,6 +1311,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   fb->lds3 = lds_total_words_host((uint32_t)p3, g.four_pass ? g.logMa : g.logM) * sizeof(cf);
   fb->lds4 = g.four_pass ? lds_total_words_host((uint32_t)p4, g.logMb) * sizeof(cf) : 0;
   fb->wg3 = (!g.four_pass && 2 * fb->lds3 + 1024 <= 160 * 1024) ? 2 * fb->wg_per_cu : fb->wg_per_cu;
+  fb->wg1 = (2 * fb->lds1 + 1024 <= 160 * 1024 && fb->nt1 <= 256) ? 2 * fb->wg_per_cu : fb->wg_per_cu;
   fb->max_parts = cfg->max_parts ? cfg->max_parts : 1;
   // per part: nseq sequences of L points; the two-pass inverse re-uses A for 2 polarisations x N bins
   fb->part_elems = fb->nseq * fb->L;
@@ -1441,7 +1475,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         ci.kind = 3;
         ci.base = fb->Rt;
       }
-      hipLaunchKernelGGL(k1, dim3(grid_for(n1, fb->ncu * fb->wg_per_cu)), dim3(fb->nt1), fb->lds1, ctx->stream, g, ci, fb->A, ctx->tw,
+      hipLaunchKernelGGL(k1, dim3(grid_for(n1, fb->ncu * fb->wg1)), dim3(fb->nt1), fb->lds1, ctx->stream, g, ci, fb->A, ctx->tw,
                          part0, nb, fb->nseq, run1);
       ci = in; ci.ichan = ichan; ci.nchan = fb->cfg.input_nchan;
       if (in.kind == 0) ci.base = in_f32 + ichan * in_chan_stride_bytes_or_floats;

@@ -250,15 +250,22 @@ DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const 
   const int logQ = logF - logP - LOGR;
   const uint32_t stride = 1u << (logF - LOGR + logT);
   cx2 v[H][R];
+  // Padded addresses without per-element arithmetic: lds_pad(e0 + c) == lds_pad(e0) + c + ((c >> 6) << 2) whenever
+  // (e0 & 63) + (c & 63) < 64.  For the reads c = i*stride with stride a multiple of 64; for the writes
+  // c = k*step, step = P*T, and e0 & 63 < step because R*P*T is a multiple of 64 (uniform conditions, folded at
+  // compile time for the full-size tiles).
+  const bool raff = (stride & 63) == 0;
 #pragma unroll
   for (int h = 0; h < H; h++) {
     const uint32_t u = G * tid + 2 * h;
+    const uint32_t rbase = lds_pad(u);
 #pragma unroll
     for (int i = 0; i < R; i++) {
       if constexpr (FIRST) {
         v[h][i] = x[h * R + i];
       } else {
-        const float4 pr = *(const float4*)&lds[lds_pad(u + i * stride)];
+        const uint32_t c = i * stride;
+        const float4 pr = *(const float4*)&lds[raff ? rbase + c + ((c >> 6) << 2) : lds_pad(u + c)];
         v[h][i].x = (v2f){pr.x, pr.y};
         v[h][i].y = (v2f){pr.z, pr.w};
       }
@@ -293,10 +300,14 @@ DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const 
     if constexpr (LAST) {
       out(col, p, 1u << logP, v[h]);     // Q == 1, s == 0
     } else {
+      const uint32_t e0 = ((((s << (logP + LOGR)) + p) << logT) | col), step = 1u << (logP + logT);
+      const bool waff = LOGR + logP + logT >= 6 && logP + logT <= 6;    // step divides 64 or is a multiple of it
+      const bool waff2 = waff || (step & 63) == 0;
+      const uint32_t wbase = lds_pad(e0);
 #pragma unroll
       for (int k = 0; k < R; k++) {
-        const uint32_t pos = (s << (logP + LOGR)) + ((uint32_t)k << logP) + p;
-        *(float4*)&lds[lds_pad((pos << logT) | col)] =
+        const uint32_t c = k * step;
+        *(float4*)&lds[waff2 ? wbase + c + ((c >> 6) << 2) : lds_pad(e0 + c)] =
             make_float4(v[h][k].x[0], v[h][k].x[1], v[h][k].y[0], v[h][k].y[1]);
       }
     }
