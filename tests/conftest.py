@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the built libraries are git-ignored: a fresh checkout builds them once (hipcc cross-compiles without a GPU)
+    need = [os.path.join(ROOT, "dspsr_amd", "libdspsr_amd.so"), os.path.join(ROOT, "oracle", "liboracle_c.so")]
+    if not all(os.path.exists(p) for p in need):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "dspsr_amd", "csrc")])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
 
 
 @pytest.fixture(scope="session")
