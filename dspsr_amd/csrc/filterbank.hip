@@ -57,6 +57,7 @@ struct FbOut {
   uint32_t nbin;                                // kind 3
   const uint32_t* pstart;                       // kind 3: per-part active-bin plan (fold_internal.h), nparts_plan parts
   uint32_t nparts_plan;
+  uint32_t plan_cap;                            // kind 3: plan entries per LDS buffer (two buffers behind the twiddles)
   const Interval* piv;                          // kind 3: intervals (offset within the part, hits), time ordered per bin
 };
 
@@ -732,6 +733,9 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
+  // FOLD: two buffers of out.plan_cap plan entries behind the twiddle tables (cf index, 16-byte aligned)
+  const uint32_t plan_off = (ltw_off + ltw_entries_dev<LOGF>() + 1) & ~1u;
+  uint32_t jt = 0;                                              // tiles done by this workgroup
   uint64_t item, next;
   uint32_t j = 0;
   // FOLD: workgroup b takes tiles b, b + grid, ... and walks the parts of each in order
@@ -768,6 +772,17 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     {
       cf kk[PTS / 2];
       load_chirp(item, kk);
+      if constexpr (FOLD) {
+        // this part's active-bin entries travel with the chirp loads and are parked in LDS (double buffered:
+        // slower waves may still be folding the previous tile from the other half)
+        const uint64_t fpart = part0 + item % nparts;
+        const uint32_t fe0 = out.pstart[fpart], fn = out.pstart[fpart + 1] - fe0;
+        if (fn <= out.plan_cap && !(g.dbg & 16)) {
+          const uint4* __restrict__ fent = (const uint4*)(out.pstart + ((out.nparts_plan + 1 + 3) & ~3u)) + fe0;
+          uint4* pl = (uint4*)&lds[plan_off] + (jt & 1) * out.plan_cap;
+          for (uint32_t q = tid; q < fn; q += blockDim.x) pl[q] = fent[q];
+        }
+      }
 #pragma unroll
       for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
@@ -859,32 +874,38 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 #endif
     if constexpr (FOLD) {
       __syncthreads();                       // the tile's detected samples are staged
-      // active phase bins of this part: entries {bin, first interval, count} (fold_internal.h); one (entry, channel)
-      // accumulator per work item; the samples of an interval are fetched from LDS eight at a time (independent
-      // loads) and then added one after the other, so the sum keeps the time order
-      const uint32_t e0 = out.pstart[part], e1 = out.pstart[part + 1];
-      const uint32_t* __restrict__ ent = out.pstart + out.nparts_plan + 1;
-      for (uint32_t w = tid; w < ((g.dbg & 16) ? 0u : ((e1 - e0) << logT3)); w += blockDim.x) {
+      // active phase bins of this part: entries {bin, first interval, count<<16 | hits0, offset0} (fold_internal.h),
+      // copied to LDS at the start of the tile when they fit; one (entry, channel) accumulator per work item; the
+      // samples of an interval are fetched from LDS eight at a time (independent loads) and then added one after the
+      // other, so the sum keeps the time order
+      const uint32_t e0 = out.pstart[part], nact = out.pstart[part + 1] - e0;
+      const uint4* __restrict__ ent = (const uint4*)(out.pstart + ((out.nparts_plan + 1 + 3) & ~3u)) + e0;
+      const uint4* planl = (const uint4*)&lds[plan_off] + (jt & 1) * out.plan_cap;
+      const bool in_lds = nact <= out.plan_cap;
+      for (uint32_t w = tid; w < ((g.dbg & 16) ? 0u : (nact << logT3)); w += blockDim.x) {
         const uint32_t slo = w & (T3 - 1);
-        const uint32_t* __restrict__ en = ent + 3 * (e0 + (w >> logT3));
-        const uint32_t b = en[0], i0 = en[1], i1 = i0 + en[2];
+        const uint4 en = in_lds ? planl[w >> logT3] : ent[w >> logT3];
+        const uint32_t b = en.x, nint = en.z >> 16;
         float4* __restrict__ pp = (float4*)out.base + (uint64_t)(out.chan0 + tile * T3 + slo) * out.nbin + b;
         float4 acc = *pp;
-        for (uint32_t i = i0; i < i1; i++) {
-          const Interval iv = out.piv[i];
-          const uint32_t l0 = slo * g.nkeep + (uint32_t)iv.offset;
+        uint32_t off = en.w, hits = en.z & 0xffffu;
+        for (uint32_t i = 0;;) {
+          const uint32_t l0 = slo * g.nkeep + off;
           uint32_t h = 0;
-          for (; h + 8 <= iv.hits; h += 8) {
+          for (; h + 8 <= hits; h += 8) {
             float4 sm[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) sm[q] = *(const float4*)&lds[lds_pad(2 * (l0 + h + q))];
 #pragma unroll
             for (int q = 0; q < 8; q++) { acc.x += sm[q].x; acc.y += sm[q].y; acc.z += sm[q].z; acc.w += sm[q].w; }
           }
-          for (; h < iv.hits; h++) {
+          for (; h < hits; h++) {
             const float4 sm = *(const float4*)&lds[lds_pad(2 * (l0 + h))];
             acc.x += sm.x; acc.y += sm.y; acc.z += sm.z; acc.w += sm.w;
           }
+          if (++i >= nint) break;
+          const Interval iv = out.piv[en.y + i];           // further intervals of the bin in this part (rare)
+          off = (uint32_t)iv.offset; hits = iv.hits;
         }
         *pp = acc;
       }
@@ -897,6 +918,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 #endif
     if (!more) break;
     item = next;
+    jt++;
   }
 #if defined(FB_STAMPS) && FB_STAMPS == 3
   if (threadIdx.x == 0 && blockIdx.x < 1024)
@@ -1484,7 +1506,18 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
       if (!g.four_pass) {
         // fused fold: one workgroup owns a tile (T3 channels) for all parts of the launch
         const uint64_t items3 = co.kind == 3 ? (uint64_t)(g.C >> g.logT3) : n3;
-        hipLaunchKernelGGL(k3, dim3(grid_for(items3, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern, co,
+        size_t lds3 = fb->lds3;
+        if (co.kind == 3) {                      // LDS left over behind the twiddle tables holds the part's fold plan
+          const size_t spare = 160 * 1024 - 64 - fb->lds3 - 16;
+          uint32_t cap = fb->lds3 + 64 + 16 < 160 * 1024 ? (uint32_t)(spare / 32) : 0;
+          if (cap > 512) cap = 512;
+          if (cap < 16) cap = 0;
+          co.plan_cap = cap;
+          lds3 += 16 + (size_t)cap * 32;
+          if ((e = allow_lds(k3, lds3)) != hipSuccess)
+            return fb_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_filterbank_perform: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(k3, dim3(grid_for(items3, fb->ncu * fb->wg3)), dim3(fb->nt3), lds3, ctx->stream, g, fb->X, kern, co,
                            ctx->tw, part0, nb, run3);
       } else {
         // two-pass inverse: X (natural order) -> U (in the A buffer, dead after pass 2) -> output
@@ -1621,7 +1654,7 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
   PlanSlot* slot = nullptr;
   int rc = fold_build_part_plan(fold, fb->g.nkeep, (uint32_t)npart, &d_start, &d_iv, &slot);
   if (rc != DSPSR_AMD_OK) return rc;
-  FbOut out = {3, fold->profile, 0, 0, 0, state, 4, 0, fold->nbin, d_start, (uint32_t)npart, d_iv};
+  FbOut out = {3, fold->profile, 0, 0, 0, state, 4, 0, fold->nbin, d_start, (uint32_t)npart, 0, d_iv};
   rc = fb_run(fb, in, out, npart, in_chan_stride);
   const int rc2 = fold_part_plan_submitted(fold, slot);
   return rc != DSPSR_AMD_OK ? rc : rc2;

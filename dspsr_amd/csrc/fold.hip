@@ -398,8 +398,8 @@ int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, cons
                          const Interval** d_iv, PlanSlot** slot)
 {
   // Layout on the device (one uint32 array + the interval array):
-  //   start[0 .. npart]            : first active-bin entry of every part (start[npart] = total)
-  //   start[npart+1 + 3*e + 0..2]  : entry e = { bin, first interval, number of intervals }
+  //   start[0 .. npart]                  : first active-bin entry of every part (start[npart] = total)
+  //   start[align4(npart+1) + 4*e + 0..3] : entry e = { bin, first interval, count << 16 | hits0, offset0 }
   // Only the phase bins that receive samples in a part are listed, so a workgroup finds its work with two
   // dependent loads (entry, then interval + accumulator) instead of walking all nbin bins.
   dspsr_amd_ctx* ctx = f->ctx;
@@ -441,11 +441,18 @@ int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, cons
     if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "fused fold: %s", hipGetErrorString(e));
     sl.pending = false;
   }
-  const size_t nwords = (size_t)npart + 1 + 3 * nentry;
+  const size_t ent_off = ((size_t)npart + 1 + 3) & ~(size_t)3;         // entries are 16-byte aligned uint4
+  const size_t nwords = ent_off + 4 * nentry;
   if (!slot_reserve(sl, nwords, npiece ? npiece : 1))
     return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "fused fold: plan allocation failed");
+  std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
+  for_each_piece([&](uint32_t part, uint32_t ibin, uint64_t within, uint32_t n) {
+    Interval v; v.offset = within; v.hits = n; v.pad = 0;
+    sl.h_iv[fill[(size_t)part * nbin + ibin]++] = v;
+  });
   uint32_t* st = sl.h_bin_start;
-  uint32_t* ent = st + npart + 1;
+  uint32_t* ent = st + ent_off;
+  for (size_t i = npart + 1; i < ent_off; i++) st[i] = 0;
   size_t e = 0;
   for (uint32_t part = 0; part < npart; part++) {
     st[part] = (uint32_t)e;
@@ -453,16 +460,14 @@ int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, cons
       const size_t i = (size_t)part * nbin + b;
       const uint32_t n = cnt[i + 1] - cnt[i];
       if (!n) continue;
-      ent[3 * e] = b; ent[3 * e + 1] = cnt[i]; ent[3 * e + 2] = n;
+      const Interval& first = sl.h_iv[cnt[i]];
+      // {bin, first interval index, count << 16 | hits of the first interval, offset of the first interval}:
+      // count, hits and offsets are < nkeep <= 8192 on the three-pass path
+      ent[4 * e] = b; ent[4 * e + 1] = cnt[i]; ent[4 * e + 2] = (n << 16) | first.hits; ent[4 * e + 3] = (uint32_t)first.offset;
       e++;
     }
   }
   st[npart] = (uint32_t)e;
-  std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
-  for_each_piece([&](uint32_t part, uint32_t ibin, uint64_t within, uint32_t n) {
-    Interval v; v.offset = within; v.hits = n; v.pad = 0;
-    sl.h_iv[fill[(size_t)part * nbin + ibin]++] = v;
-  });
   hipError_t er = hipMemcpyAsync(sl.d_bin_start, sl.h_bin_start, nwords * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
   if (er == hipSuccess && npiece)
     er = hipMemcpyAsync(sl.d_iv, sl.h_iv, npiece * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);

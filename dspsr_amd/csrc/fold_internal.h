@@ -38,8 +38,9 @@ struct dspsr_amd_fold {
 
 // Fused path (filterbank.hip): turns the pending run-length plan into a per-part plan on the device --
 // runs split at multiples of `nkeep`, bucketed by (part, bin), offsets relative to the start of the part.
-// start[0..npart] = first active-bin entry of each part, followed by the entries {bin, first interval, count}
-// (3 words each) indexing `iv`.  The plan is consumed (cleared).
+// start[0..npart] = first active-bin entry of each part, followed (16-byte aligned) by the entries
+// {bin, first interval, count << 16 | hits0, offset0} indexing `iv`.  nkeep must be < 65536.  The plan is
+// consumed (cleared).
 // fold_part_plan_submitted() must be called after the kernels that read the plan have been enqueued.
 int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, const uint32_t** d_start,
                          const dspsr_amd::Interval** d_iv, PlanSlot** slot);

@@ -40,6 +40,7 @@ inline uint32_t ltw_entries_host(int logF)
 }
 inline uint32_t lds_total_words_host(uint32_t points, int logF) { return lds_words_host(points) + ltw_entries_host(logF) + 8; }
 
+
 constexpr int PTS = 32;      // points per thread
 constexpr int LOG_PTS = 5;
 constexpr int NPAIR = PTS / 2;
@@ -213,6 +214,14 @@ template <int LOGF> DEV void ltw_fill(cf* lds, const uint32_t ltw_off, const cf*
     off += 4 * Q;
   }
   __syncthreads();
+}
+
+template <int LOGF> constexpr uint32_t ltw_entries_dev()
+{
+  constexpr int NQ = LOGF / 4, REM = LOGF % 4, NTW = NQ - (REM ? 0 : 1);
+  uint32_t n = 0;
+  for (int st = 0; st < NTW; st++) n += 4u << (LOGF - 4 * (st + 1));
+  return n;
 }
 
 // radix plan of an F = 2^LOGF transform
