@@ -211,15 +211,8 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
   }
 }
 
-// exp(-2*pi*i*j/2^logL), j < 2^logL : coarse table (2*pi/TWN steps, built in double) times fine table
-// (the remaining low bits of j), both correctly rounded -> about 1.2e-7 relative error
-DEV cf twiddle_big(const uint64_t j, const int logL, const cf* __restrict__ tw, const cf* __restrict__ tw_lo)
-{
-  if (logL <= LOG_TWN) return tw[j << (LOG_TWN - logL)];
-  const int sh = logL - LOG_TWN;
-  return cmul(tw[j >> sh], tw_lo[j & ((1u << sh) - 1)]);
-}
-
+// Pass twiddles exp(-2*pi*i*j/2^logL), j < 2^logL: a coarse table (2*pi/TWN steps, built in double) times a fine
+// table (the remaining low bits of j), both correctly rounded -> about 1.2e-7 relative error.
 // NT twiddles exp(-2*pi*i*j[q]/2^logL) at once: all table loads are issued back to back (one memory round trip)
 // and only then combined -- evaluating them one by one costs a dependent L1/L2 round trip each
 template <int NT> DEV void twiddles_big(cf (&t)[NT], const uint64_t (&j)[NT], const int logL, const cf* __restrict__ tw,
@@ -961,19 +954,27 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
       for (int i = 0; i < NPAIR; i++) { raw[i].a = make_float2(tid, i); raw[i].b = raw[i].a; }
       return;
     }
+    // element i of the first-stage butterfly is bin k0 + i*step (m1 advances by MS): base plus a multiple of a
+    // wave-uniform step; the mirror bin L - k runs down with the same step (k = 0, its own mirror, can only be i = 0)
+    constexpr uint32_t MS = 1u << (LOGF - P::LOGR1);
+    const int64_t step = (int64_t)MS << g.logMb;
 #pragma unroll
-    for (int g2 = 0; g2 < P::G1; g2 += 2)
+    for (int g2 = 0; g2 < P::G1; g2 += 2) {
+      const uint32_t eb = P::G1 * tid + g2;
+      const uint32_t j = (eb & ((1u << logT) - 1)) >> 1, m1b = eb >> logT;
+      const uint64_t k0 = ((uint64_t)c << g.logMf) + ((uint64_t)m1b << g.logMb) + tile * Tm + j;
+      const cf* __restrict__ pa = X0s + k0;
+      const cf* __restrict__ pb = g.real_input ? X0s + (L - k0) : pa + (g.npol == 2 ? L : 0);
+      const int64_t stepb = g.real_input ? -step : step;
+      const cf* __restrict__ pb0 = (g.real_input && k0 == 0) ? X0s : pb;
 #pragma unroll
       for (int i = 0; i < P::R1; i++) {
-        const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
-        const uint32_t j = (e & ((1u << logT) - 1)) >> 1, m1 = e >> logT;
-        const uint64_t k = ((uint64_t)c << g.logMf) + ((uint64_t)m1 << g.logMb) + tile * Tm + j;
-        const uint64_t kb = g.real_input ? ((L - k) & (L - 1)) : (g.npol == 2 ? L + k : k);
         Abk q;
-        q.a = ld_stream(&X0s[k]);
-        q.b = ld_stream(&X0s[kb]);
+        q.a = ld_stream(pa + i * step);
+        q.b = ld_stream(i == 0 ? pb0 : pb + i * stepb);
         raw[(g2 / 2) * P::R1 + i] = q;
       }
+    }
   };
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;
@@ -991,14 +992,15 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
     {
       cf kk[PTS / 2];
       if (kernel && !(g.dbg & 2)) {
+        constexpr uint32_t MS = 1u << (LOGF - P::LOGR1);
 #pragma unroll
-        for (int g2 = 0; g2 < P::G1; g2 += 2)
+        for (int g2 = 0; g2 < P::G1; g2 += 2) {
+          const uint32_t eb = P::G1 * tid + g2;
+          const cf* __restrict__ pk = kernel + ((uint64_t)c << g.logMf) + ((uint64_t)(eb >> logT) << g.logMb) + tile * Tm +
+                                      ((eb & ((1u << logT) - 1)) >> 1);
 #pragma unroll
-          for (int i = 0; i < P::R1; i++) {
-            const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
-            const uint32_t j = (e & ((1u << logT) - 1)) >> 1, m1 = e >> logT;
-            kk[(g2 / 2) * P::R1 + i] = kernel[((uint64_t)c << g.logMf) + ((uint64_t)m1 << g.logMb) + tile * Tm + j];
-          }
+          for (int i = 0; i < P::R1; i++) kk[(g2 / 2) * P::R1 + i] = pk[((uint64_t)i * MS) << g.logMb];
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < PTS / 2; i++) kk[i] = make_float2(1.f, 0.f);
