@@ -28,7 +28,7 @@ __global__ void k_fold_direct(const float* __restrict__ in, const uint64_t chan_
   const uint32_t ipol = blockIdx.x, npol = gridDim.x, ichan = blockIdx.y;
   const float* __restrict__ row = in + ichan * chan_stride + ipol * pol_stride;
   float* __restrict__ out = prof + ((uint64_t)ichan * npol + ipol) * nbin * NDIM;
-  for (uint32_t b = threadIdx.x; b < nbin; b += blockDim.x) {
+  for (uint32_t b = blockIdx.z + gridDim.z * threadIdx.x; b < nbin; b += gridDim.z * blockDim.x) {
     const uint32_t i0 = bin_start[b], i1 = bin_start[b + 1];
     if (i0 == i1) continue;
     float acc[NDIM];
@@ -51,7 +51,9 @@ __global__ void k_fold_direct(const float* __restrict__ in, const uint64_t chan_
 // chunk is already in flight in registers while the current one is folded); thread b owns phase
 // bins b, b+blockDim, ... and walks each bin's time-ordered interval list with a cursor, adding
 // the samples that fall inside the current chunk one by one.  Per (chan, pol, bin, dim) the adds
-// therefore happen in time order, as in Fold.C:844-852.
+// therefore happen in time order, as in Fold.C:844-852.  With few (chan, pol) rows the bins of a row are dealt to
+// gridDim.z workgroups (each streams the whole row: the re-reads come from L2 / Infinity Cache), so that the chip
+// is filled without touching the order of any sum.
 constexpr uint32_t FOLD_CHUNK = 2048;   // samples per chunk
 constexpr int FOLD_BPT = 4;             // bins per thread (nbin <= FOLD_BPT * blockDim)
 
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
   };
 #pragma unroll
   for (int j = 0; j < FOLD_BPT; j++) {
-    const uint32_t b = tid + j * nt;
+    const uint32_t b = blockIdx.z + gridDim.z * (tid + j * nt);   // bins are dealt to the gridDim.z workgroups of a row
     cur[j] = end[j] = 0;
     if (b < nbin) { cur[j] = bin_start[b]; end[j] = bin_start[b + 1]; }
     touched[j] = cur[j] != end[j];
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
   }
 #pragma unroll
   for (int j = 0; j < FOLD_BPT; j++) {
-    const uint32_t b = tid + j * nt;
+    const uint32_t b = blockIdx.z + gridDim.z * (tid + j * nt);   // bins are dealt to the gridDim.z workgroups of a row
     if (b < nbin && touched[j])
 #pragma unroll
       for (int d = 0; d < NDIM; d++) out[b * NDIM + d] = acc[j][d];
@@ -342,7 +344,10 @@ extern "C" int dspsr_amd_fold_fold(dspsr_amd_fold* f, const float* in_dev, uint6
     e = hipMemcpyAsync(sl.d_iv, sl.h_iv, niv * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: plan copy: %s", hipGetErrorString(e));
 
-  dim3 grid(f->npol, f->nchan);
+  // rows x bin groups: at least two workgroups per CU when the band has few channels
+  uint32_t nsplit = 1;
+  while (nsplit < 8 && (uint64_t)f->npol * f->nchan * nsplit < 512 && nbin / (2 * nsplit) >= 64) nsplit *= 2;
+  dim3 grid(f->npol, f->nchan, nsplit);
   // sample span covered by the plan (intervals are time ordered)
   uint64_t first = f->binplan.front().offset, last = f->binplan.back().offset + f->binplan.back().hits;
   first -= first % 4;                                  // keeps 16-byte alignment of the chunk loads for any ndim
@@ -351,7 +356,8 @@ extern "C" int dspsr_amd_fold_fold(dspsr_amd_fold* f, const float* in_dev, uint6
   if (aligned && nbin <= (uint32_t)FOLD_BPT * 1024) {
     // FOLD_BPT bins per thread: 256-thread workgroups for nbin <= 1024, so that four of them share a CU and
     // keep 4 x 32 KiB of chunk loads in flight (the kernel is HBM-latency bound per workgroup)
-    threads = ((nbin + FOLD_BPT - 1) / FOLD_BPT + 63) / 64 * 64;
+    const uint32_t bins_wg = (nbin + nsplit - 1) / nsplit;
+    threads = ((bins_wg + FOLD_BPT - 1) / FOLD_BPT + 63) / 64 * 64;
     if (threads < 256) threads = 256;
     if (threads > 1024) threads = 1024;
     const size_t lds = (size_t)FOLD_CHUNK * f->ndim * sizeof(float);
