@@ -23,6 +23,14 @@
 #include "engine_internal.h"
 #include "fold_internal.h"
 
+// The file is compiled as ONE translation unit (no FB_PART: experiment builds) or, by the Makefile, as several in
+// parallel: FB_PART 1 = P0+P1 kernels, 2 = P2, 3 = P3, 5 = P3 with the fused fold, 4 = the two-pass inverse, 0 = host.
+#ifdef FB_PART
+#define FB_HAS(n) (FB_PART == (n))
+#else
+#define FB_HAS(n) 1
+#endif
+
 namespace dspsr_amd {
 
 struct FbGeom {
@@ -65,7 +73,7 @@ struct FbOut {
                    // (s_memtime per phase, lane 0 of wave 0 of every workgroup)
 __device__ unsigned long long g_stamps[1024][8];
 #define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-extern "C" int dspsr_amd_debug_stamps(unsigned long long* out_host, int zero)
+extern "C" int dspsr_amd_debug_stamps(unsigned long long* out_host, int zero)   // single-TU experiment builds only
 {
   if (zero) { static unsigned long long z[1024][8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
   return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
@@ -284,6 +292,7 @@ template <int R> DEV void apply_pass_twiddle_inv(cx2 (&v)[R], const uint32_t nb,
   for (int k = 0; k < R; k++) v[k] = cmuls(v[k], t[0]);
 }
 
+#if FB_HAS(1)
 // ------------------------------------------------------------------------------------ P0
 // 8-bit pre-transposition: P1 needs, for every na (stride Rr samples apart), the T1 adjacent samples of
 // its tile -- 2*T1 bytes per 2*Rr-byte row.  Reading those straight from the block costs one 128-byte line
@@ -497,6 +506,9 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
 #endif
 }
 
+#endif  // FB_HAS(1)
+
+#if FB_HAS(2)
 // ------------------------------------------------------------------------------------ P2
 // Rr-point forward FFTs along T2 adjacent rows ka of A (one contiguous block) -> spectrum rows
 // s' = kb, bin m = ka, stored as X[s'/T3][m][s'%T3].
@@ -621,7 +633,8 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
 #endif
 }
 
-// ------------------------------------------------------------------------------------ P3
+#endif  // FB_HAS(2)
+
 DEV void detect4(const cf p, const cf q, const int state, float (&r)[4])
 {
   // cross_detect.ic:23-43 / stokes_detect.ic:21-44
@@ -632,6 +645,9 @@ DEV void detect4(const cf p, const cf q, const int state, float (&r)[4])
   if (state == DSPSR_AMD_STOKES) { r[0] = pp + qq; r[1] = pp - qq; r[2] = 2.0f * re; r[3] = 2.0f * im; }
   else { r[0] = pp; r[1] = qq; r[2] = re; r[3] = im; }
 }
+
+#if FB_HAS(3) || FB_HAS(5)
+// ------------------------------------------------------------------------------------ P3
 
 // T3 output channels (both polarisations) of one part: Hermitian split of spectrum rows s and
 // Rr-1-s into the two polarisations (real input), x chirp, inverse M-point FFT, keep window,
@@ -919,6 +935,9 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 #endif
 }
 
+#endif  // FB_HAS(3) || FB_HAS(5)
+
+#if FB_HAS(4)
 // ------------------------------------------------------------------------------------ P3a / P3b
 // Two-pass inverse transform for freq_res = Ma*Mb beyond one workgroup tile (and for nchan_subband = 1,
 // i.e. dsp::Convolution): bin m = m1*Mb + m2, output sample t = t1 + Ma*t2.
@@ -1139,6 +1158,8 @@ __global__ __launch_bounds__(512) void k_inv_b(const FbGeom g, const cf* __restr
   }
 }
 
+#endif  // FB_HAS(4)
+
 // ------------------------------------------------------------------------------------ host
 typedef void (*k1_t)(FbGeom, FbIn, cf*, const cf*, uint64_t, uint32_t, uint32_t, uint32_t);
 typedef void (*k2_t)(FbGeom, const cf*, cf*, const cf*, uint32_t, uint32_t, uint32_t);
@@ -1152,15 +1173,36 @@ template <int... I> struct mkseq<0, I...> { typedef iseq<I...> type; };
 
 // full-size tiles (2^14 points) have 2^(14 - LOGF) columns: instantiated with that as a compile-time constant
 constexpr int full_logt(int logf) { return 14 - logf >= 1 ? 14 - logf : -1; }
+constexpr int MAX_LOGF = 13;    // every pass keeps >= 2 columns per workgroup
+typedef mkseq<MAX_LOGF + 1>::type seq_t;
+// kernel tables live in the translation unit that instantiates the kernels
+k1_t fb_pick1(int logf, int raww, bool full);
+k2_t fb_pick2(int logf, bool full);
+k3_t fb_pick3(int logf, bool full);       // plain
+k3_t fb_pick3f(int logf, bool full);      // fused fold
+k3a_t fb_pick3a(int logf);
+k3b_t fb_pick3b(int logf);
+void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
+
 #ifdef FB_ONLY_HEADLINE   // experiment builds: only the kernels of the headline geometry (M = 4096, Rr = 2048, 8-bit)
-template <int... I> static k1_t pick1(int logf, int raww, bool full, iseq<I...>)
-{ return logf == 12 && raww == 1 ? (full ? k_fwd_cols<12, 1, 2> : k_fwd_cols<12, 1, -1>) : nullptr; }
-template <int... I> static k2_t pick2(int logf, bool full, iseq<I...>) { return logf == 11 ? (full ? k_fwd_rows<11, 3> : k_fwd_rows<11, -1>) : nullptr; }
-template <int... I> static k3_t pick3(int logf, bool full, iseq<I...>) { return logf == 12 ? (full ? k_inv_chan<12, false, 2> : k_inv_chan<12, false, -1>) : nullptr; }
-template <int... I> static k3_t pick3f(int logf, bool full, iseq<I...>) { return logf == 12 ? (full ? k_inv_chan<12, true, 2> : k_inv_chan<12, true, -1>) : nullptr; }
-template <int... I> static k3a_t pick3a(int, iseq<I...>) { return nullptr; }
-template <int... I> static k3b_t pick3b(int, iseq<I...>) { return nullptr; }
+#if FB_HAS(1)
+k1_t fb_pick1(int logf, int raww, bool full) { return logf == 12 && raww == 1 ? (full ? k_fwd_cols<12, 1, 2> : k_fwd_cols<12, 1, -1>) : nullptr; }
+#endif
+#if FB_HAS(2)
+k2_t fb_pick2(int logf, bool full) { return logf == 11 ? (full ? k_fwd_rows<11, 3> : k_fwd_rows<11, -1>) : nullptr; }
+#endif
+#if FB_HAS(3)
+k3_t fb_pick3(int logf, bool full) { return logf != 12 ? nullptr : (full ? k_inv_chan<12, false, 2> : k_inv_chan<12, false, -1>); }
+#endif
+#if FB_HAS(5)
+k3_t fb_pick3f(int logf, bool full) { return logf != 12 ? nullptr : (full ? k_inv_chan<12, true, 2> : k_inv_chan<12, true, -1>); }
+#endif
+#if FB_HAS(4)
+k3a_t fb_pick3a(int) { return nullptr; }
+k3b_t fb_pick3b(int) { return nullptr; }
+#endif
 #else
+#if FB_HAS(1)
 template <int... I> static k1_t pick1(int logf, int raww, bool full, iseq<I...>)
 {
   static const k1_t t4[] = {k_fwd_cols<I, 4, -1>...};
@@ -1169,29 +1211,50 @@ template <int... I> static k1_t pick1(int logf, int raww, bool full, iseq<I...>)
   static const k1_t f1[] = {k_fwd_cols<I, 1, full_logt(I)>...};
   return full ? (raww == 1 ? f1[logf] : f4[logf]) : (raww == 1 ? t1[logf] : t4[logf]);
 }
+k1_t fb_pick1(int logf, int raww, bool full) { return pick1(logf, raww, full, seq_t()); }
+#endif
+#if FB_HAS(2)
 template <int... I> static k2_t pick2(int logf, bool full, iseq<I...>)
 {
   static const k2_t t[] = {k_fwd_rows<I, -1>...};
   static const k2_t f[] = {k_fwd_rows<I, full_logt(I)>...};
   return full ? f[logf] : t[logf];
 }
+k2_t fb_pick2(int logf, bool full) { return pick2(logf, full, seq_t()); }
+#endif
+#if FB_HAS(3)
 template <int... I> static k3_t pick3(int logf, bool full, iseq<I...>)
 {
   static const k3_t t[] = {k_inv_chan<I, false, -1>...};
   static const k3_t f[] = {k_inv_chan<I, false, full_logt(I)>...};
   return full ? f[logf] : t[logf];
 }
+k3_t fb_pick3(int logf, bool full) { return pick3(logf, full, seq_t()); }
+#endif
+#if FB_HAS(5)
 template <int... I> static k3_t pick3f(int logf, bool full, iseq<I...>)
 {
   static const k3_t t[] = {k_inv_chan<I, true, -1>...};
   static const k3_t f[] = {k_inv_chan<I, true, full_logt(I)>...};
   return full ? f[logf] : t[logf];
 }
+k3_t fb_pick3f(int logf, bool full) { return pick3f(logf, full, seq_t()); }
+#endif
+#if FB_HAS(4)
 template <int... I> static k3a_t pick3a(int logf, iseq<I...>) { static const k3a_t t[] = {k_inv_a<I>...}; return t[logf]; }
 template <int... I> static k3b_t pick3b(int logf, iseq<I...>) { static const k3b_t t[] = {k_inv_b<I>...}; return t[logf]; }
+k3a_t fb_pick3a(int logf) { return pick3a(logf, seq_t()); }
+k3b_t fb_pick3b(int logf) { return pick3b(logf, seq_t()); }
+#endif
+#endif
+#if FB_HAS(1)
+void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0)
+{
+  hipLaunchKernelGGL(k_raw_transpose, grid, dim3(256), 0, stream, g, in, Rt, part0);
+}
 #endif
 
-constexpr int MAX_LOGF = 13;    // every pass keeps >= 2 columns per workgroup
+#if FB_HAS(0)
 constexpr int LOG_POINTS_DEFAULT = 14;  // points per workgroup (32 per thread, 512 threads)
 
 static inline int ilog2(uint64_t v) { int l = 0; while ((1ull << l) < v) l++; return l; }
@@ -1450,7 +1513,6 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
     return fb_fail(ctx, DSPSR_AMD_ESTATE, "dspsr_amd_filterbank_perform: set_kernel (Engine::setup) not called");
   if (npart == 0) return DSPSR_AMD_OK;
   const FbGeom& g = fb->g;
-  typedef mkseq<MAX_LOGF + 1>::type seq_t;
   // 8-bit real dual-pol single-channel input: one 32-bit word per sample pair; regroup it per tile first
   // (k_raw_transpose) unless the rows are already long enough or the layout preconditions fail
   const bool fast8 = (in.kind == 1 || in.kind == 2) && g.real_input && g.npol == 2 && fb->cfg.input_nchan == 1 &&
@@ -1465,11 +1527,11 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   const bool notfixed = getenv("DSPSR_AMD_RUNTIME_LOGT") != nullptr;    // experiments: force the generic kernels
   const bool full1 = !notfixed && g.logT1 == full_logt(g.logM), full2 = !notfixed && g.logT2 == full_logt(g.logR),
              full3 = !notfixed && !g.four_pass && g.logT3 + 1 == full_logt(g.logM);
-  k1_t k1 = pick1(g.logM, raww, full1, seq_t());
-  k2_t k2 = pick2(g.logR, full2, seq_t());
-  k3_t k3 = g.four_pass ? nullptr : (out.kind == 3 ? pick3f(g.logM, full3, seq_t()) : pick3(g.logM, full3, seq_t()));
-  k3a_t k3a = g.four_pass ? pick3a(g.logMa, seq_t()) : nullptr;
-  k3b_t k3b = g.four_pass ? pick3b(g.logMb, seq_t()) : nullptr;
+  k1_t k1 = fb_pick1(g.logM, raww, full1);
+  k2_t k2 = fb_pick2(g.logR, full2);
+  k3_t k3 = g.four_pass ? nullptr : (out.kind == 3 ? fb_pick3f(g.logM, full3) : fb_pick3(g.logM, full3));
+  k3a_t k3a = g.four_pass ? fb_pick3a(g.logMa) : nullptr;
+  k3b_t k3b = g.four_pass ? fb_pick3b(g.logMb) : nullptr;
   if (!k1 || !k2 || (g.four_pass ? (!k3a || !k3b) : !k3))
     return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: geometry not in this (experiment) build");
   hipError_t e;
@@ -1494,8 +1556,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
                      n3 = g.four_pass ? 0 : (uint64_t)(g.C >> g.logT3) * nb;
       const uint32_t run1 = 32, run2 = 4, run3 = nb;
       if (pret) {
-        hipLaunchKernelGGL(k_raw_transpose, dim3((Rr + 255) / 256, (M + 63) / 64, nb), dim3(256), 0, ctx->stream, g, ci,
-                           fb->Rt, part0);
+        fb_launch_raw_transpose(dim3((Rr + 255) / 256, (M + 63) / 64, nb), ctx->stream, g, ci, fb->Rt, part0);
         ci.kind = 3;
         ci.base = fb->Rt;
       }
@@ -1661,3 +1722,7 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
   const int rc2 = fold_part_plan_submitted(fold, slot);
   return rc != DSPSR_AMD_OK ? rc : rc2;
 }
+
+#else
+}  // namespace dspsr_amd
+#endif  // FB_HAS(0)
