@@ -63,6 +63,11 @@ SYMBOLS = {
     "dspsr_amd_filterbank_perform_detect": (_i, [_vp, _vp, _u64, _u64, _u64, _vp, _i, _f, _i, _u32, _vp, _u64, _u64,
                                                  _u64]),
     "dspsr_amd_filterbank_perform_fold": (_i, [_vp, _vp, _u64, _u64, _u64, _vp, _i, _f, _i, _vp, _u64]),
+    "dspsr_amd_rescale_create": (_i, [_vp, _u32, _u32, _u64, _i, _pp]),
+    "dspsr_amd_rescale_destroy": (None, [_vp]),
+    "dspsr_amd_rescale_transform": (_i, [_vp, _vp, _vp, _u64]),
+    "dspsr_amd_rescale_get": (_i, [_vp, _vp, _vp]),
+    "dspsr_amd_sigproc_digitize": (_i, [_vp, _vp, _u64, _u32, _u32, _i, _i, _d, _f, _i, _i, _vp]),
     "dspsr_amd_detect_polarimetry": (_i, [_vp, _i, _u32, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u64]),
     "dspsr_amd_detect_square_law": (_i, [_vp, _i, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u32, _u64]),
     "dspsr_amd_tfp_filterbank": (_i, [_vp, C.POINTER(TfpConfig), _vp, _i, _f, _vp, _u64]),

@@ -1,0 +1,289 @@
+// Search-mode output stage for gfx950: dsp::Rescale followed by dsp::SigProcDigitizer on
+// time-major (TFP) detected data, as digifil wires them after the TFP filterbank and the scrunches
+// (Signal/General/LoadToFil.C:318-362).
+//
+//   dsp::Rescale::transformation  (Signal/General/Rescale.C:157-388): per (pol, chan) running sums of x and x^2
+//       (double) over intervals of `nsample` samples; at the end of an interval -- and right after the very first
+//       call -- compute_various (:390-420) sets offset = -mean, scale = 1/sqrt(variance) (1 when the variance is 0),
+//       unless `constant` freezes the first estimate; every sample leaves as (x + offset) * scale.
+//   dsp::SigProcDigitizer::pack, TFP branch (Kernel/Formats/sigproc/SigProcDigitizer.C:80-236): nbit 1/2/4/8/16,
+//       result = int(x * digi_scale + digi_mean + 0.5) clipped to [0, 2^nbit - 1], digi_scale = digi_mean/6 (8-bit:
+//       127.5/6) divided by input_scale * scale_fac; output channel k takes input channel ChannelSort(k) (:38-66);
+//       sub-byte samples are packed LSB first; -32 (pack_float, :309-342) writes TPF floats divided by the scale.
+//
+// The reference runs both on the host after a device-to-host transfer; here the block stays in HBM.  The sums are
+// tree reductions in double (the reference adds sample by sample in double): means agree to ~1e-16 relative, so a
+// digitised value can differ by one level only when x*scale falls within that distance of a rounding boundary.
+#include <math.h>
+
+#include "engine_internal.h"
+
+namespace dspsr_amd {
+
+// partial sums over a slice of time samples: block (x: chan-pol tile of 256 columns, y: time slice)
+__global__ __launch_bounds__(256) void k_rescale_sums(const float* __restrict__ in, const uint64_t ndat, const uint32_t ncol,
+                                                      const uint32_t rows_per_block, double* __restrict__ part_sum,
+                                                      double* __restrict__ part_sq)
+{
+  const uint32_t col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= ncol) return;
+  const uint64_t r0 = (uint64_t)blockIdx.y * rows_per_block;
+  const uint64_t r1 = r0 + rows_per_block < ndat ? r0 + rows_per_block : ndat;
+  double s = 0.0, q = 0.0;
+  for (uint64_t r = r0; r < r1; r++) {               // consecutive threads read consecutive floats of a row
+    const float v = in[r * ncol + col];
+    s += (double)v;
+    q += (double)__fmul_rn(v, v);                    // the reference squares in float and accumulates in double (:243-244)
+  }
+  part_sum[(uint64_t)blockIdx.y * ncol + col] = s;
+  part_sq[(uint64_t)blockIdx.y * ncol + col] = q;
+}
+
+// total += sum over slices (slice order fixed => deterministic)
+__global__ __launch_bounds__(256) void k_rescale_accumulate(const double* __restrict__ part_sum, const double* __restrict__ part_sq,
+                                                            const uint32_t nslice, const uint32_t ncol,
+                                                            double* __restrict__ total, double* __restrict__ totalsq)
+{
+  const uint32_t col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= ncol) return;
+  double s = total[col], q = totalsq[col];
+  for (uint32_t i = 0; i < nslice; i++) { s += part_sum[(uint64_t)i * ncol + col]; q += part_sq[(uint64_t)i * ncol + col]; }
+  total[col] = s;
+  totalsq[col] = q;
+}
+
+// Rescale::compute_various + zeroing of the running sums (Rescale.C:390-420, :318-325)
+__global__ __launch_bounds__(256) void k_rescale_update(double* __restrict__ total, double* __restrict__ totalsq, const uint32_t ncol,
+                                                        const double isample, const int set_scale, float* __restrict__ offset,
+                                                        float* __restrict__ scale)
+{
+  const uint32_t col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= ncol) return;
+  const double mean = total[col] / isample, meansq = totalsq[col] / isample;
+  const double variance = __dsub_rn(meansq, __dmul_rn(mean, mean));   // no fma contraction: the host code rounds the product
+  if (set_scale) {
+    offset[col] = (float)(-mean);
+    scale[col] = variance == 0.0 ? 1.0f : (float)(1.0 / sqrt(variance));
+  }
+  total[col] = 0.0;
+  totalsq[col] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_rescale_apply(const float* __restrict__ in, float* __restrict__ out, const uint64_t n,
+                                                       const uint32_t ncol, const float* __restrict__ offset,
+                                                       const float* __restrict__ scale)
+{
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t col = (uint32_t)(i % ncol);
+    out[i] = __fmul_rn(__fadd_rn(in[i], offset[col]), scale[col]);      // Rescale.C:352
+  }
+}
+
+// SigProcDigitizer::pack, TFP order.  One thread per output byte (8-bit: one sample; sub-byte: 8/nbit samples of
+// consecutive output channels; 16-bit: one thread per sample).
+__global__ __launch_bounds__(256) void k_sigproc_digitize(const float* __restrict__ in, uint8_t* __restrict__ out, const uint64_t ndat,
+                                                          const uint32_t nchan, const uint32_t npol, const int nbit,
+                                                          const float digi_scale, const float digi_mean, const float xpol_offset,
+                                                          const int digi_max, const int flip_band, const int swap_band)
+{
+  const uint32_t spb = nbit >= 8 ? 1 : 8 / nbit;                 // samples per byte
+  const uint64_t units_per_row = (uint64_t)npol * (nchan / spb);  // bytes (16-bit: samples) per time sample
+  const uint64_t total = ndat * units_per_row;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += stride) {
+    const uint64_t idat = u / units_per_row;
+    const uint32_t w = (uint32_t)(u % units_per_row);
+    const uint32_t ipol = w / (nchan / spb), k0 = (w % (nchan / spb)) * spb;
+    const float mean = digi_mean + (ipol > 1 ? xpol_offset : 0.0f);
+    uint32_t byte = 0;
+    for (uint32_t j = 0; j < spb; j++) {
+      uint32_t ic = k0 + j;                                       // ChannelSort, SigProcDigitizer.C:52-65
+      if (swap_band) ic = (ic + nchan / 2) % nchan;
+      if (flip_band) ic = nchan - ic - 1;
+      const float x = in[(idat * nchan + ic) * npol + ipol];
+      // :198  float multiply, float add, then + 0.5 in double (the literal is a double), truncation
+      const double d = (double)__fadd_rn(__fmul_rn(x, digi_scale), mean) + 0.5;
+      // out-of-range and NaN conversions yield INT_MIN on the reference's x86 hosts (cvttsd2si), i.e. clip to 0
+      int r = (d >= 2147483648.0 || d <= -2147483649.0 || d != d) ? (int)0x80000000 : (int)d;
+      r = r < 0 ? 0 : r;
+      r = r > digi_max ? digi_max : r;
+      byte |= (uint32_t)r << (j * (nbit >= 8 ? 0 : nbit));
+    }
+    if (nbit == 16) ((uint16_t*)out)[u] = (uint16_t)byte;
+    else out[u] = (uint8_t)byte;
+  }
+}
+
+// SigProcDigitizer::pack_float, TFP branch (:325-342): out[idat][ipol][k] = in[idat][ChannelSort(k)][ipol] / scale
+__global__ __launch_bounds__(256) void k_sigproc_float(const float* __restrict__ in, float* __restrict__ out, const uint64_t ndat,
+                                                       const uint32_t nchan, const uint32_t npol, const float scale,
+                                                       const int flip_band, const int swap_band)
+{
+  const uint64_t row = (uint64_t)nchan * npol, total = ndat * row;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += stride) {
+    const uint64_t idat = u / row;
+    const uint32_t w = (uint32_t)(u % row), ipol = w / nchan;
+    uint32_t ic = w % nchan;
+    if (swap_band) ic = (ic + nchan / 2) % nchan;
+    if (flip_band) ic = nchan - ic - 1;
+    out[u] = __fdiv_rn(in[(idat * nchan + ic) * npol + ipol], scale);
+  }
+}
+
+}  // namespace dspsr_amd
+
+using namespace dspsr_amd;
+
+struct dspsr_amd_rescale {
+  dspsr_amd_ctx* ctx;
+  uint32_t nchan, npol, ncol;
+  uint64_t nsample;        // interval in samples (0 => the length of the first block, Rescale.C:100-105)
+  uint64_t isample = 0;
+  bool first_call = true, constant = false;
+  double *total = nullptr, *totalsq = nullptr, *part_sum = nullptr, *part_sq = nullptr;
+  float *offset = nullptr, *scale = nullptr;
+  uint32_t part_cap = 0;
+};
+
+extern "C" int dspsr_amd_rescale_create(dspsr_amd_ctx* ctx, uint32_t nchan, uint32_t npol, uint64_t interval_samples,
+                                        int constant, dspsr_amd_rescale** out)
+{
+  if (!ctx || !out || !nchan || !npol) return DSPSR_AMD_EINVAL;
+  dspsr_amd_rescale* r = new dspsr_amd_rescale;
+  r->ctx = ctx;
+  r->nchan = nchan; r->npol = npol; r->ncol = nchan * npol;
+  r->nsample = interval_samples;
+  r->constant = constant != 0;
+  const size_t nd = (size_t)r->ncol * sizeof(double), nf = (size_t)r->ncol * sizeof(float);
+  if (hipMalloc((void**)&r->total, nd) != hipSuccess || hipMalloc((void**)&r->totalsq, nd) != hipSuccess ||
+      hipMalloc((void**)&r->offset, nf) != hipSuccess || hipMalloc((void**)&r->scale, nf) != hipSuccess) {
+    dspsr_amd_rescale_destroy(r);
+    return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_rescale_create: hipMalloc failed");
+  }
+  (void)hipMemsetAsync(r->total, 0, nd, ctx->stream);
+  (void)hipMemsetAsync(r->totalsq, 0, nd, ctx->stream);
+  *out = r;
+  return DSPSR_AMD_OK;
+}
+
+extern "C" void dspsr_amd_rescale_destroy(dspsr_amd_rescale* r)
+{
+  if (!r) return;
+  (void)hipStreamSynchronize(r->ctx->stream);
+  if (r->total) (void)hipFree(r->total);
+  if (r->totalsq) (void)hipFree(r->totalsq);
+  if (r->part_sum) (void)hipFree(r->part_sum);
+  if (r->part_sq) (void)hipFree(r->part_sq);
+  if (r->offset) (void)hipFree(r->offset);
+  if (r->scale) (void)hipFree(r->scale);
+  delete r;
+}
+
+extern "C" int dspsr_amd_rescale_transform(dspsr_amd_rescale* r, const float* in_tfp_dev, float* out_tfp_dev, uint64_t ndat)
+{
+  if (!r || (!in_tfp_dev && ndat) || (!out_tfp_dev && ndat)) return DSPSR_AMD_EINVAL;
+  if (!ndat) return DSPSR_AMD_OK;
+  dspsr_amd_ctx* ctx = r->ctx;
+  if (!r->nsample) r->nsample = ndat;                       // Rescale::init: nsample = input->get_ndat()
+  const uint32_t ncol = r->ncol;
+  const uint32_t gx = (ncol + 255) / 256;
+  uint64_t start = 0;
+  do {                                                       // Rescale.C:217-380 (not `exact`)
+    uint64_t end = ndat;
+    const uint64_t interval_end = start + r->nsample - r->isample;
+    if (interval_end < end) end = interval_end;
+    const uint64_t n = end - start;
+    // sums over [start, end): slices of time so that the chip is filled, then a fixed-order accumulation
+    uint32_t rows_per_block = 64;
+    uint32_t nslice = (uint32_t)((n + rows_per_block - 1) / rows_per_block);
+    while (nslice > 4096) { rows_per_block *= 2; nslice = (uint32_t)((n + rows_per_block - 1) / rows_per_block); }
+    if (nslice > r->part_cap) {
+      if (r->part_sum) (void)hipFree(r->part_sum);
+      if (r->part_sq) (void)hipFree(r->part_sq);
+      r->part_sum = r->part_sq = nullptr;
+      r->part_cap = 0;
+      const size_t bytes = (size_t)nslice * ncol * sizeof(double);
+      if (hipMalloc((void**)&r->part_sum, bytes) != hipSuccess || hipMalloc((void**)&r->part_sq, bytes) != hipSuccess)
+        return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_rescale_transform: hipMalloc of the partial sums failed");
+      r->part_cap = nslice;
+    }
+    const float* seg = in_tfp_dev + start * ncol;
+    hipLaunchKernelGGL(k_rescale_sums, dim3(gx, nslice), dim3(256), 0, ctx->stream, seg, n, ncol, rows_per_block,
+                       r->part_sum, r->part_sq);
+    hipLaunchKernelGGL(k_rescale_accumulate, dim3(gx), dim3(256), 0, ctx->stream, r->part_sum, r->part_sq, nslice, ncol,
+                       r->total, r->totalsq);
+    r->isample += n;
+    if (r->isample == r->nsample || r->first_call) {        // :303-326
+      hipLaunchKernelGGL(k_rescale_update, dim3(gx), dim3(256), 0, ctx->stream, r->total, r->totalsq, ncol,
+                         (double)r->isample, (!r->constant || r->first_call) ? 1 : 0, r->offset, r->scale);
+      r->isample = 0;
+      r->first_call = false;
+    }
+    const uint64_t nel = n * ncol;
+    uint64_t gb = (nel + 255) / 256;
+    if (gb > 4096) gb = 4096;
+    hipLaunchKernelGGL(k_rescale_apply, dim3((uint32_t)gb), dim3(256), 0, ctx->stream, seg, out_tfp_dev + start * ncol, nel,
+                       ncol, r->offset, r->scale);
+    start = end;
+  } while (start < ndat);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_rescale_transform: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_rescale_get(dspsr_amd_rescale* r, float* offset_host, float* scale_host)
+{
+  if (!r) return DSPSR_AMD_EINVAL;
+  hipError_t e = hipSuccess;
+  if (offset_host) e = hipMemcpyAsync(offset_host, r->offset, r->ncol * sizeof(float), hipMemcpyDeviceToHost, r->ctx->stream);
+  if (e == hipSuccess && scale_host)
+    e = hipMemcpyAsync(scale_host, r->scale, r->ncol * sizeof(float), hipMemcpyDeviceToHost, r->ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(r->ctx->stream);
+  if (e != hipSuccess) return ctx_fail(r->ctx, DSPSR_AMD_EHIP, "dspsr_amd_rescale_get: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_sigproc_digitize(dspsr_amd_ctx* ctx, const float* in_tfp_dev, uint64_t ndat, uint32_t nchan,
+                                          uint32_t npol, int nbit, int use_digi_scales, double input_scale, float scale_fac,
+                                          int flip_band, int swap_band, void* out_dev)
+{
+  if (!ctx || ((!in_tfp_dev || !out_dev) && ndat)) return DSPSR_AMD_EINVAL;
+  if (nbit != 1 && nbit != 2 && nbit != 4 && nbit != 8 && nbit != 16 && nbit != -32)
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dsp::SigProcDigitizer::set_nbit nbit=%i not understood", nbit);
+  if (!ndat) return DSPSR_AMD_OK;
+  if (nbit == -32) {                                         // pack_float: TPF floats divided by the input scale
+    uint64_t gb = (ndat * nchan * npol + 255) / 256;
+    if (gb > 8192) gb = 8192;
+    hipLaunchKernelGGL(k_sigproc_float, dim3((uint32_t)gb), dim3(256), 0, ctx->stream, in_tfp_dev, (float*)out_dev, ndat, nchan,
+                       npol, (float)input_scale, flip_band, swap_band);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_sigproc_digitize: %s", hipGetErrorString(e));
+    return DSPSR_AMD_OK;
+  }
+  if (nbit < 8 && nchan % (8 / nbit))
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_sigproc_digitize: nchan=%u not a multiple of %d samples per byte", nchan, 8 / nbit);
+  float digi_mean = 0.f, digi_scale = 0.f;
+  const float digi_sigma = 6.f;
+  int digi_max = 0;
+  switch (nbit) {                                            // SigProcDigitizer.C:112-143
+    case 1: digi_mean = 0.5f; digi_scale = 1.f; digi_max = 1; break;
+    case 2: digi_mean = 1.5f; digi_scale = 1.f; digi_max = 3; break;
+    case 4: digi_mean = 7.5f; digi_scale = digi_mean / digi_sigma; digi_max = 15; break;
+    case 8: digi_mean = 127.5f; digi_scale = digi_mean / digi_sigma; digi_max = 255; break;
+    case 16: digi_mean = 32768.0f; digi_scale = digi_mean / digi_sigma; digi_max = 65535; break;
+  }
+  float xpol_offset = 0.f;
+  if (!use_digi_scales) { xpol_offset = digi_mean; digi_mean = 0.f; digi_scale = 1.f; }   // :148-154
+  digi_scale = (float)((double)digi_scale / (input_scale * (double)scale_fac));           // :158 (get_scale() is a double)
+  const uint32_t spb = nbit >= 8 ? 1 : 8 / nbit;
+  const uint64_t units = ndat * npol * (nchan / spb);
+  uint64_t gb = (units + 255) / 256;
+  if (gb > 8192) gb = 8192;
+  hipLaunchKernelGGL(k_sigproc_digitize, dim3((uint32_t)gb), dim3(256), 0, ctx->stream, in_tfp_dev, (uint8_t*)out_dev, ndat, nchan,
+                     npol, nbit, digi_scale, digi_mean, xpol_offset, digi_max, flip_band, swap_band);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_sigproc_digitize: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}

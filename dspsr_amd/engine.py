@@ -250,6 +250,48 @@ def tfp_filterbank(ctx: Context, raw, nchan, npart, out, pscrunch=False, tscrunc
                                                     out.data_ptr(), npart), "dspsr_amd_tfp_filterbank")
 
 
+class Rescale:
+    """Mirror of dsp::Rescale for TFP-ordered detected data (Signal/General/Rescale.C): offset/scale per (pol, chan)."""
+
+    def __init__(self, ctx: Context, nchan, npol=1, interval_samples=0, constant=False):
+        self.ctx = ctx
+        self.nchan, self.npol = nchan, npol
+        h = C.c_void_p()
+        _check(ctx.handle, lib.dspsr_amd_rescale_create(ctx.handle, nchan, npol, interval_samples, int(constant), C.byref(h)),
+               "dspsr_amd_rescale_create")
+        self.handle = h
+
+    def transform(self, inp, out=None):
+        """inp/out: float32 device tensors [ndat][nchan][npol] (out defaults to in place)."""
+        out = inp if out is None else out
+        ndat = inp.numel() // (self.nchan * self.npol)
+        _check(self.ctx.handle, lib.dspsr_amd_rescale_transform(self.handle, inp.data_ptr(), out.data_ptr(), ndat),
+               "dspsr_amd_rescale_transform")
+        return out
+
+    def get(self):
+        off = np.empty(self.nchan * self.npol, np.float32)
+        sc = np.empty(self.nchan * self.npol, np.float32)
+        _check(self.ctx.handle, lib.dspsr_amd_rescale_get(self.handle, off.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)),
+               "dspsr_amd_rescale_get")
+        return off.reshape(self.nchan, self.npol), sc.reshape(self.nchan, self.npol)
+
+    def close(self):
+        if self.handle:
+            lib.dspsr_amd_rescale_destroy(self.handle)
+            self.handle = None
+
+
+def sigproc_digitize(ctx: Context, inp, out, nchan, npol=1, nbit=8, use_digi_scales=True, input_scale=1.0, scale_fac=1.0,
+                     flip_band=False, swap_band=False):
+    """dsp::SigProcDigitizer::pack on TFP-ordered float32 device data -> packed n-bit device bytes."""
+    ndat = inp.numel() // (nchan * npol)
+    _check(ctx.handle, lib.dspsr_amd_sigproc_digitize(ctx.handle, inp.data_ptr(), ndat, nchan, npol, nbit, int(use_digi_scales),
+                                                      input_scale, scale_fac, int(flip_band), int(swap_band), out.data_ptr()),
+           "dspsr_amd_sigproc_digitize")
+    return out
+
+
 class DetectionEngine:
     """dsp::Detection::Engine."""
 

@@ -181,6 +181,24 @@ uint64_t dspsr_amd_fold_get_ndat_folded(const dspsr_amd_fold* fold);
 int dspsr_amd_fold_zero(dspsr_amd_fold* fold);                                            /* Engine::zero */
 int dspsr_amd_fold_synch(dspsr_amd_fold* fold, float* profile_host);                      /* FoldCUDA.cu:127-152 (blocks) */
 
+/* ---- search-mode output stage: dsp::Rescale + dsp::SigProcDigitizer on TFP-ordered data ----------
+ * dspsr_amd_rescale_*        : dsp::Rescale (Signal/General/Rescale.C:157-420), scalar offset/scale per (pol, chan)
+ *                              re-estimated every `interval_samples` samples (0 = length of the first block) and once
+ *                              right after the first call; `constant` keeps the first estimate (set_constant, :50).
+ *                              in == out is allowed (digifil rescales in place, LoadToFil.C:325-326).
+ * dspsr_amd_sigproc_digitize : dsp::SigProcDigitizer::pack, TFP branch (Kernel/Formats/sigproc/SigProcDigitizer.C:80-236)
+ *                              nbit 1/2/4/8/16 or -32 (pack_float :309-342); flip_band = input bandwidth > 0,
+ *                              swap_band = input->get_swap() (ChannelSort :38-66); input_scale = input->get_scale(). */
+typedef struct dspsr_amd_rescale dspsr_amd_rescale;
+int dspsr_amd_rescale_create(dspsr_amd_ctx* ctx, uint32_t nchan, uint32_t npol, uint64_t interval_samples, int constant,
+                             dspsr_amd_rescale** out);
+void dspsr_amd_rescale_destroy(dspsr_amd_rescale* r);
+int dspsr_amd_rescale_transform(dspsr_amd_rescale* r, const float* in_tfp_dev, float* out_tfp_dev, uint64_t ndat);
+int dspsr_amd_rescale_get(dspsr_amd_rescale* r, float* offset_host, float* scale_host);   /* [npol*nchan]: index ichan*npol+ipol */
+int dspsr_amd_sigproc_digitize(dspsr_amd_ctx* ctx, const float* in_tfp_dev, uint64_t ndat, uint32_t nchan, uint32_t npol,
+                               int nbit, int use_digi_scales, double input_scale, float scale_fac, int flip_band,
+                               int swap_band, void* out_dev);
+
 /* ---- host-side preparation (stays on the host in the reference as well) --------------------- */
 typedef struct {
   double centre_frequency;   /* MHz */

@@ -640,8 +640,120 @@ def tscrunch_tfp(x: np.ndarray, sfactor: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------
+# Search-mode output stage (f-1): Rescale + SigProcDigitizer
+# --------------------------------------------------------------------------------------
+
+
+class Rescale:
+    """dsp::Rescale on TFP-ordered detected data (Signal/General/Rescale.C:157-420), `exact`/decay off.
+
+    Per (pol, chan) running sums of x and x*x (the square is taken in float, the sums are doubles: :243-244) over
+    intervals of `interval_samples` samples (0: the length of the first block, :100-105); at the end of an interval,
+    and right after the first block segment, compute_various (:390-420) sets offset = -mean and
+    scale = 1/sqrt(variance) (1 if the variance is 0) unless `constant` froze the first estimate; each sample
+    leaves as (x + offset) * scale in float (:352).  Arrays are indexed [chan][pol] like the TFP data."""
+
+    def __init__(self, interval_samples: int = 0, constant: bool = False):
+        self.interval_samples, self.constant = interval_samples, constant
+        self.nsample = 0
+        self.isample = 0
+        self.total = self.totalsq = self.offset = self.scale = None
+
+    def transform(self, x: np.ndarray) -> np.ndarray:
+        """x: float32 [ndat][nchan][npol]; returns the rescaled block."""
+        x = np.asarray(x, np.float32)
+        ndat = x.shape[0]
+        out = np.empty_like(x)
+        first_call = self.nsample == 0                                   # :174
+        if first_call:                                                    # init, :94-130
+            self.nsample = self.interval_samples or ndat
+            if not self.nsample:
+                raise OracleError("dsp::Rescale::init nsample == 0")
+            self.isample = 0
+            self.total = np.zeros(x.shape[1:], np.float64)
+            self.totalsq = np.zeros(x.shape[1:], np.float64)
+            self.offset = np.zeros(x.shape[1:], np.float32)
+            self.scale = np.ones(x.shape[1:], np.float32)
+        if not ndat:
+            return out
+        start = 0
+        while True:                                                       # :217-380
+            end = min(ndat, start + self.nsample - self.isample)
+            seg = x[start:end]
+            # sequential double accumulation, sample by sample (:236-247); cumsum adds in that order
+            self.total = (self.total[None] + np.cumsum(seg.astype(np.float64), axis=0))[-1] if len(seg) else self.total
+            sq = (seg * seg).astype(np.float64)                           # float product, then widened
+            self.totalsq = (self.totalsq[None] + np.cumsum(sq, axis=0))[-1] if len(seg) else self.totalsq
+            self.isample += end - start
+            if self.isample == self.nsample or first_call:               # :298-326
+                mean = self.total / self.isample
+                variance = self.totalsq / self.isample - mean * mean
+                if not self.constant or first_call:
+                    self.offset = (-mean).astype(np.float32)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        self.scale = np.where(variance == 0.0, 1.0, 1.0 / np.sqrt(variance)).astype(np.float32)
+                self.isample = 0
+                first_call = False
+                self.total = np.zeros_like(self.total)
+                self.totalsq = np.zeros_like(self.totalsq)
+            out[start:end] = (seg + self.offset[None]) * self.scale[None]   # float32 add, float32 multiply (:352)
+            start = end
+            if end >= ndat:
+                break
+        return out
+
+
+def channel_sort(nchan: int, flip_band: bool, swap_band: bool) -> np.ndarray:
+    """ChannelSort (Kernel/Formats/sigproc/SigProcDigitizer.C:38-66, nsub_swap <= 1): input channel of each output
+    channel; flip_band = input bandwidth > 0, swap_band = input->get_swap()."""
+    k = np.arange(nchan)
+    if swap_band:
+        k = (k + nchan // 2) % nchan
+    if flip_band:
+        k = nchan - k - 1
+    return k
+
+
+def sigproc_digitize(x: np.ndarray, nbit: int, use_digi_scales: bool = True, input_scale: float = 1.0,
+                     scale_fac: float = 1.0, flip_band: bool = False, swap_band: bool = False) -> np.ndarray:
+    """dsp::SigProcDigitizer::pack, TFP branch (SigProcDigitizer.C:80-246; pack_float :309-342).
+
+    x: float32 [ndat][nchan][npol].  Returns the raw output bytes (uint8; nbit 16: uint16; nbit -32: float32) in
+    [ndat][npol][nchan] order, sub-byte samples packed LSB first."""
+    x = np.asarray(x, np.float32)
+    ndat, nchan, npol = x.shape
+    sel = x[:, channel_sort(nchan, flip_band, swap_band), :].transpose(0, 2, 1)      # [ndat][npol][out chan]
+    if nbit == -32:
+        return (sel / np.float32(input_scale)).astype(np.float32)
+    table = {1: (0.5, 1.0, 1), 2: (1.5, 1.0, 3), 4: (7.5, None, 15), 8: (127.5, None, 255), 16: (32768.0, None, 65535)}
+    if nbit not in table:
+        raise OracleError("dsp::SigProcDigitizer::set_nbit nbit=%d not understood" % nbit)
+    digi_mean, digi_scale, digi_max = table[nbit]
+    digi_mean = np.float32(digi_mean)
+    digi_scale = np.float32(digi_scale) if digi_scale is not None else digi_mean / np.float32(6)    # :112-143
+    xpol_offset = np.float32(0)
+    if not use_digi_scales:                                                                           # :148-154
+        xpol_offset, digi_mean, digi_scale = digi_mean, np.float32(0), np.float32(1)
+    digi_scale = np.float32(np.float64(digi_scale) / (np.float64(input_scale) * np.float64(np.float32(scale_fac))))   # :158
+    mean = np.full(npol, digi_mean, np.float32)
+    mean[2:] += xpol_offset                                                                           # :176-177
+    with np.errstate(invalid="ignore", over="ignore"):
+        y = (sel * digi_scale + mean[None, :, None]).astype(np.float64) + 0.5                         # :198
+        bad = ~((y < 2147483648.0) & (y > -2147483649.0))                  # x86 cvttsd2si: indefinite integer
+        r = np.where(bad, -2147483648, np.trunc(np.where(bad, 0, y))).astype(np.int64)
+    r = np.clip(r, 0, digi_max)
+    if nbit == 16:
+        return r.astype(np.uint16)
+    if nbit == 8:
+        return r.astype(np.uint8)
+    spb = 8 // nbit
+    r = r.reshape(ndat, npol, nchan // spb, spb)
+    return (r << (np.arange(spb) * nbit)).sum(axis=-1).astype(np.uint8)
+
+# --------------------------------------------------------------------------------------
 # Fold (a9 - a13)
 # --------------------------------------------------------------------------------------
+
 
 @dataclass
 class Polyco:

@@ -612,3 +612,72 @@ def test_tfp_filterbank_search_mode(oracle, gpu, nchan, tscrunch, pscrunch, npar
     rms = np.sqrt(np.mean(want.astype(np.float64) ** 2))
     assert np.abs(got - want).max() <= 2e-5 * rms * 8
     assert np.sqrt(np.mean((got - want).astype(np.float64) ** 2)) <= 2e-6 * rms
+
+
+@pytest.mark.parametrize("nchan,npol,ndat,interval,constant,blocks", [
+    (1024, 1, 4096, 0, False, 1), (256, 2, 3000, 1000, False, 3), (64, 4, 2500, 700, True, 2), (4096, 1, 1024, 512, False, 2),
+    (16, 1, 100000, 0, False, 1), (33, 2, 777, 100, False, 2)])
+def test_rescale_matches_oracle(oracle, gpu, nchan, npol, ndat, interval, constant, blocks):
+    """dsp::Rescale (SURVEY 8f-1 output stage): same state machine over several blocks as the oracle.  The sums are tree
+    reductions in double instead of sample-by-sample: offsets/scales agree to a float ulp, outputs to a few ulp."""
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(21)
+    r = dspsr_amd.Rescale(ctx, nchan, npol, interval, constant)
+    ro = oracle.Rescale(interval, constant)
+    for b in range(blocks):
+        gain = rng.uniform(0.5, 20.0, (1, nchan, npol)).astype(np.float32) * (1 + b)
+        x = (rng.standard_normal((ndat, nchan, npol)).astype(np.float32) ** 2 * gain + gain).astype(np.float32)
+        if b == 0:
+            x[:, 0, 0] = 3.0                                   # zero variance => scale 1 (Rescale.C:411-412)
+        want = ro.transform(x)
+        got = r.transform(torch.from_numpy(x).cuda(), torch.empty(x.shape, dtype=torch.float32, device="cuda")).cpu().numpy()
+        off, sc = r.get()
+        assert np.abs(off - ro.offset).max() <= 1.2e-7 * np.abs(ro.offset).max()
+        assert np.abs(sc / ro.scale - 1).max() <= 2.4e-7
+        assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    assert sc[0, 0] == 1.0 or blocks > 1
+    r.close()
+
+
+@pytest.mark.parametrize("nbit", [1, 2, 4, 8, 16, -32])
+@pytest.mark.parametrize("nchan,npol,flip,swap,rescale", [(1024, 1, True, False, True), (64, 4, False, True, False),
+                                                         (256, 2, True, True, True)])
+def test_sigproc_digitizer_bit_exact(oracle, gpu, nbit, nchan, npol, flip, swap, rescale):
+    """dsp::SigProcDigitizer::pack on identical float input: integer output, bit exact (incl. clipping, NaN/inf)."""
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(22)
+    ndat = 513
+    x = (rng.standard_normal((ndat, nchan, npol)) * (3.0 if rescale else 40.0)).astype(np.float32)
+    x[3, 5, 0], x[4, 6, 0], x[5, 7, 0], x[6, 8, 0] = np.inf, -np.inf, np.nan, 1e30
+    want = oracle.sigproc_digitize(x, nbit, rescale, 1.5, 0.75, flip, swap)
+    out = torch.zeros(want.nbytes, dtype=torch.uint8, device="cuda")
+    dspsr_amd.sigproc_digitize(ctx, torch.from_numpy(x).cuda(), out, nchan, npol, nbit, rescale, 1.5, 0.75, flip, swap)
+    got = out.cpu().numpy().view(want.dtype).reshape(want.shape)
+    if nbit == -32:
+        assert np.array_equal(got, want, equal_nan=True)
+    else:
+        assert np.array_equal(got, want)
+
+
+def test_search_mode_chain_digifil(oracle, gpu):
+    """digifil's chain (LoadToFil.C:318-362): TFP filterbank + pscrunch + tscrunch -> Rescale -> 8-bit SigProcDigitizer,
+    everything resident in HBM.  FFT rounding makes a handful of samples fall on the other side of a rounding
+    boundary: at most one level apart, and in well under 0.1% of the samples."""
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(23)
+    nchan, tscrunch, npart = 1024, 8, 256
+    raw = np.clip(np.rint(rng.standard_normal(npart * 2 * nchan * 2) * 24.0), -128, 127).astype(np.int8)
+    obs = oracle.Observation()
+    det = oracle.tscrunch_tfp(oracle.tfp_filterbank(oracle.unpack_8bit(raw, obs), nchan, True), tscrunch)
+    want = oracle.sigproc_digitize(oracle.Rescale().transform(det), 8, flip_band=True)
+    out = torch.zeros((npart // tscrunch, nchan, 1), dtype=torch.float32, device="cuda")
+    dspsr_amd.tfp_filterbank(ctx, torch.from_numpy(raw).cuda(), nchan, npart, out, True, tscrunch, scale=float(oracle.S8))
+    r = dspsr_amd.Rescale(ctx, nchan, 1)
+    r.transform(out)                                                        # in place, as digifil does
+    packed = torch.zeros(want.size, dtype=torch.uint8, device="cuda")
+    dspsr_amd.sigproc_digitize(ctx, out, packed, nchan, 1, 8, flip_band=True)
+    got = packed.cpu().numpy().reshape(want.shape)
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1
+    assert (d != 0).mean() < 1e-3
+    r.close()
