@@ -63,6 +63,12 @@ SYMBOLS = {
     "dspsr_amd_filterbank_perform_detect": (_i, [_vp, _vp, _u64, _u64, _u64, _vp, _i, _f, _i, _u32, _vp, _u64, _u64,
                                                  _u64]),
     "dspsr_amd_filterbank_perform_fold": (_i, [_vp, _vp, _u64, _u64, _u64, _vp, _i, _f, _i, _vp, _u64]),
+    "dspsr_amd_sample_delay_create": (_i, [_vp, _u32, _u32, _vp, _i, _pp]),
+    "dspsr_amd_sample_delay_destroy": (None, [_vp]),
+    "dspsr_amd_sample_delay_zero_delay": (C.c_int64, [_vp]),
+    "dspsr_amd_sample_delay_total_delay": (_u64, [_vp]),
+    "dspsr_amd_sample_delay_transform": (_i, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u64, C.POINTER(_u64)]),
+    "dspsr_amd_dedispersion_sample_delays": (_i, [_d, _d, _d, _u32, _d, _i, _u32, _i, _vp]),
     "dspsr_amd_rescale_create": (_i, [_vp, _u32, _u32, _u64, _i, _pp]),
     "dspsr_amd_rescale_destroy": (None, [_vp]),
     "dspsr_amd_rescale_transform": (_i, [_vp, _vp, _vp, _u64]),

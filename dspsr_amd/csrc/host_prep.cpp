@@ -197,6 +197,31 @@ extern "C" int dspsr_amd_dedispersion_build(const dspsr_amd_dedispersion_config*
   return DSPSR_AMD_OK;
 }
 
+// Dedispersion::SampleDelay::match (DedispersionSampleDelay.C:24-75) with Observation::get_centre_frequency(ichan)
+// (Kernel/Classes/Observation.C:420-451)
+extern "C" int dspsr_amd_dedispersion_sample_delays(double centre_frequency, double bandwidth, double dispersion_measure,
+                                                    uint32_t nchan, double rate_hz, int swap, uint32_t nsub_swap,
+                                                    int dc_centred, int64_t* delays_host)
+{
+  if (!delays_host || !nchan) return DSPSR_AMD_EINVAL;
+  if (rate_hz == 0 || bandwidth == 0 || centre_frequency == 0) return DSPSR_AMD_EINVAL;   // :50-55 "invalid input"
+  const double dispersion = dispersion_measure / 2.41e-4;                                 // dm_dispersion, Dedispersion.C:28
+  const double base = dc_centred ? centre_frequency - 0.5 * bandwidth
+                                 : centre_frequency - 0.5 * bandwidth + 0.5 * bandwidth / double(nchan);
+  for (uint32_t ichan = 0; ichan < nchan; ichan++) {
+    uint32_t c = ichan;
+    if (swap) c = (c + nchan / 2) % nchan;
+    if (nsub_swap) {
+      const uint32_t sub_nchan = nchan / nsub_swap;
+      c = (c / sub_nchan) * sub_nchan + (c % sub_nchan + sub_nchan / 2) % sub_nchan;
+    }
+    const double freq = base + double(c) * bandwidth / double(nchan);
+    const double delay = dispersion * (1.0 / (centre_frequency * centre_frequency) - 1.0 / (freq * freq));
+    delays_host[ichan] = int64_t(floor(delay * rate_hz + 0.5));
+  }
+  return DSPSR_AMD_OK;
+}
+
 extern "C" double dspsr_amd_eight_bit_scale(double input_spacing)               // BitTable.C:165-218
 {
   const unsigned unique_values = 256;

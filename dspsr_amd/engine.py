@@ -250,6 +250,56 @@ def tfp_filterbank(ctx: Context, raw, nchan, npart, out, pscrunch=False, tscrunc
                                                     out.data_ptr(), npart), "dspsr_amd_tfp_filterbank")
 
 
+def copy_data_fpt(ctx: Context, to, frm):
+    """dsp::TimeSeries::Engine::copy_data_fpt: device rows [nchan][npol][nfloat] (strided views allowed)."""
+    nchan, npol, nfloat = frm.shape
+    _check(ctx.handle, lib.dspsr_amd_copy_fpt(ctx.handle, to.data_ptr(), to.stride(0), to.stride(1), frm.data_ptr(), frm.stride(0),
+                                             frm.stride(1), nchan, npol, nfloat), "dspsr_amd_copy_fpt")
+
+
+def dedispersion_sample_delays(centre_frequency, bandwidth, dispersion_measure, nchan, rate_hz, swap=False, nsub_swap=0,
+                               dc_centred=False):
+    """Dedispersion::SampleDelay::match (DedispersionSampleDelay.C:24-75): int64 delay of each channel in samples."""
+    d = np.zeros(nchan, np.int64)
+    rc = lib.dspsr_amd_dedispersion_sample_delays(centre_frequency, bandwidth, dispersion_measure, nchan, rate_hz, int(swap),
+                                                  nsub_swap, int(dc_centred), d.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise DspsrAmdError("dsp::Dedispersion::SampleDelay::match invalid input")
+    return d
+
+
+class SampleDelay:
+    """Mirror of dsp::SampleDelay (Signal/General/SampleDelay.C): delays[ichan][ipol] from a SampleDelayFunction."""
+
+    def __init__(self, ctx: Context, delays, npol=1, absolute=False):
+        self.ctx = ctx
+        d = np.ascontiguousarray(np.asarray(delays, np.int64))
+        if d.ndim == 1:                                       # per channel, same for every polarisation
+            d = np.ascontiguousarray(np.repeat(d[:, None], npol, axis=1))
+        self.nchan, self.npol = d.shape
+        h = C.c_void_p()
+        _check(ctx.handle, lib.dspsr_amd_sample_delay_create(ctx.handle, self.nchan, self.npol, d.ctypes.data_as(C.c_void_p),
+                                                             int(absolute), C.byref(h)), "dspsr_amd_sample_delay_create")
+        self.handle = h
+        self.zero_delay = lib.dspsr_amd_sample_delay_zero_delay(h)
+        self.total_delay = lib.dspsr_amd_sample_delay_total_delay(h)
+
+    def transform(self, inp, out=None):
+        """inp/out: float32 device tensors [nchan][npol][ndat][ndim] (the last axis may be absent); returns ndat_out."""
+        out = inp if out is None else out
+        ndim = inp.shape[3] if inp.dim() == 4 else 1
+        n = C.c_uint64(0)
+        _check(self.ctx.handle, lib.dspsr_amd_sample_delay_transform(
+            self.handle, inp.data_ptr(), inp.stride(0), inp.stride(1), out.data_ptr(), out.stride(0), out.stride(1), ndim,
+            inp.shape[2], C.byref(n)), "dspsr_amd_sample_delay_transform")
+        return n.value
+
+    def close(self):
+        if self.handle:
+            lib.dspsr_amd_sample_delay_destroy(self.handle)
+            self.handle = None
+
+
 class Rescale:
     """Mirror of dsp::Rescale for TFP-ordered detected data (Signal/General/Rescale.C): offset/scale per (pol, chan)."""
 

@@ -17,7 +17,8 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from .engine import Context, Dedispersion, DspsrAmdError, FilterbankEngine, FoldEngine, eight_bit_scale
+from .engine import (Context, Dedispersion, DspsrAmdError, FilterbankEngine, FoldEngine, SampleDelay, copy_data_fpt,
+                     dedispersion_sample_delays, eight_bit_scale)
 
 
 @dataclass
@@ -35,6 +36,7 @@ class Config:
     max_parts: int = 8                # parts per launch group
     fused_fold: bool = True           # fold inside the last filterbank pass when possible (identical sums, no
                                       # detected time series in HBM); False = Detection and Fold as separate ops
+    interchan_dedispersion: bool = False   # -K: remove the inter-channel dispersion delay (LoadToFold1.C:605-624)
 
 
 @dataclass
@@ -182,7 +184,8 @@ class LoadToFold:
         self.ctx = Context(device, stream)
         # kernel (host) --------------------------------------------------------------------
         self.response = Dedispersion(info.centre_frequency, info.bandwidth, cfg.dispersion_measure,
-                                     input_nchan=info.nchan, ndim=info.ndim)
+                                     input_nchan=info.nchan, ndim=info.ndim,
+                                     fractional_delay=cfg.interchan_dedispersion)       # LoadToFold1.C:620-621
         if cfg.freq_res:
             self.response.set_frequency_resolution(cfg.freq_res)
         self.response.match(cfg.nchan)
@@ -206,11 +209,28 @@ class LoadToFold:
         self.out_rate = info.rate * (float(r.ndat) / float(nsamp_fft))
         self.out_start = info.start_seconds + r.impulse_pos / self.out_rate
         self.scalefac = float(n_fft) * float(r.ndat)
-        self.detected = torch.empty((cfg.nchan, self.npol_out, cfg.parts_per_block * self.nkeep * cfg.ndim),
+        # -K: dsp::SampleDelay on the filterbank output.  Detection acts sample by sample, so delaying the detected rows
+        # gives the same numbers as delaying the complex rows first (the reference's order) and keeps the fused
+        # filterbank+detect launch group.  The last `total_delay` samples of a block are re-presented in front of the
+        # next one (InputBuffering, SampleDelay.C:117,146): they live in the head room in front of `detected`.
+        self.sample_delay, self.sd_carried, head = None, 0, 0
+        if cfg.interchan_dedispersion:
+            dual = info.ndim == 2                              # Observation.C:80-87; Filterbank.C:358-364
+            delays = dedispersion_sample_delays(info.centre_frequency, info.bandwidth, cfg.dispersion_measure, cfg.nchan,
+                                                self.out_rate, swap=dual and info.nchan == 1,
+                                                nsub_swap=info.nchan if dual and info.nchan > 1 else 0)
+            self.sample_delay = SampleDelay(self.ctx, delays, self.npol_out)
+            head = self.sample_delay.total_delay
+            if head > cfg.parts_per_block * self.nkeep:
+                raise DspsrAmdError("dspsr_amd.LoadToFold: inter-channel delay of %d samples exceeds the block of %d"
+                                    % (head, cfg.parts_per_block * self.nkeep))
+            self.out_start += self.sample_delay.zero_delay / self.out_rate       # SampleDelay.C:159
+        self.sd_head = head
+        self.detected = torch.empty((cfg.nchan, self.npol_out, (head + cfg.parts_per_block * self.nkeep) * cfg.ndim),
                                     dtype=torch.float32, device="cuda:%d" % device)
         # fused filterbank+detect+fold (no detected time series in HBM): ndim 4, three-pass geometries
         self.fused_fold = bool(cfg.fused_fold) and cfg.ndim == 4 and r.ndat <= 8192 and \
-            (cfg.nchan // info.nchan) * (2 if info.ndim == 1 else 1) >= 2
+            (cfg.nchan // info.nchan) * (2 if info.ndim == 1 else 1) >= 2 and self.sample_delay is None
         # fold bookkeeping (PhaseSeries) ---------------------------------------------------
         self.hits = np.zeros(cfg.nbin, dtype=np.uint32)
         self.integration_length = 0.0
@@ -242,12 +262,14 @@ class LoadToFold:
             raise DspsrAmdError("dspsr_amd.LoadToFold.process_block: block holds %d bytes, %d needed"
                                 % (raw.numel(), self.block_bytes(npart)))
         ndat = npart * self.nkeep
+        state = _lib.STOKES if cfg.stokes else _lib.COHERENCE
+        if self.sample_delay is not None:
+            return self._process_block_interchan(raw, npart, ndat, state, events)
         # Subint<Fold>::transformation: fold piece by piece, emitting a sub-integration at every boundary
         if self.cfg.subint_seconds > 0:
             pieces = subint_pieces(self.ndat_out, ndat, self.cfg.subint_seconds, self.out_rate)
         else:
             pieces = [(0, ndat, 0, False)]
-        state = _lib.STOKES if cfg.stokes else _lib.COHERENCE
         if self.fused_fold and len(pieces) == 1:
             # one fold call covers the block: filterbank, detection and fold in one launch group.  Same sums in the
             # same order as the unfused chain below (blocks holding a sub-integration boundary take that chain).
@@ -277,6 +299,38 @@ class LoadToFold:
         self.ndat_out += ndat
         self.nsamples_in += npart * self.nsamp_step
 
+    def _process_block_interchan(self, raw, npart, ndat, state, events):
+        """-K chain: filterbank+detect -> SampleDelay (in place, LoadToFold1.C:617-618) -> fold."""
+        cfg, nd, head = self.cfg, self.cfg.ndim, self.sd_head
+        if events is not None:
+            events[0].record()
+        self.fb.perform_detect(self.detected[:, :, head * nd:], npart, state, nd, raw=raw, layout=self.layout,
+                               scale=self.scale8)
+        if events is not None:
+            events[1].record()
+        off, nin = head - self.sd_carried, self.sd_carried + ndat
+        rows = self.detected[:, :, off * nd:(off + nin) * nd]
+        nout = self.sample_delay.transform(rows.unflatten(2, (nin, nd)))
+        if nout:
+            if cfg.subint_seconds > 0:
+                pieces = subint_pieces(self.ndat_out, nout, cfg.subint_seconds, self.out_rate)
+            else:
+                pieces = [(0, nout, 0, False)]
+            for idat_start, ndat_fold, _division, complete in pieces:
+                folded = self._set_plan(idat_start, ndat_fold)
+                self.fold.fold(rows)
+                self.integration_length += folded / self.out_rate
+                self.ndat_total += ndat_fold
+                if complete:
+                    self.finish_subint(*self._subint_comm)
+        # InputBuffering::set_next_start(output_ndat): the unshifted tail goes in front of the next block
+        carry = nin - nout
+        if carry:
+            copy_data_fpt(self.ctx, self.detected[:, :, (head - carry) * nd:head * nd], rows[:, :, nout * nd:])
+        self.sd_carried = carry
+        self.ndat_out += nout
+        self.nsamples_in += npart * self.nsamp_step
+
     _subint_comm = (None, 0, 1, None)     # (dist, rank, world, gather_buffer) used at sub-integration dumps
 
     def set_communicator(self, dist, rank, world, gather_buffer):
@@ -294,7 +348,7 @@ class LoadToFold:
     def _fold_piece(self, idat_start, ndat_fold):
         """Fold::fold (Fold.C:650-657,718-803) on detected[idat_start : idat_start+ndat_fold]."""
         folded = self._set_plan(idat_start, ndat_fold)
-        self.fold.fold(self.detected)
+        self.fold.fold(self.detected)                  # (no head room without -K)
         self.integration_length += folded / self.out_rate
         self.ndat_total += ndat_fold
 
@@ -328,6 +382,8 @@ class LoadToFold:
         self.ctx.synchronize()
 
     def close(self):
+        if self.sample_delay is not None:
+            self.sample_delay.close()
         self.fb.close()
         self.fold.close()
         self.ctx.close()

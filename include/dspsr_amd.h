@@ -181,6 +181,23 @@ uint64_t dspsr_amd_fold_get_ndat_folded(const dspsr_amd_fold* fold);
 int dspsr_amd_fold_zero(dspsr_amd_fold* fold);                                            /* Engine::zero */
 int dspsr_amd_fold_synch(dspsr_amd_fold* fold, float* profile_host);                      /* FoldCUDA.cu:127-152 (blocks) */
 
+/* ---- integer-sample inter-channel delay (-K): dsp::SampleDelay (Signal/General/SampleDelay.C:52-195) --------------
+ * create    : SampleDelay::build (:52-102) from the delay of each row, delays_host[ichan*npol+ipol] (the values
+ *             SampleDelayFunction::get_delay returns); absolute = function->get_absolute()
+ * transform : SampleDelay::transformation (:123-195): out row i = in row shifted by its applied delay, ndat_out =
+ *             ndat_in - total_delay (0 if negative); in == out allowed (LoadToFold1.C:617-618); strides in floats.
+ *             The caller shifts the start time by zero_delay samples (:159) and re-presents the last total_delay
+ *             samples with the next block (InputBuffering, :117,146). */
+typedef struct dspsr_amd_sample_delay dspsr_amd_sample_delay;
+int dspsr_amd_sample_delay_create(dspsr_amd_ctx* ctx, uint32_t nchan, uint32_t npol, const int64_t* delays_host,
+                                  int absolute, dspsr_amd_sample_delay** out);
+void dspsr_amd_sample_delay_destroy(dspsr_amd_sample_delay* h);
+int64_t dspsr_amd_sample_delay_zero_delay(const dspsr_amd_sample_delay* h);
+uint64_t dspsr_amd_sample_delay_total_delay(const dspsr_amd_sample_delay* h);
+int dspsr_amd_sample_delay_transform(dspsr_amd_sample_delay* h, const float* in_dev, uint64_t in_chan_stride,
+                                     uint64_t in_pol_stride, float* out_dev, uint64_t out_chan_stride,
+                                     uint64_t out_pol_stride, uint32_t ndim, uint64_t ndat_in, uint64_t* ndat_out);
+
 /* ---- search-mode output stage: dsp::Rescale + dsp::SigProcDigitizer on TFP-ordered data ----------
  * dspsr_amd_rescale_*        : dsp::Rescale (Signal/General/Rescale.C:157-420), scalar offset/scale per (pol, chan)
  *                              re-estimated every `interval_samples` samples (0 = length of the first block) and once
@@ -228,6 +245,11 @@ int dspsr_amd_dedispersion_prepare(const dspsr_amd_dedispersion_config* cfg, dsp
 /* Dedispersion::build + Response::match ordering (Dedispersion.C:261-331,478-556; Response.C:132-181):
  * kernel_host receives nchan*ndat complex floats */
 int dspsr_amd_dedispersion_build(const dspsr_amd_dedispersion_config* cfg, uint32_t ndat, float* kernel_host);
+/* Dedispersion::SampleDelay::match (DedispersionSampleDelay.C:24-75): delay of each channel in samples relative to the
+ * centre frequency, channel frequencies as Observation::get_centre_frequency(ichan) (Observation.C:420-451) */
+int dspsr_amd_dedispersion_sample_delays(double centre_frequency, double bandwidth, double dispersion_measure,
+                                         uint32_t nchan, double rate_hz, int swap, uint32_t nsub_swap, int dc_centred,
+                                         int64_t* delays_host);
 uint64_t dspsr_amd_optimal_fft_length(uint64_t nbadperfft, uint64_t nfft_max);           /* optimize_fft.c:63-127 */
 /* (int8+0.5)*scale constant of the 8-bit LUT (BitTable.C:165-218) for a given JA98 spacing (ext) */
 double dspsr_amd_eight_bit_scale(double ja98_spacing);

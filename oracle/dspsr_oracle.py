@@ -640,6 +640,65 @@ def tscrunch_tfp(x: np.ndarray, sfactor: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------
+# Integer-sample inter-channel delay, -K (f-4)
+# --------------------------------------------------------------------------------------
+
+def observation_channel_frequency(obs: "Observation", ichan: int, nchan: int | None = None, swap: bool = False,
+                                  nsub_swap: int = 0) -> float:
+    """Observation::get_centre_frequency(ichan) (Kernel/Classes/Observation.C:420-451)."""
+    nchan = nchan or obs.nchan
+    c = ichan
+    if swap:
+        c = (c + nchan // 2) % nchan
+    if nsub_swap:
+        sub = nchan // nsub_swap
+        c = (c // sub) * sub + (c % sub + sub // 2) % sub
+    base = obs.centre_frequency - 0.5 * obs.bandwidth
+    if not obs.dc_centred:
+        base += 0.5 * obs.bandwidth / float(nchan)
+    return base + float(c) * obs.bandwidth / float(nchan)
+
+
+def dedispersion_sample_delays(obs: "Observation", nchan: int, rate_hz: float, swap: bool = False, nsub_swap: int = 0):
+    """Dedispersion::SampleDelay::match (Signal/General/DedispersionSampleDelay.C:24-75)."""
+    if rate_hz == 0 or obs.bandwidth == 0 or obs.centre_frequency == 0:
+        raise OracleError("dsp::Dedispersion::SampleDelay::match invalid input")
+    dispersion = obs.dispersion_measure / DM_DISPERSION
+    out = np.zeros(nchan, np.int64)
+    for ichan in range(nchan):
+        freq = observation_channel_frequency(obs, ichan, nchan, swap, nsub_swap)
+        delay = dispersion * (1.0 / (obs.centre_frequency * obs.centre_frequency) - 1.0 / (freq * freq))
+        out[ichan] = int(math.floor(delay * rate_hz + 0.5))
+    return out
+
+
+def sample_delay(x: np.ndarray, delays: np.ndarray, absolute: bool = False):
+    """dsp::SampleDelay::build + transformation (Signal/General/SampleDelay.C:52-195).
+
+    x: [nchan][npol][ndat](...) ; delays: [nchan] or [nchan][npol] as SampleDelayFunction::get_delay returns.
+    Returns (output [nchan][npol][ndat - total_delay](...), zero_delay, total_delay)."""
+    nchan, npol, ndat = x.shape[:3]
+    d = np.asarray(delays, np.int64)
+    if d.ndim == 1:
+        d = np.repeat(d[:, None], npol, axis=1)
+    if absolute:                                            # :60-73
+        zero_delay, total_delay = 0, int(d.max())
+        applied = d
+    else:                                                   # :75-99
+        zero_delay = int(d.max())
+        applied = zero_delay - d if zero_delay else d       # :166-172
+        total_delay = int((zero_delay - d).max())
+    assert applied.min() >= 0                               # :174
+    nout = max(0, ndat - total_delay)                       # :137-145
+    out = np.empty((nchan, npol, nout) + x.shape[3:], x.dtype)
+    for c in range(nchan):
+        for p in range(npol):
+            a = int(applied[c, p])
+            out[c, p] = x[c, p, a:a + nout]
+    return out, zero_delay, total_delay
+
+
+# --------------------------------------------------------------------------------------
 # Search-mode output stage (f-1): Rescale + SigProcDigitizer
 # --------------------------------------------------------------------------------------
 

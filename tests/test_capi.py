@@ -141,3 +141,19 @@ def test_fractional_delay_kernel_matches_oracle(oracle):
     slope = np.diff(ph, axis=1)
     assert np.abs(slope - slope.mean(axis=1, keepdims=True)).max() < 2e-3       # float-phase quantisation only
     assert np.abs(slope.mean(axis=1)).max() > 0                                  # and it is not the identity
+
+
+@pytest.mark.parametrize("f0,bw,dm,nchan,swap,nsub,dc", [(1382.0, -400.0, 71.0, 1024, False, 0, False), (1400.0, 64.0, 10.0, 16, True, 0, False),
+                                                         (2000.0, -400.0, 500.0, 256, False, 4, True), (1382.0, -64.0, 3.0, 1, False, 0, False)])
+def test_dedispersion_sample_delays_match_oracle(oracle, f0, bw, dm, nchan, swap, nsub, dc):
+    """-K integer delays: DedispersionSampleDelay.C:24-75 in the product's host code vs the oracle (double, exact)."""
+    import dspsr_amd
+    rate = abs(bw) * 1e6 / nchan
+    obs = oracle.Observation(centre_frequency=f0, bandwidth=bw, dispersion_measure=dm, dc_centred=dc)
+    got = dspsr_amd.dedispersion_sample_delays(f0, bw, dm, nchan, rate, swap, nsub, dc)
+    want = oracle.dedispersion_sample_delays(obs, nchan, rate, swap, nsub)
+    assert np.array_equal(got, want)
+    if nchan > 1:
+        assert got.max() > 0 > got.min()                     # relative to the centre frequency
+    with pytest.raises(dspsr_amd.DspsrAmdError):
+        dspsr_amd.dedispersion_sample_delays(f0, 0.0, dm, nchan, rate)

@@ -681,3 +681,89 @@ def test_search_mode_chain_digifil(oracle, gpu):
     assert d.max() <= 1
     assert (d != 0).mean() < 1e-3
     r.close()
+
+
+@pytest.mark.parametrize("nchan,npol,ndim,ndat,inplace", [(64, 2, 2, 5000, True), (64, 2, 2, 5000, False), (1024, 2, 2, 3000, True),
+                                                         (3, 1, 1, 300000, False), (3, 1, 1, 300000, True), (16, 4, 4, 4099, True)])
+def test_sample_delay_matches_oracle(oracle, gpu, nchan, npol, ndim, ndat, inplace):
+    """dsp::SampleDelay with the dispersive delays of Dedispersion::SampleDelay (-K): a pure copy, bit exact; in place
+    (as LoadToFold1.C:617-618 wires it) and out of place."""
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(31)
+    obs = oracle.Observation(centre_frequency=1382.0, bandwidth=-64.0, dispersion_measure=3.0)
+    rate = 64e6 / nchan
+    delays = dspsr_amd.dedispersion_sample_delays(1382.0, -64.0, 3.0, nchan, rate)
+    assert np.array_equal(delays, oracle.dedispersion_sample_delays(obs, nchan, rate))
+    x = rng.standard_normal((nchan, npol, ndat, ndim)).astype(np.float32)
+    want, zero, total = oracle.sample_delay(x, delays)
+    sd = dspsr_amd.SampleDelay(ctx, delays, npol)
+    assert (sd.zero_delay, sd.total_delay) == (zero, total) and total > 0
+    xin = torch.from_numpy(x).cuda()
+    out = xin if inplace else torch.zeros_like(xin)
+    nout = sd.transform(xin, out)
+    assert nout == ndat - total > 0
+    assert np.array_equal(out.cpu().numpy()[:, :, :nout], want)
+    # fewer samples than the total delay: nothing comes out (SampleDelay.C:137-143)
+    short = torch.zeros((nchan, npol, max(total - 1, 0), ndim), dtype=torch.float32, device="cuda")
+    assert sd.transform(short) == 0
+    sd.close()
+    # absolute delays per (chan, pol)
+    dabs = rng.integers(0, 50, (nchan, npol))
+    want, zero, total = oracle.sample_delay(x, dabs, absolute=True)
+    sd = dspsr_amd.SampleDelay(ctx, dabs, npol, absolute=True)
+    assert (sd.zero_delay, sd.total_delay) == (0, total)
+    out = torch.zeros_like(xin)
+    nout = sd.transform(torch.from_numpy(x).cuda(), out)
+    assert np.array_equal(out.cpu().numpy()[:, :, :nout], want)
+    sd.close()
+
+
+@pytest.mark.parametrize("ndim", [4, 2])
+def test_pipeline_interchan_dedispersion(oracle, gpu, ndim):
+    """dspsr -K (LoadToFold1.C:605-624): fractional-delay chirp + SampleDelay between filterbank and detection, over several
+    blocks (the delayed tail is carried like InputBuffering does), against the oracle composed in the reference's order."""
+    dspsr_amd, _ = gpu
+    from dspsr_amd import pipeline, synth
+    o = oracle
+    freq, bw, tsamp, dm, period, nchan, nbin = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004, 16, 64
+    cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=ndim,
+                          parts_per_block=3, max_parts=2, interchan_dedispersion=True)
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
+    lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    assert not lt.fused_fold and lt.sample_delay.total_delay > 0
+    nblocks = 4
+    step = cfg.parts_per_block * lt.nsamp_step
+    raw = synth.voltages(nblocks * step + lt.nsamp_overlap, freq, bw, tsamp, dm, period)
+    d_raw = torch.from_numpy(raw).cuda()
+    for b in range(nblocks):
+        lt.process_block(d_raw[2 * b * step: 2 * (b * step + step + lt.nsamp_overlap)])
+    lt.finish_subint()
+    lt.synchronize()
+    sub = lt.subints[0]
+    prof = sub["profile_dev"].cpu().numpy().reshape(nchan, 4 // ndim, nbin, ndim)
+    # oracle, whole stream at once
+    obs = o.Observation(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, dispersion_measure=dm)
+    resp = o.Dedispersion()
+    resp.fractional_delay = True
+    resp.match(obs, nchan)
+    assert np.abs(lt.response.kernel - resp.buffer).max() <= 1.2e-7
+    plan = o.filterbank_plan(obs, nchan, resp)
+    fb = o.filterbank(o.unpack_8bit(raw, obs), plan, lt.response.kernel, dtype=np.float64)
+    fobs = o.filterbank_output_observation(obs, plan)
+    delays = o.dedispersion_sample_delays(fobs, nchan, fobs.rate)
+    fbd, zero, total = o.sample_delay(fb, delays)
+    assert (zero, total) == (lt.sample_delay.zero_delay, lt.sample_delay.total_delay)
+    fobs.start_seconds += zero / fobs.rate                                   # SampleDelay.C:159
+    det = o.detect_layout(o.detect_products(fbd, "Coherence"), ndim)
+    ps = o.PhaseSeries(nchan, 4 // ndim, ndim, nbin, data=np.zeros((nchan, 4 // ndim, nbin, ndim), np.float64))
+    fcfg = o.FoldConfig(nbin=nbin, folding_period=period)
+    block_out = cfg.parts_per_block * plan.nkeep
+    pos = 0
+    for b in range(nblocks):                                                 # the first block comes out `total` short
+        n = block_out - (total if b == 0 else 0)
+        o.fold(det, fobs, fcfg, ps, idat_start=pos, ndat_fold=n)
+        pos += n
+    assert pos == fbd.shape[2] == lt.ndat_out
+    assert np.array_equal(sub["hits"], ps.hits)
+    assert np.abs(prof - ps.data).max() <= 1e-5 * np.abs(ps.data).max()
+    lt.close()
