@@ -188,8 +188,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
-    ap.add_argument("--parts-per-block", type=int, default=16)
-    ap.add_argument("--max-parts", type=int, default=8)
+    ap.add_argument("--parts-per-block", type=int, default=0,
+                    help="overlap-save parts per block; 0 = 16 for the headline geometry (2^23 samples per part), "
+                         "more for smaller parts so that a block stays near 1e8 samples (capped at 256)")
+    ap.add_argument("--max-parts", type=int, default=0, help="parts per launch group; 0 = parts_per_block/2, at most 64")
     ap.add_argument("--dump-steps", type=int, default=8, help="steps per sub-integration dump")
     ap.add_argument("--ndim", type=int, default=4, choices=[1, 2, 4])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -235,6 +237,12 @@ def main():
     freq = wl["freq"] + rank * wl["bw"]
     info = pipeline.InputInfo(centre_frequency=freq, bandwidth=wl["bw"], nchan=wl["in_nchan"], npol=2,
                               ndim=wl["ndim"], tsamp_us=wl["tsamp_us"], machine=wl["machine"])
+    if not args.parts_per_block:
+        n_fft = (wl["nchan"] // wl["in_nchan"]) * wl["freq_res"]
+        nsamp_fft = 2 * n_fft if wl["ndim"] == 1 else n_fft
+        args.parts_per_block = max(16, min(256, (1 << 27) // nsamp_fft))
+    if not args.max_parts:
+        args.max_parts = max(1, min(64, args.parts_per_block // 2))
     cfg = pipeline.Config(nchan=wl["nchan"], dispersion_measure=wl["dm"], nbin=wl["nbin"],
                           folding_period=0.0893, freq_res=wl["freq_res"], ndim=args.ndim,
                           parts_per_block=args.parts_per_block, max_parts=args.max_parts,

@@ -171,25 +171,42 @@ template <int W> DEV RawW<W> fetch_pair(const FbGeom& g, const FbIn& in, const u
   } else if (g.real_input) {                            // generic 8-bit, byte (t*nchan + c)*npol + p
     const uint64_t skip = (uint64_t)in.nchan * g.npol;
     const uint8_t* b = (const uint8_t*)in.base + t * skip + (uint64_t)in.ichan * g.npol;
+    // (loads are never combined here: the words stay in flight until decode_pair, see the complex case)
     if (g.npol == 2) {
-      if (in.nchan == 1 && (((uintptr_t)b) & 3) == 0) {
-        r.w[0] = *(const uint32_t*)b;                   // (p0,p1)[t], (p0,p1)[t+1]
+      if (in.nchan == 1 && (((uintptr_t)in.base) & 3) == 0) {
+        r.w[0] = *(const uint32_t*)b;                   // (p0,p1)[t], (p0,p1)[t+1]   (t is even)
+      } else if ((((uintptr_t)in.base) & 1) == 0) {
+        r.w[0] = *(const uint16_t*)b;
+        r.w[1] = *(const uint16_t*)(b + skip);
       } else {
-        r.w[0] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[skip] << 16) | ((uint32_t)b[skip + 1] << 24);
+        r.w[0] = b[0]; r.w[2] = b[1]; r.w[1] = b[skip]; r.w[3] = b[skip + 1];
       }
     } else {
-      r.w[0] = (uint32_t)b[0] | ((uint32_t)b[skip] << 16);
+      r.w[0] = b[0];
+      r.w[1] = b[skip];
     }
   } else {                                              // generic 8-bit complex: ((t*nchan+c)*npol+p)*2+d
     const uint64_t skip = (uint64_t)in.nchan * g.npol * 2;
     const uint8_t* b = (const uint8_t*)in.base + t * skip + ((uint64_t)in.ichan * g.npol + seq) * 2;
-    r.w[0] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[skip] << 16) | ((uint32_t)b[skip + 1] << 24);
+    // two independent 16-bit loads, combined only in decode_pair: the words stay in flight while the previous tile
+    // is transformed (combining them here would wait for the loads at the prefetch)
+    if (in.nchan == 1 && g.npol == 2 && (((uintptr_t)in.base) & 7) == 0) {
+      // single channel, two polarisations: samples t, t+1 (t even) are one aligned 8-byte group holding both
+      // polarisations; one coalesced load, the polarisation is picked in decode_pair
+      const uint2 v = *(const uint2*)((const uint8_t*)in.base + t * 4);
+      r.w[0] = v.x; r.w[1] = v.y;
+    } else if ((((uintptr_t)in.base) & 1) == 0) {
+      r.w[0] = *(const uint16_t*)b;
+      r.w[1] = *(const uint16_t*)(b + skip);
+    } else {
+      r.w[0] = b[0]; r.w[2] = b[1]; r.w[1] = b[skip]; r.w[3] = b[skip + 1];
+    }
   }
   return r;
   }
 }
 
-template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const RawW<W>& r, cf& a, cf& b)
+template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const RawW<W>& r, cf& a, cf& b, const uint32_t seq = 0)
 {
   if constexpr (W == 1) {
     a = make_float2(cvt8((int8_t)(r.w[0] & 0xff), in.scale), cvt8((int8_t)((r.w[0] >> 8) & 0xff), in.scale));
@@ -211,10 +228,21 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
     a = make_float2(cvt8((int8_t)(r.w[0] & 0xff), in.scale), cvt8((int8_t)(r.w[1] & 0xff), in.scale));
     b = make_float2(cvt8((int8_t)((r.w[0] >> 8) & 0xff), in.scale), cvt8((int8_t)((r.w[1] >> 8) & 0xff), in.scale));
   } else {
-    const float v0 = cvt8((int8_t)(r.w[0] & 0xff), in.scale), v1 = cvt8((int8_t)((r.w[0] >> 8) & 0xff), in.scale);
-    const float v2 = cvt8((int8_t)((r.w[0] >> 16) & 0xff), in.scale), v3 = cvt8((int8_t)(r.w[0] >> 24), in.scale);
-    if (g.real_input && g.npol == 1) { a = make_float2(v0, 0.0f); b = make_float2(v2, 0.0f); }
-    else { a = make_float2(v0, v1); b = make_float2(v2, v3); }
+    if (g.real_input && g.npol == 1) {
+      a = make_float2(cvt8((int8_t)(r.w[0] & 0xff), in.scale), 0.0f);
+      b = make_float2(cvt8((int8_t)(r.w[1] & 0xff), in.scale), 0.0f);
+    } else if (g.real_input && in.nchan == 1 && (((uintptr_t)in.base) & 3) == 0) {     // one word: (p0,p1)[t], (p0,p1)[t+1]
+      a = make_float2(cvt8((int8_t)(r.w[0] & 0xff), in.scale), cvt8((int8_t)((r.w[0] >> 8) & 0xff), in.scale));
+      b = make_float2(cvt8((int8_t)((r.w[0] >> 16) & 0xff), in.scale), cvt8((int8_t)(r.w[0] >> 24), in.scale));
+    } else {                  // byte pair of sample t in w[0] (| w[2] << 8), of sample t+1 in w[1] (| w[3] << 8)
+      uint32_t w0 = r.w[0] | (r.w[2] << 8), w1 = r.w[1] | (r.w[3] << 8);
+      if (!g.real_input && in.nchan == 1 && g.npol == 2 && (((uintptr_t)in.base) & 7) == 0) {   // whole samples were loaded
+        w0 = r.w[0] >> (16 * seq);
+        w1 = r.w[1] >> (16 * seq);
+      }
+      a = make_float2(cvt8((int8_t)(w0 & 0xff), in.scale), cvt8((int8_t)((w0 >> 8) & 0xff), in.scale));
+      b = make_float2(cvt8((int8_t)(w1 & 0xff), in.scale), cvt8((int8_t)((w1 >> 8) & 0xff), in.scale));
+    }
   }
   }
 }
@@ -424,10 +452,11 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(ts0);
 #endif
+    const uint32_t seq_cur = (uint32_t)((item / ntile) % nseq);
 #pragma unroll
     for (int h = 0; h < NPAIR; h++) {
       cf a, b;
-      decode_pair<RAWW>(g, in, raw[h], a, b);
+      decode_pair<RAWW>(g, in, raw[h], a, b, seq_cur);
       x[h] = make_cx2(a, b);
     }
 #if defined(FB_STAMPS) && FB_STAMPS == 1
@@ -1275,6 +1304,8 @@ struct dspsr_amd_filterbank_impl {
   cf* tw_lo = nullptr;
   cf* tw_lo_m = nullptr;
   uint16_t* Rt = nullptr;   // pre-transposed 8-bit pairs of the parts of one launch group
+  float* det = nullptr;     // detected block of perform_fold when the fused kernel would not fill the chip
+  size_t det_floats = 0;
   bool kernel_set = false;
 };
 
@@ -1450,6 +1481,7 @@ extern "C" void dspsr_amd_filterbank_destroy(dspsr_amd_filterbank* fb)
   if (fb->X) (void)hipFree(fb->X);
   if (fb->kernel) (void)hipFree(fb->kernel);
   if (fb->Rt) (void)hipFree(fb->Rt);
+  if (fb->det) (void)hipFree(fb->det);
   if (fb->tw_lo) (void)hipFree(fb->tw_lo);
   if (fb->tw_lo_m) (void)hipFree(fb->tw_lo_m);
   delete fb;
@@ -1673,6 +1705,14 @@ extern "C" int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, con
   return fb_run(fb, in, out, npart, in_chan_stride);
 }
 
+extern "C" int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb)
+{
+  if (!fb || fb->g.four_pass || fb->g.nkeep >= 65536) return 0;
+  const uint64_t tiles = (uint64_t)(fb->g.C >> fb->g.logT3);
+  const uint64_t min_tiles = getenv("DSPSR_AMD_FUSED_MIN_TILES") ? (uint64_t)atoll(getenv("DSPSR_AMD_FUSED_MIN_TILES")) : fb->ncu;
+  return tiles >= min_tiles ? 1 : 0;
+}
+
 extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const float* in_f32_dev,
                                                  uint64_t in_chan_stride, uint64_t in_pol_stride, uint64_t in_step,
                                                  const int8_t* raw_dev, int raw_layout, float scale, int state,
@@ -1684,10 +1724,6 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
     return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_fold: Cannot detect polarization when npol != 2");
   if (state != DSPSR_AMD_COHERENCE && state != DSPSR_AMD_STOKES)
     return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_fold: invalid state=%d", state);
-  if (fb->g.four_pass)
-    return fb_fail(ctx, DSPSR_AMD_EINVAL,
-                   "dspsr_amd_filterbank_perform_fold: the fused fold needs the three-pass geometry (freq_res <= 8192); "
-                   "use perform_detect + dspsr_amd_fold_fold");
   const uint32_t nchan = fb->cfg.input_nchan * fb->g.C;
   if (!fold->profile || fold->nchan != nchan || fold->npol != 1 || fold->ndim != 4)
     return fb_fail(ctx, DSPSR_AMD_EINVAL,
@@ -1711,6 +1747,29 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
     if (raw_layout != DSPSR_AMD_RAW_CASPSR && raw_layout != DSPSR_AMD_RAW_GENERIC && raw_layout != DSPSR_AMD_RAW_UWB16)
       return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_fold: unknown raw layout %d", raw_layout);
     in = {raw_kind(raw_layout), raw_dev, 0, step, fb->cfg.input_nchan, 0, scale};
+  }
+  // In the fused kernel one workgroup owns a tile of channels for all parts of a launch (that keeps the sums in
+  // time order), so it only pays when the channel tiles alone fill the chip: measured on MI355X, 512 tiles
+  // (-F 1024:D -x 4096) +14 %, 128 tiles (-F 256:D) -13 %, 32 tiles (-F 512:D on a 50 MHz sub-band) 4x slower.
+  // Below the threshold, and for the four-pass geometry, Detection and Fold run as separate launches on an
+  // internal block -- the sums are bit-identical either way.
+  if (!dspsr_amd_filterbank_fold_is_fused(fb)) {
+    const uint64_t row = npart * fb->g.nkeep * 4;                       // floats per channel
+    const size_t need = (size_t)row * nchan;
+    if (!need) return DSPSR_AMD_OK;
+    if (need > fb->det_floats) {
+      (void)hipStreamSynchronize(ctx->stream);
+      if (fb->det) (void)hipFree(fb->det);
+      fb->det = nullptr;
+      fb->det_floats = 0;
+      if (hipMalloc((void**)&fb->det, need * sizeof(float)) != hipSuccess)
+        return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform_fold: hipMalloc of %zu bytes failed", need * sizeof(float));
+      fb->det_floats = need;
+    }
+    FbOut dout = {2, fb->det, row, 0, 0, state, 4, 0};
+    const int rc = fb_run(fb, in, dout, npart, in_chan_stride);
+    if (rc != DSPSR_AMD_OK) return rc;
+    return dspsr_amd_fold_fold(fold, fb->det, row, 0);
   }
   const uint32_t* d_start = nullptr;
   const Interval* d_iv = nullptr;

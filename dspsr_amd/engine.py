@@ -199,6 +199,10 @@ class FilterbankEngine:
                                                        state, ndim, det.data_ptr(), dcs, dps, npart),
                "dspsr_amd_filterbank_perform_detect")
 
+    def fold_is_fused(self) -> bool:
+        """True when perform_fold folds inside the last filterbank pass (else it runs Detection + Fold launches)."""
+        return bool(lib.dspsr_amd_filterbank_fold_is_fused(self.handle))
+
     def perform_fold(self, fold, npart, state=_lib.COHERENCE, inp=None, in_step=0, raw=None,
                      layout=_lib.RAW_GENERIC, scale=1.0):
         """Fused filterbank -> detection (ndim 4) -> fold into `fold`'s device profile; the bin plan of the

@@ -229,8 +229,9 @@ class LoadToFold:
         self.detected = torch.empty((cfg.nchan, self.npol_out, (head + cfg.parts_per_block * self.nkeep) * cfg.ndim),
                                     dtype=torch.float32, device="cuda:%d" % device)
         # fused filterbank+detect+fold (no detected time series in HBM): ndim 4, three-pass geometries
-        self.fused_fold = bool(cfg.fused_fold) and cfg.ndim == 4 and r.ndat <= 8192 and \
-            (cfg.nchan // info.nchan) * (2 if info.ndim == 1 else 1) >= 2 and self.sample_delay is None
+        # (the library decides whether fusing pays for this geometry; when it does not, this driver keeps the
+        # separate Detection and Fold operations on its own `detected` block)
+        self.fused_fold = bool(cfg.fused_fold) and cfg.ndim == 4 and self.sample_delay is None and self.fb.fold_is_fused()
         # fold bookkeeping (PhaseSeries) ---------------------------------------------------
         self.hits = np.zeros(cfg.nbin, dtype=np.uint32)
         self.integration_length = 0.0

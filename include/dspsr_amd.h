@@ -129,8 +129,11 @@ int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, const float* i
  * The bin plan of the npart*nkeep output samples of this call must have been handed to `fold` beforehand
  * (dspsr_amd_fold_set_nbin / set_ndat / set_bin(s) with sample indices counted from the first output sample of
  * this call); it is consumed.  Sums are accumulated into the device profile of `fold` in time order per
- * (chan, bin), bit-identical to perform_detect followed by dspsr_amd_fold_fold.  Three-pass geometries only
- * (freq_res <= 8192); otherwise DSPSR_AMD_EINVAL and the caller uses the unfused chain. */
+ * (chan, bin), bit-identical to perform_detect followed by dspsr_amd_fold_fold.
+ * The fold happens inside the last filterbank pass when that fills the chip (three-pass geometry, at least one
+ * tile of channels per compute unit: dspsr_amd_filterbank_fold_is_fused() == 1); otherwise the same call runs
+ * Detection and Fold as separate launches on a block owned by the filterbank object -- same sums either way. */
+int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb);
 int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const float* in_f32_dev, uint64_t in_chan_stride,
                                       uint64_t in_pol_stride, uint64_t in_step, const int8_t* raw_dev, int raw_layout,
                                       float scale, int state, dspsr_amd_fold* fold, uint64_t npart);

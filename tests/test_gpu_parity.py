@@ -253,7 +253,7 @@ def test_copy_data_fpt(gpu):
 
 def test_edge_cases_empty_and_ragged(oracle, gpu):
     """npart = 0 is a no-op, an empty fold plan leaves the profile untouched, a ragged last block (fewer parts
-    than the block size) folds like the oracle, and the fused fold refuses the four-pass geometry loudly."""
+    than the block size) folds like the oracle, and perform_fold on a four-pass geometry takes the unfused chain."""
     dspsr_amd, ctx = gpu
     o = oracle
     C, M, nfilt = 8, 64, (5, 7)
@@ -272,15 +272,26 @@ def test_edge_cases_empty_and_ragged(oracle, gpu):
     eng.perform_fold(fold, 0, dspsr_amd.COHERENCE, raw=raw, scale=1.0)             # zero parts, empty plan
     assert float(np.abs(fold.synch()).max()) == 0.0
     eng.close()
-    # fused fold on a four-pass geometry: EINVAL, the caller falls back to detect + fold
+    # perform_fold on a four-pass geometry: not fused, the library runs Detection and Fold itself -- same sums
     big = dspsr_amd.FilterbankEngine(ctx).setup(2, 16384, 100, 100, 1, 2, True, None, max_parts=1)
-    f2 = dspsr_amd.FoldEngine(ctx)
-    f2.set_shape(2, 1, 4, 16)
-    f2.set_nbin(16)
-    with pytest.raises(dspsr_amd.DspsrAmdError):
-        big.perform_fold(f2, 1, dspsr_amd.COHERENCE, raw=torch.zeros(1 << 17, dtype=torch.int8, device="cuda"), scale=1.0)
+    assert not big.fold_is_fused()
+    nk = 16384 - 200
+    braw = torch.from_numpy(_raw(1 << 16, seed=9)).cuda()
+    f2, f3 = dspsr_amd.FoldEngine(ctx), dspsr_amd.FoldEngine(ctx)
+    h2, h3 = np.zeros(16, np.uint32), np.zeros(16, np.uint32)
+    for f, h in ((f2, h2), (f3, h3)):
+        f.set_shape(2, 1, 4, 16)
+        f.set_nbin(16)
+        f.set_ndat(nk, 0)
+        f.set_bins(0.1, 1.0 / 77.7, nk, 0, h)
+    big.perform_fold(f2, 1, dspsr_amd.COHERENCE, raw=braw, scale=1.0)
+    bdet = torch.zeros((2, 1, 4 * nk), dtype=torch.float32, device="cuda")
+    big.perform_detect(bdet, 1, dspsr_amd.COHERENCE, 4, raw=braw, scale=1.0)
+    f3.fold(bdet)
+    assert np.array_equal(f2.synch(), f3.synch()) and np.abs(f2.synch()).max() > 0
     big.close()
     f2.close()
+    f3.close()
     fold.close()
     # ragged block through the pipeline driver: 3 parts, then 1 part
     from dspsr_amd import pipeline, synth
@@ -483,10 +494,15 @@ def test_end_to_end_folded_profile(oracle, gpu):
     (64, 128, (9, 10), 100, 1234.5, "Stokes"),          # nbin not a power of two
     (2, 2048, (100, 50), 1500, 333.3, "Coherence"),     # nbin beyond the workgroup size
 ])
-def test_fused_fold_bit_identical(oracle, gpu, C, M, nfilt, nbin, period_samples, state):
+@pytest.mark.parametrize("force_fused", [True, False])
+def test_fused_fold_bit_identical(oracle, gpu, monkeypatch, C, M, nfilt, nbin, period_samples, state, force_fused):
     """perform_fold (fold inside the last filterbank pass) == perform_detect + FoldEngine.fold, bit for bit,
-    over several calls and launch groups (accumulators re-loaded from the device profile)."""
+    over several calls and launch groups (accumulators re-loaded from the device profile).  These geometries have
+    fewer channel tiles than the chip has compute units, where the library would not fuse by itself:
+    DSPSR_AMD_FUSED_MIN_TILES=0 forces the fused kernel, the default takes the internal Detection + Fold chain."""
     dspsr_amd, ctx = gpu
+    if force_fused:
+        monkeypatch.setenv("DSPSR_AMD_FUSED_MIN_TILES", "0")
     o = oracle
     N = C * M
     nkeep = M - sum(nfilt)
@@ -496,6 +512,7 @@ def test_fused_fold_bit_identical(oracle, gpu, C, M, nfilt, nbin, period_samples
     kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, N)).astype(np.complex64)
     st = dspsr_amd.STOKES if state == "Stokes" else dspsr_amd.COHERENCE
     eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, 2, True, kernel, max_parts=2)
+    assert eng.fold_is_fused() == force_fused
     folds = [dspsr_amd.FoldEngine(ctx), dspsr_amd.FoldEngine(ctx)]
     hits = [np.zeros(nbin, np.uint32), np.zeros(nbin, np.uint32)]
     for f in folds:
@@ -521,9 +538,10 @@ def test_fused_fold_bit_identical(oracle, gpu, C, M, nfilt, nbin, period_samples
         f.close()
 
 
-def test_pipeline_fused_equals_unfused(oracle, gpu):
+def test_pipeline_fused_equals_unfused(oracle, gpu, monkeypatch):
     """LoadToFold with and without the fused fold over blocks with sub-integration boundaries: identical dumps."""
     dspsr_amd, _ = gpu
+    monkeypatch.setenv("DSPSR_AMD_FUSED_MIN_TILES", "0")      # small geometry: fuse although it does not fill the chip
     from dspsr_amd import pipeline, synth
     freq, bw, tsamp, dm, period, nchan, nbin = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004, 16, 64
     info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")

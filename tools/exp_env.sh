@@ -6,6 +6,6 @@ i=0
 for e in "$@"; do
   i=$((i+1))
   rm -rf gpurun_out/ee_$i
-  env $e timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ee_$i -- python bench.py --steps 6 --warmup 1 --no-cpu-baseline > gpurun_out/ee_$i.log 2>&1
+  env $e timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ee_$i -- python bench.py --steps 6 --warmup 1 --no-cpu-baseline $BENCH_ARGS > gpurun_out/ee_$i.log 2>&1
   echo "== $n [$e]"; python tools/kstats.py gpurun_out/ee_$i; grep -o '"value": [0-9.]*' gpurun_out/ee_$i.log
 done
