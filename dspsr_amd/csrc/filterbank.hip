@@ -148,6 +148,12 @@ template <int W> DEV RawW<W> fetch_pair(const FbGeom& g, const FbIn& in, const u
     // the pre-transposed copy; t is the byte-pair index
     r.w[0] = *(const uint32_t*)((const uint8_t*)in.base + 2 * t);
     return r;
+  } else if constexpr (W == 2) {
+    // tiles of 4 columns read straight from the 8-bit stream: the 4 samples x 2 polarisations of a row are one
+    // aligned 8-byte group (CASPSR: 4 B pol0, 4 B pol1; generic: (p0,p1) x 4); both column pairs load the group
+    const uint2 v = *(const uint2*)((const uint8_t*)in.base + (t >> 2) * 8);
+    r.w[0] = v.x; r.w[1] = v.y;
+    return r;
   } else {
   if (in.kind == 0) {                                   // float32 rows
     if (g.real_input) {
@@ -211,6 +217,17 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
   if constexpr (W == 1) {
     a = make_float2(cvt8((int8_t)(r.w[0] & 0xff), in.scale), cvt8((int8_t)((r.w[0] >> 8) & 0xff), in.scale));
     b = make_float2(cvt8((int8_t)((r.w[0] >> 16) & 0xff), in.scale), cvt8((int8_t)(r.w[0] >> 24), in.scale));
+    return;
+  } else if constexpr (W == 2) {                        // `seq` carries the first column of the pair (0 or 2)
+    if (in.kind == 2) {
+      const uint32_t p0 = r.w[0] >> (8 * seq), p1 = r.w[1] >> (8 * seq);
+      a = make_float2(cvt8((int8_t)(p0 & 0xff), in.scale), cvt8((int8_t)(p1 & 0xff), in.scale));
+      b = make_float2(cvt8((int8_t)((p0 >> 8) & 0xff), in.scale), cvt8((int8_t)((p1 >> 8) & 0xff), in.scale));
+    } else {
+      const uint32_t w = seq ? r.w[1] : r.w[0];
+      a = make_float2(cvt8((int8_t)(w & 0xff), in.scale), cvt8((int8_t)((w >> 8) & 0xff), in.scale));
+      b = make_float2(cvt8((int8_t)((w >> 16) & 0xff), in.scale), cvt8((int8_t)(w >> 24), in.scale));
+    }
     return;
   } else {
   if (in.kind == 0) {
@@ -456,7 +473,8 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
 #pragma unroll
     for (int h = 0; h < NPAIR; h++) {
       cf a, b;
-      decode_pair<RAWW>(g, in, raw[h], a, b, seq_cur);
+      decode_pair<RAWW>(g, in, raw[h], a, b,
+                        RAWW == 2 ? ((P::G1 * tid + 2 * (h / P::R1)) & (T - 1)) : seq_cur);
       x[h] = make_cx2(a, b);
     }
 #if defined(FB_STAMPS) && FB_STAMPS == 1
@@ -1215,7 +1233,11 @@ void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, con
 
 #ifdef FB_ONLY_HEADLINE   // experiment builds: only the kernels of the headline geometry (M = 4096, Rr = 2048, 8-bit)
 #if FB_HAS(1)
-k1_t fb_pick1(int logf, int raww, bool full) { return logf == 12 && raww == 1 ? (full ? k_fwd_cols<12, 1, 2> : k_fwd_cols<12, 1, -1>) : nullptr; }
+k1_t fb_pick1(int logf, int raww, bool full)
+{
+  if (logf == 12 && raww == 2 && full) return k_fwd_cols<12, 2, 2>;
+  return logf == 12 && raww == 1 ? (full ? k_fwd_cols<12, 1, 2> : k_fwd_cols<12, 1, -1>) : nullptr;
+}
 #endif
 #if FB_HAS(2)
 k2_t fb_pick2(int logf, bool full) { return logf == 11 ? (full ? k_fwd_rows<11, 3> : k_fwd_rows<11, -1>) : nullptr; }
@@ -1555,7 +1577,13 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
     if (hipMalloc((void**)&fb->Rt, (size_t)fb->max_parts * fb->L * sizeof(uint16_t)) != hipSuccess)
       return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of the 8-bit regroup buffer failed");
   }
-  const int raww = (pret || (fast8 && in.kind == 1)) ? 1 : 4;
+  int raww = (pret || (fast8 && in.kind == 1)) ? 1 : 4;
+#ifdef FB_ONLY_HEADLINE
+  if (fast8 && getenv("DSPSR_AMD_DIRECT8") && g.logT1 == 2 && (in.part_step % 4) == 0 && ((uintptr_t)in.base % 8) == 0) {
+    pret = false;     // experiment: 4-column tiles read straight from the stream (no regroup pass)
+    raww = 2;
+  }
+#endif
   const bool notfixed = getenv("DSPSR_AMD_RUNTIME_LOGT") != nullptr;    // experiments: force the generic kernels
   const bool full1 = !notfixed && g.logT1 == full_logt(g.logM), full2 = !notfixed && g.logT2 == full_logt(g.logR),
              full3 = !notfixed && !g.four_pass && g.logT3 + 1 == full_logt(g.logM);

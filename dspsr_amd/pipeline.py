@@ -147,6 +147,86 @@ def normalise_profile(profile, hits, scale):
     return amps.astype(np.float32)
 
 
+# ---- archive hand-off: a PhaseSeries on disk, one file per sub-integration ------------------------
+# DSPSR's Archiver needs PSRCHIVE (not available to this library), so a finished sub-integration is handed over as a
+# self-describing file that carries exactly the members dsp::Archiver::set reads from a dsp::PhaseSeries
+# (Archiver.C:430-893): the Observation keys in the DADA ASCII convention (ASCIIObservation.C:82-415), then
+# hits[nbin] (uint32, little endian) and the profile sums [nchan][npol][nbin][ndim] (float32, little endian,
+# un-normalised: Archiver divides by scale*hits, :773-893).  INTEGRATION.md shows the reader a maintainer adds.
+PHASE_SERIES_MAGIC = "DSPSR_AMD_PHASESERIES"
+PHASE_SERIES_HDR_SIZE = 4096
+
+
+def write_phase_series(path, sub, info: "InputInfo", cfg: "Config", *, nchan=None, npol=1, scale=1.0, division=0,
+                       start_seconds=0.0, folding_period=0.0, reference_phase=0.0, state=None):
+    """sub: a dict as LoadToFold.subints holds (hits, integration_length, ndat_total, profile or profile_dev)."""
+    prof = sub.get("profile")
+    if prof is None:
+        prof = sub["profile_dev"].cpu().numpy()
+    nchan = nchan or cfg.nchan
+    nbin = len(sub["hits"])
+    prof = np.ascontiguousarray(np.asarray(prof, dtype="<f4").reshape(nchan, npol, nbin, cfg.ndim))
+    keys = [("HDR_MAGIC", PHASE_SERIES_MAGIC), ("HDR_VERSION", "1.0"), ("HDR_SIZE", PHASE_SERIES_HDR_SIZE),
+            ("FREQ", repr(float(info.centre_frequency))), ("BW", repr(float(info.bandwidth))), ("NCHAN", nchan),
+            ("NPOL", npol), ("NDIM", cfg.ndim), ("NBIN", nbin),
+            ("STATE", state or ("Stokes" if cfg.stokes else "Coherence")),
+            ("DM", repr(float(cfg.dispersion_measure))), ("SCALE", repr(float(scale))),
+            ("MJD_DAY", info.mjd_day), ("MJD_SEC", repr(float(info.mjd_sec))),
+            ("OBS_OFFSET_SECONDS", repr(float(start_seconds))), ("DIVISION", division),
+            ("INTEGRATION_LENGTH", repr(float(sub["integration_length"]))), ("NDAT_TOTAL", int(sub["ndat_total"])),
+            ("FOLDING_PERIOD", repr(float(folding_period))), ("REFERENCE_PHASE", repr(float(reference_phase)))]
+    text = "".join("%-20s %s\n" % (k, v) for k, v in keys)
+    if len(text) >= PHASE_SERIES_HDR_SIZE:
+        raise DspsrAmdError("write_phase_series: header does not fit %d bytes" % PHASE_SERIES_HDR_SIZE)
+    with open(path, "wb") as f:
+        f.write(text.encode("ascii").ljust(PHASE_SERIES_HDR_SIZE, b"\0"))
+        f.write(np.asarray(sub["hits"], dtype="<u4").tobytes())
+        f.write(prof.tobytes())
+
+
+def read_phase_series(path):
+    """Returns (header dict, hits uint32[nbin], profile float32 [nchan][npol][nbin][ndim])."""
+    with open(path, "rb") as f:
+        raw = f.read(PHASE_SERIES_HDR_SIZE)
+        hdr = {}
+        for line in raw.split(b"\0", 1)[0].decode("ascii").splitlines():
+            parts = line.split(None, 1)
+            if len(parts) == 2:
+                hdr[parts[0]] = parts[1].strip()
+        if hdr.get("HDR_MAGIC") != PHASE_SERIES_MAGIC:
+            raise DspsrAmdError("read_phase_series: %s is not a %s file" % (path, PHASE_SERIES_MAGIC))
+        nchan, npol, nbin, ndim = (int(hdr[k]) for k in ("NCHAN", "NPOL", "NBIN", "NDIM"))
+        hits = np.frombuffer(f.read(4 * nbin), dtype="<u4").copy()
+        body = f.read(4 * nchan * npol * nbin * ndim)
+        if len(hits) != nbin or len(body) != 4 * nchan * npol * nbin * ndim:
+            raise DspsrAmdError("read_phase_series: %s is truncated" % path)
+        prof = np.frombuffer(body, dtype="<f4").reshape(nchan, npol, nbin, ndim).copy()
+    return hdr, hits, prof
+
+
+def combine_phase_series(a, b):
+    """dsp::PhaseSeries::combine (PhaseSeries.C:442-484) on sub-integration dicts (host arrays): how UnloaderShare
+    merges the pieces of one division folded by time-sliced replicas.  An empty `a` (integration_length 0) becomes a
+    copy of `b`; otherwise profiles, hits, integration_length and ndat_total add."""
+    if b is None or len(b["hits"]) == 0:
+        return a
+    pb = b.get("profile")
+    if pb is None:
+        pb = b["profile_dev"].cpu().numpy()
+    if a is None or not a["integration_length"]:
+        return {"hits": np.array(b["hits"], dtype=np.uint32), "integration_length": float(b["integration_length"]),
+                "ndat_total": int(b["ndat_total"]), "profile": np.array(pb, dtype=np.float32)}
+    pa = a.get("profile")
+    if pa is None:
+        pa = a["profile_dev"].cpu().numpy()
+    if np.shape(pa) != np.shape(pb) or len(a["hits"]) != len(b["hits"]):
+        raise DspsrAmdError("PhaseSeries::combine PhaseSeries !mixable")
+    return {"hits": (np.asarray(a["hits"], dtype=np.uint32) + np.asarray(b["hits"], dtype=np.uint32)),
+            "integration_length": float(a["integration_length"]) + float(b["integration_length"]),
+            "ndat_total": int(a["ndat_total"]) + int(b["ndat_total"]),
+            "profile": (np.asarray(pa, dtype=np.float32) + np.asarray(pb, dtype=np.float32))}
+
+
 def reduce_subbands(prof, dist=None, rank=0, world=1, gather_buffer=None):
     """The ONE collective of the path.  Each rank holds the folded profile of its own frequency sub-band
     (flat [nchan*npol*nbin*ndim] float32).  The full-band buffer [world][...] is zero outside the rank's

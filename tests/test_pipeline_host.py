@@ -65,3 +65,60 @@ def test_normalise_profile_matches_oracle(oracle):
     ps.hits[0] = 0
     got = pipeline.normalise_profile(ps.data, ps.hits, 4096.0 * 4194304.0)
     assert np.array_equal(got, oracle.archive_profile(ps, 4096.0 * 4194304.0))
+
+
+def test_phase_series_file_round_trip(tmp_path):
+    """Archive hand-off: the sub-integration file carries hits + un-normalised sums + the observation keys."""
+    from dspsr_amd import pipeline
+    rng = np.random.default_rng(3)
+    cfg = pipeline.Config(nchan=8, dispersion_measure=12.5, nbin=32, folding_period=0.0893, ndim=4)
+    info = pipeline.InputInfo(centre_frequency=1382.0, bandwidth=-16.0)
+    sub = {"hits": rng.integers(0, 100, 32).astype(np.uint32), "integration_length": 1.25, "ndat_total": 12345,
+           "profile": rng.standard_normal((8, 1, 32, 4)).astype(np.float32)}
+    path = str(tmp_path / "sub0.ps")
+    pipeline.write_phase_series(path, sub, info, cfg, scale=4096.0 * 32, division=3, start_seconds=0.5,
+                                folding_period=0.0893)
+    hdr, hits, prof = pipeline.read_phase_series(path)
+    assert hdr["HDR_MAGIC"] == pipeline.PHASE_SERIES_MAGIC and int(hdr["HDR_SIZE"]) == 4096
+    assert (float(hdr["FREQ"]), float(hdr["BW"]), float(hdr["DM"])) == (1382.0, -16.0, 12.5)
+    assert (int(hdr["DIVISION"]), int(hdr["NDAT_TOTAL"]), float(hdr["INTEGRATION_LENGTH"])) == (3, 12345, 1.25)
+    assert hdr["STATE"] == "Coherence" and float(hdr["SCALE"]) == 4096.0 * 32
+    assert np.array_equal(hits, sub["hits"]) and np.array_equal(prof, sub["profile"])
+    with open(path, "r+b") as f:
+        f.truncate(4096 + 4 * 32 + 10)
+    with pytest.raises(pipeline.DspsrAmdError, match="truncated"):
+        pipeline.read_phase_series(path)
+    bad = tmp_path / "bad.ps"
+    bad.write_bytes(b"HDR_MAGIC something\n".ljust(4096, b"\0"))
+    with pytest.raises(pipeline.DspsrAmdError, match="is not a"):
+        pipeline.read_phase_series(str(bad))
+
+
+def test_combine_phase_series_matches_oracle_fold_of_time_slices(oracle):
+    """PhaseSeries::combine semantics: two replicas folding consecutive time slices of the same division, merged,
+    equal one fold of the whole span (hits exactly; sums to float rounding)."""
+    from dspsr_amd import pipeline
+    o = oracle
+    rng = np.random.default_rng(4)
+    nchan, nbin, ndat = 4, 16, 4000
+    det = rng.standard_normal((nchan, 1, ndat, 4)).astype(np.float32)
+    obs = o.Observation(centre_frequency=1382.0, bandwidth=-4.0, tsamp_us=1.0)
+    cfg = o.FoldConfig(nbin=nbin, folding_period=0.000731)
+    parts = []
+    for a, b in ((0, 1500), (1500, 4000)):
+        ps = o.PhaseSeries(nchan, 1, 4, nbin, data=np.zeros((nchan, 1, nbin, 4), np.float32))
+        o.fold(det, obs, cfg, ps, idat_start=a, ndat_fold=b - a)
+        parts.append({"hits": ps.hits.copy(), "integration_length": ps.integration_length, "ndat_total": ps.ndat_total,
+                      "profile": ps.data.copy()})
+    whole = o.PhaseSeries(nchan, 1, 4, nbin, data=np.zeros((nchan, 1, nbin, 4), np.float64))
+    o.fold(det, obs, cfg, whole, idat_start=0, ndat_fold=1500)
+    o.fold(det, obs, cfg, whole, idat_start=1500, ndat_fold=2500)
+    merged = pipeline.combine_phase_series(None, parts[0])
+    assert merged["integration_length"] == parts[0]["integration_length"]         # empty + b = copy of b
+    merged = pipeline.combine_phase_series(merged, parts[1])
+    assert np.array_equal(merged["hits"], whole.hits) and merged["ndat_total"] == ndat
+    assert abs(merged["integration_length"] - whole.integration_length) < 1e-12
+    assert np.abs(merged["profile"] - whole.data).max() <= 1e-5 * np.abs(whole.data).max()
+    with pytest.raises(pipeline.DspsrAmdError, match="mixable"):
+        pipeline.combine_phase_series(merged, {"hits": np.zeros(8, np.uint32), "integration_length": 1.0, "ndat_total": 1,
+                                               "profile": np.zeros((nchan, 1, 8, 4), np.float32)})
