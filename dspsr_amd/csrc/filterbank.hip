@@ -268,10 +268,23 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
 // table (the remaining low bits of j), both correctly rounded -> about 1.2e-7 relative error.
 // NT twiddles exp(-2*pi*i*j[q]/2^logL) at once: all table loads are issued back to back (one memory round trip)
 // and only then combined -- evaluating them one by one costs a dependent L1/L2 round trip each
+#ifndef FB_TABLE_TWIDDLES
+#define FB_TABLE_TWIDDLES 0   // 1: pass twiddles from the (coarse x fine) tables for every length (comparison builds)
+#endif
 template <int NT> DEV void twiddles_big(cf (&t)[NT], const uint64_t (&j)[NT], const int logL, const cf* __restrict__ tw,
                                         const cf* __restrict__ tw_lo)
 {
-  if (logL <= LOG_TWN) {                       // uniform
+  if (logL <= 24 && !FB_TABLE_TWIDDLES) {      // uniform
+    // v_cos_f32 / v_sin_f32 take their argument in revolutions: j / 2^logL is exact in float, and the measured
+    // error over all j of 2^23 (tools/sincos_probe.hip) is 1.25e-7 max, 3.5e-8 rms -- the same as the product of the
+    // coarse and fine table entries, without their loads and the memory round trip in front of the ladder
+    const float sc = __uint_as_float((uint32_t)(127 - logL) << 23);
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+      const float x = (float)(uint32_t)j[q] * sc;
+      t[q] = make_float2(__builtin_amdgcn_cosf(x), -__builtin_amdgcn_sinf(x));
+    }
+  } else if (logL <= LOG_TWN) {                // uniform
 #pragma unroll
     for (int q = 0; q < NT; q++) t[q] = tw[j[q] << (LOG_TWN - logL)];
   } else {
