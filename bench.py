@@ -117,14 +117,19 @@ def algorithmic_bytes_per_part(npol, nsamp_fft, nbit, N, nchan_subband, nkeep):
 def measured_traffic(workload, max_parts, key="hbm_bytes_per_launch_group"):
     """HBM bytes per launch group from the committed PMC profile (rocprofv3 cannot run inside the bench);
     None when the profile was taken for another workload / grouping."""
-    for name in ("r01e_traffic.json", "r01c_traffic.json", "r01b_traffic.json"):
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):   # newest round first
         try:
-            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            d = json.load(open(path))
             if d["workload"] == workload and d["parts_per_launch_group"] == max_parts and key in d:
+                measured_traffic.source = os.path.relpath(path, ROOT)
                 return d[key]
         except Exception:
             pass
     return None
+
+
+measured_traffic.source = None
 
 
 def _cpu_port_run(args):
@@ -189,8 +194,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--parts-per-block", type=int, default=0,
-                    help="overlap-save parts per block; 0 = 16 for the headline geometry (2^23 samples per part), "
-                         "more for smaller parts so that a block stays near 1e8 samples (capped at 256)")
+                    help="overlap-save parts per block; 0 = 64 for the headline geometry (2^23 samples per part), "
+                         "more for smaller parts so that a block stays near 5e8 samples (capped at 256)")
     ap.add_argument("--max-parts", type=int, default=0, help="parts per launch group; 0 = parts_per_block/2, at most 64")
     ap.add_argument("--dump-steps", type=int, default=8, help="steps per sub-integration dump")
     ap.add_argument("--ndim", type=int, default=4, choices=[1, 2, 4])
@@ -240,7 +245,7 @@ def main():
     if not args.parts_per_block:
         n_fft = (wl["nchan"] // wl["in_nchan"]) * wl["freq_res"]
         nsamp_fft = 2 * n_fft if wl["ndim"] == 1 else n_fft
-        args.parts_per_block = max(16, min(256, (1 << 27) // nsamp_fft))
+        args.parts_per_block = max(16, min(256, (1 << 29) // nsamp_fft))
     if not args.max_parts:
         args.max_parts = max(1, min(64, args.parts_per_block // 2))
     cfg = pipeline.Config(nchan=wl["nchan"], dispersion_measure=wl["dm"], nbin=wl["nbin"],
@@ -331,7 +336,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic(args.workload, cfg.max_parts),
-                         "traffic_unit": "HBM bytes per launch group of %d parts (PMC, profiles/r01e_traffic.json); "
+                         "traffic_unit": "HBM bytes per launch group of %d parts (PMC, profiles/r*_traffic.json, newest); "
                                          "algorithmic bytes for the same group: %d" % (cfg.max_parts, b_alg * cfg.max_parts),
                          "kernel": "filterbank launch group k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,false> "
                                    "(FFT+chirp+detect, detected output written)",

@@ -936,27 +936,59 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         }
       }
     };
+    // FOLD: active phase bins of this part: entries {bin, first interval, count<<16 | hits0, offset0}
+    // (fold_internal.h), copied to LDS at the start of the tile when they fit; one (entry, channel) accumulator per
+    // work item.  The accumulator of a thread's first work item (nearly always its only one) is requested in the
+    // middle of the transform -- behind two barriers, so the previous part's stores of this workgroup are visible --
+    // and arrives while the last stage runs, instead of costing a memory round trip in the fold phase.
+    uint32_t f_e0 = 0, f_nact = 0;
+    const uint4* __restrict__ ent = nullptr;
+    const uint4* planl = nullptr;
+    bool in_lds = false;
+    uint4 en_pre = make_uint4(0, 0, 0, 0);
+    float4 acc_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr bool PRE = FOLD && FftPlan<LOGF>::NS >= 2;
+    if constexpr (FOLD) {
+      f_e0 = out.pstart[part];
+      f_nact = (g.dbg & 16) ? 0u : out.pstart[part + 1] - f_e0;
+      ent = (const uint4*)(out.pstart + ((out.nparts_plan + 1 + 3) & ~3u)) + f_e0;
+      planl = (const uint4*)&lds[plan_off] + (jt & 1) * out.plan_cap;
+      in_lds = f_nact <= out.plan_cap;
+    }
+    auto acc_ptr = [&](const uint32_t w, const uint32_t b) {
+      return (float4*)out.base + (uint64_t)(out.chan0 + tile * T3 + (w & (T3 - 1))) * out.nbin + b;
+    };
+    auto mid = [&](const int phase) {
+      if constexpr (PRE) {
+        if (phase == 2 && tid < (f_nact << logT3)) {
+          en_pre = in_lds ? planl[tid >> logT3] : ent[tid >> logT3];
+          acc_pre = *acc_ptr(tid, en_pre.x);
+        }
+      }
+    };
     if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
-    else wgfft<LOGF, +1, FOLD>(lds, ltw_off, tid, logT, x, store);
+    else wgfft<LOGF, +1, FOLD>(lds, ltw_off, tid, logT, x, store, mid);
 #if defined(FB_STAMPS) && FB_STAMPS == 3
     STAMP(ts3);
 #endif
     if constexpr (FOLD) {
       __syncthreads();                       // the tile's detected samples are staged
-      // active phase bins of this part: entries {bin, first interval, count<<16 | hits0, offset0} (fold_internal.h),
-      // copied to LDS at the start of the tile when they fit; one (entry, channel) accumulator per work item; the
-      // samples of an interval are fetched from LDS eight at a time (independent loads) and then added one after the
-      // other, so the sum keeps the time order
-      const uint32_t e0 = out.pstart[part], nact = out.pstart[part + 1] - e0;
-      const uint4* __restrict__ ent = (const uint4*)(out.pstart + ((out.nparts_plan + 1 + 3) & ~3u)) + e0;
-      const uint4* planl = (const uint4*)&lds[plan_off] + (jt & 1) * out.plan_cap;
-      const bool in_lds = nact <= out.plan_cap;
-      for (uint32_t w = tid; w < ((g.dbg & 16) ? 0u : (nact << logT3)); w += blockDim.x) {
+      // the samples of an interval are fetched from LDS eight at a time (independent loads) and then added one after
+      // the other, so the sum keeps the time order
+      const bool pre = PRE && !(g.dbg & 4);
+      for (uint32_t w = tid; w < (f_nact << logT3); w += blockDim.x) {
         const uint32_t slo = w & (T3 - 1);
-        const uint4 en = in_lds ? planl[w >> logT3] : ent[w >> logT3];
-        const uint32_t b = en.x, nint = en.z >> 16;
-        float4* __restrict__ pp = (float4*)out.base + (uint64_t)(out.chan0 + tile * T3 + slo) * out.nbin + b;
-        float4 acc = *pp;
+        uint4 en;
+        float4 acc;
+        if (pre && w == tid) {
+          en = en_pre;
+          acc = acc_pre;
+        } else {
+          en = in_lds ? planl[w >> logT3] : ent[w >> logT3];
+          acc = *acc_ptr(w, en.x);
+        }
+        const uint32_t nint = en.z >> 16;
+        float4* __restrict__ pp = acc_ptr(w, en.x);
         uint32_t off = en.w, hits = en.z & 0xffffu;
         for (uint32_t i = 0;;) {
           const uint32_t l0 = slo * g.nkeep + off;

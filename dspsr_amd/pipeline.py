@@ -32,8 +32,8 @@ class Config:
     subint_seconds: float = 0.0       # -L  (0 => single integration)
     stokes: bool = False              # -4? (default Coherence, LoadToFold1.C:1119-1134)
     ndim: int = 4                     # detected layout (CPU default 4, CUDA engine 2; LoadToFoldConfig.C:104)
-    parts_per_block: int = 16         # block size in overlap-save parts (LoadToFold1.C:825-835 sizes blocks likewise)
-    max_parts: int = 8                # parts per launch group
+    parts_per_block: int = 64         # block size in overlap-save parts (LoadToFold1.C:825-835 sizes blocks likewise)
+    max_parts: int = 32               # parts per launch group (persistent kernels: 32 amortise ramp-up and tail)
     fused_fold: bool = True           # fold inside the last filterbank pass when possible (identical sums, no
                                       # detected time series in HBM); False = Detection and Fold as separate ops
     interchan_dedispersion: bool = False   # -K: remove the inter-channel dispersion delay (LoadToFold1.C:605-624)
