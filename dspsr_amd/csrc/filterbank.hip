@@ -1659,7 +1659,11 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
       // persistent grids: one workgroup per CU (LDS-limited), a multiple of 8 so the XCD-aware item order applies
       const uint64_t n1 = (uint64_t)(Rr >> g.logT1) * fb->nseq * nb, n2 = (uint64_t)(M >> g.logT2) * fb->nseq * nb,
                      n3 = g.four_pass ? 0 : (uint64_t)(g.C >> g.logT3) * nb;
-      const uint32_t run1 = 32, run2 = 4, run3 = nb;
+      // XCD dealing of the persistent items (wgfft.h persistent_item); the environment overrides are for experiments
+      static const int env_run1 = getenv("DSPSR_AMD_RUN1") ? atoi(getenv("DSPSR_AMD_RUN1")) : 0,
+                       env_run2 = getenv("DSPSR_AMD_RUN2") ? atoi(getenv("DSPSR_AMD_RUN2")) : 0,
+                       env_run3 = getenv("DSPSR_AMD_RUN3") ? atoi(getenv("DSPSR_AMD_RUN3")) : 0;
+      const uint32_t run1 = env_run1 > 0 ? env_run1 : 32, run2 = env_run2 > 0 ? env_run2 : 4, run3 = env_run3 > 0 ? env_run3 : nb;
       if (pret) {
         fb_launch_raw_transpose(dim3((Rr + 255) / 256, (M + 63) / 64, nb), ctx->stream, g, ci, fb->Rt, part0);
         ci.kind = 3;
