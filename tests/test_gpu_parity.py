@@ -785,3 +785,42 @@ def test_pipeline_interchan_dedispersion(oracle, gpu, ndim):
     assert np.array_equal(sub["hits"], ps.hits)
     assert np.abs(prof - ps.data).max() <= 1e-5 * np.abs(ps.data).max()
     lt.close()
+
+
+def test_headline_size_fused_fold_properties(oracle, gpu):
+    """BASELINE headline geometry (-F 1024:D -x 4096, N = 2^22, 422/422) at full size, where the library fuses the fold by
+    itself (512 channel tiles): size-independent properties instead of an oracle run -- fused == Detection + Fold bit for
+    bit over two launch groups, every sample lands in exactly one phase bin, and the total power (PP + QQ planes) of
+    the profile equals the sum over the detected time series."""
+    dspsr_amd, ctx = gpu
+    C, M, nfilt, nbin, npart = 1024, 4096, (422, 422), 1024, 3
+    N = C * M
+    nkeep = M - sum(nfilt)
+    step, ovl = 2 * (N - sum(nfilt) * C), 2 * sum(nfilt) * C
+    rng = np.random.default_rng(41)
+    kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, N)).astype(np.complex64)
+    eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, 2, True, kernel, max_parts=2)
+    assert eng.fold_is_fused()
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    raw = torch.randn(2 * (npart * step + ovl), generator=gen, device="cuda").mul_(24.0).round_().clamp_(-128, 127).to(torch.int8)
+    ndat = npart * nkeep
+    folds, hits = [dspsr_amd.FoldEngine(ctx), dspsr_amd.FoldEngine(ctx)], [np.zeros(nbin, np.uint32), np.zeros(nbin, np.uint32)]
+    for f, h in zip(folds, hits):
+        f.set_shape(C, 1, 4, nbin)
+        f.set_nbin(nbin)
+        f.set_ndat(ndat, 0)
+        f.set_bins(0.123, 1.0 / 34879.3, ndat, 0, h)
+    det = torch.zeros((C, 1, 4 * ndat), dtype=torch.float32, device="cuda")
+    eng.perform_detect(det, npart, dspsr_amd.COHERENCE, 4, raw=raw, layout=dspsr_amd.RAW_CASPSR, scale=float(oracle.S8))
+    folds[0].fold(det)
+    eng.perform_fold(folds[1], npart, dspsr_amd.COHERENCE, raw=raw, layout=dspsr_amd.RAW_CASPSR, scale=float(oracle.S8))
+    a, b = folds[0].synch(), folds[1].synch()
+    assert np.array_equal(a, b) and np.abs(a).max() > 0
+    assert int(hits[0].sum()) == ndat and np.array_equal(hits[0], hits[1])
+    d = det.view(C, ndat, 4).double()
+    want = d.sum(dim=1).cpu().numpy()                                     # per channel: sum over time of (PP, QQ, Re, Im)
+    got = a.reshape(C, nbin, 4).astype(np.float64).sum(axis=1)
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+    eng.close()
+    for f in folds:
+        f.close()
