@@ -278,19 +278,38 @@ extern "C" int dspsr_amd_fold_set_bins(dspsr_amd_fold* f, double phi, double pha
   if (!f) return DSPSR_AMD_EINVAL;
   if (!f->folding_nbin) return ctx_fail(f->ctx, DSPSR_AMD_ESTATE, "dsp::Fold::fold nbin not set");
   const double double_nbin = (double)f->folding_nbin;     // Fold.C:719
-  uint64_t folded = 0;
-  for (uint64_t idat = idat_start; idat < idat_start + ndat; idat++) {   // Fold.C:744-787
-    phi -= floor(phi);
-    const double double_ibin = phi * double_nbin;
-    const uint32_t ibin = (uint32_t)double_ibin;
+  const uint32_t nbin = f->folding_nbin;
+  // Fold.C:744-787, the same double recurrence sample by sample (the sums are not associative, so nothing is
+  // skipped), written so that the loop-carried chain is the one addition: phi -= floor(phi) changes phi only when
+  // phi is outside [0, 1) (phi - 0.0 == phi), the run-length bookkeeping of set_bin (FoldCUDA.cu:84-113) is inlined
+  // and hits[] is updated once per run.  At 6 MHz output rates the plan loop is what a block waits for.
+  uint32_t cur_bin = f->current_bin, cur_hits = f->current_hits;
+  uint32_t counted = cur_hits;          // hits of the open run already added to hits_host by an earlier call
+  const uint64_t end = idat_start + ndat;
+  for (uint64_t idat = idat_start; idat < end; idat++) {
+    if (!(phi >= 0.0 && phi < 1.0)) phi -= floor(phi);
+    const uint32_t ibin = (uint32_t)(phi * double_nbin);
     phi += phase_per_sample;
-    if (ibin >= f->folding_nbin)
-      return ctx_fail(f->ctx, DSPSR_AMD_EINVAL, "dsp::Fold::fold ibin=%u >= nbin=%u", ibin, f->folding_nbin);
-    dspsr_amd_fold_set_bin(f, idat, double_ibin, phase_per_sample * double_nbin);
-    if (hits_host) hits_host[ibin]++;
-    folded++;
+    if (ibin >= nbin) {
+      f->current_bin = cur_bin; f->current_hits = cur_hits;
+      return ctx_fail(f->ctx, DSPSR_AMD_EINVAL, "dsp::Fold::fold ibin=%u >= nbin=%u", ibin, nbin);
+    }
+    if (ibin != cur_bin) {                // set_bin: a new run starts
+      if (!f->binplan.empty()) f->binplan.back().hits = cur_hits;
+      if (hits_host && cur_bin < nbin) hits_host[cur_bin] += cur_hits - counted;
+      RunBin start; start.offset = idat; start.ibin = ibin; start.hits = 0;
+      f->binplan.push_back(start);
+      cur_bin = ibin;
+      cur_hits = 0;
+      counted = 0;
+    }
+    cur_hits++;
   }
-  if (ndat_folded) *ndat_folded = folded;
+  if (hits_host && cur_bin < nbin) hits_host[cur_bin] += cur_hits - counted;
+  f->ndat_fold += ndat;
+  f->current_bin = cur_bin;
+  f->current_hits = cur_hits;
+  if (ndat_folded) *ndat_folded = ndat;
   return DSPSR_AMD_OK;
 }
 
