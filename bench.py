@@ -53,24 +53,29 @@ WORKLOADS = {
                  cmd="dspsr -F 512:D -D 1000 -b 1024 per 50 MHz complex sub-band"),
     # SURVEY 8f-1 / BASELINE config 5: search-mode front end, detect only (no fold)
     "cfg5": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=4096, dm=0.0, freq_res=1,
-                 nbin=0, machine="DADA", tscrunch=16, nparts=4096,
-                 cmd="digifil -F 4096 -t 16 (TFP filterbank + square law + pscrunch + tscrunch, no fold)"),
+                 nbin=0, machine="DADA", tscrunch=16, nparts=32768,
+                 cmd="digifil -F 4096 -t 16 -b 8 (TFP filterbank + square law + tscrunch, Rescale, PScrunch, 8-bit digitizer; no fold)"),
 }
 
 
 def bench_search_mode(args, wl, torch):
-    """cfg5: one step = one block of nparts FFT blocks (2*nchan samples each) through the fused search-mode kernel."""
-    import dspsr_amd
+    """cfg5: one step = one block of nparts FFT blocks (2*nchan samples each) through digifil's chain
+    (dspsr_amd.pipeline.LoadToFil): TFP filterbank + square law + tscrunch [one kernel, the roofline kernel] ->
+    Rescale -> PScrunch -> 8-bit SigProcDigitizer, everything resident in HBM."""
+    from dspsr_amd import pipeline
     nchan, sf, npart = wl["nchan"], wl["tscrunch"], wl["nparts"]
-    ctx = dspsr_amd.Context(0, torch.cuda.current_stream().cuda_stream)
-    nbytes = npart * 2 * nchan * 2
+    info = pipeline.InputInfo(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=1, npol=2, ndim=1, tsamp_us=wl["tsamp_us"],
+                              machine=wl["machine"])
+    lf = pipeline.LoadToFil(pipeline.SearchConfig(nchan=nchan, tscrunch=sf, nbit=8, parts_per_block=npart), info, device=0,
+                            stream=torch.cuda.current_stream().cuda_stream)
+    ctx = lf.ctx
+    nbytes = lf.block_bytes()
     gen = torch.Generator(device="cuda").manual_seed(20100413)
     raw = torch.randn(nbytes, generator=gen, device="cuda").mul_(24.0).round_().clamp_(-128, 127).to(torch.int8)
-    out = torch.empty((npart // sf, nchan, 1), dtype=torch.float32, device="cuda")
-    scale = dspsr_amd.eight_bit_scale()
+    out = lf.detected
 
     def step():
-        dspsr_amd.tfp_filterbank(ctx, raw, nchan, npart, out, True, sf, scale=scale)
+        lf.process_block(raw)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -84,6 +89,16 @@ def bench_search_mode(args, wl, torch):
     elapsed = time.perf_counter() - t0
     k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     samples = npart * 2 * nchan
+    # the front-end kernel alone, timed on extra calls (the step above also runs Rescale, PScrunch and the digitizer on
+    # the 16x smaller scrunched block)
+    import dspsr_amd
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(3, args.steps // 4))]
+    for a, b in ev:
+        a.record()
+        dspsr_amd.tfp_filterbank(ctx, raw, nchan, npart, out, False, sf, lf.layout, lf.scale8)
+        b.record()
+    torch.cuda.synchronize()
+    k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     b_alg = nbytes + out.numel() * 4
     achieved = b_alg / (k_ms * 1e-3) / 1e9
     res = {"metric": "Msamples/s dedispersed+folded", "value": round(samples * args.steps / elapsed / 1e6, 2),
@@ -92,7 +107,8 @@ def bench_search_mode(args, wl, torch):
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "cfg5", "command": wl["cmd"], "nchan": nchan, "tscrunch": sf,
                       "parts_per_block": npart, "input": "8-bit dual-pol, resident in HBM",
-                      "note": "search mode: detected + scrunched, NOT folded"},
+                      "chain": "TFPFilterbank+detect+TScrunch -> Rescale(10 s) -> PScrunch -> SigProcDigitizer(8 bit)",
+                      "note": "search mode: detected, scrunched and digitised, NOT folded"},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_tfp<13>",
                         "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(k_ms, 4)}}
@@ -101,12 +117,13 @@ def bench_search_mode(args, wl, torch):
         n = 512
         rr = raw[: n * 4 * nchan].cpu().numpy()
         t1 = time.perf_counter()
-        o.tscrunch_tfp(o.tfp_filterbank(o.unpack_8bit(rr, o.Observation()), nchan, True), sf)
+        det = o.tscrunch_tfp(o.tfp_filterbank(o.unpack_8bit(rr, o.Observation()), nchan, False), sf)
+        o.sigproc_digitize(o.pscrunch_tfp(o.Rescale().transform(det)), 8, flip_band=wl["bw"] > 0)
         dt = time.perf_counter() - t1
         res["cpu_baseline"] = {"value": n * 2 * nchan / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
                                "sample": "%d FFT blocks of the same workload, numpy oracle, %.1f s" % (n, dt)}
     print(json.dumps(res), flush=True)
-    ctx.close()
+    lf.close()
 
 
 def algorithmic_bytes_per_part(npol, nsamp_fft, nbit, N, nchan_subband, nkeep):

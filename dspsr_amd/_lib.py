@@ -70,6 +70,7 @@ SYMBOLS = {
     "dspsr_amd_sample_delay_total_delay": (_u64, [_vp]),
     "dspsr_amd_sample_delay_transform": (_i, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u64, C.POINTER(_u64)]),
     "dspsr_amd_dedispersion_sample_delays": (_i, [_d, _d, _d, _u32, _d, _i, _u32, _i, _vp]),
+    "dspsr_amd_pscrunch_tfp": (_i, [_vp, _vp, _vp, _u64, _u32, _u32]),
     "dspsr_amd_rescale_create": (_i, [_vp, _u32, _u32, _u64, _i, _pp]),
     "dspsr_amd_rescale_destroy": (None, [_vp]),
     "dspsr_amd_rescale_transform": (_i, [_vp, _vp, _vp, _u64]),

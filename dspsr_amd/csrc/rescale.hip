@@ -132,9 +132,36 @@ __global__ __launch_bounds__(256) void k_sigproc_float(const float* __restrict__
   }
 }
 
+// dsp::PScrunch::transformation, TFP branch (Signal/General/PScrunch.C:52,72-90): out[t][c] = (p0 + p1) * float(1/sqrt(2))
+__global__ __launch_bounds__(256) void k_pscrunch_tfp(const float* __restrict__ in, float* __restrict__ out, const uint64_t n,
+                                                      const uint32_t npol, const float scale)
+{
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = __fmul_rn(__fadd_rn(in[i * npol], in[i * npol + 1]), scale);
+}
+
 }  // namespace dspsr_amd
 
 using namespace dspsr_amd;
+
+extern "C" int dspsr_amd_pscrunch_tfp(dspsr_amd_ctx* ctx, const float* in_tfp_dev, float* out_tfp_dev, uint64_t ndat,
+                                      uint32_t nchan, uint32_t npol)
+{
+  if (!ctx || ((!in_tfp_dev || !out_tfp_dev) && ndat)) return DSPSR_AMD_EINVAL;
+  if (npol == 1) return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dsp::PScrunch::transformation invalid npol=%u", npol);   // :36-38
+  if (in_tfp_dev == out_tfp_dev)
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_pscrunch_tfp: in place is not supported on the device (use a second block)");
+  if (!ndat || !nchan) return DSPSR_AMD_OK;
+  const uint64_t n = ndat * nchan;
+  uint64_t gb = (n + 255) / 256;
+  if (gb > 8192) gb = 8192;
+  const float scale = (float)(1.0 / sqrt(2.0));                        // PScrunch.C:52
+  hipLaunchKernelGGL(k_pscrunch_tfp, dim3((uint32_t)gb), dim3(256), 0, ctx->stream, in_tfp_dev, out_tfp_dev, n, npol, scale);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_pscrunch_tfp: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}
 
 struct dspsr_amd_rescale {
   dspsr_amd_ctx* ctx;

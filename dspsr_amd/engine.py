@@ -336,6 +336,14 @@ class Rescale:
             self.handle = None
 
 
+def pscrunch_tfp(ctx: Context, inp, out, nchan, npol=2):
+    """dsp::PScrunch on TFP-ordered device data: out[t][c] = (p0 + p1) * float(1/sqrt(2)); out of place."""
+    ndat = inp.numel() // (nchan * npol)
+    _check(ctx.handle, lib.dspsr_amd_pscrunch_tfp(ctx.handle, inp.data_ptr(), out.data_ptr(), ndat, nchan, npol),
+           "dspsr_amd_pscrunch_tfp")
+    return out
+
+
 def sigproc_digitize(ctx: Context, inp, out, nchan, npol=1, nbit=8, use_digi_scales=True, input_scale=1.0, scale_fac=1.0,
                      flip_band=False, swap_band=False):
     """dsp::SigProcDigitizer::pack on TFP-ordered float32 device data -> packed n-bit device bytes."""

@@ -17,8 +17,8 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from .engine import (Context, Dedispersion, DspsrAmdError, FilterbankEngine, FoldEngine, SampleDelay, copy_data_fpt,
-                     dedispersion_sample_delays, eight_bit_scale)
+from .engine import (Context, Dedispersion, DspsrAmdError, FilterbankEngine, FoldEngine, Rescale, SampleDelay, copy_data_fpt,
+                     dedispersion_sample_delays, eight_bit_scale, pscrunch_tfp, sigproc_digitize, tfp_filterbank)
 
 
 @dataclass
@@ -467,4 +467,138 @@ class LoadToFold:
             self.sample_delay.close()
         self.fb.close()
         self.fold.close()
+        self.ctx.close()
+
+
+# ---- search mode: digifil (Signal/General/LoadToFil.C) ------------------------------------------------------------
+
+@dataclass
+class SearchConfig:
+    """The digifil options on this path (LoadToFil.C:60-100 defaults, digifil.C)."""
+    nchan: int = 4096                 # -F nchan  (non-convolving TFPFilterbank)
+    tscrunch: int = 16                # -t
+    nbit: int = 2                     # -b  (digifil default 2; 1, 2, 4, 8, 16, -32)
+    rescale_seconds: float = 10.0     # -I  (0 disables Rescale and the digitizer's own scales, LoadToFil.C:318,360)
+    rescale_constant: bool = False    # -c
+    scale_fac: float = 1.0            # -s
+    parts_per_block: int = 4096       # FFT blocks (2*nchan samples each) per call; a multiple of tscrunch
+
+
+def write_sigproc_header(f, *, source_name="unknown", rawdatafile="unknown", machine_id=0, telescope_id=0, src_raj=0.0, src_dej=0.0,
+                         fch1, foff, nchans, nbits, tstart_mjd, tsamp, nifs=1):
+    """The SIGPROC filterbank header digifil writes (Kernel/Formats/sigproc/filterbank_header.c:42-105, send_stuff.c,
+    values as SigProcObservation::unload fills them, SigProcObservation.C:228-270): length-prefixed keywords, native
+    (little-endian) int32 / float64 values."""
+    import struct
+
+    def send_string(sv):
+        b = sv.encode("ascii")
+        f.write(struct.pack("<i", len(b)) + b)
+
+    def send_int(name, v):
+        send_string(name)
+        f.write(struct.pack("<i", int(v)))
+
+    def send_double(name, v):
+        send_string(name)
+        f.write(struct.pack("<d", float(v)))
+
+    send_string("HEADER_START")
+    if rawdatafile:
+        send_string("rawdatafile")
+        send_string(rawdatafile)
+    if source_name:
+        send_string("source_name")
+        send_string(source_name)
+    send_int("machine_id", machine_id)
+    send_int("telescope_id", telescope_id)
+    for name, v in (("src_raj", src_raj), ("src_dej", src_dej), ("az_start", 0.0), ("za_start", 0.0)):   # send_coords
+        send_double(name, v)
+    send_int("data_type", 1)
+    send_double("fch1", fch1)
+    send_double("foff", foff)
+    send_int("nchans", nchans)
+    send_int("nbeams", 0)
+    send_int("ibeam", 0)
+    send_int("nbits", nbits)
+    send_double("tstart", tstart_mjd)
+    send_double("tsamp", tsamp)
+    send_int("nifs", nifs)
+    send_string("HEADER_END")
+
+
+class LoadToFil:
+    """digifil's chain for 8-bit real dual-polarisation input and one output polarisation, every stage on the device
+    (LoadToFil.C:196-362): TFPFilterbank (PPQQ) + TScrunch [one kernel] -> Rescale (per pol and channel, in place)
+    -> PScrunch -> SigProcDigitizer.  process_block returns the packed block (device uint8, [time][chan] n-bit)."""
+
+    def __init__(self, cfg: SearchConfig, info: InputInfo, device: int = 0, stream: int | None = None):
+        import torch
+        self.torch = torch
+        self.cfg, self.info = cfg, info
+        if info.npol != 2 or info.ndim != 1 or info.nchan != 1:
+            raise DspsrAmdError("dspsr_amd.LoadToFil: 8-bit real dual-polarisation single-channel input only")
+        if cfg.parts_per_block % cfg.tscrunch:
+            raise DspsrAmdError("dspsr_amd.LoadToFil: parts_per_block=%d is not a multiple of tscrunch=%d"
+                                % (cfg.parts_per_block, cfg.tscrunch))
+        self.ctx = Context(device, stream)
+        self.scale8 = eight_bit_scale()
+        self.layout = _lib.RAW_CASPSR if info.machine == "CASPSR" else _lib.RAW_GENERIC
+        self.out_rate = info.rate / (2.0 * cfg.nchan) / cfg.tscrunch           # TFPFilterbank + TScrunch
+        nout = cfg.parts_per_block // cfg.tscrunch
+        dev = "cuda:%d" % device
+        self.detected = torch.empty((nout, cfg.nchan, 2), dtype=torch.float32, device=dev)      # PPQQ, TFP order
+        self.intensity = torch.empty((nout, cfg.nchan, 1), dtype=torch.float32, device=dev)
+        self.rescale = None
+        if cfg.rescale_seconds:
+            interval = int(cfg.rescale_seconds * self.out_rate)                   # Rescale::init, Rescale.C:102-103
+            if not interval:
+                raise DspsrAmdError("dsp::Rescale::init nsample == 0")
+            self.rescale = Rescale(self.ctx, cfg.nchan, 2, interval, cfg.rescale_constant)
+        nbits = 32 if cfg.nbit == -32 else cfg.nbit
+        self.bytes_per_sample = cfg.nchan * nbits // 8
+        self.packed = torch.empty(nout * self.bytes_per_sample, dtype=torch.uint8, device=dev)
+        self.ndat_out = 0
+
+    def block_bytes(self, npart=None):
+        return (npart or self.cfg.parts_per_block) * 2 * self.cfg.nchan * 2
+
+    def process_block(self, raw, npart=None):
+        cfg = self.cfg
+        npart = npart or cfg.parts_per_block
+        if npart % cfg.tscrunch or npart > cfg.parts_per_block:
+            raise DspsrAmdError("dspsr_amd.LoadToFil.process_block: npart=%d must be a multiple of tscrunch=%d and <= %d"
+                                % (npart, cfg.tscrunch, cfg.parts_per_block))
+        if raw.numel() < self.block_bytes(npart):
+            raise DspsrAmdError("dspsr_amd.LoadToFil.process_block: block holds %d bytes, %d needed"
+                                % (raw.numel(), self.block_bytes(npart)))
+        nout = npart // cfg.tscrunch
+        det = self.detected[:nout]
+        tfp_filterbank(self.ctx, raw, cfg.nchan, npart, det, False, cfg.tscrunch, self.layout, self.scale8)
+        if self.rescale is not None:
+            self.rescale.transform(det)                                            # in place, LoadToFil.C:325-326
+        inten = self.intensity[:nout]
+        pscrunch_tfp(self.ctx, det, inten, cfg.nchan, 2)                            # LoadToFil.C:333-343
+        packed = self.packed[:nout * self.bytes_per_sample]
+        # after Rescale the input scale is 1 (Rescale.C:204); without it the TFP filterbank leaves scale 1 as well
+        sigproc_digitize(self.ctx, inten, packed, cfg.nchan, 1, cfg.nbit, use_digi_scales=self.rescale is not None,
+                         input_scale=1.0, scale_fac=cfg.scale_fac, flip_band=self.info.bandwidth > 0, swap_band=False)
+        self.ndat_out += nout
+        return packed
+
+    def header_values(self):
+        """fch1/foff/tsamp/tstart as SigProcObservation::unload derives them from the digitizer's output observation
+        (bandwidth forced negative, SigProcDigitizer.C:83-85; channel 0 centred half a channel inside the band edge)."""
+        nchan, bw = self.cfg.nchan, -abs(self.info.bandwidth)
+        fch1 = self.info.centre_frequency - 0.5 * bw + 0.5 * bw / nchan
+        nbits = 32 if self.cfg.nbit == -32 else self.cfg.nbit
+        return dict(fch1=fch1, foff=bw / nchan, nchans=nchan, nbits=nbits, tsamp=1.0 / self.out_rate,
+                    tstart_mjd=self.info.mjd_day + (self.info.mjd_sec + self.info.start_seconds) / 86400.0, nifs=1)
+
+    def synchronize(self):
+        self.ctx.synchronize()
+
+    def close(self):
+        if self.rescale is not None:
+            self.rescale.close()
         self.ctx.close()

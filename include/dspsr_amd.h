@@ -208,7 +208,11 @@ int dspsr_amd_sample_delay_transform(dspsr_amd_sample_delay* h, const float* in_
  *                              in == out is allowed (digifil rescales in place, LoadToFil.C:325-326).
  * dspsr_amd_sigproc_digitize : dsp::SigProcDigitizer::pack, TFP branch (Kernel/Formats/sigproc/SigProcDigitizer.C:80-236)
  *                              nbit 1/2/4/8/16 or -32 (pack_float :309-342); flip_band = input bandwidth > 0,
- *                              swap_band = input->get_swap() (ChannelSort :38-66); input_scale = input->get_scale(). */
+ *                              swap_band = input->get_swap() (ChannelSort :38-66); input_scale = input->get_scale().
+ * dspsr_amd_pscrunch_tfp     : dsp::PScrunch, TFP branch (Signal/General/PScrunch.C:36-90): (p0 + p1) * float(1/sqrt 2), the
+ *                              step digifil runs between Rescale and the digitizer (LoadToFil.C:333-343); out of place. */
+int dspsr_amd_pscrunch_tfp(dspsr_amd_ctx* ctx, const float* in_tfp_dev, float* out_tfp_dev, uint64_t ndat, uint32_t nchan,
+                           uint32_t npol);
 typedef struct dspsr_amd_rescale dspsr_amd_rescale;
 int dspsr_amd_rescale_create(dspsr_amd_ctx* ctx, uint32_t nchan, uint32_t npol, uint64_t interval_samples, int constant,
                              dspsr_amd_rescale** out);

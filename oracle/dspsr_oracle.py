@@ -762,6 +762,15 @@ class Rescale:
         return out
 
 
+def pscrunch_tfp(x: np.ndarray) -> np.ndarray:
+    """dsp::PScrunch::transformation, TFP branch (Signal/General/PScrunch.C:36-90): (p0 + p1) * float(1/sqrt(2))."""
+    x = np.asarray(x, np.float32)
+    if x.shape[2] == 1:
+        raise OracleError("dsp::PScrunch::transformation invalid npol=1")
+    scale = np.float32(1.0 / math.sqrt(2.0))
+    return ((x[:, :, 0] + x[:, :, 1]) * scale)[:, :, None]
+
+
 def channel_sort(nchan: int, flip_band: bool, swap_band: bool) -> np.ndarray:
     """ChannelSort (Kernel/Formats/sigproc/SigProcDigitizer.C:38-66, nsub_swap <= 1): input channel of each output
     channel; flip_band = input bandwidth > 0, swap_band = input->get_swap()."""

@@ -824,3 +824,39 @@ def test_headline_size_fused_fold_properties(oracle, gpu):
     eng.close()
     for f in folds:
         f.close()
+
+
+@pytest.mark.parametrize("nbit,rescale_seconds,constant", [(8, 10.0, False), (2, 0.002, False), (4, 0.002, True), (8, 0.0, False)])
+def test_load_to_fil_matches_oracle_chain(oracle, gpu, nbit, rescale_seconds, constant):
+    """digifil as LoadToFil.C wires it: TFPFilterbank (PPQQ) -> TScrunch -> Rescale (2 pols) -> PScrunch -> SigProcDigitizer,
+    over three blocks (the Rescale state carries over).  The FFT rounds differently from pocketfft, so a few samples land
+    on the other side of a digitiser boundary: at most one level apart, in well under 0.2 % of the samples."""
+    dspsr_amd, _ = gpu
+    from dspsr_amd import pipeline
+    o = oracle
+    nchan, tscr, npart, nblocks = 256, 4, 512, 3
+    info = pipeline.InputInfo(centre_frequency=1382.0, bandwidth=400.0, tsamp_us=0.00125, machine="DADA")   # positive bw: flipped
+    cfg = pipeline.SearchConfig(nchan=nchan, tscrunch=tscr, nbit=nbit, rescale_seconds=rescale_seconds, rescale_constant=constant,
+                                parts_per_block=npart)
+    lf = pipeline.LoadToFil(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    obs = o.Observation()
+    ro = o.Rescale(int(rescale_seconds * lf.out_rate), constant) if rescale_seconds else None
+    rng = np.random.default_rng(51)
+    worst, frac = 0, 0.0
+    for b in range(nblocks):
+        raw = np.clip(np.rint(rng.standard_normal(npart * 2 * nchan * 2) * (20.0 + 6 * b)), -128, 127).astype(np.int8)
+        got = lf.process_block(torch.from_numpy(raw).cuda()).cpu().numpy()
+        det = o.tscrunch_tfp(o.tfp_filterbank(o.unpack_8bit(raw, obs), nchan, False), tscr)
+        if ro is not None:
+            det = ro.transform(det)
+        want = o.sigproc_digitize(o.pscrunch_tfp(det), nbit, use_digi_scales=ro is not None, flip_band=True)
+        assert got.size == want.size
+        spb = 8 // nbit
+        lv = lambda a: ((a.reshape(-1)[:, None] >> (np.arange(spb) * nbit)) & ((1 << nbit) - 1)).astype(np.int32)
+        d = np.abs(lv(got) - lv(want))
+        worst, frac = max(worst, int(d.max())), max(frac, float((d != 0).mean()))
+    assert worst <= 1 and frac < 2e-3
+    h = lf.header_values()
+    assert h["nchans"] == nchan and h["foff"] == -400.0 / nchan and h["fch1"] == 1382.0 + 200.0 - 200.0 / nchan
+    assert abs(h["tsamp"] - 2 * nchan * tscr * 0.00125e-6) < 1e-18
+    lf.close()

@@ -122,3 +122,25 @@ def test_combine_phase_series_matches_oracle_fold_of_time_slices(oracle):
     with pytest.raises(pipeline.DspsrAmdError, match="mixable"):
         pipeline.combine_phase_series(merged, {"hits": np.zeros(8, np.uint32), "integration_length": 1.0, "ndat_total": 1,
                                                "profile": np.zeros((nchan, 1, 8, 4), np.float32)})
+
+
+def test_sigproc_header_bytes():
+    """filterbank_header.c / send_stuff.c: length-prefixed keywords, int32 and float64 values, HEADER_START..HEADER_END."""
+    import io
+    import struct
+    from dspsr_amd import pipeline
+    f = io.BytesIO()
+    pipeline.write_sigproc_header(f, source_name="J0835-4510", fch1=1581.951171875, foff=-0.09765625, nchans=4096, nbits=8,
+                                  tstart_mjd=55299.087326388886, tsamp=0.00016384)
+    b = f.getvalue()
+    assert b.startswith(struct.pack("<i", 12) + b"HEADER_START") and b.endswith(struct.pack("<i", 10) + b"HEADER_END")
+
+    def value(key, fmt):
+        k = struct.pack("<i", len(key)) + key.encode()
+        i = b.index(k) + len(k)
+        return struct.unpack_from(fmt, b, i)[0]
+    assert value("nchans", "<i") == 4096 and value("nbits", "<i") == 8 and value("nifs", "<i") == 1 and value("data_type", "<i") == 1
+    assert value("fch1", "<d") == 1581.951171875 and value("foff", "<d") == -0.09765625 and value("tsamp", "<d") == 0.00016384
+    assert value("tstart", "<d") == 55299.087326388886
+    i = b.index(b"source_name") + len("source_name")
+    assert b[i:i + 4] == struct.pack("<i", 10) and b[i + 4:i + 14] == b"J0835-4510"
