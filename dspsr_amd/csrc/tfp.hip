@@ -25,16 +25,28 @@ struct TfpParams {
   int caspsr;
 };
 
-DEV uint32_t tfp_fetch(const TfpParams& p, const uint64_t t)   // (pol0, pol1) bytes of sample t
+// (pol0, pol1) bytes of sample t: issued as independent loads and combined only when the tile is decoded, so that the
+// words of the NEXT tile stay in flight during the transform (combining here would wait for them at the prefetch)
+template <bool CASPSR> struct TfpRaw { uint32_t w[CASPSR ? 2 : 1]; };
+template <bool CASPSR> DEV TfpRaw<CASPSR> tfp_fetch(const TfpParams& p, const uint64_t t, const bool valid)
 {
-  if (p.caspsr) {
+  TfpRaw<CASPSR> r;
+  if constexpr (CASPSR) {
     const uint8_t* b = p.raw + (t >> 2) * 8 + (t & 3);
-    return (uint32_t)b[0] | ((uint32_t)b[4] << 8);
+    r.w[0] = valid ? b[0] : 0x80u;
+    r.w[1] = valid ? b[4] : 0x80u;
+  } else {
+    r.w[0] = valid ? *(const uint16_t*)(p.raw + 2 * t) : 0x8080u;
   }
-  return *(const uint16_t*)(p.raw + 2 * t);
+  return r;
+}
+template <bool CASPSR> DEV uint32_t tfp_pair(const TfpRaw<CASPSR>& r)
+{
+  if constexpr (CASPSR) return (r.w[0] & 0xffu) | ((r.w[1] & 0xffu) << 8);
+  else return r.w[0] & 0xffffu;
 }
 
-template <int LOGF>
+template <int LOGF, bool CASPSR>
 __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __restrict__ tw)
 {
   typedef FftPlan<LOGF> P;
@@ -56,7 +68,7 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
   const uint32_t groups_per_out = p.sfactor > T ? p.sfactor >> logT : 1;
   const uint64_t nitem = p.sfactor > T ? nout : (nout * p.sfactor + T - 1) >> logT;
 
-  auto fetch = [&](const uint64_t group, uint32_t (&raw)[NPAIR]) {
+  auto fetch = [&](const uint64_t group, TfpRaw<CASPSR> (&ra)[NPAIR], TfpRaw<CASPSR> (&rb)[NPAIR]) {
     const uint64_t part0 = group << logT;
 #pragma unroll
     for (int g2 = 0; g2 < P::G1; g2 += 2)
@@ -65,12 +77,15 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
         const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
         const uint32_t col = e & (T - 1), n = e >> logT;
         const uint64_t pa = part0 + col, pb = pa + 1;
-        const uint32_t wa = pa < p.npart ? tfp_fetch(p, pa * L + n) : 0x80808080u;
-        const uint32_t wb = pb < p.npart ? tfp_fetch(p, pb * L + n) : 0x80808080u;
-        raw[(g2 / 2) * P::R1 + i] = (wa & 0xffffu) | (wb << 16);
+        ra[(g2 / 2) * P::R1 + i] = tfp_fetch<CASPSR>(p, pa * L + n, pa < p.npart);
+        rb[(g2 / 2) * P::R1 + i] = tfp_fetch<CASPSR>(p, pb * L + n, pb < p.npart);
       }
   };
 
+  // the 8-bit samples of the next group are requested while the current one is transformed (register prefetch,
+  // as in the filterbank passes); past the end the loads are skipped by the part bound inside fetch()
+  TfpRaw<CASPSR> ra[NPAIR], rb[NPAIR];
+  if (blockIdx.x < nitem) fetch((uint64_t)blockIdx.x * groups_per_out, ra, rb);
   for (uint64_t item = blockIdx.x; item < nitem; item += gridDim.x) {
     float acc[NB][2];
 #pragma unroll
@@ -78,14 +93,16 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
     for (uint32_t gi = 0; gi < groups_per_out; gi++) {
       const uint64_t group = item * groups_per_out + gi;
       asm volatile("" : "+v"(tid));
-      uint32_t raw[NPAIR];
-      fetch(group, raw);
       cx2 x[NPAIR];
 #pragma unroll
       for (int h = 0; h < NPAIR; h++) {
-        const uint32_t w = raw[h];
+        const uint32_t w = tfp_pair<CASPSR>(ra[h]) | (tfp_pair<CASPSR>(rb[h]) << 16);
         x[h] = make_cx2(make_float2(((float)(int8_t)(w & 0xff) + 0.5f) * p.scale, ((float)(int8_t)((w >> 8) & 0xff) + 0.5f) * p.scale),
                         make_float2(((float)(int8_t)((w >> 16) & 0xff) + 0.5f) * p.scale, ((float)(int8_t)(w >> 24) + 0.5f) * p.scale));
+      }
+      {
+        const uint64_t next = gi + 1 < groups_per_out ? group + 1 : (item + gridDim.x) * groups_per_out;
+        if (gi + 1 < groups_per_out || item + gridDim.x < nitem) fetch(next, ra, rb);
       }
       auto store = [&](const uint32_t col, const uint32_t pp, const uint32_t pstride, auto& v) {
         constexpr int R = sizeof(v) / sizeof(v[0]);
@@ -98,27 +115,33 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
       wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
       __syncthreads();
       // Hermitian split, power, time scrunch (columns = consecutive parts, added in time order)
+      const uint64_t part_first = group << logT, part_end = nout * p.sfactor;
+      const uint32_t phase_first = (uint32_t)(part_first % p.sfactor);       // wave-uniform: no division per bin
+      const uint64_t out_first = part_first / p.sfactor;
 #pragma unroll
       for (int j = 0; j < NB; j++) {
         const uint32_t k = tid + j * nt;
         if (k < nchan) {
           const uint32_t km = (L - k) & (L - 1);
+          uint32_t phase = phase_first;
+          uint64_t oidx = out_first;
           for (uint32_t c = 0; c < T; c++) {
-            const uint64_t part = (group << logT) + c;
-            if (part >= nout * p.sfactor) break;
+            const uint64_t part = part_first + c;
+            if (part >= part_end) break;
             const cf a = lds[lds_pad((k << logT) | c)], b = lds[lds_pad((km << logT) | c)];
             const float x0r = 0.5f * (a.x + b.x), x0i = 0.5f * (a.y - b.y);
             const float x1r = 0.5f * (a.y + b.y), x1i = 0.5f * (b.x - a.x);
             float p0 = x0r * x0r; p0 += x0i * x0i;            // TFPFilterbank.C:56-59
             float p1 = x1r * x1r; p1 += x1i * x1i;
             if (p.pscrunch) { p0 += p1; p1 = 0.f; }                 // TFPFilterbank.C:79-80: pol sum BEFORE the time sum
-            const uint32_t phase = (uint32_t)(part % p.sfactor);
             if (phase == 0) { acc[j][0] = p0; acc[j][1] = p1; }     // TScrunch.C:193-194
             else { acc[j][0] += p0; acc[j][1] += p1; }               // TScrunch.C:199-200
-            if (phase == p.sfactor - 1) {
-              float* o = p.out + ((part / p.sfactor) * nchan + k) * npol_out;
+            if (++phase == p.sfactor) {
+              float* o = p.out + (oidx * nchan + k) * npol_out;
               o[0] = acc[j][0];
               if (!p.pscrunch) o[1] = acc[j][1];
+              phase = 0;
+              oidx++;
             }
           }
         }
@@ -132,7 +155,12 @@ typedef void (*ktfp_t)(TfpParams, const cf*);
 template <int... I> struct iseq_t {};
 template <int N, int... I> struct mkseq_t : mkseq_t<N - 1, N - 1, I...> {};
 template <int... I> struct mkseq_t<0, I...> { typedef iseq_t<I...> type; };
-template <int... I> static ktfp_t pick_tfp(int logf, iseq_t<I...>) { static const ktfp_t t[] = {k_tfp<I>...}; return t[logf]; }
+template <int... I> static ktfp_t pick_tfp(int logf, bool caspsr, iseq_t<I...>)
+{
+  static const ktfp_t t[] = {k_tfp<I, false>...};
+  static const ktfp_t c[] = {k_tfp<I, true>...};
+  return caspsr ? c[logf] : t[logf];
+}
 
 }  // namespace dspsr_amd
 
@@ -164,7 +192,7 @@ extern "C" int dspsr_amd_tfp_filterbank(dspsr_amd_ctx* ctx, const dspsr_amd_tfp_
   TfpParams p;
   p.raw = (const uint8_t*)raw_dev; p.out = out_dev; p.npart = npart; p.sfactor = sf; p.pscrunch = cfg->pscrunch ? 1 : 0;
   p.scale = scale; p.logT = logT; p.caspsr = raw_layout == DSPSR_AMD_RAW_CASPSR;
-  ktfp_t k = pick_tfp(logF, mkseq_t<14>::type());
+  ktfp_t k = pick_tfp(logF, p.caspsr != 0, mkseq_t<14>::type());
   const size_t lds = lds_total_words_host(16384, logF) * sizeof(cf);
   hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_tfp_filterbank: %s", hipGetErrorString(e));
