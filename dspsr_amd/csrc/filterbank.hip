@@ -110,6 +110,7 @@ DEV void st_stream(float2* p, const float2 v)
   *p = v;
 #endif
 }
+DEV bool getenv_pair16_off(const FbGeom& g) { return (g.dbg & 64) != 0; }   // DSPSR_AMD_DEBUG bit 64: 8-byte loads in the inverse pass
 DEV float4 ld_stream(const float4* p)
 {
 #if FB_NT_LOAD
@@ -748,6 +749,11 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   // chunk < 0: all elements; otherwise the elements i with i % NCHUNK == chunk (the prefetch of the next tile is
   // issued in NCHUNK groups spread over the transform, see wgfft_stage)
   constexpr int NCHUNK = P::NS + 1;
+  // T = 4 columns = 2 channels x 2 polarisations per tile.  Only where the pass is memory bound (detected or complex
+  // output written): -3.7 % there; the fused kernel is issue bound and loses 1.6 % to the exchange (r01g_experiments.txt)
+  constexpr bool PAIR16 = LOGT == 2 && P::G1 == 2 && !FOLD;
+  const bool pair16 = PAIR16 && g.real_input && logX3 == 1 && !getenv_pair16_off(g);
+  cf special = make_float2(0.f, 0.f);                   // mirror element of bin 0 (pair16 path)
   auto fetch = [&](const uint64_t item, Abk (&raw)[PTS / 2], const int chunk) {
     const uint32_t tile = (uint32_t)(item / nparts);
     const cf* __restrict__ X0s = X + (item % nparts) * nseq * L;
@@ -763,6 +769,30 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     // divergent code between the loads (the m = 0 mirror element, the only irregular one, can only be i = 0)
     constexpr uint32_t MS = 1u << (LOGF - P::LOGR1);
     const int64_t step = (int64_t)MS << logX3;
+    if constexpr (PAIR16) {
+      if (pair16) {
+        // Two channels per tile and X3 = 2: the elements of lanes 2j (channel 0) and 2j+1 (channel 1) for the same bin
+        // are one aligned 16-byte pair, in both streams.  Lane parity q loads the pairs of the elements i = 2u + q --
+        // 16 B per lane, half the load instructions (8-byte-per-lane streams run at 5.6 TB/s, 16-byte ones at 7.1 on this
+        // chip, tools/load_width_probe.hip); the halves are exchanged between the two lanes when the tile is consumed.
+        const uint32_t q = tid & 1, mb = tid >> 1;
+        const uint32_t m0 = mb + q * MS;                                  // bin of element i = q
+        const cf* __restrict__ pa2 = X0s + ((((uint64_t)tile << LOGF) + m0) << 1);
+        const uint64_t rowb = (uint64_t)((Rr >> 1) - 1 - tile) << LOGF;   // row pair of the mirror rows Rr-1-s
+        const cf* __restrict__ pb2 = X0s + ((rowb + (M - m0)) << 1);        // mirror bin M - m of element i = q
+#pragma unroll
+        for (int u = 0; u < P::R1 / 2; u++) {
+          const float4 A = ld_stream((const float4*)(pa2 + (int64_t)u * 4 * MS));
+          // bin 0 has its own mirror (loaded below): its pair would lie past the row, read the one before instead
+          const float4 B = ld_stream((const float4*)((u == 0 && m0 == 0 ? pb2 - 2 : pb2) - (int64_t)u * 4 * MS));
+          raw[2 * u].a = make_float2(A.x, A.y); raw[2 * u + 1].a = make_float2(A.z, A.w);
+          raw[2 * u].b = make_float2(B.x, B.y); raw[2 * u + 1].b = make_float2(B.z, B.w);
+        }
+        const uint32_t s = tile * T3 + q;
+        special = ld_stream(mb == 0 ? X0s + xi((Rr - s) & (Rr - 1), 0) : X0s + xi(Rr - 1 - s, M - mb));
+        return;
+      }
+    }
 #pragma unroll
     for (int g2 = 0; g2 < P::G1; g2 += 2) {
       const uint32_t eb = P::G1 * tid + g2;
@@ -850,6 +880,27 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
           const uint4* __restrict__ fent = (const uint4*)(out.pstart + ((out.nparts_plan + 1 + 3) & ~3u)) + fe0;
           uint4* pl = (uint4*)&lds[plan_off] + (jt & 1) * out.plan_cap;
           for (uint32_t q = tid; q < fn; q += blockDim.x) pl[q] = fent[q];
+        }
+      }
+      if constexpr (PAIR16) {
+        if (pair16) {                       // hand the other channel's halves of the 16-byte pairs to the neighbour lane
+          const bool q = tid & 1;
+          auto swap1 = [](const cf v) {     // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
+            return make_float2(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0xB1, 0xf, 0xf, false)),
+                               __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0xB1, 0xf, 0xf, false)));
+          };
+#pragma unroll
+          for (int u = 0; u < P::R1 / 2; u++) {
+            const cf alo = raw[2 * u].a, ahi = raw[2 * u + 1].a;            // (channel 0, channel 1) of element 2u + q
+            const cf aown = q ? ahi : alo, arecv = swap1(q ? alo : ahi);
+            raw[2 * u].a = q ? arecv : aown;
+            raw[2 * u + 1].a = q ? aown : arecv;
+            const cf blo = raw[2 * u].b, bhi = raw[2 * u + 1].b;            // mirror rows: (channel 1, channel 0)
+            const cf bown = q ? blo : bhi, brecv = swap1(q ? bhi : blo);
+            raw[2 * u].b = q ? brecv : bown;
+            raw[2 * u + 1].b = q ? bown : brecv;
+          }
+          if ((tid >> 1) == 0) raw[0].b = special;
         }
       }
 #pragma unroll
