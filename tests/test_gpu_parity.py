@@ -860,3 +860,28 @@ def test_load_to_fil_matches_oracle_chain(oracle, gpu, nbit, rescale_seconds, co
     assert h["nchans"] == nchan and h["foff"] == -400.0 / nchan and h["fch1"] == 1382.0 + 200.0 - 200.0 / nchan
     assert abs(h["tsamp"] - 2 * nchan * tscr * 0.00125e-6) < 1e-18
     lf.close()
+
+
+def test_search_mode_and_delay_error_paths(gpu):
+    """The C-ABI reports misuse with the reference's wording instead of corrupting memory."""
+    dspsr_amd, ctx = gpu
+    x = torch.zeros((8, 6, 2), dtype=torch.float32, device="cuda")
+    out = torch.zeros(8 * 6 * 4, dtype=torch.uint8, device="cuda")
+    with pytest.raises(dspsr_amd.DspsrAmdError, match="nbit=3 not understood"):
+        dspsr_amd.sigproc_digitize(ctx, x, out, 6, 2, nbit=3)
+    with pytest.raises(dspsr_amd.DspsrAmdError, match="not a multiple of 4 samples per byte"):
+        dspsr_amd.sigproc_digitize(ctx, x, out, 6, 2, nbit=2)
+    with pytest.raises(dspsr_amd.DspsrAmdError, match="in place is not supported"):
+        dspsr_amd.pscrunch_tfp(ctx, x, x, 6, 2)
+    with pytest.raises(dspsr_amd.DspsrAmdError, match="invalid npol=1"):
+        dspsr_amd.pscrunch_tfp(ctx, x, torch.zeros_like(x), 12, 1)
+    with pytest.raises(dspsr_amd.DspsrAmdError, match="must not be negative"):
+        dspsr_amd.SampleDelay(ctx, np.array([3, -1, 2]), 1, absolute=True)
+    with pytest.raises(dspsr_amd.DspsrAmdError):
+        dspsr_amd.Rescale(ctx, 0, 1)
+    sd = dspsr_amd.SampleDelay(ctx, np.zeros(4, np.int64), 2)          # all-zero relative delays: identity
+    assert (sd.zero_delay, sd.total_delay) == (0, 0)
+    y = torch.arange(4 * 2 * 10 * 2, dtype=torch.float32, device="cuda").reshape(4, 2, 10, 2)
+    z = torch.zeros_like(y)
+    assert sd.transform(y, z) == 10 and torch.equal(y, z)
+    sd.close()
