@@ -411,6 +411,19 @@ __global__ __launch_bounds__(256) void k_raw_transpose(const FbGeom g, const FbI
   uint32_t* __restrict__ dst = (uint32_t*)(Rt + part * ((uint64_t)M << g.logR));
   const int logW = logT - 1;                        // 32-bit words per (row, tile) piece
   const uint32_t ntl = ncol >> logT, W = 1u << logW;
+  if (logW == 1 && (nrow & 1) == 0) {
+    // 4-column tiles (the headline geometry): two rows of a tile are 16 contiguous bytes of the output -- one
+    // 16-byte store per lane instead of four 4-byte ones (narrow per-lane accesses stream slower on this chip,
+    // tools/load_width_probe.hip)
+    const uint32_t nr2 = nrow >> 1;
+    for (uint32_t q = tid; q < ntl * nr2; q += 256) {
+      const uint32_t r = (q % nr2) * 2, tl = q / nr2;
+      const uint32_t* s0 = &sm[r * PITCH + 2 * tl];
+      const uint32_t* s1 = s0 + PITCH;
+      *(uint4*)&dst[((((uint64_t)((nb0 >> logT) + tl) << g.logM) + na0 + r) << 1)] = make_uint4(s0[0], s0[1], s1[0], s1[1]);
+    }
+    return;
+  }
   for (uint32_t q = tid; q < ntl * nrow * W; q += 256) {           // [tile][row][word]: runs of nrow*T pairs
     const uint32_t wd = q & (W - 1), r = (q >> logW) % nrow, tl = (q >> logW) / nrow;
     dst[((((uint64_t)((nb0 >> logT) + tl) << g.logM) + na0 + r) << logW) + wd] = sm[r * PITCH + (tl << logW) + wd];
