@@ -1511,6 +1511,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     int t3 = LOG_POINTS - g.logM - logPol;
     if (t3 < 0) t3 = 0;
     g.logX3 = imin(logC, t3);                    // X layout: keeps the pass-2 store runs at T2*X3 elements
+    if (getenv("DSPSR_AMD_LOG_X3")) g.logX3 = imin(logC, atoi(getenv("DSPSR_AMD_LOG_X3")) > t3 ? atoi(getenv("DSPSR_AMD_LOG_X3")) : t3);   // experiment: longer pass-2 runs
     // pass-3 tile: may be smaller than a layout block (DSPSR_AMD_P3_LOG_POINTS), two workgroups then share a CU
     const int LOG_POINTS3 = getenv("DSPSR_AMD_P3_LOG_POINTS") ? atoi(getenv("DSPSR_AMD_P3_LOG_POINTS")) : LOG_POINTS;
     int t3t = LOG_POINTS3 - g.logM - logPol;
