@@ -370,7 +370,11 @@ __global__ __launch_bounds__(256) void k_raw_transpose(const FbGeom g, const FbI
   const uint32_t M = 1u << g.logM, Rr = 1u << g.logR;
   const int logT = g.logT1;
   const uint32_t nb0 = blockIdx.x * COLS, na0 = blockIdx.y * ROWS;
-  const uint64_t part = blockIdx.z;
+  // complex dual-pol input (generic order, 4 bytes per sample: p0 re, p0 im, p1 re, p1 im): one polarisation = one
+  // sequence per blockIdx.z, its (re, im) byte pairs take the place of the (pol0, pol1) pairs of real input
+  const uint32_t nsq = g.real_input ? 1u : g.npol;
+  const uint64_t part = blockIdx.z / nsq;
+  const uint32_t seq = blockIdx.z % nsq;
   const uint64_t t0 = (part0 + part) * in.part_step;
   const uint32_t ncol = Rr - nb0 < COLS ? Rr - nb0 : COLS, nrow = M - na0 < ROWS ? M - na0 : ROWS;
   if (ncol % 8 == 0) {
@@ -378,7 +382,15 @@ __global__ __launch_bounds__(256) void k_raw_transpose(const FbGeom g, const FbI
       const uint32_t r = q / (ncol / 8), c8 = (q % (ncol / 8)) * 8;
       const uint64_t t = t0 + (((uint64_t)(na0 + r)) << g.logR) + nb0 + c8;   // multiple of 4 (8 unless t0 is odd*4)
       uint32_t w[4];
-      if (in.kind == 2) {                                              // CASPSR: 4 B pol0 | 4 B pol1
+      if (!g.real_input) {                                             // 8 samples x 4 bytes, keep this polarisation
+        const uint4* p = (const uint4*)((const uint8_t*)in.base + 4 * t);
+        const uint4 s0 = p[0], s1 = p[1];
+        const int sh = 16 * seq;
+        w[0] = ((s0.x >> sh) & 0xffffu) | (((s0.y >> sh) & 0xffffu) << 16);
+        w[1] = ((s0.z >> sh) & 0xffffu) | (((s0.w >> sh) & 0xffffu) << 16);
+        w[2] = ((s1.x >> sh) & 0xffffu) | (((s1.y >> sh) & 0xffffu) << 16);
+        w[3] = ((s1.z >> sh) & 0xffffu) | (((s1.w >> sh) & 0xffffu) << 16);
+      } else if (in.kind == 2) {                                       // CASPSR: 4 B pol0 | 4 B pol1
         const uint32_t* p = (const uint32_t*)((const uint8_t*)in.base + (t >> 2) * 8);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -398,7 +410,10 @@ __global__ __launch_bounds__(256) void k_raw_transpose(const FbGeom g, const FbI
       const uint32_t r = q / (ncol / 2), c2 = (q % (ncol / 2)) * 2;
       const uint64_t t = t0 + (((uint64_t)(na0 + r)) << g.logR) + nb0 + c2;
       uint32_t w;
-      if (in.kind == 2) {
+      if (!g.real_input) {
+        const uint32_t* p = (const uint32_t*)((const uint8_t*)in.base + 4 * t);
+        w = ((p[0] >> (16 * seq)) & 0xffffu) | (((p[1] >> (16 * seq)) & 0xffffu) << 16);
+      } else if (in.kind == 2) {
         const uint8_t* b = (const uint8_t*)in.base + (t >> 2) * 8 + (t & 3);
         w = (uint32_t)b[0] | ((uint32_t)b[4] << 8) | ((uint32_t)b[1] << 16) | ((uint32_t)b[5] << 24);
       } else {
@@ -408,7 +423,7 @@ __global__ __launch_bounds__(256) void k_raw_transpose(const FbGeom g, const FbI
     }
   }
   __syncthreads();
-  uint32_t* __restrict__ dst = (uint32_t*)(Rt + part * ((uint64_t)M << g.logR));
+  uint32_t* __restrict__ dst = (uint32_t*)(Rt + (part * nsq + seq) * ((uint64_t)M << g.logR));
   const int logW = logT - 1;                        // 32-bit words per (row, tile) piece
   const uint32_t ntl = ncol >> logT, W = 1u << logW;
   if (logW == 1 && (nrow & 1) == 0) {
@@ -421,6 +436,15 @@ __global__ __launch_bounds__(256) void k_raw_transpose(const FbGeom g, const FbI
       const uint32_t* s0 = &sm[r * PITCH + 2 * tl];
       const uint32_t* s1 = s0 + PITCH;
       *(uint4*)&dst[((((uint64_t)((nb0 >> logT) + tl) << g.logM) + na0 + r) << 1)] = make_uint4(s0[0], s0[1], s1[0], s1[1]);
+    }
+    return;
+  }
+  if (logW >= 2) {                                                   // tiles of >= 8 columns: 16 bytes of a row piece per lane
+    const int logV = logW - 2;
+    for (uint32_t q = tid; q < (ntl * nrow) << logV; q += 256) {
+      const uint32_t v4 = q & ((1u << logV) - 1), r = (q >> logV) % nrow, tl = (q >> logV) / nrow;
+      const uint32_t* s0 = &sm[r * PITCH + (tl << logW) + 4 * v4];
+      *(uint4*)&dst[((((uint64_t)((nb0 >> logT) + tl) << g.logM) + na0 + r) << logW) + 4 * v4] = make_uint4(s0[0], s0[1], s0[2], s0[3]);
     }
     return;
   }
@@ -458,7 +482,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     const uint64_t rest = item / ntile;
     const uint32_t seq = (uint32_t)(rest % nseq);
     const bool pret = in.kind == 3;   // pre-transposed: [part][tile][na][T] pairs, contiguous per tile
-    const uint64_t t0 = pret ? ((rest / nseq) * ntile + tile) * ((uint64_t)T << LOGF)
+    const uint64_t t0 = pret ? (rest * ntile + tile) * ((uint64_t)T << LOGF)       // rest = part*nseq + seq
                              : (part0 + rest / nseq) * in.part_step + tile * T;
     if (g.dbg & 2) {     // ablation only; hoisted so that the real path has no per-load branch
 #pragma unroll
@@ -1681,10 +1705,14 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   // (k_raw_transpose) unless the rows are already long enough or the layout preconditions fail
   const bool fast8 = (in.kind == 1 || in.kind == 2) && g.real_input && g.npol == 2 && fb->cfg.input_nchan == 1 &&
                      ((uintptr_t)in.base % 4) == 0;
-  bool pret = fast8 && g.logR >= 2 && g.logT1 <= 5 && !getenv("DSPSR_AMD_NO_PRETRANSPOSE");   // rows of >= 128 B need no regrouping
+  // complex dual-pol generic order: the same regroup per polarisation; pass 1 then reads (re, im) byte pairs exactly
+  // like the (pol0, pol1) pairs of real input, one aligned word per two columns
+  const bool fastc = in.kind == 1 && !g.real_input && g.npol == 2 && fb->cfg.input_nchan == 1 &&
+                     ((uintptr_t)in.base % 16) == 0 && (in.part_step % 4) == 0 && g.logR >= 3;
+  bool pret = (fast8 || fastc) && g.logR >= 2 && g.logT1 <= 5 && !getenv("DSPSR_AMD_NO_PRETRANSPOSE");   // rows of >= 128 B need no regrouping
   if (pret && in.kind == 2 && (in.part_step % 4) != 0) pret = false;
   if (pret && !fb->Rt) {
-    if (hipMalloc((void**)&fb->Rt, (size_t)fb->max_parts * fb->L * sizeof(uint16_t)) != hipSuccess)
+    if (hipMalloc((void**)&fb->Rt, (size_t)fb->max_parts * fb->nseq * fb->L * sizeof(uint16_t)) != hipSuccess)
       return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of the 8-bit regroup buffer failed");
   }
   int raww = (pret || (fast8 && in.kind == 1)) ? 1 : 4;
@@ -1730,7 +1758,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
                        env_run3 = getenv("DSPSR_AMD_RUN3") ? atoi(getenv("DSPSR_AMD_RUN3")) : 0;
       const uint32_t run1 = env_run1 > 0 ? env_run1 : 32, run2 = env_run2 > 0 ? env_run2 : 4, run3 = env_run3 > 0 ? env_run3 : nb;
       if (pret) {
-        fb_launch_raw_transpose(dim3((Rr + 255) / 256, (M + 63) / 64, nb), ctx->stream, g, ci, fb->Rt, part0);
+        fb_launch_raw_transpose(dim3((Rr + 255) / 256, (M + 63) / 64, nb * fb->nseq), ctx->stream, g, ci, fb->Rt, part0);
         ci.kind = 3;
         ci.base = fb->Rt;
       }

@@ -113,6 +113,13 @@ def test_filterbank_caspsr_layout(oracle, gpu):
     _fb_case(oracle, gpu, 16, 256, (20, 21), 2, layout="caspsr")
 
 
+def test_filterbank_subband_shard_size(oracle, gpu):
+    # BASELINE cfg 4 geometry: one 50 MHz complex dual-pol sub-band, -F 512:D (N = 2^18, freq_res 512), 27/27 at DM 1000;
+    # 8-bit complex input takes the per-polarisation regroup pass and the one-word-per-pair loads of pass 1
+    _fb_case(oracle, gpu, 512, 512, (27, 27), 2, npol=2, real=False, max_parts=2)
+    _fb_case(oracle, gpu, 512, 512, (27, 27), 3, npol=2, real=False, max_parts=2, use_raw=False)
+
+
 def test_filterbank_single_pol(oracle, gpu):
     _fb_case(oracle, gpu, 16, 256, (20, 21), 2, npol=1)
 
