@@ -1766,7 +1766,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
                          part0, nb, fb->nseq, run1);
       ci = in; ci.ichan = ichan; ci.nchan = fb->cfg.input_nchan;
       if (in.kind == 0) ci.base = in_f32 + ichan * in_chan_stride_bytes_or_floats;
-      // Output written (not folded in the kernel): pass 2 and the inverse pass run in sub-groups of a few parts, so that
+      // Pass 2 and the inverse pass run in sub-groups of a few parts, so that
       // part of the spectrum pass 2 has just written is still in the 256 MB Infinity Cache when the inverse pass reads
       // it (measured with whole groups of 8 / 16 / 32 parts: 31.5 / 33.4 / 35.2 µs per part in the inverse pass, pass 2
       // unchanged) while passes 0 and 1 keep the long launch their persistent workgroups want.
@@ -1775,16 +1775,30 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
       static const int p23sub_env = getenv("DSPSR_AMD_P23_SUB") ? atoi(getenv("DSPSR_AMD_P23_SUB")) : -1;
       uint64_t p23auto = (512ull << 20) / (fb->part_elems * sizeof(cf));
       if (p23auto < 1) p23auto = 1;
-      const uint32_t p23sub = (g.four_pass || co.kind == 3 || p23sub_env == 0) ? nb
+      // (the fused kernel gains less, +1.4 % Msamples/s measured in three alternating runs, but consistently)
+      static const bool sub_fused = !(getenv("DSPSR_AMD_P23_SUB_FUSED") && atoi(getenv("DSPSR_AMD_P23_SUB_FUSED")) == 0);
+      const uint32_t p23sub = (g.four_pass || (co.kind == 3 && !sub_fused) || p23sub_env == 0) ? nb
                               : (p23sub_env > 0 ? (uint32_t)p23sub_env : (uint32_t)(p23auto < nb ? p23auto : nb));
       if (p23sub < nb) {
+        size_t lds3s = fb->lds3;
+        if (co.kind == 3) {
+          const size_t spare = 160 * 1024 - 64 - fb->lds3 - 16;
+          uint32_t cap = fb->lds3 + 64 + 16 < 160 * 1024 ? (uint32_t)(spare / 32) : 0;
+          if (cap > 512) cap = 512;
+          if (cap < 16) cap = 0;
+          co.plan_cap = cap;
+          lds3s += 16 + (size_t)cap * 32;
+          if ((e = allow_lds(k3, lds3s)) != hipSuccess)
+            return fb_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_filterbank_perform: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
         for (uint32_t s0 = 0; s0 < nb; s0 += p23sub) {
           const uint32_t ns = nb - s0 < p23sub ? nb - s0 : p23sub;
           const uint64_t off = (uint64_t)s0 * fb->part_elems;
-          const uint64_t n2s = (uint64_t)(M >> g.logT2) * fb->nseq * ns, n3s = (uint64_t)(g.C >> g.logT3) * ns;
+          const uint64_t n2s = (uint64_t)(M >> g.logT2) * fb->nseq * ns;
+          const uint64_t n3s = co.kind == 3 ? (uint64_t)(g.C >> g.logT3) : (uint64_t)(g.C >> g.logT3) * ns;
           hipLaunchKernelGGL(k2, dim3(grid_for(n2s, fb->ncu * fb->wg_per_cu)), dim3(fb->nt2), fb->lds2, ctx->stream, g, fb->A + off,
                              fb->X + off, ctx->tw, ns, fb->nseq, run2);
-          hipLaunchKernelGGL(k3, dim3(grid_for(n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X + off, kern, co,
+          hipLaunchKernelGGL(k3, dim3(grid_for(n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), lds3s, ctx->stream, g, fb->X + off, kern, co,
                              ctx->tw, part0 + s0, ns, env_run3 > 0 ? (uint32_t)env_run3 : ns);
         }
         continue;
