@@ -623,12 +623,19 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
   const uint64_t L = 1ull << (g.logM + LOGF);
   const uint32_t ntile = 1u << (g.logM - logT);
   const uint64_t total = (uint64_t)ntile * nseq * nparts;
+  // The sequences of the launch are walked backwards: the parts written last -- the ones still in the Infinity Cache
+  // when the launch ends -- are then the ones the inverse pass, which walks the parts forwards, meets first
+  // (+0.8 % Msamples/s in three alternating runs; DSPSR_AMD_DEBUG bit 128 restores the forward order)
+  auto seq_of = [&](const uint64_t item) -> uint64_t {
+    const uint64_t sq = item / ntile;
+    return (g.dbg & 128) ? sq : (uint64_t)nseq * nparts - 1 - sq;
+  };
 
   // the prefetch keeps the loaded 16-byte pairs untouched (any use would wait for the loads at once);
   // they are rearranged into split form when the tile is started
   auto fetch = [&](const uint64_t item, float4 (&y)[NPAIR]) {
     const uint32_t tile = (uint32_t)(item % ntile);
-    const cf* __restrict__ Ablk = A + (item / ntile) * L + (((uint64_t)tile << LOGF) << logT);     // g.logR == LOGF
+    const cf* __restrict__ Ablk = A + seq_of(item) * L + (((uint64_t)tile << LOGF) << logT);     // g.logR == LOGF
     if (g.dbg & 2) {     // ablation only; hoisted so that the real path has no per-load branch (and vmcnt(0))
 #pragma unroll
       for (int i = 0; i < NPAIR; i++) y[i] = make_float4(tid, i, 1.f, 1.f);
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
 #endif
 
     const uint32_t tile = (uint32_t)(item % ntile);
-    cf* __restrict__ Xseq = X + (item / ntile) * L;
+    cf* __restrict__ Xseq = X + seq_of(item) * L;
     // last-stage outputs go to LDS in X-layout order [s'/T3][klo][s'%T3]; after a barrier the tile is
     // written out as whole runs of T2*T3 elements with 16-byte-per-lane stores.  XOR swizzle of the image
     // (bits 1,2 ^= bits 4,5) against bank conflicts of the 8-byte scatter (42 % of this pass's LDS cycles)
