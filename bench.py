@@ -207,8 +207,8 @@ def cpu_baseline(wl, lt, parts_per_worker=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--parts-per-block", type=int, default=0,
                     help="overlap-save parts per block; 0 = 64 for the headline geometry (2^23 samples per part), "
