@@ -15,12 +15,14 @@ OK, EINVAL, EHIP, ENOMEM, ESTATE = 0, -1, -2, -3, -4
 H2D, D2H, D2D = 1, 2, 3
 RAW_GENERIC, RAW_CASPSR, RAW_UWB16 = 0, 1, 2
 COHERENCE, STOKES = 0, 1
+FUSED_AUTO, FUSED_ALWAYS, FUSED_NEVER = 0, 1, 2
 
 
 class FilterbankConfig(C.Structure):
     _fields_ = [("nchan_subband", C.c_uint32), ("freq_res", C.c_uint32), ("nfilt_pos", C.c_uint32),
                 ("nfilt_neg", C.c_uint32), ("input_nchan", C.c_uint32), ("npol", C.c_uint32),
-                ("real_input", C.c_uint32), ("max_parts", C.c_uint32)]
+                ("real_input", C.c_uint32), ("max_parts", C.c_uint32), ("force_four_pass", C.c_uint32),
+                ("fused_fold", C.c_uint32)]
 
 
 class TfpConfig(C.Structure):

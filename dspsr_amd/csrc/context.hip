@@ -21,6 +21,9 @@ extern "C" int dspsr_amd_ctx_create(int device, void* hip_stream, dspsr_amd_ctx*
   dspsr_amd_ctx* ctx = new dspsr_amd_ctx;
   ctx->device = device;
   ctx->error[0] = 0;
+  hipDeviceProp_t prop;
+  ctx->ncu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                 ? (uint32_t)prop.multiProcessorCount : 256u;
   ctx->own_stream = (hip_stream == DSPSR_AMD_NEW_STREAM);
   ctx->stream = ctx->own_stream ? nullptr : (hipStream_t)hip_stream;
   if (ctx->own_stream && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {

@@ -7,14 +7,16 @@
 
 namespace dspsr_amd {
 
-__global__ void k_polarimetry(const int state, const uint32_t ndim, const float* __restrict__ in,
-                              const uint64_t in_chan_stride, const uint64_t in_pol_stride, float* __restrict__ out,
+// `in` and `out` may be the same buffer (ndim 2, LoadToFold1.C:545-546): every thread reads its two samples before it
+// writes the same elements back, so the pointers carry no __restrict__.
+__global__ void k_polarimetry(const int state, const uint32_t ndim, const float* in,
+                              const uint64_t in_chan_stride, const uint64_t in_pol_stride, float* out,
                               const uint64_t out_chan_stride, const uint64_t out_pol_stride, const uint64_t ndat)
 {
   const uint32_t chan = blockIdx.y;
-  const float2* __restrict__ p = (const float2*)(in + chan * in_chan_stride);
-  const float2* __restrict__ q = (const float2*)(in + chan * in_chan_stride + in_pol_stride);
-  float* __restrict__ row = out + chan * out_chan_stride;
+  const float2* p = (const float2*)(in + chan * in_chan_stride);
+  const float2* q = (const float2*)(in + chan * in_chan_stride + in_pol_stride);
+  float* row = out + chan * out_chan_stride;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndat; i += (uint64_t)gridDim.x * blockDim.x) {
     const float2 a = p[i], b = q[i];
     const float pp = a.x * a.x + a.y * a.y;

@@ -23,6 +23,19 @@
 #include "engine_internal.h"
 #include "fold_internal.h"
 
+// Experiment switches (ablation bits that make results wrong, geometry overrides) exist only in builds made with
+// -DDSPSR_AMD_EXPERIMENT (tools/build_variant.sh).  The shipped library never reads the environment: its behaviour
+// depends on the configuration structs of the C-ABI alone.
+#ifdef DSPSR_AMD_EXPERIMENT
+#define FB_DBG(g) ((g).dbg)
+#define FB_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define FB_ENV_SET(name) (getenv(name) != nullptr)
+#else
+#define FB_DBG(g) 0
+#define FB_ENV_INT(name, dflt) (dflt)
+#define FB_ENV_SET(name) false
+#endif
+
 // The file is compiled as ONE translation unit (no FB_PART: experiment builds) or, by the Makefile, as several in
 // parallel: FB_PART 1 = P0+P1 kernels, 2 = P2, 3 = P3, 5 = P3 with the fused fold, 4 = the two-pass inverse, 0 = host.
 #ifdef FB_PART
@@ -110,7 +123,7 @@ DEV void st_stream(float2* p, const float2 v)
   *p = v;
 #endif
 }
-DEV bool getenv_pair16_off(const FbGeom& g) { return (g.dbg & 64) != 0; }   // DSPSR_AMD_DEBUG bit 64: 8-byte loads in the inverse pass
+DEV bool getenv_pair16_off(const FbGeom& g) { return (FB_DBG(g) & 64) != 0; }   // DSPSR_AMD_DEBUG bit 64: 8-byte loads in the inverse pass
 DEV float4 ld_stream(const float4* p)
 {
 #if FB_NT_LOAD
@@ -484,7 +497,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     const bool pret = in.kind == 3;   // pre-transposed: [part][tile][na][T] pairs, contiguous per tile
     const uint64_t t0 = pret ? (rest * ntile + tile) * ((uint64_t)T << LOGF)       // rest = part*nseq + seq
                              : (part0 + rest / nseq) * in.part_step + tile * T;
-    if (g.dbg & 2) {     // ablation only; hoisted so that the real path has no per-load branch
+    if (FB_DBG(g) & 2) {     // ablation only; hoisted so that the real path has no per-load branch
 #pragma unroll
       for (int i = 0; i < NPAIR; i++) { RawW<RAWW> z; z.w[0] = tid + i; raw[i] = z; }
       return;
@@ -548,7 +561,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
       const uint32_t nb = tile * T + col;
-      if (!(g.dbg & 8)) apply_pass_twiddle<R>(v, nb, p, pstride, logL, tw, g.tw_lo);
+      if (!(FB_DBG(g) & 8)) apply_pass_twiddle<R>(v, nb, p, pstride, logL, tw, g.tw_lo);
       // image index of element k: l0 + k*(pstride << logT) (pstride is a multiple of T2), so when that step is a
       // multiple of 64 the swizzle and the padding of l0 carry over: one address per column, constant offsets
       auto img = [&](const uint32_t l) { return lds_pad(l ^ (((l >> 4) & swz) << 3)); };
@@ -574,13 +587,13 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
         }
       }
     };
-    if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
+    if (FB_DBG(g) & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
     else wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
     __syncthreads();
 #if defined(FB_STAMPS) && FB_STAMPS == 1
     STAMP(ts3);
 #endif
-    if (!(g.dbg & 1)) {
+    if (!(FB_DBG(g) & 1)) {
       const uint32_t nthr = blockDim.x;
 #pragma unroll 4
       for (int jj = 0; jj < PTS / 2; jj++) {
@@ -628,7 +641,7 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
   // (+0.8 % Msamples/s in three alternating runs; DSPSR_AMD_DEBUG bit 128 restores the forward order)
   auto seq_of = [&](const uint64_t item) -> uint64_t {
     const uint64_t sq = item / ntile;
-    return (g.dbg & 128) ? sq : (uint64_t)nseq * nparts - 1 - sq;
+    return (FB_DBG(g) & 128) ? sq : (uint64_t)nseq * nparts - 1 - sq;
   };
 
   // the prefetch keeps the loaded 16-byte pairs untouched (any use would wait for the loads at once);
@@ -636,7 +649,7 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
   auto fetch = [&](const uint64_t item, float4 (&y)[NPAIR]) {
     const uint32_t tile = (uint32_t)(item % ntile);
     const cf* __restrict__ Ablk = A + seq_of(item) * L + (((uint64_t)tile << LOGF) << logT);     // g.logR == LOGF
-    if (g.dbg & 2) {     // ablation only; hoisted so that the real path has no per-load branch (and vmcnt(0))
+    if (FB_DBG(g) & 2) {     // ablation only; hoisted so that the real path has no per-load branch (and vmcnt(0))
 #pragma unroll
       for (int i = 0; i < NPAIR; i++) y[i] = make_float4(tid, i, 1.f, 1.f);
       return;
@@ -708,13 +721,13 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
         }
       }
     };
-    if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
+    if (FB_DBG(g) & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
     else wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
     __syncthreads();
 #if defined(FB_STAMPS) && FB_STAMPS == 2
     STAMP(ts3);
 #endif
-    if (!(g.dbg & 1)) {
+    if (!(FB_DBG(g) & 1)) {
       const uint32_t nthr = blockDim.x;
 #pragma unroll 4
       for (int jj = 0; jj < PTS / 2; jj++) {
@@ -801,7 +814,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   auto fetch = [&](const uint64_t item, Abk (&raw)[PTS / 2], const int chunk) {
     const uint32_t tile = (uint32_t)(item / nparts);
     const cf* __restrict__ X0s = X + (item % nparts) * nseq * L;
-    if (g.dbg & 2) {     // ablation only; hoisted so that the real path has no per-load branch
+    if (FB_DBG(g) & 2) {     // ablation only; hoisted so that the real path has no per-load branch
       if (chunk <= 0) {
 #pragma unroll
         for (int i = 0; i < NPAIR; i++) { raw[i].a = make_float2(tid, i); raw[i].b = raw[i].a; }
@@ -859,7 +872,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   // chirp of a tile (fetched at the start of the item: keeps the prefetch at 64 registers)
   auto load_chirp = [&](const uint64_t item, cf (&kk)[PTS / 2]) {
     const uint32_t ktile = (uint32_t)(item / nparts);
-    if (kernel && !(g.dbg & (2 | 32))) {      // uniform; outside the unrolled loads (no per-load branch / vmcnt(0))
+    if (kernel && !(FB_DBG(g) & (2 | 32))) {      // uniform; outside the unrolled loads (no per-load branch / vmcnt(0))
       constexpr uint32_t MS = 1u << (LOGF - P::LOGR1);
 #pragma unroll
       for (int g2 = 0; g2 < P::G1; g2 += 2) {
@@ -920,7 +933,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         // slower waves may still be folding the previous tile from the other half)
         const uint64_t fpart = part0 + item % nparts;
         const uint32_t fe0 = out.pstart[fpart], fn = out.pstart[fpart + 1] - fe0;
-        if (fn <= out.plan_cap && !(g.dbg & 16)) {
+        if (fn <= out.plan_cap && !(FB_DBG(g) & 16)) {
           const uint4* __restrict__ fent = (const uint4*)(out.pstart + ((out.nparts_plan + 1 + 3) & ~3u)) + fe0;
           uint4* pl = (uint4*)&lds[plan_off] + (jt & 1) * out.plan_cap;
           for (uint32_t q = tid; q < fn; q += blockDim.x) pl[q] = fent[q];
@@ -995,7 +1008,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         return;
       }
       if (out.kind == 0) return;
-      if (g.dbg & 1) { if (v[0].x[0] == 1.2345f && v[R - 1].y[1] == 3.3f) out.base[0] = v[0].x[0]; return; }
+      if (FB_DBG(g) & 1) { if (v[0].x[0] == 1.2345f && v[R - 1].y[1] == 3.3f) out.base[0] = v[0].x[0]; return; }
       const uint32_t chan = out.chan0 + tile * T3 + (col >> 1);
       float* __restrict__ row = out.base + chan * out.chan_stride;
       // output sample of element k: t0 + k*pstride (kept when 0 <= t < nkeep); the addresses are a base plus a
@@ -1045,7 +1058,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     constexpr bool PRE = FOLD && FftPlan<LOGF>::NS >= 2;
     if constexpr (FOLD) {
       f_e0 = out.pstart[part];
-      f_nact = (g.dbg & 16) ? 0u : out.pstart[part + 1] - f_e0;
+      f_nact = (FB_DBG(g) & 16) ? 0u : out.pstart[part + 1] - f_e0;
       ent = (const uint4*)(out.pstart + ((out.nparts_plan + 1 + 3) & ~3u)) + f_e0;
       planl = (const uint4*)&lds[plan_off] + (jt & 1) * out.plan_cap;
       in_lds = f_nact <= out.plan_cap;
@@ -1061,7 +1074,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         }
       }
     };
-    if (g.dbg & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
+    if (FB_DBG(g) & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
     else wgfft<LOGF, +1, FOLD>(lds, ltw_off, tid, logT, x, store, mid);
 #if defined(FB_STAMPS) && FB_STAMPS == 3
     STAMP(ts3);
@@ -1070,7 +1083,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       __syncthreads();                       // the tile's detected samples are staged
       // the samples of an interval are fetched from LDS eight at a time (independent loads) and then added one after
       // the other, so the sum keeps the time order
-      const bool pre = PRE && !(g.dbg & 4);
+      const bool pre = PRE && !(FB_DBG(g) & 4);
       for (uint32_t w = tid; w < (f_nact << logT3); w += blockDim.x) {
         const uint32_t slo = w & (T3 - 1);
         uint4 en;
@@ -1155,7 +1168,7 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
     const uint64_t part = item / per_part, r = item % per_part;
     const uint32_t c = (uint32_t)(r / ntile), tile = (uint32_t)(r % ntile);
     const cf* __restrict__ X0s = X + part * nseq * L;
-    if (g.dbg & 2) {
+    if (FB_DBG(g) & 2) {
 #pragma unroll
       for (int i = 0; i < NPAIR; i++) { raw[i].a = make_float2(tid, i); raw[i].b = raw[i].a; }
       return;
@@ -1197,7 +1210,7 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
     cx2 x[NPAIR];
     {
       cf kk[PTS / 2];
-      if (kernel && !(g.dbg & 2)) {
+      if (kernel && !(FB_DBG(g) & 2)) {
         constexpr uint32_t MS = 1u << (LOGF - P::LOGR1);
 #pragma unroll
         for (int g2 = 0; g2 < P::G1; g2 += 2) {
@@ -1276,7 +1289,7 @@ __global__ __launch_bounds__(512) void k_inv_b(const FbGeom g, const cf* __restr
     const uint64_t part = item / per_part, r = item % per_part;
     const uint32_t c = (uint32_t)(r / ntile), tile = (uint32_t)(r % ntile);
     const cf* __restrict__ blk = U + (part * g.C + c) * (2ull << g.logMf) + (((uint64_t)tile << g.logMb) << logT);
-    if (g.dbg & 2) {
+    if (FB_DBG(g) & 2) {
 #pragma unroll
       for (int i = 0; i < NPAIR; i++) y[i] = make_float4(tid, i, 1.f, 1.f);
       return;
@@ -1469,6 +1482,14 @@ struct dspsr_amd_filterbank_impl {
   float* det = nullptr;     // detected block of perform_fold when the fused kernel would not fill the chip
   size_t det_floats = 0;
   bool kernel_set = false;
+  // kernels of this geometry, chosen and given their dynamic-LDS limit once, at create time
+  k1_t k1_w1 = nullptr, k1_w4 = nullptr, k1_w2 = nullptr;   // pass 1: one word per sample pair / generic loads / direct 8-bit (experiment)
+  k2_t k2 = nullptr;
+  k3_t k3 = nullptr, k3f = nullptr;                          // inverse pass: plain, fused fold
+  k3a_t k3a = nullptr;
+  k3b_t k3b = nullptr;
+  uint32_t plan_cap = 0;     // fused fold: plan entries per LDS buffer behind the twiddle tables
+  size_t lds3f = 0;          // dynamic LDS of the fused inverse pass
 };
 
 }  // namespace dspsr_amd
@@ -1485,6 +1506,8 @@ static int fb_fail(dspsr_amd_ctx* ctx, int code, const char* fmt, ...)
   va_end(ap);
   return code;
 }
+
+template <typename K> static hipError_t allow_lds(K kern, size_t bytes) { return dspsr_amd_allow_lds((const void*)kern, bytes); }
 
 extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_filterbank_config* cfg,
                                            dspsr_amd_filterbank** out)
@@ -1525,26 +1548,27 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   g.C = (uint32_t)C;
   g.nfilt_pos = cfg->nfilt_pos;
   g.nkeep = cfg->freq_res - cfg->nfilt_pos - cfg->nfilt_neg;
-  g.dbg = getenv("DSPSR_AMD_DEBUG") ? atoi(getenv("DSPSR_AMD_DEBUG")) : 0;
+  g.dbg = FB_ENV_INT("DSPSR_AMD_DEBUG", 0);
   fb->nseq = cfg->real_input ? 1 : cfg->npol;
   // tiles: every workgroup holds min(2^14, available) points = 32 per thread
-  const int LOG_POINTS = getenv("DSPSR_AMD_LOG_POINTS") ? atoi(getenv("DSPSR_AMD_LOG_POINTS")) : LOG_POINTS_DEFAULT;
-  fb->wg_per_cu = getenv("DSPSR_AMD_WG_PER_CU") ? atoi(getenv("DSPSR_AMD_WG_PER_CU")) : 1;
+  const int LOG_POINTS = FB_ENV_INT("DSPSR_AMD_LOG_POINTS", LOG_POINTS_DEFAULT);
+  fb->wg_per_cu = FB_ENV_INT("DSPSR_AMD_WG_PER_CU", 1);
+  if (fb->wg_per_cu < 1) fb->wg_per_cu = 1;
   auto imin = [](int a, int b) { return a < b ? a : b; };
   const int logPol = 1;   // the inverse passes always carry (pol0, pol1) column pairs
   // three passes (freq_res and the spectrum rows each fit one workgroup tile) when possible ...
   uint64_t p1 = 0, p2 = 0, p3 = 0, p4 = 0;
   bool three_ok = g.logM <= MAX_LOGF && g.logR <= MAX_LOGF;
-  const int LOG_POINTS1 = getenv("DSPSR_AMD_P1_LOG_POINTS") ? atoi(getenv("DSPSR_AMD_P1_LOG_POINTS")) : LOG_POINTS;
+  const int LOG_POINTS1 = FB_ENV_INT("DSPSR_AMD_P1_LOG_POINTS", LOG_POINTS);
   if (three_ok) {
     g.logT1 = imin(g.logR, LOG_POINTS1 - g.logM);
     g.logT2 = imin(g.logM, LOG_POINTS - g.logR);
     int t3 = LOG_POINTS - g.logM - logPol;
     if (t3 < 0) t3 = 0;
     g.logX3 = imin(logC, t3);                    // X layout: keeps the pass-2 store runs at T2*X3 elements
-    if (getenv("DSPSR_AMD_LOG_X3")) g.logX3 = imin(logC, atoi(getenv("DSPSR_AMD_LOG_X3")) > t3 ? atoi(getenv("DSPSR_AMD_LOG_X3")) : t3);   // experiment: longer pass-2 runs
+    if (FB_ENV_SET("DSPSR_AMD_LOG_X3")) g.logX3 = imin(logC, FB_ENV_INT("DSPSR_AMD_LOG_X3", 0) > t3 ? FB_ENV_INT("DSPSR_AMD_LOG_X3", 0) : t3);   // experiment: longer pass-2 runs
     // pass-3 tile: may be smaller than a layout block (DSPSR_AMD_P3_LOG_POINTS), two workgroups then share a CU
-    const int LOG_POINTS3 = getenv("DSPSR_AMD_P3_LOG_POINTS") ? atoi(getenv("DSPSR_AMD_P3_LOG_POINTS")) : LOG_POINTS;
+    const int LOG_POINTS3 = FB_ENV_INT("DSPSR_AMD_P3_LOG_POINTS", LOG_POINTS);
     int t3t = LOG_POINTS3 - g.logM - logPol;
     if (t3t < 0) t3t = 0;
     g.logT3 = imin(g.logX3, t3t);
@@ -1553,8 +1577,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   }
   // ... otherwise four: L = Fa*Fb forward (spectrum in natural order), freq_res = Ma*Mb inverse in two passes.
   // This also covers nchan_subband = 1 (dsp::Convolution) and freq_res up to 2^26.
-  const char* force = getenv("DSPSR_AMD_FOUR_PASS");
-  if ((force && atoi(force) == 1) || !three_ok) {
+  if (cfg->force_four_pass || !three_ok) {
     int la = (logL + 1) / 2;
     if (la > MAX_LOGF) la = MAX_LOGF;
     const int lb = logL - la;
@@ -1584,15 +1607,56 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   fb->nt2 = (uint32_t)(p2 / PTS);
   fb->nt3 = (uint32_t)(p3 / PTS);
   fb->nt4 = (uint32_t)(p4 / PTS);
-  hipDeviceProp_t prop;
-  fb->ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
-                ? (uint32_t)prop.multiProcessorCount : 256u;
+  fb->ncu = ctx->ncu;
   fb->lds1 = lds_total_words_host((uint32_t)p1, g.logM) * sizeof(cf);
   fb->lds2 = lds_total_words_host((uint32_t)p2, g.logR) * sizeof(cf);
   fb->lds3 = lds_total_words_host((uint32_t)p3, g.four_pass ? g.logMa : g.logM) * sizeof(cf);
   fb->lds4 = g.four_pass ? lds_total_words_host((uint32_t)p4, g.logMb) * sizeof(cf) : 0;
   fb->wg3 = (!g.four_pass && 2 * fb->lds3 + 1024 <= 160 * 1024) ? 2 * fb->wg_per_cu : fb->wg_per_cu;
   fb->wg1 = (2 * fb->lds1 + 1024 <= 160 * 1024 && fb->nt1 <= 256) ? 2 * fb->wg_per_cu : fb->wg_per_cu;
+  {
+    // kernels of this geometry and their dynamic-LDS limits (once; perform only launches)
+    const bool notfixed = FB_ENV_SET("DSPSR_AMD_RUNTIME_LOGT");    // experiments: force the generic kernels
+    const bool full1 = !notfixed && g.logT1 == full_logt(g.logM), full2 = !notfixed && g.logT2 == full_logt(g.logR),
+               full3 = !notfixed && !g.four_pass && g.logT3 + 1 == full_logt(g.logM);
+    fb->k1_w1 = fb_pick1(g.logM, 1, full1);
+    fb->k1_w4 = fb_pick1(g.logM, 4, full1);
+#if defined(FB_ONLY_HEADLINE) && defined(DSPSR_AMD_EXPERIMENT)
+    fb->k1_w2 = fb_pick1(g.logM, 2, full1);
+#endif
+    fb->k2 = fb_pick2(g.logR, full2);
+    if (g.four_pass) {
+      fb->k3a = fb_pick3a(g.logMa);
+      fb->k3b = fb_pick3b(g.logMb);
+    } else {
+      fb->k3 = fb_pick3(g.logM, full3);
+      fb->k3f = fb_pick3f(g.logM, full3);
+      // fused fold: the LDS left over behind the twiddle tables holds the part's fold plan (two buffers)
+      const size_t spare = 160 * 1024 - 64 - fb->lds3 - 16;
+      uint32_t cap = fb->lds3 + 64 + 16 < 160 * 1024 ? (uint32_t)(spare / 32) : 0;
+      if (cap > 512) cap = 512;
+      if (cap < 16) cap = 0;
+      fb->plan_cap = cap;
+      fb->lds3f = fb->lds3 + 16 + (size_t)cap * 32;
+    }
+    hipError_t e = hipSuccess;
+    bool have = (fb->k1_w1 || fb->k1_w4) && fb->k2 && (g.four_pass ? (fb->k3a && fb->k3b) : (fb->k3 != nullptr));
+    if (have) {
+      if (fb->k1_w1) e = allow_lds(fb->k1_w1, fb->lds1);
+      if (e == hipSuccess && fb->k1_w4) e = allow_lds(fb->k1_w4, fb->lds1);
+      if (e == hipSuccess && fb->k1_w2) e = allow_lds(fb->k1_w2, fb->lds1);
+      if (e == hipSuccess) e = allow_lds(fb->k2, fb->lds2);
+      if (e == hipSuccess && fb->k3) e = allow_lds(fb->k3, fb->lds3);
+      if (e == hipSuccess && fb->k3f) e = allow_lds(fb->k3f, fb->lds3f);
+      if (e == hipSuccess && fb->k3a) e = allow_lds(fb->k3a, fb->lds3);
+      if (e == hipSuccess && fb->k3b) e = allow_lds(fb->k3b, fb->lds4);
+    }
+    if (!have || e != hipSuccess) {
+      delete fb;
+      return have ? fb_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_filterbank_create: hipFuncSetAttribute: %s", hipGetErrorString(e))
+                  : fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: geometry not in this (experiment) build");
+    }
+  }
   fb->max_parts = cfg->max_parts ? cfg->max_parts : 1;
   // per part: nseq sequences of L points; the two-pass inverse re-uses A for 2 polarisations x N bins
   fb->part_elems = fb->nseq * fb->L;
@@ -1696,10 +1760,6 @@ static uint32_t grid_for(uint64_t items, uint32_t ncu)
   return (uint32_t)gsz;
 }
 
-template <typename K> static hipError_t allow_lds(K kern, size_t bytes)
-{
-  return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
 
 static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, uint64_t in_chan_stride_bytes_or_floats)
 {
@@ -1716,7 +1776,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   // like the (pol0, pol1) pairs of real input, one aligned word per two columns
   const bool fastc = in.kind == 1 && !g.real_input && g.npol == 2 && fb->cfg.input_nchan == 1 &&
                      ((uintptr_t)in.base % 16) == 0 && (in.part_step % 4) == 0 && g.logR >= 3;
-  bool pret = (fast8 || fastc) && g.logR >= 2 && g.logT1 <= 5 && !getenv("DSPSR_AMD_NO_PRETRANSPOSE");   // rows of >= 128 B need no regrouping
+  bool pret = (fast8 || fastc) && g.logR >= 2 && g.logT1 <= 5 && !FB_ENV_SET("DSPSR_AMD_NO_PRETRANSPOSE");   // rows of >= 128 B need no regrouping
   if (pret && in.kind == 2 && (in.part_step % 4) != 0) pret = false;
   if (pret && !fb->Rt) {
     if (hipMalloc((void**)&fb->Rt, (size_t)fb->max_parts * fb->nseq * fb->L * sizeof(uint16_t)) != hipSuccess)
@@ -1724,26 +1784,19 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   }
   int raww = (pret || (fast8 && in.kind == 1)) ? 1 : 4;
 #ifdef FB_ONLY_HEADLINE
-  if (fast8 && getenv("DSPSR_AMD_DIRECT8") && g.logT1 == 2 && (in.part_step % 4) == 0 && ((uintptr_t)in.base % 8) == 0) {
+  if (fast8 && FB_ENV_SET("DSPSR_AMD_DIRECT8") && g.logT1 == 2 && (in.part_step % 4) == 0 && ((uintptr_t)in.base % 8) == 0) {
     pret = false;     // experiment: 4-column tiles read straight from the stream (no regroup pass)
     raww = 2;
   }
 #endif
-  const bool notfixed = getenv("DSPSR_AMD_RUNTIME_LOGT") != nullptr;    // experiments: force the generic kernels
-  const bool full1 = !notfixed && g.logT1 == full_logt(g.logM), full2 = !notfixed && g.logT2 == full_logt(g.logR),
-             full3 = !notfixed && !g.four_pass && g.logT3 + 1 == full_logt(g.logM);
-  k1_t k1 = fb_pick1(g.logM, raww, full1);
-  k2_t k2 = fb_pick2(g.logR, full2);
-  k3_t k3 = g.four_pass ? nullptr : (out.kind == 3 ? fb_pick3f(g.logM, full3) : fb_pick3(g.logM, full3));
-  k3a_t k3a = g.four_pass ? fb_pick3a(g.logMa) : nullptr;
-  k3b_t k3b = g.four_pass ? fb_pick3b(g.logMb) : nullptr;
+  k1_t k1 = raww == 1 ? fb->k1_w1 : raww == 2 ? fb->k1_w2 : fb->k1_w4;
+  k2_t k2 = fb->k2;
+  k3_t k3 = out.kind == 3 ? fb->k3f : fb->k3;
+  k3a_t k3a = fb->k3a;
+  k3b_t k3b = fb->k3b;
   if (!k1 || !k2 || (g.four_pass ? (!k3a || !k3b) : !k3))
     return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: geometry not in this (experiment) build");
   hipError_t e;
-  if ((e = allow_lds(k1, fb->lds1)) != hipSuccess || (e = allow_lds(k2, fb->lds2)) != hipSuccess ||
-      (k3 && (e = allow_lds(k3, fb->lds3)) != hipSuccess) || (k3a && (e = allow_lds(k3a, fb->lds3)) != hipSuccess) ||
-      (k3b && (e = allow_lds(k3b, fb->lds4)) != hipSuccess))
-    return fb_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_filterbank_perform: hipFuncSetAttribute: %s", hipGetErrorString(e));
   const uint32_t Rr = 1u << g.logR, M = 1u << g.logM;
   const float* in_f32 = (const float*)in.base;
   for (uint32_t ichan = 0; ichan < fb->cfg.input_nchan; ichan++) {
@@ -1760,9 +1813,8 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
       const uint64_t n1 = (uint64_t)(Rr >> g.logT1) * fb->nseq * nb, n2 = (uint64_t)(M >> g.logT2) * fb->nseq * nb,
                      n3 = g.four_pass ? 0 : (uint64_t)(g.C >> g.logT3) * nb;
       // XCD dealing of the persistent items (wgfft.h persistent_item); the environment overrides are for experiments
-      static const int env_run1 = getenv("DSPSR_AMD_RUN1") ? atoi(getenv("DSPSR_AMD_RUN1")) : 0,
-                       env_run2 = getenv("DSPSR_AMD_RUN2") ? atoi(getenv("DSPSR_AMD_RUN2")) : 0,
-                       env_run3 = getenv("DSPSR_AMD_RUN3") ? atoi(getenv("DSPSR_AMD_RUN3")) : 0;
+      const int env_run1 = FB_ENV_INT("DSPSR_AMD_RUN1", 0), env_run2 = FB_ENV_INT("DSPSR_AMD_RUN2", 0),
+                env_run3 = FB_ENV_INT("DSPSR_AMD_RUN3", 0);
       const uint32_t run1 = env_run1 > 0 ? env_run1 : 32, run2 = env_run2 > 0 ? env_run2 : 4, run3 = env_run3 > 0 ? env_run3 : nb;
       if (pret) {
         fb_launch_raw_transpose(dim3((Rr + 255) / 256, (M + 63) / 64, nb * fb->nseq), ctx->stream, g, ci, fb->Rt, part0);
@@ -1779,25 +1831,16 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
       // unchanged) while passes 0 and 1 keep the long launch their persistent workgroups want.
       // Sub-group = about 512 MB of spectrum (8 parts of the headline geometry; small geometries keep whole launches:
       // cut into 8 parts, -F 256:D loses 9 % and the 50 MHz sub-band geometry 24 %).
-      static const int p23sub_env = getenv("DSPSR_AMD_P23_SUB") ? atoi(getenv("DSPSR_AMD_P23_SUB")) : -1;
+      const int p23sub_env = FB_ENV_INT("DSPSR_AMD_P23_SUB", -1);
       uint64_t p23auto = (512ull << 20) / (fb->part_elems * sizeof(cf));
       if (p23auto < 1) p23auto = 1;
       // (the fused kernel gains less, +1.4 % Msamples/s measured in three alternating runs, but consistently)
-      static const bool sub_fused = !(getenv("DSPSR_AMD_P23_SUB_FUSED") && atoi(getenv("DSPSR_AMD_P23_SUB_FUSED")) == 0);
+      const bool sub_fused = FB_ENV_INT("DSPSR_AMD_P23_SUB_FUSED", 1) != 0;
       const uint32_t p23sub = (g.four_pass || (co.kind == 3 && !sub_fused) || p23sub_env == 0) ? nb
                               : (p23sub_env > 0 ? (uint32_t)p23sub_env : (uint32_t)(p23auto < nb ? p23auto : nb));
       if (p23sub < nb) {
-        size_t lds3s = fb->lds3;
-        if (co.kind == 3) {
-          const size_t spare = 160 * 1024 - 64 - fb->lds3 - 16;
-          uint32_t cap = fb->lds3 + 64 + 16 < 160 * 1024 ? (uint32_t)(spare / 32) : 0;
-          if (cap > 512) cap = 512;
-          if (cap < 16) cap = 0;
-          co.plan_cap = cap;
-          lds3s += 16 + (size_t)cap * 32;
-          if ((e = allow_lds(k3, lds3s)) != hipSuccess)
-            return fb_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_filterbank_perform: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        }
+        const size_t lds3s = co.kind == 3 ? fb->lds3f : fb->lds3;
+        if (co.kind == 3) co.plan_cap = fb->plan_cap;
         for (uint32_t s0 = 0; s0 < nb; s0 += p23sub) {
           const uint32_t ns = nb - s0 < p23sub ? nb - s0 : p23sub;
           const uint64_t off = (uint64_t)s0 * fb->part_elems;
@@ -1815,17 +1858,8 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
       if (!g.four_pass) {
         // fused fold: one workgroup owns a tile (T3 channels) for all parts of the launch
         const uint64_t items3 = co.kind == 3 ? (uint64_t)(g.C >> g.logT3) : n3;
-        size_t lds3 = fb->lds3;
-        if (co.kind == 3) {                      // LDS left over behind the twiddle tables holds the part's fold plan
-          const size_t spare = 160 * 1024 - 64 - fb->lds3 - 16;
-          uint32_t cap = fb->lds3 + 64 + 16 < 160 * 1024 ? (uint32_t)(spare / 32) : 0;
-          if (cap > 512) cap = 512;
-          if (cap < 16) cap = 0;
-          co.plan_cap = cap;
-          lds3 += 16 + (size_t)cap * 32;
-          if ((e = allow_lds(k3, lds3)) != hipSuccess)
-            return fb_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_filterbank_perform: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        }
+        const size_t lds3 = co.kind == 3 ? fb->lds3f : fb->lds3;
+        if (co.kind == 3) co.plan_cap = fb->plan_cap;       // LDS left over behind the twiddle tables holds the part's fold plan
         hipLaunchKernelGGL(k3, dim3(grid_for(items3, fb->ncu * fb->wg3)), dim3(fb->nt3), lds3, ctx->stream, g, fb->X, kern, co,
                            ctx->tw, part0, nb, run3);
       } else {
@@ -1857,6 +1891,12 @@ extern "C" int dspsr_amd_filterbank_perform(dspsr_amd_filterbank* fb, const floa
   if (out_dev && out_step < 2ull * fb->g.nkeep)
     return fb_fail(fb->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: out_step=%llu < 2*nkeep=%u",
                    (unsigned long long)out_step, 2 * fb->g.nkeep);
+  const uint64_t nchan_out = (uint64_t)fb->cfg.input_nchan * fb->g.C;
+  const uint64_t row = npart ? (npart - 1) * out_step + 2ull * fb->g.nkeep : 0;      // floats one output row spans
+  if (out_dev && npart && ((fb->cfg.npol > 1 && out_pol_stride < row) || (nchan_out > 1 && out_chan_stride < row)))
+    return fb_fail(fb->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: output rows of %llu floats overlap "
+                   "(chan stride %llu, pol stride %llu)", (unsigned long long)row, (unsigned long long)out_chan_stride,
+                   (unsigned long long)out_pol_stride);
   FbIn in = {0, in_dev, in_pol_stride, in_step / ndim, fb->cfg.input_nchan, 0, 1.0f};
   FbOut out = {out_dev ? 1 : 0, out_dev, out_chan_stride, out_pol_stride, out_step, 0, 2, 0};
   return fb_run(fb, in, out, npart, in_chan_stride);
@@ -1902,6 +1942,8 @@ extern "C" int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, con
   FbIn in;
   if (in_f32_dev) {
     const uint32_t idim = fb->cfg.real_input ? 1 : 2;
+    if (in_step % idim)
+      return fb_fail(fb->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_detect: in_step=%llu not a multiple of ndim", (unsigned long long)in_step);
     in = {0, in_f32_dev, in_pol_stride, in_step / idim, fb->cfg.input_nchan, 0, 1.0f};
   } else {
     if (raw_layout == DSPSR_AMD_RAW_CASPSR &&
@@ -1915,6 +1957,14 @@ extern "C" int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, con
       return fb_fail(fb->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_detect: unknown raw layout %d", raw_layout);
     in = {raw_kind(raw_layout), raw_dev, 0, step, fb->cfg.input_nchan, 0, scale};
   }
+  {
+    const uint64_t nchan_out = (uint64_t)fb->cfg.input_nchan * fb->g.C, row = npart * fb->g.nkeep * ndim;   // floats per plane
+    if (npart && ((ndim < 4 && det_pol_stride < row) || (nchan_out > 1 && det_chan_stride < row * (4 / ndim) &&
+                                                         det_chan_stride < det_pol_stride * (4 / ndim - 1) + row)))
+      return fb_fail(fb->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_detect: detected rows of %llu floats overlap "
+                     "(chan stride %llu, pol stride %llu)", (unsigned long long)row, (unsigned long long)det_chan_stride,
+                     (unsigned long long)det_pol_stride);
+  }
   FbOut out = {2, det_dev, det_chan_stride, det_pol_stride, 0, state, ndim, 0};
   return fb_run(fb, in, out, npart, in_chan_stride);
 }
@@ -1922,9 +1972,10 @@ extern "C" int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, con
 extern "C" int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb)
 {
   if (!fb || fb->g.four_pass || fb->g.nkeep >= 65536) return 0;
+  if (fb->cfg.fused_fold == DSPSR_AMD_FUSED_ALWAYS) return 1;
+  if (fb->cfg.fused_fold == DSPSR_AMD_FUSED_NEVER) return 0;
   const uint64_t tiles = (uint64_t)(fb->g.C >> fb->g.logT3);
-  const uint64_t min_tiles = getenv("DSPSR_AMD_FUSED_MIN_TILES") ? (uint64_t)atoll(getenv("DSPSR_AMD_FUSED_MIN_TILES")) : fb->ncu;
-  return tiles >= min_tiles ? 1 : 0;
+  return tiles >= fb->ncu ? 1 : 0;
 }
 
 extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const float* in_f32_dev,
@@ -1952,6 +2003,8 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
   FbIn in;
   if (in_f32_dev) {
     const uint32_t idim = fb->cfg.real_input ? 1 : 2;
+    if (in_step % idim)
+      return fb_fail(fb->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_fold: in_step=%llu not a multiple of ndim", (unsigned long long)in_step);
     in = {0, in_f32_dev, in_pol_stride, in_step / idim, fb->cfg.input_nchan, 0, 1.0f};
   } else {
     if (raw_layout == DSPSR_AMD_RAW_CASPSR && !(fb->cfg.real_input && fb->cfg.npol == 2 && fb->cfg.input_nchan == 1))

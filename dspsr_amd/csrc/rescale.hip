@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_rescale_update(double* __restrict__ tot
   totalsq[col] = 0.0;
 }
 
-__global__ __launch_bounds__(256) void k_rescale_apply(const float* __restrict__ in, float* __restrict__ out, const uint64_t n,
+__global__ __launch_bounds__(256) void k_rescale_apply(const float* in, float* out /* may alias in */, const uint64_t n,
                                                        const uint32_t ncol, const float* __restrict__ offset,
                                                        const float* __restrict__ scale)
 {

@@ -19,7 +19,7 @@ namespace dspsr_amd {
 
 constexpr uint32_t SD_THREADS = 256, SD_PER_THREAD = 8;
 
-__global__ __launch_bounds__(SD_THREADS) void k_sample_delay(const float* __restrict__ in, const uint64_t ics, const uint64_t ips,
+__global__ __launch_bounds__(SD_THREADS) void k_sample_delay(const float* in /* may be out */, const uint64_t ics, const uint64_t ips,
                                                              float* out, const uint64_t ocs, const uint64_t ops,
                                                              const uint32_t npol, const uint32_t ndim, const uint64_t nfloat,
                                                              const int64_t* __restrict__ applied, const uint64_t seg_floats)
@@ -129,9 +129,21 @@ extern "C" int dspsr_amd_sample_delay_transform(dspsr_amd_sample_delay* h, const
   if (!nout) return DSPSR_AMD_OK;
   if (!in_dev || !out_dev) return DSPSR_AMD_EINVAL;
   const uint64_t nfloat = nout * ndim;
+  // In place means the SAME rows (LoadToFold1.C:617-618): one workgroup per row then loads every chunk before it stores
+  // it.  Buffers that overlap in any other way would race between workgroups: refused.
+  const bool inplace = in_dev == out_dev;
+  if (inplace && (in_chan_stride != out_chan_stride || in_pol_stride != out_pol_stride))
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_sample_delay_transform: in place needs equal strides");
+  if (!inplace) {
+    const uint64_t in_span = (h->nchan - 1) * in_chan_stride + (h->npol - 1) * in_pol_stride + ndat_in * ndim;
+    const uint64_t out_span = (h->nchan - 1) * out_chan_stride + (h->npol - 1) * out_pol_stride + nfloat;
+    if (in_dev < out_dev + out_span && out_dev < in_dev + in_span)
+      return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_sample_delay_transform: input and output overlap without being "
+                                             "the same buffer");
+  }
   constexpr uint64_t CHUNK = (uint64_t)SD_THREADS * SD_PER_THREAD;
   uint64_t nseg = 1;
-  if (in_dev != out_dev) {                                  // out of place: cut rows so that >= ~2048 workgroups exist
+  if (!inplace) {                                           // out of place: cut rows so that >= ~2048 workgroups exist
     const uint64_t rows = (uint64_t)h->nchan * h->npol;
     nseg = (2048 + rows - 1) / rows;
     const uint64_t max_seg = (nfloat + CHUNK - 1) / CHUNK;

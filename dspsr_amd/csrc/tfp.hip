@@ -194,12 +194,10 @@ extern "C" int dspsr_amd_tfp_filterbank(dspsr_amd_ctx* ctx, const dspsr_amd_tfp_
   p.scale = scale; p.logT = logT; p.caspsr = raw_layout == DSPSR_AMD_RAW_CASPSR;
   ktfp_t k = pick_tfp(logF, p.caspsr != 0, mkseq_t<14>::type());
   const size_t lds = lds_total_words_host(16384, logF) * sizeof(cf);
-  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = dspsr_amd_allow_lds((const void*)k, lds);      // raised once per kernel, not per call
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_tfp_filterbank: %s", hipGetErrorString(e));
   const uint64_t nitem = sf > T ? nout : (nout * sf + T - 1) >> logT;
-  hipDeviceProp_t prop;
-  uint32_t ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
-                     ? (uint32_t)prop.multiProcessorCount : 256u;
+  const uint32_t ncu = ctx->ncu;
   const uint32_t grid = (uint32_t)(nitem < ncu ? nitem : ncu);
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, ctx->stream, p, ctx->tw);
   e = hipGetLastError();

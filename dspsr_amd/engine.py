@@ -141,12 +141,13 @@ class FilterbankEngine:
         self.handle = None
 
     def setup(self, nchan_subband, freq_res, nfilt_pos, nfilt_neg, input_nchan=1, npol=2, real_input=True,
-              kernel: np.ndarray | None = None, max_parts: int = 1):
+              kernel: np.ndarray | None = None, max_parts: int = 1, force_four_pass: bool = False,
+              fused_fold: int = _lib.FUSED_AUTO):
         if self.handle:
             lib.dspsr_amd_filterbank_destroy(self.handle)
             self.handle = None
         cfg = _lib.FilterbankConfig(nchan_subband, freq_res, nfilt_pos, nfilt_neg, input_nchan, npol,
-                                    1 if real_input else 0, max_parts)
+                                    1 if real_input else 0, max_parts, 1 if force_four_pass else 0, fused_fold)
         h = C.c_void_p()
         _check(self.ctx.handle, lib.dspsr_amd_filterbank_create(self.ctx.handle, C.byref(cfg), C.byref(h)),
                "dspsr_amd_filterbank_create")
@@ -163,8 +164,21 @@ class FilterbankEngine:
         self.nsamp_fft, self.nsamp_overlap, self.nsamp_step, self.nkeep = a.value, b.value, c.value, d.value
         return self
 
+    def _need(self, what, have, need):
+        if have < need:
+            raise DspsrAmdError("dspsr_amd.FilterbankEngine: %s holds %d elements per row, %d needed" % (what, have, need))
+
+    def _raw_bytes(self, npart):
+        c = self.cfg
+        return (npart * self.nsamp_step + self.nsamp_overlap) * c.input_nchan * c.npol * (1 if c.real_input else 2)
+
     def perform(self, inp, out, npart, in_step, out_step):
         ics, ips = _strides3(inp)
+        if npart:
+            ndim = 1 if self.cfg.real_input else 2
+            self._need("input", inp.shape[2], (npart - 1) * in_step + self.nsamp_fft * ndim)
+            if out is not None:
+                self._need("output", out.shape[2], (npart - 1) * out_step + 2 * self.nkeep)
         if out is not None:
             ocs, ops = _strides3(out)
             optr = out.data_ptr()
@@ -179,6 +193,11 @@ class FilterbankEngine:
         ocs, ops = _strides3(out) if out is not None else (0, 0)
         if out_step is None:
             out_step = 2 * self.nkeep
+        if npart:
+            if layout != _lib.RAW_UWB16:
+                self._need("raw block", raw.numel(), self._raw_bytes(npart))
+            if out is not None:
+                self._need("output", out.shape[2], (npart - 1) * out_step + 2 * self.nkeep)
         _check(self.ctx.handle,
                lib.dspsr_amd_filterbank_perform_raw(self.handle, raw.data_ptr(), layout, scale,
                                                     out.data_ptr() if out is not None else None, ocs, ops, npart,
@@ -187,6 +206,15 @@ class FilterbankEngine:
     def perform_detect(self, det, npart, state=_lib.COHERENCE, ndim=4, inp=None, in_step=0, raw=None,
                        layout=_lib.RAW_GENERIC, scale=1.0):
         dcs, dps = _strides3(det)
+        if npart:
+            self._need("detected block", det.shape[2], npart * self.nkeep * ndim)
+            if det.shape[1] != 4 // ndim:
+                raise DspsrAmdError("dspsr_amd.FilterbankEngine.perform_detect: ndim=%d needs %d planes, the block has %d"
+                                    % (ndim, 4 // ndim, det.shape[1]))
+            if raw is not None and layout != _lib.RAW_UWB16:
+                self._need("raw block", raw.numel(), self._raw_bytes(npart))
+            if inp is not None:
+                self._need("input", inp.shape[2], (npart - 1) * in_step + self.nsamp_fft * (1 if self.cfg.real_input else 2))
         if inp is not None:
             ics, ips = _strides3(inp)
             iptr = inp.data_ptr()
@@ -207,6 +235,11 @@ class FilterbankEngine:
                      layout=_lib.RAW_GENERIC, scale=1.0):
         """Fused filterbank -> detection (ndim 4) -> fold into `fold`'s device profile; the bin plan of the
         npart*nkeep output samples must already have been given to `fold` (set_nbin/set_ndat/set_bins)."""
+        if npart:
+            if raw is not None and layout != _lib.RAW_UWB16:
+                self._need("raw block", raw.numel(), self._raw_bytes(npart))
+            if inp is not None:
+                self._need("input", inp.shape[2], (npart - 1) * in_step + self.nsamp_fft * (1 if self.cfg.real_input else 2))
         if inp is not None:
             ics, ips = _strides3(inp)
             iptr = inp.data_ptr()
@@ -240,8 +273,10 @@ class ConvolutionEngine(FilterbankEngine):
     One forward FFT, response multiply and backward FFT of `ndat` points per (channel, pol, part) -- the
     filterbank object with nchan_subband = 1."""
 
-    def prepare(self, ndat, nfilt_pos, nfilt_neg, nchan=1, npol=2, real_input=False, kernel=None, max_parts=1):
-        return self.setup(1, ndat, nfilt_pos, nfilt_neg, nchan, npol, real_input, kernel, max_parts=max_parts)
+    def prepare(self, ndat, nfilt_pos, nfilt_neg, nchan=1, npol=2, real_input=False, kernel=None, max_parts=1,
+                force_four_pass=False):
+        return self.setup(1, ndat, nfilt_pos, nfilt_neg, nchan, npol, real_input, kernel, max_parts=max_parts,
+                          force_four_pass=force_four_pass)
 
 
 def tfp_filterbank(ctx: Context, raw, nchan, npart, out, pscrunch=False, tscrunch=1, layout=_lib.RAW_GENERIC,

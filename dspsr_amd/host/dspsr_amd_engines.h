@@ -92,6 +92,8 @@ namespace HIP
       cfg.real_input = filterbank->get_input()->get_state () == Signal::Nyquist;
       cfg.nfilt_pos = cfg.nfilt_neg = 0;
       cfg.max_parts = 0;
+      cfg.force_four_pass = 0;
+      cfg.fused_fold = DSPSR_AMD_FUSED_AUTO;
       const float* kernel = 0;
       uint64_t ncomplex = 0;
       if (filterbank->has_response ())
@@ -167,6 +169,8 @@ namespace HIP
       cfg.npol = input->get_npol ();
       cfg.real_input = input->get_state () == Signal::Nyquist;    // CUFFT_R2C vs C2C (:219-222)
       cfg.max_parts = 0;
+      cfg.force_four_pass = 0;
+      cfg.fused_fold = DSPSR_AMD_FUSED_AUTO;
       const uint64_t nsamp_step = convolution->get_minimum_samples () - convolution->get_minimum_samples_lost ();
       in_step = nsamp_step * (cfg.real_input ? 1 : 2);             // floats between parts (Convolution.C:386)
       out_step = in_step;                                          // the output is written at the same float offset (:441)

@@ -36,6 +36,7 @@ class Config:
     max_parts: int = 32               # parts per launch group (persistent kernels: 32 amortise ramp-up and tail)
     fused_fold: bool = True           # fold inside the last filterbank pass when possible (identical sums, no
                                       # detected time series in HBM); False = Detection and Fold as separate ops
+    force_fused: bool = False         # fuse also where the channel tiles do not fill the chip (slower there, same sums)
     interchan_dedispersion: bool = False   # -K: remove the inter-channel dispersion delay (LoadToFold1.C:605-624)
 
 
@@ -276,7 +277,9 @@ class LoadToFold:
         # engines --------------------------------------------------------------------------
         self.fb = FilterbankEngine(self.ctx).setup(cfg.nchan // info.nchan, r.ndat, r.impulse_pos, r.impulse_neg,
                                                    info.nchan, info.npol, info.ndim == 1, r.kernel,
-                                                   max_parts=cfg.max_parts)
+                                                   max_parts=cfg.max_parts,
+                                                   fused_fold=(_lib.FUSED_NEVER if not cfg.fused_fold else
+                                                               _lib.FUSED_ALWAYS if cfg.force_fused else _lib.FUSED_AUTO))
         self.nkeep, self.nsamp_step, self.nsamp_overlap = self.fb.nkeep, self.fb.nsamp_step, self.fb.nsamp_overlap
         self.npol_out = 4 // cfg.ndim
         self.fold = FoldEngine(self.ctx)

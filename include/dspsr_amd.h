@@ -78,7 +78,14 @@ typedef struct {
   uint32_t npol;            /* 1 or 2 */
   uint32_t real_input;      /* 1: Signal::Nyquist (ndim 1), 0: Signal::Analytic (ndim 2) */
   uint32_t max_parts;       /* parts processed per launch group (scratch is sized for this); 0 => default */
+  uint32_t force_four_pass; /* 1: two-pass inverse (the path of freq_res > 8192 and of dsp::Convolution) also where the
+                               single-pass inverse would do; same results to rounding.  0 => chosen from the geometry */
+  uint32_t fused_fold;      /* dspsr_amd_filterbank_perform_fold: DSPSR_AMD_FUSED_AUTO (fold inside the last filterbank
+                               pass when the channel tiles fill the chip), _ALWAYS, _NEVER -- same sums bit for bit */
 } dspsr_amd_filterbank_config;
+#define DSPSR_AMD_FUSED_AUTO 0
+#define DSPSR_AMD_FUSED_ALWAYS 1
+#define DSPSR_AMD_FUSED_NEVER 2
 
 int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_filterbank_config* cfg,
                                 dspsr_amd_filterbank** fb);

@@ -29,6 +29,17 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == names
 
 
+def test_shipped_library_reads_no_environment():
+    """Ablation bits ('results are wrong when set') and geometry overrides exist only in -DDSPSR_AMD_EXPERIMENT builds
+    (tools/build_variant.sh): the shipped library neither imports getenv nor holds any of the knob names."""
+    import subprocess
+    import dspsr_amd
+    blob = open(dspsr_amd.LIB_PATH, "rb").read()
+    assert b"DSPSR_AMD_DEBUG" not in blob and b"DSPSR_AMD_FUSED_MIN_TILES" not in blob and b"DSPSR_AMD_WG_PER_CU" not in blob
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", dspsr_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+
+
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     from dspsr_amd import _lib
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))

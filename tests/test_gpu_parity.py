@@ -33,7 +33,7 @@ def _raw(ndat, npol=2, ndim=1, nchan=1, seed=1):
 
 
 def _fb_case(oracle, gpu, C, M, nfilt, npart, npol=2, real=True, input_nchan=1, layout="generic", use_raw=True,
-             max_parts=1, seed=3):
+             max_parts=1, seed=3, four_pass=False):
     dspsr_amd, ctx = gpu
     o = oracle
     nchan = C * input_nchan
@@ -55,7 +55,7 @@ def _fb_case(oracle, gpu, C, M, nfilt, npart, npol=2, real=True, input_nchan=1, 
     ref = o.filterbank(unpacked, plan, kernel, npart=npart, dtype=np.float64)
 
     eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt_pos, nfilt_neg, input_nchan, npol, real, kernel,
-                                                max_parts=max_parts)
+                                                max_parts=max_parts, force_four_pass=four_pass)
     assert (eng.nsamp_fft, eng.nsamp_overlap, eng.nsamp_step, eng.nkeep) == \
         (plan.nsamp_fft, plan.nsamp_overlap, plan.nsamp_step, plan.nkeep)
     out = torch.zeros((nchan, npol, 2 * npart * plan.nkeep), dtype=torch.float32, device="cuda")
@@ -136,12 +136,6 @@ def test_filterbank_batched_parts_identical(oracle, gpu):
     assert np.array_equal(a, b)
 
 
-@pytest.fixture
-def four_pass(monkeypatch):
-    """Forces the two-pass inverse (k_inv_a + k_inv_b) also where three passes would do."""
-    monkeypatch.setenv("DSPSR_AMD_FOUR_PASS", "1")
-
-
 @pytest.mark.parametrize("C,M,nfilt,npart", [
     (8, 64, (5, 7), 3),
     (16, 256, (20, 21), 2),
@@ -149,16 +143,17 @@ def four_pass(monkeypatch):
     (2, 2048, (100, 50), 2),
     (512, 32, (3, 4), 2),
 ])
-def test_filterbank_four_pass_forced(oracle, gpu, four_pass, C, M, nfilt, npart):
-    _fb_case(oracle, gpu, C, M, nfilt, npart)
+def test_filterbank_four_pass_forced(oracle, gpu, C, M, nfilt, npart):
+    """force_four_pass: the two-pass inverse (k_inv_a + k_inv_b) also where three passes would do."""
+    _fb_case(oracle, gpu, C, M, nfilt, npart, four_pass=True)
 
 
-def test_filterbank_four_pass_other_inputs(oracle, gpu, four_pass):
-    _fb_case(oracle, gpu, 16, 256, (20, 21), 2, layout="caspsr")
-    _fb_case(oracle, gpu, 16, 256, (20, 21), 2, npol=1)
-    _fb_case(oracle, gpu, 16, 256, (20, 21), 3, use_raw=False, max_parts=2)
+def test_filterbank_four_pass_other_inputs(oracle, gpu):
+    _fb_case(oracle, gpu, 16, 256, (20, 21), 2, layout="caspsr", four_pass=True)
+    _fb_case(oracle, gpu, 16, 256, (20, 21), 2, npol=1, four_pass=True)
+    _fb_case(oracle, gpu, 16, 256, (20, 21), 3, use_raw=False, max_parts=2, four_pass=True)
     for input_nchan, npol in [(1, 2), (4, 2), (2, 1)]:
-        _fb_case(oracle, gpu, 32, 128, (9, 10), 2, npol=npol, real=False, input_nchan=input_nchan)
+        _fb_case(oracle, gpu, 32, 128, (9, 10), 2, npol=npol, real=False, input_nchan=input_nchan, four_pass=True)
 
 
 @pytest.mark.parametrize("C,M,nfilt,real", [
@@ -502,14 +497,12 @@ def test_end_to_end_folded_profile(oracle, gpu):
     (2, 2048, (100, 50), 1500, 333.3, "Coherence"),     # nbin beyond the workgroup size
 ])
 @pytest.mark.parametrize("force_fused", [True, False])
-def test_fused_fold_bit_identical(oracle, gpu, monkeypatch, C, M, nfilt, nbin, period_samples, state, force_fused):
+def test_fused_fold_bit_identical(oracle, gpu, C, M, nfilt, nbin, period_samples, state, force_fused):
     """perform_fold (fold inside the last filterbank pass) == perform_detect + FoldEngine.fold, bit for bit,
     over several calls and launch groups (accumulators re-loaded from the device profile).  These geometries have
     fewer channel tiles than the chip has compute units, where the library would not fuse by itself:
-    DSPSR_AMD_FUSED_MIN_TILES=0 forces the fused kernel, the default takes the internal Detection + Fold chain."""
+    fused_fold=FUSED_ALWAYS forces the fused kernel, the default takes the internal Detection + Fold chain."""
     dspsr_amd, ctx = gpu
-    if force_fused:
-        monkeypatch.setenv("DSPSR_AMD_FUSED_MIN_TILES", "0")
     o = oracle
     N = C * M
     nkeep = M - sum(nfilt)
@@ -518,7 +511,8 @@ def test_fused_fold_bit_identical(oracle, gpu, monkeypatch, C, M, nfilt, nbin, p
     rng = np.random.default_rng(23)
     kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, N)).astype(np.complex64)
     st = dspsr_amd.STOKES if state == "Stokes" else dspsr_amd.COHERENCE
-    eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, 2, True, kernel, max_parts=2)
+    eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, 2, True, kernel, max_parts=2,
+                                                fused_fold=dspsr_amd.FUSED_ALWAYS if force_fused else dspsr_amd.FUSED_AUTO)
     assert eng.fold_is_fused() == force_fused
     folds = [dspsr_amd.FoldEngine(ctx), dspsr_amd.FoldEngine(ctx)]
     hits = [np.zeros(nbin, np.uint32), np.zeros(nbin, np.uint32)]
@@ -545,17 +539,17 @@ def test_fused_fold_bit_identical(oracle, gpu, monkeypatch, C, M, nfilt, nbin, p
         f.close()
 
 
-def test_pipeline_fused_equals_unfused(oracle, gpu, monkeypatch):
+def test_pipeline_fused_equals_unfused(oracle, gpu):
     """LoadToFold with and without the fused fold over blocks with sub-integration boundaries: identical dumps."""
     dspsr_amd, _ = gpu
-    monkeypatch.setenv("DSPSR_AMD_FUSED_MIN_TILES", "0")      # small geometry: fuse although it does not fill the chip
     from dspsr_amd import pipeline, synth
     freq, bw, tsamp, dm, period, nchan, nbin = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004, 16, 64
     info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
     dumps = []
     for fused in (True, False):
         cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=4,
-                              parts_per_block=3, max_parts=2, subint_seconds=0.004, fused_fold=fused)
+                              parts_per_block=3, max_parts=2, subint_seconds=0.004, fused_fold=fused,
+                              force_fused=fused)      # small geometry: fuse although it does not fill the chip
         lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
         assert lt.fused_fold == fused
         nblocks = 5
