@@ -2,13 +2,22 @@
 """Benchmark of the hot path: 8-bit dual-pol voltages -> coherent-dedispersion filterbank (-F N:D)
 -> detection -> fold, on N MI355X GPUs (one process per GPU).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|cfg3|cfg2|cfg4]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|cfg3|cfg2|cfg4|...]
 
 A "step" is one pass of the hot path over one block (parts_per_block overlap-save parts) of synthetic
 8-bit input already resident in HBM.  metric = Msamples/s = unique input time samples per polarisation
-consumed per second, summed over all ranks.  With N > 1 every rank holds one
-frequency sub-band of the same geometry (weak scaling) and ONE RCCL reduce of the folded profiles is
-done per sub-integration dump (every --dump-steps steps), inside the timed region.
+consumed per second, each rank's own samples summed over all ranks.
+
+--gpus N is ONE command: without WORLD_SIZE in the environment the N ranks are spawned here (before anything touches
+the GPU); under torch.distributed.run the ranks are taken from the environment.  One process per GPU, weak scaling:
+  * multi-channel input (cfg4: one 400 MHz band as NCHAN 8 complex 50 MHz sub-bands, dspsr -F 4096:D): SUB-BAND
+    SHARDING as SURVEY 8(e) -- rank g = input channel g, the g-th 512-channel slice of the ONE full-band kernel, the
+    common nfilt_pos/neg, identical hits on every rank (asserted in the parity gate); no exchange until the
+    sub-integration dump, then ONE reduce (RCCL) delivers every slice of the band to rank 0.
+  * single-channel input (target, cfg1-3: no exchange-free frequency split): TIME-SLICE REPLICAS, the reference's own
+    strategy (MultiThread.C:65-82): rank r takes blocks r, r+N, ... and the dump SUMS profiles, hits and
+    integration length (PhaseSeries::combine).
+The dump (every --dump-steps steps) is inside the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline     : algorithmic bytes of the FFT+chirp launch group / its measured duration (HIP events)
@@ -47,10 +56,11 @@ WORKLOADS = {
     "cfg2": dict(freq=2000.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=256, dm=500.0,
                  freq_res=4096, nbin=1024, machine="CASPSR",
                  cmd="dspsr -F 256:D -x 4096 -D 500 -b 1024 (band moved to 2000 MHz, SURVEY Appendix B)"),
-    # one 50 MHz complex sub-band per rank of an 8-channel 400 MHz band
-    "cfg4": dict(freq=1382.0, bw=-50.0, in_nchan=1, ndim=2, tsamp_us=0.02, nchan=512, dm=1000.0,
+    # BASELINE cfg 4: the 400 MHz band as NCHAN 8 complex 50 MHz sub-bands, one sub-band (input channel) per rank
+    # (= dspsr -F 4096:D on the 8-channel file; 8 ranks x -F 512:D), common 27/27 of the full-band kernel
+    "cfg4": dict(freq=1382.0, bw=-400.0, in_nchan=8, ndim=2, tsamp_us=0.02, nchan=4096, dm=1000.0,
                  freq_res=512, nbin=1024, machine="DADA",
-                 cmd="dspsr -F 512:D -D 1000 -b 1024 per 50 MHz complex sub-band"),
+                 cmd="dspsr -F 4096:D -x 512 -D 1000 -b 1024 on NCHAN 8 complex 50 MHz sub-bands, one per GPU (8 x -F 512:D)"),
     # SURVEY 8f-1 / BASELINE config 5: search-mode front end, detect only (no fold)
     "cfg5": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=4096, dm=0.0, freq_res=1,
                  nbin=0, machine="DADA", tscrunch=16, nparts=32768,
@@ -178,30 +188,177 @@ def _cpu_port_run(args):
     binplan = o.fold_binplan(phi, (1.0 / fobs.rate) / pfold, wl["nbin"], det.shape[2])
     prof = np.zeros((det.shape[0], wl["nbin"], 4), np.float32)
     np.add.at(prof, (slice(None), binplan), det[:, 0])
-    return nparts * plan.nsamp_step, time.perf_counter() - t0
+    return nparts * plan.nsamp_step * wl["in_nchan"], time.perf_counter() - t0
 
 
-def cpu_baseline(wl, lt, parts_per_worker=2):
-    """Times the CPU port on the host cores of this node with the reference's own parallelisation model --
-    one worker per time block (dspsr -t <ncores>, MultiThread.C:65-82) -- on a bounded sample of the workload."""
-    import multiprocessing as mp
+def _host_cores():
     try:
-        ncore = len(os.sched_getaffinity(0))
+        cores = sorted(os.sched_getaffinity(0))
     except AttributeError:
-        ncore = os.cpu_count() or 1
-    ncore = max(1, min(ncore, 16))
-    wl = {k: v for k, v in wl.items() if k != "cmd"}
-    ctx = mp.get_context("spawn")         # the parent holds a HIP context: never fork it
-    with ctx.Pool(ncore) as pool:
-        pool.map(_cpu_port_run, [(wl, 0, 0)] * ncore)                      # start-up, imports, response build
+        cores = list(range(os.cpu_count() or 1))
+    return cores
+
+
+def cpu_baseline_c(wl, geom, ncore, parts_per_worker=4):
+    """The plain-C restatement (oracle/oracle_c.c: float32, its own radix-2 FFT) on the same workload, one thread per
+    time block (ctypes releases the GIL): unpack -> filterbank+chirp -> cross_detect -> bin plan -> fold."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_c.so"))
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint
+    lib.oracle_unpack8.argtypes = [vp, u64, u32, u32, u32, C.c_int, C.c_float, vp]
+    lib.oracle_filterbank.argtypes = [vp, u64, u32, u32, C.c_int, u32, u32, u32, u32, u64, u64, vp, vp]
+    lib.oracle_cross_detect.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32]
+    lib.oracle_fold_binplan.argtypes = [C.c_double, C.c_double, u32, u64, vp, vp]
+    lib.oracle_fold.argtypes = [vp, u64, u32, u32, u32, u64, u64, vp, u32, vp]
+    in_nchan, ndim, nchan, M, nbin = wl["in_nchan"], wl["ndim"], wl["nchan"], geom["freq_res"], wl["nbin"]
+    C_sub, nkeep, step, ovl = nchan // in_nchan, geom["nkeep"], geom["nsamp_step"], geom["nsamp_overlap"]
+    kernel = np.ascontiguousarray(geom["kernel"], dtype=np.complex64)
+    caspsr = 1 if wl["machine"] == "CASPSR" else 0
+    scale = float(geom["scale8"])
+
+    def work(seed):
+        npart = parts_per_worker
+        ndat = npart * step + ovl
+        rng = np.random.default_rng(seed)
+        raw = np.clip(np.rint(rng.standard_normal(ndat * in_nchan * 2 * ndim) * 24), -128, 127).astype(np.int8)
         t0 = time.perf_counter()
-        res = pool.map(_cpu_port_run, [(wl, parts_per_worker, 1 + i) for i in range(ncore)], chunksize=1)
+        unp = np.empty((in_nchan, 2, ndat * ndim), np.float32)
+        lib.oracle_unpack8(raw.ctypes.data, ndat, in_nchan, 2, ndim, caspsr, scale, unp.ctypes.data)
+        fb = np.empty((nchan, 2, npart * nkeep), np.complex64)
+        lib.oracle_filterbank(unp.ctypes.data, ndat * ndim, in_nchan, 2, 1 if ndim == 1 else 0, C_sub, M, geom["nfilt_pos"],
+                              nkeep, step, npart, kernel.ctypes.data, fb.ctypes.data)
+        nd = npart * nkeep
+        det = np.empty((nchan, 1, nd, 4), np.float32)
+        for c in range(nchan):
+            d = det[c, 0]
+            lib.oracle_cross_detect(nd, fb[c, 0].ctypes.data, fb[c, 1].ctypes.data, d.ctypes.data, d.ctypes.data + 4,
+                                    d.ctypes.data + 8, d.ctypes.data + 12, 4)
+        plan = np.empty(nd, np.uint32)
+        hits = np.zeros(nbin, np.uint32)
+        lib.oracle_fold_binplan(0.123, (1.0 / geom["out_rate"]) / 0.089, nbin, nd, plan.ctypes.data, hits.ctypes.data)
+        prof = np.zeros((nchan, 1, nbin, 4), np.float32)
+        lib.oracle_fold(det.ctypes.data, nd * 4, nchan, 1, 4, 0, nd, plan.ctypes.data, nbin, prof.ctypes.data)
+        return npart * step * in_nchan, time.perf_counter() - t0
+
+    with ThreadPoolExecutor(ncore) as ex:
+        t0 = time.perf_counter()
+        res = list(ex.map(work, [101 + i for i in range(ncore)]))
         wall = time.perf_counter() - t0
     samples = sum(r[0] for r in res)
     return {"value": samples / wall / 1e6, "unit": "Msamples/s", "cores": ncore, "kind": "port",
-            "sample": "%d workers x %d overlap-save part(s) of the same workload (%.1f Msamples/pol in all), numpy "
-                      "oracle with pocketfft float32, one process per time block, %.1f s wall, %.1f core-seconds"
-                      % (ncore, parts_per_worker, samples / 1e6, wall, sum(r[1] for r in res))}
+            "sample": "%d threads x %d overlap-save part(s) of the same workload (%.1f Msamples/pol in all), plain-C oracle "
+                      "(oracle/oracle_c.c: float32, own radix-2 FFT, no SIMD FFT library), one thread per time block, "
+                      "%.1f s wall, %.1f core-seconds" % (ncore, parts_per_worker, samples / 1e6, wall, sum(r[1] for r in res))}
+
+
+def cpu_baseline(wl, geom, parts_per_worker=8):
+    """Times the CPU port on ALL host cores of this process's affinity mask with the reference's own parallelisation
+    model -- one worker per time block (dspsr -t <ncores>, MultiThread.C:65-82) -- on a bounded sample of the workload.
+    Two stated baselines: the numpy oracle (pocketfft float32) as `cpu_baseline`, the plain-C oracle beside it."""
+    import multiprocessing as mp
+    cores = _host_cores()
+    ncore = len(cores)
+    wlc = {k: v for k, v in wl.items() if k != "cmd"}
+    ctx = mp.get_context("spawn")         # the parent holds a HIP context: never fork it
+    with ctx.Pool(ncore) as pool:
+        pool.map(_cpu_port_run, [(wlc, 0, 0)] * ncore)                      # start-up, imports, response build
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_port_run, [(wlc, parts_per_worker, 1 + i) for i in range(ncore)], chunksize=1)
+        wall = time.perf_counter() - t0
+    samples = sum(r[0] for r in res)
+    out = {"value": samples / wall / 1e6, "unit": "Msamples/s", "cores": ncore, "kind": "port",
+           "affinity": "%d cores: %s" % (ncore, ",".join(str(c) for c in cores) if ncore <= 64 else "%d..%d" % (cores[0], cores[-1])),
+           "sample": "%d workers x %d overlap-save part(s) of the same workload (%.1f Msamples/pol in all), numpy "
+                     "oracle with pocketfft float32, one process per time block, %.1f s wall, %.1f core-seconds"
+                     % (ncore, parts_per_worker, samples / 1e6, wall, sum(r[1] for r in res))}
+    try:
+        out["c_oracle"] = cpu_baseline_c(wl, geom, ncore, max(1, parts_per_worker // 2))
+    except Exception as e:  # reported baseline only
+        out["c_oracle"] = {"value": None, "sample": "failed: %r" % (e,)}
+    return out
+
+
+def spawn_ranks(argv, ngpu):
+    """bench.py --gpus N as ONE command: start the N ranks as child processes (one per GPU) BEFORE this process touches
+    the GPU, relay rank 0's JSON line, exit non-zero if any rank fails."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(ngpu):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpu), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    try:
+        for p in procs:
+            p.wait()
+            if p.returncode != 0:
+                rc = rc or p.returncode or 1
+                for q in procs:                  # a rank died: the others would wait in a collective for ever
+                    if q.poll() is None:
+                        q.terminate()
+    except KeyboardInterrupt:
+        for q in procs:
+            q.kill()
+        rc = 130
+    return rc
+
+
+class ParityGateError(SystemExit):
+    pass
+
+
+def parity_gate(lt, raw, torch, dist, rank, world, sharded):
+    """Outside the timed region, on one more block: (i) the fused launch group and Detection + Fold as separate
+    operations give the same profile bit for bit, (ii) every output sample landed in exactly one phase bin,
+    (iii) the profile holds the power of the detected time series, (iv) sub-band ranks agree on hits[].
+    Any failure ends the run with a non-zero exit code and no result line."""
+    from dspsr_amd import pipeline
+    was = lt.fused_fold
+    ndat = lt.cfg.parts_per_block * lt.nkeep
+    res = {}
+    lt.subints.clear()
+    for fused in ([True, False] if was else [False]):
+        lt.fused_fold = fused
+        lt.process_block(raw)
+        if fused is False:
+            det = lt.detected.view(lt.nchan_out, lt.npol_out, -1)
+        hits = lt.hits.copy()
+        prof = lt.profiles_tensor().clone()
+        lt.fold.zero()
+        lt.hits[:] = 0
+        lt.integration_length, lt.ndat_total = 0.0, 0
+        res[fused] = (hits, prof)
+    lt.fused_fold = was
+    hits, prof = res[False]
+    fails = []
+    if was and not (np.array_equal(res[True][0], hits) and bool(torch.equal(res[True][1], prof))):
+        fails.append("fused fold differs from Detection + Fold")
+    if int(hits.astype(np.int64).sum()) != ndat:
+        fails.append("hits.sum()=%d != ndat=%d" % (int(hits.sum()), ndat))
+    nd = lt.cfg.ndim
+    if nd == 4:                                   # PP and QQ (or I and Q) of every channel: sum over bins == sum over time
+        want = det[:, 0, :ndat * 4].view(lt.nchan_out, ndat, 4)[:, :, :2].double().sum(dim=1)
+        got = prof.view(lt.nchan_out, lt.cfg.nbin, 4)[:, :, :2].double().sum(dim=1)
+        rel = float((got - want).abs().max() / want.abs().max())
+        if not rel <= 2e-5:
+            fails.append("profile power differs from the detected time series by %.3g" % rel)
+        res["power_rel"] = rel
+    if sharded and world > 1:
+        try:
+            pipeline.check_identical_hits(hits, dist, rank, world)
+        except pipeline.DspsrAmdError as e:
+            fails.append(str(e))
+    if fails:
+        raise ParityGateError("bench.py parity gate FAILED on rank %d: %s" % (rank, "; ".join(fails)))
+    return {"status": "ok", "checks": (["fused == Detection+Fold bit for bit"] if was else []) +
+            ["hits.sum() == ndat", "profile power == detected power (rel %.1e)" % res.get("power_rel", 0.0)] +
+            (["identical hits on all sub-band ranks"] if sharded and world > 1 else [])}
 
 
 def main():
@@ -224,6 +381,9 @@ def main():
                     help="Detection and Fold as separate operations (detected time series through HBM)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(sys.argv[1:], args.gpus))          # nothing has touched the GPU yet
+
     import torch
     import torch.distributed as dist
     from dspsr_amd import pipeline
@@ -232,9 +392,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (the product has no CPU path)")
     # test hook: DSPSR_AMD_SINGLE_DEVICE=1 maps every rank to GPU 0 with the gloo backend, so the N>1 code path
@@ -255,9 +413,10 @@ def main():
         if world > 1:
             sys.exit("bench.py: the search-mode workload runs as independent replicas; use --gpus 1")
         return bench_search_mode(args, wl, torch)
-    # sub-band sharding: rank g holds the g-th band of the same geometry (centre frequencies stacked downwards)
-    freq = wl["freq"] + rank * wl["bw"]
-    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=wl["bw"], nchan=wl["in_nchan"], npol=2,
+    sharded = wl["in_nchan"] > 1                 # sub-band sharding; otherwise time-slice replicas
+    if sharded and world > wl["in_nchan"]:
+        sys.exit("bench.py: workload %s has %d sub-bands, --gpus %d is more" % (args.workload, wl["in_nchan"], world))
+    info = pipeline.InputInfo(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=wl["in_nchan"], npol=2,
                               ndim=wl["ndim"], tsamp_us=wl["tsamp_us"], machine=wl["machine"])
     if not args.parts_per_block:
         n_fft = (wl["nchan"] // wl["in_nchan"]) * wl["freq_res"]
@@ -269,7 +428,8 @@ def main():
                           folding_period=0.0893, freq_res=wl["freq_res"], ndim=args.ndim,
                           parts_per_block=args.parts_per_block, max_parts=args.max_parts,
                           fused_fold=not args.no_fused_fold)
-    lt = pipeline.LoadToFold(cfg, info, device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    lt = pipeline.LoadToFold(cfg, info, device=local_rank, stream=torch.cuda.current_stream().cuda_stream,
+                             subband=rank if sharded else None)
 
     # synthetic block resident in HBM: seeded Gaussian noise, sigma = 24 LSB (content does not change the work)
     nbytes = lt.block_bytes()
@@ -281,63 +441,84 @@ def main():
         raw[s:e] = torch.randn(e - s, generator=gen, device="cuda").mul_(24.0).round_().clamp_(-128, 127).to(torch.int8)
 
     gather = None
-    if world > 1:
-        gather = torch.zeros(world * cfg.nchan * lt.npol_out * cfg.nbin * cfg.ndim, dtype=torch.float32, device="cuda")
+    if world > 1 and sharded:
+        gather = torch.zeros(world * lt.nchan_out * lt.npol_out * cfg.nbin * cfg.ndim, dtype=torch.float32, device="cuda")
+    comm = dist if world > 1 else None
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def dump():
+        lt.finish_subint(comm, rank, world, gather, replicas=not sharded)
+        lt.subints.clear()
+
+    blocks_done = [0]
+
     def step(i, ev=None):
+        if not sharded:
+            lt.seek_block(blocks_done[0] * world + rank)       # replica r takes blocks r, r + N, ... of the stream
+        blocks_done[0] += 1
         lt.process_block(raw, events=ev)
         if (i + 1) % args.dump_steps == 0:
-            lt.finish_subint(dist if world > 1 else None, rank, world, gather)
-            lt.subints.clear()
+            dump()
 
     for i in range(args.warmup):
         step(i)
     barrier()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    nsamp0 = lt.nsamples_in
     t_start = time.perf_counter()
     for i in range(args.steps):
         step(i, events[i])
-    lt.finish_subint(dist if world > 1 else None, rank, world, gather)
+    dump()
     barrier()
     elapsed = time.perf_counter() - t_start
+    samples = float((lt.nsamples_in - nsamp0) * lt.in_nchan)          # this rank's own samples (per pol)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        t = torch.tensor([samples], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        samples = float(t.item())
+    value = samples / elapsed / 1e6
 
-    samples_per_step = cfg.parts_per_block * lt.nsamp_step            # per rank, per pol
-    value = world * samples_per_step * args.steps / elapsed / 1e6
-
+    # ---- outside the timed region: roofline blocks, parity gate, baselines ------------------------------------
+    timed_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)   # launch group of the timed region
+    fused = lt.fused_fold
+    fb_ms = timed_ms
+    extra = 0
+    if fused:
+        # The timed region ran the fused kernels (the detected time series never reaches HBM).  The roofline
+        # of the FFT+chirp(+detect) pass as SURVEY 8(d) defines it -- input once, chirp once, kept output once --
+        # is measured on extra blocks right after the timed region, with Detection and Fold as separate
+        # operations; the fused launch group is reported beside it with its own (smaller) algorithmic bytes.
+        lt.fused_fold = False
+        extra = max(4, args.steps // 4)
+        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(extra)]
+        lt.process_block(raw)
+        for e in ev2:
+            lt.process_block(raw, events=e)
+        torch.cuda.synchronize()
+        fb_ms = sum(a.elapsed_time(b) for a, b in ev2) / len(ev2)
+        lt.fused_fold = True
+        lt.fold.zero()
+        lt.hits[:] = 0
+        lt.integration_length, lt.ndat_total = 0.0, 0
+    gate = parity_gate(lt, raw, torch, dist, rank, world, sharded)       # every rank; raises on failure
     if rank == 0:
-        timed_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)   # launch group of the timed region
-        fused = lt.fused_fold
-        fb_ms = timed_ms
-        extra = 0
-        if fused:
-            # The timed region ran the fused kernels (the detected time series never reaches HBM).  The roofline
-            # of the FFT+chirp(+detect) pass as SURVEY 8(d) defines it -- input once, chirp once, kept output once --
-            # is measured on extra blocks right after the timed region, with Detection and Fold as separate
-            # operations; the fused launch group is reported beside it with its own (smaller) algorithmic bytes.
-            lt.fused_fold = False
-            extra = max(4, args.steps // 4)
-            ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(extra)]
-            lt.process_block(raw)
-            for e in ev2:
-                lt.process_block(raw, events=e)
-            torch.cuda.synchronize()
-            fb_ms = sum(a.elapsed_time(b) for a, b in ev2) / len(ev2)
-            lt.fused_fold = True
         r = lt.response
         nchan_subband = cfg.nchan // info.nchan
         N = nchan_subband * r.ndat
         nsamp_fft = 2 * N if info.ndim == 1 else N
         b_alg = algorithmic_bytes_per_part(2, nsamp_fft * info.ndim, 8, N, nchan_subband, lt.nkeep)
-        achieved = b_alg * cfg.parts_per_block * info.nchan / (fb_ms * 1e-3) / 1e9
+        achieved = b_alg * cfg.parts_per_block * lt.in_nchan / (fb_ms * 1e-3) / 1e9
+        par = ("sub-band per GPU x%d (input channel g of %d, slice g of the full-band kernel, one reduce per dump)"
+               % (world, info.nchan)) if sharded else \
+              ("time-slice replicas x%d (blocks dealt round robin, SUM reduce of profiles+hits per dump)" % world
+               if world > 1 else "single GPU")
         out = {
             "metric": "Msamples/s dedispersed+folded", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -346,15 +527,18 @@ def main():
             "config": {"workload": args.workload, "command": wl["cmd"], "nchan": cfg.nchan, "freq_res": r.ndat,
                        "n_fft": N, "nfilt_pos": r.impulse_pos, "nfilt_neg": r.impulse_neg, "nkeep": lt.nkeep,
                        "nsamp_step": lt.nsamp_step, "dm": cfg.dispersion_measure, "nbin": cfg.nbin,
-                       "parts_per_block": cfg.parts_per_block, "input": "8-bit dual-pol, resident in HBM",
-                       "detected_ndim": cfg.ndim, "fused_fold": bool(fused),
-                       "parallelism": "sub-band per GPU x%d" % world,
+                       "parts_per_block": cfg.parts_per_block, "max_parts": cfg.max_parts,
+                       "input": "8-bit dual-pol, resident in HBM",
+                       "detected_ndim": cfg.ndim, "fused_fold": bool(fused), "parallelism": par,
                        "realtime_factor": round(value / world / (info.rate / 1e6), 3)},
+            "parity_gate": gate,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic(args.workload, cfg.max_parts),
-                         "traffic_unit": "HBM bytes per launch group of %d parts (PMC, profiles/r*_traffic.json, newest); "
-                                         "algorithmic bytes for the same group: %d" % (cfg.max_parts, b_alg * cfg.max_parts),
+                         "traffic_unit": "HBM bytes per launch group of %d parts (PMC, %s); "
+                                         "algorithmic bytes for the same group: %d"
+                                         % (cfg.max_parts, measured_traffic.source or "profiles/r*_traffic.json: none for this shape",
+                                            b_alg * cfg.max_parts),
                          "kernel": "filterbank launch group k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,false> "
                                    "(FFT+chirp+detect, detected output written)",
                          "algorithmic_bytes_per_part": b_alg, "group_ms_per_block": round(fb_ms, 4),
@@ -364,7 +548,7 @@ def main():
         }
         if fused:
             b_fused = b_alg - 2 * nchan_subband * lt.nkeep * 8         # no detected output: input once + chirp once
-            ach_f = b_fused * cfg.parts_per_block * info.nchan / (timed_ms * 1e-3) / 1e9
+            ach_f = b_fused * cfg.parts_per_block * lt.in_nchan / (timed_ms * 1e-3) / 1e9
             out["roofline_fused"] = {
                 "bound": "hbm", "achieved": round(ach_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach_f / HBM_PEAK_GBS, 4),
@@ -381,7 +565,7 @@ def main():
             copy_stream = torch.cuda.Stream()
             ready = [torch.cuda.Event(), torch.cuda.Event()]
             done = [torch.cuda.Event(), torch.cuda.Event()]
-            main = torch.cuda.current_stream()
+            main_stream = torch.cuda.current_stream()
 
             def h2d_run(nsteps):
                 with torch.cuda.stream(copy_stream):
@@ -395,27 +579,30 @@ def main():
                                 copy_stream.wait_event(done[b ^ 1])     # the kernels of block i-1 are finished with it
                             bufs[b ^ 1].copy_(host, non_blocking=True)
                             ready[b ^ 1].record(copy_stream)
-                    main.wait_event(ready[b])
+                    main_stream.wait_event(ready[b])
                     lt.process_block(bufs[b])
-                    done[b].record(main)
+                    done[b].record(main_stream)
                 torch.cuda.synchronize()
             h2d_run(3)
             t1 = time.perf_counter()
             h2d_run(args.steps)
             dt = time.perf_counter() - t1
             out["config"]["pcie_inclusive"] = {
-                "value": round(samples_per_step * args.steps / dt / 1e6, 1), "unit": "Msamples/s",
+                "value": round(cfg.parts_per_block * lt.nsamp_step * args.steps / dt / 1e6, 1), "unit": "Msamples/s",
                 "note": "blocks copied from pinned host memory (%.1f MB each) on a second stream, double buffered"
                         % (raw.numel() / 1e6)}
         if world == 1 and not args.no_cpu_baseline:
+            geom = {"freq_res": r.ndat, "nkeep": lt.nkeep, "nsamp_step": lt.nsamp_step, "nsamp_overlap": lt.nsamp_overlap,
+                    "nfilt_pos": r.impulse_pos, "kernel": r.kernel, "scale8": lt.scale8, "out_rate": lt.out_rate}
             try:
-                out["cpu_baseline"] = cpu_baseline(wl, lt)
+                out["cpu_baseline"] = cpu_baseline(wl, geom)
             except Exception as e:  # the oracle is only a reported baseline
                 out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 1, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     lt.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1958,9 +1958,13 @@ extern "C" int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, con
     in = {raw_kind(raw_layout), raw_dev, 0, step, fb->cfg.input_nchan, 0, scale};
   }
   {
-    const uint64_t nchan_out = (uint64_t)fb->cfg.input_nchan * fb->g.C, row = npart * fb->g.nkeep * ndim;   // floats per plane
-    if (npart && ((ndim < 4 && det_pol_stride < row) || (nchan_out > 1 && det_chan_stride < row * (4 / ndim) &&
-                                                         det_chan_stride < det_pol_stride * (4 / ndim - 1) + row)))
+    // rows must not overlap: channel-major (TimeSeries FPT order) or plane-major layouts are accepted
+    const uint64_t nchan_out = (uint64_t)fb->cfg.input_nchan * fb->g.C, row = npart * fb->g.nkeep * ndim, planes = 4 / ndim;
+    const bool chan_major = (planes == 1 || det_pol_stride >= row) &&
+                            (nchan_out == 1 || det_chan_stride >= (planes - 1) * det_pol_stride + row);
+    const bool plane_major = planes > 1 && (nchan_out == 1 || det_chan_stride >= row) &&
+                             det_pol_stride >= (nchan_out - 1) * det_chan_stride + row;
+    if (npart && !chan_major && !plane_major)
       return fb_fail(fb->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_detect: detected rows of %llu floats overlap "
                      "(chan stride %llu, pol stride %llu)", (unsigned long long)row, (unsigned long long)det_chan_stride,
                      (unsigned long long)det_pol_stride);

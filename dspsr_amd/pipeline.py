@@ -247,17 +247,63 @@ def reduce_subbands(prof, dist=None, rank=0, world=1, gather_buffer=None):
     return gather_buffer if rank == 0 else None
 
 
+def check_identical_hits(hits, dist, rank, world):
+    """Sub-band sharding: every rank folds with the same channel-independent bin plan (Fold.C:744-787), so hits[] must
+    be identical on all ranks (SURVEY 8e: 'assert equality in debug').  One small all-reduce pair (MAX and MIN);
+    raises on every rank when they differ.  Debug/test aid: not part of the timed path."""
+    if world <= 1:
+        return
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    h = torch.as_tensor(np.asarray(hits, dtype=np.int64), device=dev)
+    hi, lo = h.clone(), h.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    if not bool(torch.equal(hi, lo)):
+        raise DspsrAmdError("sub-band ranks disagree on hits[]: the shards are not sample aligned "
+                            "(different nfilt_pos/neg, start time or rate)")
+
+
+def reduce_replicas(prof, hits, integration_length, ndat_total, dist=None, rank=0, world=1):
+    """Time-slice replicas (single-channel input has no exchange-free frequency split; the reference runs one thread
+    per time block, MultiThread.C:65-82,120-148, and merges the pieces of a division with PhaseSeries::combine,
+    PhaseSeries.C:442-484): a true SUM of profiles, hits, integration_length and ndat_total onto rank 0.
+    prof is reduced in place (one reduce of the profile buffer -- RCCL over xGMI on GPUs, gloo in the CPU tests --
+    plus two tiny ones for the counters).  Returns (prof, hits, integration_length, ndat_total) on rank 0, None elsewhere."""
+    if world <= 1:
+        return prof, np.asarray(hits, dtype=np.uint32), float(integration_length), int(ndat_total)
+    import torch
+    dev = prof.device
+    dist.reduce(prof, dst=0, op=dist.ReduceOp.SUM)
+    cnt = torch.as_tensor(np.concatenate([np.asarray(hits, dtype=np.int64), [int(ndat_total)]]), device=dev)
+    dist.reduce(cnt, dst=0, op=dist.ReduceOp.SUM)
+    length = torch.tensor([float(integration_length)], dtype=torch.float64, device=dev)
+    dist.reduce(length, dst=0, op=dist.ReduceOp.SUM)
+    if rank != 0:
+        return None
+    cnt = cnt.cpu().numpy()
+    return prof, cnt[:-1].astype(np.uint32), float(length.item()), int(cnt[-1])
+
+
 class LoadToFold:
     """One pipeline instance = one GPU = one stream (SingleThread).  `raw` blocks are int8 torch
     tensors already resident on the device (the PCIe copy is the caller's, as TransferCUDA is a
     separate Operation in the reference)."""
 
     def __init__(self, cfg: Config, info: InputInfo, device: int = 0, stream: int | None = None,
-                 polyco: Polyco | None = None, reference_phase: float = 0.0):
+                 polyco: Polyco | None = None, reference_phase: float = 0.0, subband: int | None = None):
+        """subband = g: this instance is rank g of a sub-band sharded run.  `info`/`cfg` still describe the
+        WHOLE band (info.nchan input channels, cfg.nchan output channels); the instance processes input channel g only:
+        its block holds that channel's bytes alone ([t][pol][dim], what a rank reads from the NCHAN-interleaved file),
+        its kernel is the g-th slice of the ONE full-band kernel (Filterbank.C:563, FilterbankCUDA.cu:249-251) with the
+        COMMON nfilt_pos/neg, so all ranks stay sample aligned and fold with identical hits."""
         import torch
         self.torch = torch
         self.cfg, self.info, self.polyco = cfg, info, polyco
         self.reference_phase = reference_phase
+        self.subband = subband
+        if subband is not None and not 0 <= subband < info.nchan:
+            raise DspsrAmdError("dspsr_amd.LoadToFold: subband=%d outside the %d input channels" % (subband, info.nchan))
         if cfg.folding_period <= 0 and polyco is None:
             raise DspsrAmdError("dsp::Fold::fold no polynomial and no period specified")   # Fold.C:638-640
         if info.npol != 2:
@@ -275,15 +321,21 @@ class LoadToFold:
             raise DspsrAmdError("dsp::Filterbank::make_preparations output nchan=%d not a multiple of input nchan=%d"
                                 % (cfg.nchan, info.nchan))
         # engines --------------------------------------------------------------------------
-        self.fb = FilterbankEngine(self.ctx).setup(cfg.nchan // info.nchan, r.ndat, r.impulse_pos, r.impulse_neg,
-                                                   info.nchan, info.npol, info.ndim == 1, r.kernel,
+        nsub = cfg.nchan // info.nchan
+        kernel = r.kernel
+        if subband is not None:
+            kernel = kernel[subband * nsub * r.ndat:(subband + 1) * nsub * r.ndat]
+        self.in_nchan = 1 if subband is not None else info.nchan         # input channels in this instance's blocks
+        self.nchan_out = nsub * self.in_nchan                              # output channels this instance produces
+        self.fb = FilterbankEngine(self.ctx).setup(nsub, r.ndat, r.impulse_pos, r.impulse_neg,
+                                                   self.in_nchan, info.npol, info.ndim == 1, kernel,
                                                    max_parts=cfg.max_parts,
                                                    fused_fold=(_lib.FUSED_NEVER if not cfg.fused_fold else
                                                                _lib.FUSED_ALWAYS if cfg.force_fused else _lib.FUSED_AUTO))
         self.nkeep, self.nsamp_step, self.nsamp_overlap = self.fb.nkeep, self.fb.nsamp_step, self.fb.nsamp_overlap
         self.npol_out = 4 // cfg.ndim
         self.fold = FoldEngine(self.ctx)
-        self.fold.set_shape(cfg.nchan, self.npol_out, cfg.ndim, cfg.nbin)
+        self.fold.set_shape(self.nchan_out, self.npol_out, cfg.ndim, cfg.nbin)
         self.scale8 = eight_bit_scale()
         self.layout = _lib.RAW_CASPSR if info.machine == "CASPSR" else _lib.RAW_GENERIC
         # output observation (Filterbank::prepare_output, Filterbank.C:265-379)
@@ -302,6 +354,9 @@ class LoadToFold:
             delays = dedispersion_sample_delays(info.centre_frequency, info.bandwidth, cfg.dispersion_measure, cfg.nchan,
                                                 self.out_rate, swap=dual and info.nchan == 1,
                                                 nsub_swap=info.nchan if dual and info.nchan > 1 else 0)
+            if subband is not None:
+                raise DspsrAmdError("dspsr_amd.LoadToFold: -K with sub-band sharding is not built (the shards would "
+                                    "need the delays of the whole band)")
             self.sample_delay = SampleDelay(self.ctx, delays, self.npol_out)
             head = self.sample_delay.total_delay
             if head > cfg.parts_per_block * self.nkeep:
@@ -309,7 +364,7 @@ class LoadToFold:
                                     % (head, cfg.parts_per_block * self.nkeep))
             self.out_start += self.sample_delay.zero_delay / self.out_rate       # SampleDelay.C:159
         self.sd_head = head
-        self.detected = torch.empty((cfg.nchan, self.npol_out, (head + cfg.parts_per_block * self.nkeep) * cfg.ndim),
+        self.detected = torch.empty((self.nchan_out, self.npol_out, (head + cfg.parts_per_block * self.nkeep) * cfg.ndim),
                                     dtype=torch.float32, device="cuda:%d" % device)
         # fused filterbank+detect+fold (no detected time series in HBM): ndim 4, three-pass geometries
         # (the library decides whether fusing pays for this geometry; when it does not, this driver keeps the
@@ -327,7 +382,12 @@ class LoadToFold:
     def block_bytes(self, npart=None):
         npart = npart or self.cfg.parts_per_block
         nsamp = npart * self.nsamp_step + self.nsamp_overlap
-        return nsamp * self.info.nchan * self.info.npol * self.info.ndim
+        return nsamp * self.in_nchan * self.info.npol * self.info.ndim
+
+    def seek_block(self, k):
+        """Time-slice replicas: the next block is block k of the stream (blocks of parts_per_block parts), not the one
+        following the last (MultiThread.C:120-148 hands whole blocks to the threads in turn)."""
+        self.ndat_out = k * self.cfg.parts_per_block * self.nkeep
 
     def _phase(self, t_seconds):
         """Fold::get_phi / get_pfold (Fold.C:943-958)."""
@@ -415,10 +475,10 @@ class LoadToFold:
         self.ndat_out += nout
         self.nsamples_in += npart * self.nsamp_step
 
-    _subint_comm = (None, 0, 1, None)     # (dist, rank, world, gather_buffer) used at sub-integration dumps
+    _subint_comm = (None, 0, 1, None)     # (dist, rank, world, gather_buffer[, replicas]) used at sub-integration dumps
 
-    def set_communicator(self, dist, rank, world, gather_buffer):
-        self._subint_comm = (dist, rank, world, gather_buffer)
+    def set_communicator(self, dist, rank, world, gather_buffer=None, replicas=False):
+        self._subint_comm = (dist, rank, world, gather_buffer, replicas)
 
     def _set_plan(self, idat_start, ndat_fold):
         """The host plan loop of Fold::fold (Fold.C:650-657,718-787): phase of the first sample, then the bins."""
@@ -440,7 +500,7 @@ class LoadToFold:
         """Zero-copy torch view of the device-resident PhaseSeries (Fold::Engine::get_profiles)."""
         import ctypes as C
         torch = self.torch
-        n = self.cfg.nchan * self.npol_out * self.cfg.nbin * self.cfg.ndim
+        n = self.nchan_out * self.npol_out * self.cfg.nbin * self.cfg.ndim
         ptr = self.fold.get_profiles_ptr()
 
         class _Holder:
@@ -450,13 +510,24 @@ class LoadToFold:
                                       "strides": None}
         return torch.as_tensor(h, device="cuda:%d" % self.ctx.device)
 
-    def finish_subint(self, dist=None, rank=0, world=1, gather_buffer=None):
-        """Subint<Fold>: emit the finished sub-integration and zero the profile (Subint.h:291-303)."""
+    def finish_subint(self, dist=None, rank=0, world=1, gather_buffer=None, replicas=False, check_hits=False):
+        """Subint<Fold>: emit the finished sub-integration and zero the profile (Subint.h:291-303).  With world > 1 this
+        is the one exchange of the path: sub-band shards (gather_buffer given) deliver their slice of the full band to
+        rank 0, hits / integration_length taken from rank 0 (identical everywhere; check_hits asserts it);
+        time-slice replicas (replicas=True) SUM profiles, hits, integration_length and ndat_total."""
         prof = self.profiles_tensor()
-        result = reduce_subbands(prof, dist, rank, world, gather_buffer)
-        if rank == 0:
-            self.subints.append({"hits": self.hits.copy(), "integration_length": self.integration_length,
-                                 "ndat_total": self.ndat_total, "profile_dev": result.clone()})
+        if replicas:
+            res = reduce_replicas(prof, self.hits, self.integration_length, self.ndat_total, dist, rank, world)
+            if rank == 0:
+                self.subints.append({"hits": res[1].copy(), "integration_length": res[2], "ndat_total": res[3],
+                                     "profile_dev": res[0].clone()})
+        else:
+            if check_hits:
+                check_identical_hits(self.hits, dist, rank, world)
+            result = reduce_subbands(prof, dist, rank, world, gather_buffer)
+            if rank == 0:
+                self.subints.append({"hits": self.hits.copy(), "integration_length": self.integration_length,
+                                     "ndat_total": self.ndat_total, "profile_dev": result.clone()})
         self.fold.zero()
         self.hits[:] = 0
         self.integration_length = 0.0

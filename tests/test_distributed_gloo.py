@@ -58,6 +58,65 @@ def test_subband_reduce_gloo(tmp_path, world):
         assert np.array_equal(got[subint], np.concatenate(want))
 
 
+def _replica_worker(rank, world, port, nbin, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dspsr_amd.pipeline import DspsrAmdError, check_identical_hits, reduce_replicas
+    rng = np.random.default_rng(7 + rank)
+    prof = torch.from_numpy(rng.standard_normal(3 * nbin * 4).astype(np.float32))
+    hits = rng.integers(0, 50, nbin).astype(np.uint32)
+    res = reduce_replicas(prof, hits, 0.25 * (rank + 1), 1000 + rank, dist, rank, world)
+    # sub-band ranks: identical hits pass, diverging hits raise on EVERY rank (no rank is left waiting)
+    check_identical_hits(np.arange(nbin), dist, rank, world)
+    raised = False
+    try:
+        check_identical_hits(np.arange(nbin) + (rank == world - 1), dist, rank, world)
+    except DspsrAmdError:
+        raised = True
+    assert raised
+    if rank == 0:
+        np.savez(out_path, prof=res[0].numpy(), hits=res[1], length=res[2], ndat=res[3])
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_time_slice_replica_reduce_gloo(tmp_path, world):
+    """PhaseSeries::combine semantics over the collective (PhaseSeries.C:442-484): profiles, hits, integration_length and
+    ndat_total of all replicas ADD onto rank 0."""
+    nbin = 16
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_replica_worker, args=(world, _free_port(), nbin, out), nprocs=world, join=True)
+    got = np.load(out)
+    prof = np.zeros(3 * nbin * 4, np.float32)
+    hits = np.zeros(nbin, np.uint32)
+    for r in range(world):
+        rng = np.random.default_rng(7 + r)
+        prof = prof + rng.standard_normal(3 * nbin * 4).astype(np.float32)
+        hits += rng.integers(0, 50, nbin).astype(np.uint32)
+    assert np.array_equal(got["hits"], hits) and int(got["ndat"]) == sum(1000 + r for r in range(world))
+    assert float(got["length"]) == sum(0.25 * (r + 1) for r in range(world))
+    assert np.abs(got["prof"] - prof).max() <= 1e-6 * np.abs(prof).max()
+
+
+def test_bench_gpus_n_is_one_command_and_fails_loudly():
+    """bench.py --gpus 2 spawns its own ranks; without a HIP device every rank refuses to run (no CPU path) and the
+    parent returns non-zero instead of hanging or printing a number."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present (the GPU suite runs the real thing)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "needs a HIP device" in p.stderr and not any(ln.startswith("{") for ln in p.stdout.splitlines())
+
+
 def test_reduce_single_rank_is_identity():
     from dspsr_amd.pipeline import reduce_subbands
     p = torch.arange(10, dtype=torch.float32)

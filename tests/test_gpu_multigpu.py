@@ -1,0 +1,138 @@
+"""Multi-GPU semantics checked on ONE GPU.
+
+  * sub-band sharding: the 8 "ranks" of BASELINE cfg 4, run one after the other, concatenated == ONE full-band run of the
+    NCHAN-8 complex file (dspsr -F 4096:D), bit for bit, with identical hits on every rank;
+  * time-slice replicas (single-channel input): blocks dealt round robin to replicas and combined like
+    PhaseSeries::combine == one pipeline folding every block: identical hits, profile equal to float rounding;
+  * bench.py --gpus 2 as ONE command (self-spawned ranks, gloo on the single device) for both modes, with the parity gate.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    import dspsr_amd
+    return dspsr_amd
+
+
+def _raw(n, seed):
+    rng = np.random.default_rng(seed)
+    return np.clip(np.rint(rng.standard_normal(n) * 24.0), -128, 127).astype(np.int8)
+
+
+@pytest.mark.parametrize("force_fused", [False, True])
+def test_subband_shards_equal_fullband(oracle, gpu, force_fused):
+    from dspsr_amd import pipeline
+    nsub, nblocks = 8, 2
+    info = pipeline.InputInfo(centre_frequency=1382.0, bandwidth=-400.0, nchan=nsub, npol=2, ndim=2, tsamp_us=0.02,
+                              machine="DADA")
+    cfg = pipeline.Config(nchan=4096, dispersion_measure=1000.0, nbin=1024, folding_period=0.0893, freq_res=512, ndim=4,
+                          parts_per_block=6, max_parts=4, force_fused=force_fused)
+    stream = torch.cuda.current_stream().cuda_stream
+    full = pipeline.LoadToFold(cfg, info, device=0, stream=stream)
+    # SURVEY Appendix B cfg 4: the common 27/27 of the full-band kernel (worst channel), nkeep 458, step 234 496
+    assert (full.response.impulse_pos, full.response.impulse_neg, full.nkeep, full.nsamp_step) == (27, 27, 458, 234496)
+    # the oracle's Dedispersion on the whole band gives the same kernel and the same common discard counts
+    obs = oracle.Observation(centre_frequency=1382.0, bandwidth=-400.0, nchan=nsub, npol=2, ndim=2, tsamp_us=0.02,
+                             dispersion_measure=1000.0)
+    oresp = oracle.Dedispersion()
+    oresp.set_frequency_resolution(512)
+    oresp.match(obs, 4096)
+    assert (oresp.impulse_pos, oresp.impulse_neg) == (27, 27)
+    assert np.abs(full.response.kernel - oresp.buffer).max() <= 1.2e-7
+    step = cfg.parts_per_block * full.nsamp_step
+    ndat = nblocks * step + full.nsamp_overlap
+    raw = _raw(ndat * nsub * 4, 77)                      # generic order ((t*8 + c)*2 + p)*2 + d
+    d_full = torch.from_numpy(raw).cuda()
+    bps = nsub * 4                                       # bytes per time sample of the 8-channel stream
+    for b in range(nblocks):
+        full.process_block(d_full[b * step * bps:(b * step + step + full.nsamp_overlap) * bps])
+    full.finish_subint()
+    full.synchronize()
+    want = full.subints[0]
+    wprof = want["profile_dev"].view(4096, -1)
+    assert int(want["hits"].sum()) == nblocks * cfg.parts_per_block * full.nkeep and float(wprof.abs().max()) > 0
+    for g in range(nsub):
+        lt = pipeline.LoadToFold(cfg, info, device=0, stream=stream, subband=g)
+        assert lt.fused_fold == force_fused
+        assert (lt.nkeep, lt.nsamp_step, lt.out_start, lt.out_rate) == (full.nkeep, full.nsamp_step, full.out_start, full.out_rate)
+        mine = torch.from_numpy(np.ascontiguousarray(raw.reshape(ndat, nsub, 4)[:, g, :]).reshape(-1)).cuda()   # what rank g reads
+        for b in range(nblocks):
+            lt.process_block(mine[b * step * 4:(b * step + step + lt.nsamp_overlap) * 4])
+        lt.finish_subint()
+        lt.synchronize()
+        got = lt.subints[0]
+        assert np.array_equal(got["hits"], want["hits"]), g                       # sample aligned: identical hits
+        assert got["integration_length"] == want["integration_length"] and got["ndat_total"] == want["ndat_total"]
+        assert torch.equal(got["profile_dev"].view(512, -1), wprof[g * 512:(g + 1) * 512]), g
+        lt.close()
+    full.close()
+
+
+def test_time_slice_replicas_combine(gpu):
+    """Single-channel input: 2 replicas take alternate blocks (MultiThread.C:120-148) and are combined with
+    PhaseSeries::combine semantics; one pipeline folds all blocks in order.  hits / ndat_total identical, profile equal
+    to rounding (the partial sums associate differently, exactly as in the reference's own -t N runs)."""
+    from dspsr_amd import pipeline, synth
+    freq, bw, tsamp, dm, period, nchan, nbin = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004, 16, 64
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
+    cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=4, parts_per_block=3,
+                          max_parts=2)
+    stream = torch.cuda.current_stream().cuda_stream
+    one = pipeline.LoadToFold(cfg, info, device=0, stream=stream)
+    nblocks = 6
+    step = cfg.parts_per_block * one.nsamp_step
+    raw = torch.from_numpy(synth.voltages(nblocks * step + one.nsamp_overlap, freq, bw, tsamp, dm, period)).cuda()
+    blk = lambda b: raw[2 * b * step: 2 * (b * step + step + one.nsamp_overlap)]
+    for b in range(nblocks):
+        one.process_block(blk(b))
+    one.finish_subint()
+    want = one.subints[0]
+    reps = [pipeline.LoadToFold(cfg, info, device=0, stream=stream) for _ in range(2)]
+    for b in range(nblocks):
+        r = reps[b % 2]
+        r.seek_block(b)
+        r.process_block(blk(b))
+    acc = None
+    for r in reps:
+        r.finish_subint()
+        acc = pipeline.combine_phase_series(acc, r.subints[0])
+        r.close()
+    assert np.array_equal(acc["hits"], want["hits"]) and acc["ndat_total"] == want["ndat_total"]
+    assert abs(acc["integration_length"] - want["integration_length"]) <= 1e-12 * want["integration_length"]
+    w = want["profile_dev"].cpu().numpy()
+    assert np.abs(acc["profile"].reshape(-1) - w).max() <= 2e-6 * np.abs(w).max()
+    one.close()
+
+
+@pytest.mark.parametrize("workload,extra", [("cfg4", ["--parts-per-block", "16"]),
+                                            ("target", ["--parts-per-block", "4", "--max-parts", "2"])])
+def test_bench_two_ranks_one_command(gpu, workload, extra):
+    """bench.py --gpus 2 without a launcher: it spawns its own ranks (gloo, both on this GPU), runs the sub-integration
+    exchange inside the timed region, passes the parity gate and prints ONE JSON line."""
+    env = dict(os.environ, DSPSR_AMD_SINGLE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dump-steps", "2",
+           "--workload", workload, "--no-cpu-baseline"] + extra
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["parity_gate"]["status"] == "ok"
+    assert ("sub-band" if workload == "cfg4" else "replicas") in res["config"]["parallelism"]
