@@ -203,11 +203,31 @@ def _cpu_port_run(args):
 
 
 def _host_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota when there is one (a GPU
+    box hands out a share of the host: the mask can list every core of the machine while the quota is 16)."""
     try:
         cores = sorted(os.sched_getaffinity(0))
     except AttributeError:
         cores = list(range(os.cpu_count() or 1))
-    return cores
+    quota, src = None, ""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]            # cgroup v2
+        if q != "max":
+            quota, src = float(q) / float(per), "cgroup cpu.max"
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())     # cgroup v1
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota, src = q / per, "cgroup cfs quota"
+        except (OSError, ValueError):
+            pass
+    n = len(cores)
+    note = "%d cores in the affinity mask" % n
+    if quota is not None and quota < n:
+        n = max(1, int(quota + 0.5))
+        note += ", %s = %.1f cores -> %d workers" % (src, quota, n)
+    return n, note
 
 
 def cpu_baseline_c(wl, geom, ncore, parts_per_worker=4):
@@ -270,18 +290,17 @@ def cpu_baseline(wl, geom, parts_per_worker=8):
     model -- one worker per time block (dspsr -t <ncores>, MultiThread.C:65-82) -- on a bounded sample of the workload.
     Two stated baselines: the numpy oracle (pocketfft float32) as `cpu_baseline`, the plain-C oracle beside it."""
     import multiprocessing as mp
-    cores = _host_cores()
-    ncore = len(cores)
+    ncore, note = _host_cores()
     wlc = {k: v for k, v in wl.items() if k != "cmd"}
     ctx = mp.get_context("spawn")         # the parent holds a HIP context: never fork it
     with ctx.Pool(ncore) as pool:
-        pool.map(_cpu_port_run, [(wlc, 0, 0)] * ncore)                      # start-up, imports, response build
+        pool.map_async(_cpu_port_run, [(wlc, 0, 0)] * ncore).get(timeout=180)   # start-up, imports, response build
         t0 = time.perf_counter()
-        res = pool.map(_cpu_port_run, [(wlc, parts_per_worker, 1 + i) for i in range(ncore)], chunksize=1)
+        # bounded: a host that cannot finish the sample in 3 minutes is reported as such instead of stalling the bench
+        res = pool.map_async(_cpu_port_run, [(wlc, parts_per_worker, 1 + i) for i in range(ncore)], chunksize=1).get(timeout=180)
         wall = time.perf_counter() - t0
     samples = sum(r[0] for r in res)
-    out = {"value": samples / wall / 1e6, "unit": "Msamples/s", "cores": ncore, "kind": "port",
-           "affinity": "%d cores: %s" % (ncore, ",".join(str(c) for c in cores) if ncore <= 64 else "%d..%d" % (cores[0], cores[-1])),
+    out = {"value": samples / wall / 1e6, "unit": "Msamples/s", "cores": ncore, "kind": "port", "affinity": note,
            "sample": "%d workers x %d overlap-save part(s) of the same workload (%.1f Msamples/pol in all), numpy "
                      "oracle with pocketfft float32, one process per time block, %.1f s wall, %.1f core-seconds"
                      % (ncore, parts_per_worker, samples / 1e6, wall, sum(r[1] for r in res))}
