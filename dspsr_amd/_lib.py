@@ -84,6 +84,7 @@ SYMBOLS = {
     "dspsr_amd_fold_create": (_i, [_vp, _pp]),
     "dspsr_amd_fold_destroy": (None, [_vp]),
     "dspsr_amd_fold_set_shape": (_i, [_vp, _u32, _u32, _u32, _u32]),
+    "dspsr_amd_fold_bind_profile": (_i, [_vp, _vp, _u64, _u32, _u32, _u32, _u32]),
     "dspsr_amd_fold_set_nbin": (_i, [_vp, _u32]),
     "dspsr_amd_fold_set_ndat": (_i, [_vp, _u64, _u64]),
     "dspsr_amd_fold_set_bin": (_i, [_vp, _u64, _d, _d]),

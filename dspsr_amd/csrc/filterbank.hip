@@ -76,6 +76,7 @@ struct FbOut {
   int state;                                    // detected: coherence / stokes
   uint32_t ndim, chan0;
   uint32_t nbin;                                // kind 3
+  uint64_t prof_span4;                          // kind 3: float4 between consecutive channel rows of the profile
   const uint32_t* pstart;                       // kind 3: per-part active-bin plan (fold_internal.h), nparts_plan parts
   uint32_t nparts_plan;
   uint32_t plan_cap;                            // kind 3: plan entries per LDS buffer (two buffers behind the twiddles)
@@ -1064,7 +1065,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       in_lds = f_nact <= out.plan_cap;
     }
     auto acc_ptr = [&](const uint32_t w, const uint32_t b) {
-      return (float4*)out.base + (uint64_t)(out.chan0 + tile * T3 + (w & (T3 - 1))) * out.nbin + b;
+      return (float4*)out.base + (uint64_t)(out.chan0 + tile * T3 + (w & (T3 - 1))) * out.prof_span4 + b;
     };
     auto mid = [&](const int phase) {
       if constexpr (PRE) {
@@ -2024,7 +2025,9 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
   // (-F 1024:D -x 4096) +14 %, 128 tiles (-F 256:D) -13 %, 32 tiles (-F 512:D on a 50 MHz sub-band) 4x slower.
   // Below the threshold, and for the four-pass geometry, Detection and Fold run as separate launches on an
   // internal block -- the sums are bit-identical either way.
-  if (!dspsr_amd_filterbank_fold_is_fused(fb)) {
+  // (a bound profile whose rows are not float4 aligned also takes the separate launches: the fold kernel adds scalars)
+  const bool prof_vec4 = fold->span % 4 == 0 && ((uintptr_t)fold->profile % 16) == 0;
+  if (!dspsr_amd_filterbank_fold_is_fused(fb) || !prof_vec4) {
     const uint64_t row = npart * fb->g.nkeep * 4;                       // floats per channel
     const size_t need = (size_t)row * nchan;
     if (!need) return DSPSR_AMD_OK;
@@ -2047,7 +2050,7 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
   PlanSlot* slot = nullptr;
   int rc = fold_build_part_plan(fold, fb->g.nkeep, (uint32_t)npart, &d_start, &d_iv, &slot);
   if (rc != DSPSR_AMD_OK) return rc;
-  FbOut out = {3, fold->profile, 0, 0, 0, state, 4, 0, fold->nbin, d_start, (uint32_t)npart, 0, d_iv};
+  FbOut out = {3, fold->profile, 0, 0, 0, state, 4, 0, fold->nbin, fold->span / 4, d_start, (uint32_t)npart, 0, d_iv};
   rc = fb_run(fb, in, out, npart, in_chan_stride);
   const int rc2 = fold_part_plan_submitted(fold, slot);
   return rc != DSPSR_AMD_OK ? rc : rc2;

@@ -22,12 +22,12 @@ namespace dspsr_amd {
 // (used when nbin is too large for the chunked kernel).
 template <int NDIM>
 __global__ void k_fold_direct(const float* __restrict__ in, const uint64_t chan_stride, const uint64_t pol_stride,
-                              float* __restrict__ prof, const uint32_t nbin, const uint32_t* __restrict__ bin_start,
-                              const Interval* __restrict__ iv)
+                              float* __restrict__ prof, const uint64_t prof_span, const uint32_t nbin,
+                              const uint32_t* __restrict__ bin_start, const Interval* __restrict__ iv)
 {
   const uint32_t ipol = blockIdx.x, npol = gridDim.x, ichan = blockIdx.y;
   const float* __restrict__ row = in + ichan * chan_stride + ipol * pol_stride;
-  float* __restrict__ out = prof + ((uint64_t)ichan * npol + ipol) * nbin * NDIM;
+  float* __restrict__ out = prof + ((uint64_t)ichan * npol + ipol) * prof_span;
   for (uint32_t b = blockIdx.z + gridDim.z * threadIdx.x; b < nbin; b += gridDim.z * blockDim.x) {
     const uint32_t i0 = bin_start[b], i1 = bin_start[b + 1];
     if (i0 == i1) continue;
@@ -60,7 +60,8 @@ constexpr int FOLD_BPT = 4;             // bins per thread (nbin <= FOLD_BPT * b
 template <int NDIM>
 __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__ in, const uint64_t chan_stride,
                                                        const uint64_t pol_stride, float* __restrict__ prof,
-                                                       const uint32_t nbin, const uint32_t* __restrict__ bin_start,
+                                                       const uint64_t prof_span, const uint32_t nbin,
+                                                       const uint32_t* __restrict__ bin_start,
                                                        const Interval* __restrict__ iv, const uint64_t first,
                                                        const uint64_t last /* [first,last): sample span of the plan */)
 {
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
   const uint32_t ipol = blockIdx.x, npol = gridDim.x, ichan = blockIdx.y;
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const float* __restrict__ row = in + ichan * chan_stride + ipol * pol_stride;
-  float* __restrict__ out = prof + ((uint64_t)ichan * npol + ipol) * nbin * NDIM;
+  float* __restrict__ out = prof + ((uint64_t)ichan * npol + ipol) * prof_span;
   constexpr uint32_t NF4 = FOLD_CHUNK * NDIM / 4;        // float4 per chunk
   constexpr uint32_t MAXR = NF4 / 256;                    // float4 per thread at the minimum block size (256)
 
@@ -212,29 +213,71 @@ extern "C" void dspsr_amd_fold_destroy(dspsr_amd_fold* f)
 {
   if (!f) return;
   (void)hipStreamSynchronize(f->ctx->stream);
-  if (f->profile) (void)hipFree(f->profile);
+  if (f->profile && !f->bound) (void)hipFree(f->profile);
   slot_free(f->slot[0]);
   slot_free(f->slot[1]);
   delete f;
 }
 
+static int fold_check_shape(dspsr_amd_fold* f, const char* who, uint32_t nchan, uint32_t npol, uint32_t ndim, uint32_t nbin)
+{
+  if (ndim != 1 && ndim != 2 && ndim != 4)
+    return ctx_fail(f->ctx, DSPSR_AMD_EINVAL, "%s: ndim=%u not in {1,2,4}", who, ndim);
+  if (!nchan || !npol || !nbin) return ctx_fail(f->ctx, DSPSR_AMD_EINVAL, "%s: zero dimension", who);
+  return DSPSR_AMD_OK;
+}
+
 extern "C" int dspsr_amd_fold_set_shape(dspsr_amd_fold* f, uint32_t nchan, uint32_t npol, uint32_t ndim, uint32_t nbin)
 {
   if (!f) return DSPSR_AMD_EINVAL;
-  if (ndim != 1 && ndim != 2 && ndim != 4)
-    return ctx_fail(f->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_fold_set_shape: ndim=%u not in {1,2,4}", ndim);
-  if (!nchan || !npol || !nbin) return ctx_fail(f->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_fold_set_shape: zero dimension");
+  const int rc = fold_check_shape(f, "dspsr_amd_fold_set_shape", nchan, npol, ndim, nbin);
+  if (rc != DSPSR_AMD_OK) return rc;
+  if (f->bound) {
+    if (nchan == f->nchan && npol == f->npol && ndim == f->ndim && nbin == f->nbin) return DSPSR_AMD_OK;
+    return ctx_fail(f->ctx, DSPSR_AMD_ESTATE, "dspsr_amd_fold_set_shape: the profile is bound to a caller's buffer of another "
+                                              "shape; bind again (dspsr_amd_fold_bind_profile)");
+  }
   const size_t need = (size_t)nchan * npol * nbin * ndim;
   if (need != f->profile_floats) {
     // PhaseSeries::mixable/resize on a changed shape starts a new, zeroed profile (Fold.C:495-508)
     (void)hipStreamSynchronize(f->ctx->stream);
     if (f->profile) (void)hipFree(f->profile);
     f->profile = nullptr;
+    f->profile_floats = 0;
     if (hipMalloc((void**)&f->profile, need * sizeof(float)) != hipSuccess)
       return ctx_fail(f->ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_fold_set_shape: hipMalloc(%zu floats) failed", need);
     f->profile_floats = need;
     (void)hipMemsetAsync(f->profile, 0, need * sizeof(float), f->ctx->stream);
   }
+  f->nchan = nchan; f->npol = npol; f->ndim = ndim; f->nbin = nbin;
+  f->span = (uint64_t)nbin * ndim;
+  return DSPSR_AMD_OK;
+}
+
+// Fold::Engine::setup (Fold.C:968-1011) caches output = get_profiles()->get_datptr(0,0) and output_span =
+// get_nfloat_span(): the engine folds INTO the device PhaseSeries that Fold::get_output() hands to prepare_output /
+// zero / mixable.  The buffer stays the caller's (never freed or zeroed here except through dspsr_amd_fold_zero).
+extern "C" int dspsr_amd_fold_bind_profile(dspsr_amd_fold* f, float* profile_dev, uint64_t span_floats, uint32_t nchan,
+                                           uint32_t npol, uint32_t ndim, uint32_t nbin)
+{
+  if (!f) return DSPSR_AMD_EINVAL;
+  if (!profile_dev) {                                      // unbind: back to a library-owned profile of the same shape
+    if (f->bound) { f->profile = nullptr; f->bound = false; f->profile_floats = 0; }
+    return nchan ? dspsr_amd_fold_set_shape(f, nchan, npol, ndim, nbin) : DSPSR_AMD_OK;
+  }
+  const int rc = fold_check_shape(f, "dspsr_amd_fold_bind_profile", nchan, npol, ndim, nbin);
+  if (rc != DSPSR_AMD_OK) return rc;
+  if (span_floats < (uint64_t)nbin * ndim)
+    return ctx_fail(f->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_fold_bind_profile: span=%llu floats < nbin*ndim=%llu",
+                    (unsigned long long)span_floats, (unsigned long long)nbin * ndim);
+  if (f->profile && !f->bound) {
+    (void)hipStreamSynchronize(f->ctx->stream);
+    (void)hipFree(f->profile);
+  }
+  f->profile = profile_dev;
+  f->bound = true;
+  f->profile_floats = 0;
+  f->span = span_floats;
   f->nchan = nchan; f->npol = npol; f->ndim = ndim; f->nbin = nbin;
   return DSPSR_AMD_OK;
 }
@@ -319,7 +362,12 @@ extern "C" float* dspsr_amd_fold_profiles_dev(dspsr_amd_fold* f) { return f ? f-
 extern "C" int dspsr_amd_fold_zero(dspsr_amd_fold* f)
 {
   if (!f) return DSPSR_AMD_EINVAL;
-  if (f->profile) (void)hipMemsetAsync(f->profile, 0, f->profile_floats * sizeof(float), f->ctx->stream);
+  if (!f->profile) return DSPSR_AMD_OK;
+  const size_t row = (size_t)f->nbin * f->ndim * sizeof(float);
+  hipError_t e = f->span == (uint64_t)f->nbin * f->ndim
+                     ? hipMemsetAsync(f->profile, 0, row * f->nchan * f->npol, f->ctx->stream)
+                     : hipMemset2DAsync(f->profile, f->span * sizeof(float), 0, row, (size_t)f->nchan * f->npol, f->ctx->stream);
+  if (e != hipSuccess) return ctx_fail(f->ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_zero: %s", hipGetErrorString(e));
   return DSPSR_AMD_OK;
 }
 
@@ -382,23 +430,23 @@ extern "C" int dspsr_amd_fold_fold(dspsr_amd_fold* f, const float* in_dev, uint6
     const size_t lds = (size_t)FOLD_CHUNK * f->ndim * sizeof(float);
     if (f->ndim == 4)
       hipLaunchKernelGGL(k_fold_chunked<4>, grid, dim3(threads), lds, ctx->stream, in_dev, in_chan_stride,
-                         in_pol_stride, f->profile, nbin, sl.d_bin_start, sl.d_iv, first, last);
+                         in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv, first, last);
     else if (f->ndim == 2)
       hipLaunchKernelGGL(k_fold_chunked<2>, grid, dim3(threads), lds, ctx->stream, in_dev, in_chan_stride,
-                         in_pol_stride, f->profile, nbin, sl.d_bin_start, sl.d_iv, first, last);
+                         in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv, first, last);
     else
       hipLaunchKernelGGL(k_fold_chunked<1>, grid, dim3(threads), lds, ctx->stream, in_dev, in_chan_stride,
-                         in_pol_stride, f->profile, nbin, sl.d_bin_start, sl.d_iv, first, last);
+                         in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv, first, last);
   } else {
     if (f->ndim == 4)
       hipLaunchKernelGGL(k_fold_direct<4>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride,
-                         in_pol_stride, f->profile, nbin, sl.d_bin_start, sl.d_iv);
+                         in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv);
     else if (f->ndim == 2)
       hipLaunchKernelGGL(k_fold_direct<2>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride,
-                         in_pol_stride, f->profile, nbin, sl.d_bin_start, sl.d_iv);
+                         in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv);
     else
       hipLaunchKernelGGL(k_fold_direct<1>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride,
-                         in_pol_stride, f->profile, nbin, sl.d_bin_start, sl.d_iv);
+                         in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv);
   }
   e = hipGetLastError();
   if (e == hipSuccess) e = hipEventRecord(sl.done, ctx->stream);
@@ -412,8 +460,9 @@ extern "C" int dspsr_amd_fold_synch(dspsr_amd_fold* f, float* profile_host)   //
 {
   if (!f || !profile_host) return DSPSR_AMD_EINVAL;
   if (!f->profile) return ctx_fail(f->ctx, DSPSR_AMD_ESTATE, "dspsr_amd_fold_synch: no profile");
-  hipError_t e = hipMemcpyAsync(profile_host, f->profile, f->profile_floats * sizeof(float), hipMemcpyDeviceToHost,
-                                f->ctx->stream);
+  const size_t row = (size_t)f->nbin * f->ndim * sizeof(float);      // host copy is packed [chan][pol][nbin][ndim]
+  hipError_t e = hipMemcpy2DAsync(profile_host, row, f->profile, f->span * sizeof(float), row, (size_t)f->nchan * f->npol,
+                                  hipMemcpyDeviceToHost, f->ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(f->ctx->stream);
   if (e != hipSuccess) return ctx_fail(f->ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_synch: %s", hipGetErrorString(e));
   return DSPSR_AMD_OK;

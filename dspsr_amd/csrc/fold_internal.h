@@ -24,8 +24,10 @@ struct PlanSlot {
 struct dspsr_amd_fold {
   dspsr_amd_ctx* ctx;
   uint32_t nchan = 0, npol = 0, ndim = 0, nbin = 0;
-  float* profile = nullptr;
-  size_t profile_floats = 0;
+  float* profile = nullptr;     // [chan][pol] rows of nbin*ndim floats, `span` floats apart
+  size_t profile_floats = 0;    // floats of the library-owned buffer (0 when the profile is bound to a caller's buffer)
+  uint64_t span = 0;            // floats between consecutive (chan, pol) rows
+  bool bound = false;           // profile points into the engine-owned device PhaseSeries (dspsr_amd_fold_bind_profile)
   // run-length plan, as CUDA::FoldEngine (FoldCUDA.cu:64-113)
   std::vector<dspsr_amd::RunBin> binplan;
   uint32_t current_bin = 0, current_hits = 0, folding_nbin = 0;

@@ -429,6 +429,18 @@ class FoldEngine:
                "dspsr_amd_fold_set_shape")
         self.shape = (nchan, npol, nbin, ndim)
 
+    def bind_profile(self, prof, nchan, npol, ndim, nbin):
+        """Fold::Engine::setup: fold into the caller's device PhaseSeries buffer; prof: float32 device tensor
+        [nchan*npol][span >= nbin*ndim] (rows may be padded), None = back to a library-owned profile."""
+        if prof is None:
+            _check(self.ctx.handle, lib.dspsr_amd_fold_bind_profile(self.handle, None, 0, nchan, npol, ndim, nbin),
+                   "dspsr_amd_fold_bind_profile")
+        else:
+            assert prof.dim() == 2 and prof.shape[0] == nchan * npol and prof.stride(1) == 1
+            _check(self.ctx.handle, lib.dspsr_amd_fold_bind_profile(self.handle, prof.data_ptr(), prof.stride(0), nchan, npol,
+                                                                    ndim, nbin), "dspsr_amd_fold_bind_profile")
+        self.shape = (nchan, npol, nbin, ndim)
+
     def set_nbin(self, nbin):
         _check(self.ctx.handle, lib.dspsr_amd_fold_set_nbin(self.handle, nbin), "dspsr_amd_fold_set_nbin")
 

@@ -236,9 +236,12 @@ namespace HIP
     dspsr_amd_ctx* ctx;
   };
 
-  //! dsp::Fold::Engine (Fold.h:249-312).  The device-resident profile lives inside the library;
-  //! get_profiles() exposes it as a PhaseSeries whose Memory is a HIP::DeviceMemory so that
-  //! Fold::get_output()->zero()/resize act on the device (Fold.C:88-94).
+  //! dsp::Fold::Engine (Fold.h:249-312), the twin of CUDA::FoldEngine (FoldCUDA.cu:31-198, dsp/FoldCUDA.h:27-80).
+  //! The engine OWNS the device-resident PhaseSeries (get_profiles()): Fold::get_output() returns it, so
+  //! Fold::prepare_output / zero / mixable and the hits[] bookkeeping of Fold::fold act on it (Fold.C:88-94,495-508,
+  //! 722,781-785).  Its sums live in device memory (HIP::DeviceMemory); hits[] stay on the host, as with the reference's
+  //! default hits_on_gpu = false.  fold() binds the library to that buffer (Fold::Engine::setup's output / output_span),
+  //! synch() is CUDA::FoldEngine::synch + TransferPhaseSeriesCUDA (TransferPhaseSeriesCUDA.C:23-84).
   class FoldEngine : public dsp::Fold::Engine
   {
   public:
@@ -248,7 +251,7 @@ namespace HIP
       check (ctx, dspsr_amd_fold_create (ctx, &fold_handle), "HIP::FoldEngine");
       d_profiles = new dsp::PhaseSeries;
       d_profiles->set_memory (new DeviceMemory (ctx));
-      synchronized = true;
+      synchronized = true;                       // no data on either the host or the device (FoldCUDA.cu:52-53)
     }
     ~FoldEngine () { dspsr_amd_fold_destroy (fold_handle); }
 
@@ -258,11 +261,12 @@ namespace HIP
     { check (ctx, dspsr_amd_fold_set_ndat (fold_handle, ndat, idat_start), "HIP::FoldEngine::set_ndat"); }
     void set_bin (uint64_t idat, double ibin, double bins_per_samp)
     { check (ctx, dspsr_amd_fold_set_bin (fold_handle, idat, ibin, bins_per_samp), "HIP::FoldEngine::set_bin"); }
+    //! the double recurrence of Fold.C:744-787 inside the library; Fold::fold adds get_bin_hits to hits[] (:733-736)
     uint64_t set_bins (double phi, double phase_per_sample, uint64_t ndat, uint64_t idat_start)
     {
       uint64_t folded = 0;
       check (ctx, dspsr_amd_fold_set_bins (fold_handle, phi, phase_per_sample, ndat, idat_start,
-                                           &nbin_hits[0], &folded), "HIP::FoldEngine::set_bins");
+                                           nbin_hits.empty() ? 0 : &nbin_hits[0], &folded), "HIP::FoldEngine::set_bins");
       return folded;
     }
     uint64_t get_bin_hits (int ibin) { return nbin_hits[ibin]; }
@@ -271,24 +275,29 @@ namespace HIP
 
     void fold ()
     {
-      setup ();                                  // Fold::Engine::setup caches input/output pointers (Fold.C:973-1007)
-      check (ctx, dspsr_amd_fold_set_shape (fold_handle, nchan, npol, ndim, d_profiles->get_nbin ()),
+      setup ();                                  // Fold.C:968-1011: input, input_span, output, output_span, nchan, npol, ndim
+      check (ctx, dspsr_amd_fold_bind_profile (fold_handle, output, output_span, nchan, npol, ndim, d_profiles->get_nbin ()),
              "HIP::FoldEngine::fold");
-      const dsp::TimeSeries* in = parent->get_input ();
-      const float* ibase = in->get_datptr (0, 0);
-      check (ctx, dspsr_amd_fold_fold (fold_handle, ibase, nchan > 1 ? in->get_datptr (1, 0) - ibase : 0,
-                                       npol > 1 ? in->get_datptr (0, 1) - ibase : 0), "HIP::FoldEngine::fold");
-      synchronized = false;
+      // rows of the input are input_span floats apart, (ichan*npol + ipol)-th row, as fold1bin* index them
+      check (ctx, dspsr_amd_fold_fold (fold_handle, input, uint64_t (npol) * input_span, input_span),
+             "HIP::FoldEngine::fold");
+      synchronized = false;                      // the device profile is ahead of the host copy (FoldCUDA.cu:689)
     }
 
+    //! FoldCUDA.cu:127-152 + TransferPhaseSeriesCUDA.C:23-84: shape and attributes (hits[] included, both on the host),
+    //! then the whole buffer, then wait
     void synch (dsp::PhaseSeries* out)
     {
-      if (synchronized) return;                  // idempotent (FoldCUDA.cu:132-133)
-      check (ctx, dspsr_amd_fold_synch (fold_handle, out->get_datptr (0, 0)), "HIP::FoldEngine::synch");
+      if (synchronized) return;
+      out->internal_match (d_profiles);
+      out->copy_configuration (d_profiles);
+      check (ctx, dspsr_amd_copy (ctx, out->internal_get_buffer (), d_profiles->internal_get_buffer (),
+                                  d_profiles->internal_get_size (), DSPSR_AMD_D2H), "HIP::FoldEngine::synch");
+      check (ctx, dspsr_amd_stream_sync (ctx), "HIP::FoldEngine::synch");
       synchronized = true;
     }
 
-    void zero () { check (ctx, dspsr_amd_fold_zero (fold_handle), "HIP::FoldEngine::zero"); }
+    void zero () { get_profiles ()->zero (); }   // dsp/FoldCUDA.h:49: PhaseSeries::zero through its DeviceMemory
 
   protected:
     dspsr_amd_ctx* ctx;

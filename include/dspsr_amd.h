@@ -176,6 +176,12 @@ int dspsr_amd_fold_create(dspsr_amd_ctx* ctx, dspsr_amd_fold** fold);
 void dspsr_amd_fold_destroy(dspsr_amd_fold* fold);
 /* shape of the input TimeSeries / output PhaseSeries (Fold::Engine::setup, Fold.C:973-1007) */
 int dspsr_amd_fold_set_shape(dspsr_amd_fold* fold, uint32_t nchan, uint32_t npol, uint32_t ndim, uint32_t nbin);
+/* Fold::Engine::setup (Fold.C:968-1011): fold INTO the engine-owned device PhaseSeries -- profile_dev =
+ * get_profiles()->get_datptr(0,0), span_floats = get_nfloat_span() (floats between consecutive (chan, pol) rows, each
+ * row nbin*ndim floats) -- so that Fold::prepare_output / zero / mixable (Fold.C:88-94,123-148,495-508), which act on
+ * get_profiles(), see the sums.  The buffer stays the caller's; profile_dev = NULL returns to a library-owned profile. */
+int dspsr_amd_fold_bind_profile(dspsr_amd_fold* fold, float* profile_dev, uint64_t span_floats, uint32_t nchan,
+                                uint32_t npol, uint32_t ndim, uint32_t nbin);
 int dspsr_amd_fold_set_nbin(dspsr_amd_fold* fold, uint32_t nbin);                        /* FoldCUDA.cu:64-70 */
 int dspsr_amd_fold_set_ndat(dspsr_amd_fold* fold, uint64_t ndat, uint64_t idat_start);   /* FoldCUDA.cu:72-82 */
 int dspsr_amd_fold_set_bin(dspsr_amd_fold* fold, uint64_t idat, double ibin, double bins_per_sample); /* :84-113 */

@@ -1,0 +1,167 @@
+// Runs the host adaptor classes (dspsr_amd/host/dspsr_amd_engines.h) on a real device, driven in the call order of the
+// reference: Filterbank::Engine::setup/perform (Filterbank.C:219-225,547-553), Detection::Engine::polarimetry in place
+// (LoadToFold1.C:545-546), then Fold.C's engine sequence prepare_output -> set_nbin -> set_ndat -> set_bins -> fold ->
+// get_result (synch) -> reset (zero).  Containers are the functional miniatures of tests/host_mock (the real ones need
+// PSRCHIVE); every device buffer is allocated through HIP::DeviceMemory.  Built and run by tests/test_host_adaptor.py.
+// Exit code 77 = no HIP device (the CPU suite only builds it).
+#include <math.h>
+#include <stdio.h>
+
+#include "dspsr_amd_engines.h"
+
+#define REQUIRE(cond, ...) do { if (!(cond)) { fprintf (stderr, "FAILED %s:%d: ", __FILE__, __LINE__); fprintf (stderr, __VA_ARGS__); \
+                                               fprintf (stderr, "\n"); return 1; } } while (0)
+
+static unsigned lcg = 12345u;
+static float rnd () { lcg = lcg * 1664525u + 1013904223u; return (float) ((int) (lcg >> 8) % 2001 - 1000) / 1000.0f; }
+
+static void h2d (dspsr_amd_ctx* ctx, dsp::TimeSeries& dev, const dsp::TimeSeries& host)
+{
+  HIP::check (ctx, dspsr_amd_copy (ctx, dev.internal_get_buffer (), host.internal_get_buffer (), host.internal_get_size (), DSPSR_AMD_H2D), "h2d");
+  HIP::check (ctx, dspsr_amd_stream_sync (ctx), "h2d");
+}
+static void d2h (dspsr_amd_ctx* ctx, dsp::TimeSeries& host, const dsp::TimeSeries& dev)
+{
+  HIP::check (ctx, dspsr_amd_copy (ctx, host.internal_get_buffer (), dev.internal_get_buffer (), dev.internal_get_size (), DSPSR_AMD_D2H), "d2h");
+  HIP::check (ctx, dspsr_amd_stream_sync (ctx), "d2h");
+}
+
+int main ()
+{
+  dspsr_amd_ctx* ctx = 0;
+  if (dspsr_amd_ctx_create (0, DSPSR_AMD_NEW_STREAM, &ctx) != DSPSR_AMD_OK) { printf ("no HIP device\n"); return 77; }
+  try
+  {
+    dsp::Memory* dmem = new HIP::DeviceMemory (ctx);
+    REQUIRE (!dmem->on_host (), "DeviceMemory must not be host memory");
+
+    // ---------------------------------------------------------------- Filterbank::Engine
+    const unsigned C = 8, M = 64, pos = 5, neg = 7, nkeep = M - pos - neg, npart = 3;
+    const uint64_t N = uint64_t (C) * M, nsamp_fft = 2 * N, overlap = 2 * (pos + neg) * C, step = nsamp_fft - overlap;
+    dsp::TimeSeries in_h, in_d;
+    in_h.set_nchan (1); in_h.set_npol (2); in_h.set_ndim (1); in_h.set_state (Signal::Nyquist); in_h.set_rate (1e6);
+    in_h.resize (npart * step + overlap);
+    in_d.set_memory (dmem); in_d.internal_match (&in_h);
+    for (unsigned p = 0; p < 2; p++) for (uint64_t i = 0; i < in_h.get_ndat (); i++) in_h.get_datptr (0, p)[i] = rnd ();
+    h2d (ctx, in_d, in_h);
+    dsp::Response resp;
+    resp.impulse_pos = pos; resp.impulse_neg = neg; resp.nchan = C; resp.ndat = M;
+    resp.kernel.resize (2 * N);
+    for (uint64_t k = 0; k < N; k++) { const float a = 3.0f * rnd (); resp.kernel[2 * k] = cosf (a); resp.kernel[2 * k + 1] = sinf (a); }
+    dsp::Filterbank fbk;
+    fbk.nchan_subband = C; fbk.freq_res = M; fbk.input = &in_d; fbk.response = &resp;
+    HIP::FilterbankEngine fbe (ctx);
+    fbe.setup (&fbk);
+    REQUIRE (fbk.passband_cleared, "setup must null the passband (FilterbankCUDA.cu:78)");
+    dsp::TimeSeries out_d, out2_d, out_h, out2_h;
+    out_d.set_nchan (C); out_d.set_npol (2); out_d.set_ndim (2); out_d.set_state (Signal::Analytic); out_d.set_rate (1e6 / (2 * C));
+    out_d.set_memory (dmem); out_d.resize (npart * nkeep);
+    out2_d.set_memory (dmem); out2_d.internal_match (&out_d);
+    out_h.internal_match (&out_d); out2_h.internal_match (&out_d);
+    fbe.perform (&in_d, &out_d, npart, step, 2 * nkeep);
+    fbe.finish ();
+    {  // the same through the bare C-ABI
+      dspsr_amd_filterbank_config cfg = {C, M, pos, neg, 1, 2, 1, 0, 0, DSPSR_AMD_FUSED_AUTO};
+      dspsr_amd_filterbank* fb = 0;
+      HIP::check (ctx, dspsr_amd_filterbank_create (ctx, &cfg, &fb), "create");
+      HIP::check (ctx, dspsr_amd_filterbank_set_kernel (fb, &resp.kernel[0], N), "set_kernel");
+      HIP::check (ctx, dspsr_amd_filterbank_perform (fb, in_d.get_datptr (0, 0), 0, in_d.get_datptr (0, 1) - in_d.get_datptr (0, 0),
+               out2_d.get_datptr (0, 0), out2_d.get_datptr (1, 0) - out2_d.get_datptr (0, 0),
+               out2_d.get_datptr (0, 1) - out2_d.get_datptr (0, 0), npart, step, 2 * nkeep), "perform");
+      HIP::check (ctx, dspsr_amd_stream_sync (ctx), "sync");
+      dspsr_amd_filterbank_destroy (fb);
+    }
+    d2h (ctx, out_h, out_d); d2h (ctx, out2_h, out2_d);
+    double power = 0;
+    for (unsigned c = 0; c < C; c++) for (unsigned p = 0; p < 2; p++) for (unsigned i = 0; i < 2 * npart * nkeep; i++) {
+      REQUIRE (out_h.get_datptr (c, p)[i] == out2_h.get_datptr (c, p)[i], "FilterbankEngine::perform differs from the C-ABI at %u %u %u", c, p, i);
+      power += double (out_h.get_datptr (c, p)[i]) * out_h.get_datptr (c, p)[i];
+    }
+    REQUIRE (power > 0, "filterbank output is all zero");
+
+    // ---------------------------------------------------------------- Detection::Engine, in place (ndim 2, npol 2 -> 2)
+    HIP::DetectionEngine dete (ctx);
+    out_d.set_state (Signal::Coherence);
+    dete.polarimetry (2, &out_d, &out_d);
+    HIP::check (ctx, dspsr_amd_stream_sync (ctx), "sync");
+    dsp::TimeSeries det_h;
+    det_h.internal_match (&out_d);
+    d2h (ctx, det_h, out_d);
+    for (unsigned c = 0; c < C; c++) for (unsigned i = 0; i < npart * nkeep; i++) {
+      const float pr = out_h.get_datptr (c, 0)[2 * i], pi = out_h.get_datptr (c, 0)[2 * i + 1];
+      const float qr = out_h.get_datptr (c, 1)[2 * i], qi = out_h.get_datptr (c, 1)[2 * i + 1];
+      const float want[4] = {pr * pr + pi * pi, qr * qr + qi * qi, pr * qr + pi * qi, pr * qi - pi * qr};    // cross_detect.ic:23-43
+      const float got[4] = {det_h.get_datptr (c, 0)[2 * i], det_h.get_datptr (c, 0)[2 * i + 1], det_h.get_datptr (c, 1)[2 * i],
+                            det_h.get_datptr (c, 1)[2 * i + 1]};
+      for (int k = 0; k < 4; k++)
+        REQUIRE (fabsf (got[k] - want[k]) <= 4e-7f * (fabsf (want[0]) + fabsf (want[1]) + 1e-30f), "polarimetry %u %u %d: %g vs %g", c, i, k, got[k], want[k]);
+    }
+
+    // ---------------------------------------------------------------- Fold::Engine in Fold.C's order
+    const unsigned nbin = 24;
+    const uint64_t ndat = npart * nkeep;                       // 156 detected samples per (chan, pol) row
+    dsp::Fold fold;
+    HIP::FoldEngine* eng = new HIP::FoldEngine (ctx);
+    fold.set_input (&out_d);                                   // the detected device TimeSeries (npol 2, ndim 2)
+    fold.set_engine (eng);
+    fold.set_nbin (nbin);
+    REQUIRE (fold.get_output () == eng->get_profiles (), "Fold::get_output must be the engine's PhaseSeries (Fold.C:88-94)");
+    fold.prepare_output ();                                    // resizes and zeroes the DEVICE PhaseSeries through its Memory
+    REQUIRE (!eng->get_profiles ()->get_memory ()->on_host (), "engine profiles must live in device memory");
+    REQUIRE (eng->get_profiles ()->get_nfloat_span () > uint64_t (nbin) * 2, "the miniature pads rows: span != nbin*ndim is exercised");
+    const double pfold = 37.7 / out_d.get_rate (), pps = (1.0 / out_d.get_rate ()) / pfold;
+    std::vector<float> want (size_t (C) * 2 * nbin * 2, 0.0f);
+    std::vector<unsigned> whits (nbin, 0);
+    uint64_t wtotal = 0;
+    auto cpu_fold = [&] (double phi, uint64_t i0, uint64_t n) {       // Fold.C:744-787 plan + :835-891 accumulate, time order
+      for (uint64_t i = i0; i < i0 + n; i++) {
+        phi -= floor (phi);
+        const unsigned ibin = unsigned (phi * double (nbin));
+        phi += pps;
+        whits[ibin]++;
+        for (unsigned c = 0; c < C; c++) for (unsigned p = 0; p < 2; p++) for (unsigned d = 0; d < 2; d++)
+          want[((size_t (c) * 2 + p) * nbin + ibin) * 2 + d] += det_h.get_datptr (c, p)[2 * i + d];
+      }
+      wtotal += n;
+    };
+    fold.fold (0.37, pfold, 3, 70);  cpu_fold (0.37, 3, 70);
+    fold.fold (0.81, pfold, 73, ndat - 73);  cpu_fold (0.81, 73, ndat - 73);
+    auto check_result = [&] (const char* what) -> int {
+      dsp::PhaseSeries* res = fold.get_result ();             // engine->synch (output): internal_match + copy_configuration + buffer
+      REQUIRE (res != eng->get_profiles () && res->get_memory ()->on_host (), "%s: the result is the host PhaseSeries", what);
+      REQUIRE (res->get_nbin () == nbin && res->get_nchan () == C && res->get_npol () == 2 && res->get_ndim () == 2, "%s: result shape", what);
+      REQUIRE (res->ndat_total == wtotal, "%s: ndat_total %llu != %llu", what, (unsigned long long) res->ndat_total, (unsigned long long) wtotal);
+      REQUIRE (fabs (res->integration_length - double (wtotal) / out_d.get_rate ()) <= 1e-12, "%s: integration_length", what);
+      for (unsigned b = 0; b < nbin; b++) REQUIRE (res->get_hits ()[b] == whits[b], "%s: hits[%u] = %u != %u", what, b, res->get_hits ()[b], whits[b]);
+      for (unsigned c = 0; c < C; c++) for (unsigned p = 0; p < 2; p++) for (unsigned k = 0; k < nbin * 2; k++)
+        REQUIRE (res->get_datptr (c, p)[k] == want[(size_t (c) * 2 + p) * nbin * 2 + k], "%s: profile[%u][%u][%u] = %g != %g", what, c, p, k,
+                 res->get_datptr (c, p)[k], want[(size_t (c) * 2 + p) * nbin * 2 + k]);
+      return 0;
+    };
+    if (check_result ("two folds")) return 1;
+    if (check_result ("synch again (idempotent)")) return 1;
+    fold.fold (0.05, pfold, 0, 40);  cpu_fold (0.05, 0, 40);       // more data after a synch: the device profile moves on
+    if (check_result ("fold after synch")) return 1;
+    fold.reset ();                                                  // Engine::zero -> PhaseSeries::zero on the device, and the host copy
+    want.assign (want.size (), 0.0f); whits.assign (nbin, 0); wtotal = 0;
+    fold.fold (0.5, pfold, 10, 100);  cpu_fold (0.5, 10, 100);
+    if (check_result ("after reset")) return 1;
+
+    // ---------------------------------------------------------------- TimeSeries::Engine::copy_data_fpt
+    HIP::TimeSeriesEngine tse (ctx);
+    out2_d.zero ();
+    tse.prepare (&out2_d);
+    tse.copy_data_fpt (&out_d, 5, 20);
+    d2h (ctx, out2_h, out2_d);
+    for (unsigned c = 0; c < C; c++) for (unsigned p = 0; p < 2; p++) for (unsigned k = 0; k < 40; k++)
+      REQUIRE (out2_h.get_datptr (c, p)[k] == det_h.get_datptr (c, p)[10 + k], "copy_data_fpt %u %u %u", c, p, k);
+  }
+  catch (Error& error)
+  {
+    fprintf (stderr, "Error: %s\n", error.message.c_str ());
+    return 1;
+  }
+  dspsr_amd_ctx_destroy (ctx);
+  printf ("host adaptor driver ok\n");
+  return 0;
+}

@@ -1,4 +1,4 @@
-// MOCK (see ../Error.h)
+// FUNCTIONAL MINIATURE (see ../Error.h): dsp::Detection::Engine (Signal/General/dsp/Detection.h:98-106)
 #pragma once
 #include "dsp/Memory.h"
 namespace dsp {

@@ -1,24 +1,33 @@
-// MOCK (see ../Error.h): dsp::Response / dsp::Filterbank / dsp::Filterbank::Engine surface used by the adaptor.
+// FUNCTIONAL MINIATURE (see ../Error.h): dsp::Response / dsp::Filterbank getters and dsp::Filterbank::Engine
+// (Signal/General/dsp/FilterbankEngine.h:15-44, Filterbank.h, Response.h) as the engine's setup() reads them.
 #pragma once
 #include "dsp/Memory.h"
 namespace dsp {
   class Response : public Reference::Able {
   public:
-    unsigned get_impulse_pos () const { return 0; }
-    unsigned get_impulse_neg () const { return 0; }
-    unsigned get_nchan () const { return 1; }
-    unsigned get_ndat () const { return 1; }
-    const float* get_datptr (unsigned, unsigned) const { return 0; }
+    Response () : impulse_pos (0), impulse_neg (0), nchan (1), ndat (1) {}
+    unsigned get_impulse_pos () const { return impulse_pos; }
+    unsigned get_impulse_neg () const { return impulse_neg; }
+    unsigned get_nchan () const { return nchan; }
+    unsigned get_ndat () const { return ndat; }
+    const float* get_datptr (unsigned, unsigned) const { return kernel.empty () ? 0 : &kernel[0]; }
+    unsigned impulse_pos, impulse_neg, nchan, ndat;
+    std::vector<float> kernel;                              // nchan*ndat complex
   };
   class Filterbank : public Reference::Able {
   public:
     class Engine;
-    void set_passband (Response*) {}
-    unsigned get_nchan_subband () const { return 1; }
-    unsigned get_freq_res () const { return 1; }
-    const TimeSeries* get_input () const { return 0; }
-    bool has_response () const { return false; }
-    const Response* get_response () const { return 0; }
+    Filterbank () : nchan_subband (1), freq_res (1), input (0), response (0), passband_cleared (false) {}
+    void set_passband (Response*) { passband_cleared = true; }
+    unsigned get_nchan_subband () const { return nchan_subband; }
+    unsigned get_freq_res () const { return freq_res; }
+    const TimeSeries* get_input () const { return input; }
+    bool has_response () const { return response != 0; }
+    const Response* get_response () const { return response; }
+    unsigned nchan_subband, freq_res;
+    const TimeSeries* input;
+    const Response* response;
+    bool passband_cleared;
   };
   class Filterbank::Engine : public Reference::Able {
   public:

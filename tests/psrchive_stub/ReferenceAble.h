@@ -1,0 +1,2 @@
+// STUB (see Reference.h)
+#include "Reference.h"
