@@ -94,6 +94,8 @@ extern "C" int dspsr_amd_debug_stamps(unsigned long long* out_host, int zero)   
 }
 #endif
 
+[[maybe_unused]] constexpr uint32_t FB_PSL_MAX = 128;   // fused fold: part offsets of one launch kept in LDS (launches hold <= 64 parts)
+
 DEV float cvt8(int v, float scale) { return ((float)v + 0.5f) * scale; }
 
 // streaming accesses: scratch and output data are written once and read once by another pass, so the
@@ -489,15 +491,18 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
   const int logL = LOGF + g.logR;          // g.logM == LOGF
   const uint64_t L = 1ull << logL;
   const uint32_t ntile = 1u << (g.logR - logT);
-  const uint64_t total = (uint64_t)ntile * nseq * nparts;
+  const uint32_t total = ntile * nseq * nparts;
+  const int logNt = g.logR - logT;          // ntile = 2^logNt ; nseq is 1 or 2
+  auto seq_of = [&](const uint32_t rest) { return nseq == 2 ? (rest & 1u) : 0u; };
+  auto part_of = [&](const uint32_t rest) { return nseq == 2 ? (rest >> 1) : rest; };
 
-  auto fetch = [&](const uint64_t item, RawW<RAWW> (&raw)[PTS / 2]) {
-    const uint32_t tile = (uint32_t)(item % ntile);
-    const uint64_t rest = item / ntile;
-    const uint32_t seq = (uint32_t)(rest % nseq);
+  auto fetch = [&](const uint32_t item, RawW<RAWW> (&raw)[PTS / 2]) {
+    const uint32_t tile = item & (ntile - 1);
+    const uint32_t rest = item >> logNt;
+    const uint32_t seq = seq_of(rest);
     const bool pret = in.kind == 3;   // pre-transposed: [part][tile][na][T] pairs, contiguous per tile
-    const uint64_t t0 = pret ? (rest * ntile + tile) * ((uint64_t)T << LOGF)       // rest = part*nseq + seq
-                             : (part0 + rest / nseq) * in.part_step + tile * T;
+    const uint64_t t0 = pret ? ((uint64_t)rest * ntile + tile) * ((uint64_t)T << LOGF)       // rest = part*nseq + seq
+                             : (part0 + part_of(rest)) * in.part_step + tile * T;
     if (FB_DBG(g) & 2) {     // ablation only; hoisted so that the real path has no per-load branch
 #pragma unroll
       for (int i = 0; i < NPAIR; i++) { RawW<RAWW> z; z.w[0] = tid + i; raw[i] = z; }
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
-  uint64_t item, next;
+  uint32_t item, next;
   uint32_t j = 0;
   if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
   RawW<RAWW> raw[PTS / 2];
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(ts0);
 #endif
-    const uint32_t seq_cur = (uint32_t)((item / ntile) % nseq);
+    const uint32_t seq_cur = seq_of(item >> logNt);
 #pragma unroll
     for (int h = 0; h < NPAIR; h++) {
       cf a, b;
@@ -551,9 +556,8 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     STAMP(ts2);
 #endif
 
-    const uint32_t tile = (uint32_t)(item % ntile);
-    const uint64_t rest = item / ntile;
-    cf* __restrict__ Aseq = A + ((rest / nseq) * nseq + rest % nseq) * L;
+    const uint32_t tile = item & (ntile - 1);
+    cf* __restrict__ Aseq = A + (uint64_t)(item >> logNt) * L;                 // sequence part*nseq + seq
     // last-stage outputs go to LDS in A-layout order [ka/T2][col][ka%T2]; after a barrier the tile is
     // written out as whole runs of T*T2 elements with 16-byte-per-lane stores.  The image is XOR-swizzled
     // (bit 3 ^= bit 4; pairs of elements stay together) so that the 8-byte scatter of a wave spreads over all
@@ -636,19 +640,20 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
   const uint32_t T2 = 1u << logT, T3 = 1u << logT3;
   const uint64_t L = 1ull << (g.logM + LOGF);
   const uint32_t ntile = 1u << (g.logM - logT);
-  const uint64_t total = (uint64_t)ntile * nseq * nparts;
+  const uint32_t total = ntile * nseq * nparts;
+  const int logNt = g.logM - logT;          // ntile = 2^logNt
   // The sequences of the launch are walked backwards: the parts written last -- the ones still in the Infinity Cache
   // when the launch ends -- are then the ones the inverse pass, which walks the parts forwards, meets first
   // (+0.8 % Msamples/s in three alternating runs; DSPSR_AMD_DEBUG bit 128 restores the forward order)
-  auto seq_of = [&](const uint64_t item) -> uint64_t {
-    const uint64_t sq = item / ntile;
-    return (FB_DBG(g) & 128) ? sq : (uint64_t)nseq * nparts - 1 - sq;
+  auto seq_of = [&](const uint32_t item) -> uint64_t {
+    const uint32_t sq = item >> logNt;
+    return (FB_DBG(g) & 128) ? sq : nseq * nparts - 1 - sq;
   };
 
   // the prefetch keeps the loaded 16-byte pairs untouched (any use would wait for the loads at once);
   // they are rearranged into split form when the tile is started
-  auto fetch = [&](const uint64_t item, float4 (&y)[NPAIR]) {
-    const uint32_t tile = (uint32_t)(item % ntile);
+  auto fetch = [&](const uint32_t item, float4 (&y)[NPAIR]) {
+    const uint32_t tile = item & (ntile - 1);
     const cf* __restrict__ Ablk = A + seq_of(item) * L + (((uint64_t)tile << LOGF) << logT);     // g.logR == LOGF
     if (FB_DBG(g) & 2) {     // ablation only; hoisted so that the real path has no per-load branch (and vmcnt(0))
 #pragma unroll
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
-  uint64_t item, next;
+  uint32_t item, next;
   uint32_t j = 0;
   if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
   float4 y[NPAIR];
@@ -691,7 +696,7 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
     STAMP(ts2);
 #endif
 
-    const uint32_t tile = (uint32_t)(item % ntile);
+    const uint32_t tile = item & (ntile - 1);
     cf* __restrict__ Xseq = X + seq_of(item) * L;
     // last-stage outputs go to LDS in X-layout order [s'/T3][klo][s'%T3]; after a barrier the tile is
     // written out as whole runs of T2*T3 elements with 16-byte-per-lane stores.  XOR swizzle of the image
@@ -801,7 +806,6 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   auto xi = [&](const uint32_t row, const uint32_t m) -> uint64_t {
     return ((((uint64_t)(row >> logX3) << LOGF) + m) << logX3) | (row & (X3 - 1));
   };
-  const uint64_t total = (uint64_t)ntile * nparts;
   struct Abk { cf a, b; };   // the chirp is fetched at the start of the item (keeps the prefetch at 64 registers)
 
   // chunk < 0: all elements; otherwise the elements i with i % NCHUNK == chunk (the prefetch of the next tile is
@@ -812,9 +816,12 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   constexpr bool PAIR16 = LOGT == 2 && P::G1 == 2 && !FOLD;
   const bool pair16 = PAIR16 && g.real_input && logX3 == 1 && !getenv_pair16_off(g);
   cf special = make_float2(0.f, 0.f);                   // mirror element of bin 0 (pair16 path)
-  auto fetch = [&](const uint64_t item, Abk (&raw)[PTS / 2], const int chunk) {
-    const uint32_t tile = (uint32_t)(item / nparts);
-    const cf* __restrict__ X0s = X + (item % nparts) * nseq * L;
+  // a work item = (tile of channels, part of the launch), kept as two 32-bit numbers: a combined 64-bit index costs a
+  // software 64-bit division per use (about 300 scalar instructions per tile in the r02c listing)
+  struct Item { uint32_t tile, lp; };
+  auto fetch = [&](const Item item, Abk (&raw)[PTS / 2], const int chunk) {
+    const uint32_t tile = item.tile;
+    const cf* __restrict__ X0s = X + (uint64_t)item.lp * nseq * L;
     if (FB_DBG(g) & 2) {     // ablation only; hoisted so that the real path has no per-load branch
       if (chunk <= 0) {
 #pragma unroll
@@ -871,8 +878,8 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     }
   };
   // chirp of a tile (fetched at the start of the item: keeps the prefetch at 64 registers)
-  auto load_chirp = [&](const uint64_t item, cf (&kk)[PTS / 2]) {
-    const uint32_t ktile = (uint32_t)(item / nparts);
+  auto load_chirp = [&](const Item item, cf (&kk)[PTS / 2]) {
+    const uint32_t ktile = item.tile;
     if (kernel && !(FB_DBG(g) & (2 | 32))) {      // uniform; outside the unrolled loads (no per-load branch / vmcnt(0))
       constexpr uint32_t MS = 1u << (LOGF - P::LOGR1);
 #pragma unroll
@@ -890,30 +897,76 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
-  // FOLD: two buffers of out.plan_cap plan entries behind the twiddle tables (cf index, 16-byte aligned)
+  // FOLD: two buffers of out.plan_cap plan entries behind the twiddle tables (cf index, 16-byte aligned), followed by
+  // a copy of the launch's nparts + 1 part offsets into the plan (PSL_MAX words): a part's entries are then found
+  // without a dependent pair of global loads, and are fetched one item ahead (registers) like the tile itself
   const uint32_t plan_off = (ltw_off + ltw_entries_dev<LOGF>() + 1) & ~1u;
+  uint32_t* psl = nullptr;
+  const uint4* __restrict__ fent_all = nullptr;
+  bool use_psl = false;
+  if constexpr (FOLD) {
+    psl = (uint32_t*)&lds[plan_off + 4 * out.plan_cap];
+    fent_all = (const uint4*)(out.pstart + ((out.nparts_plan + 1 + 3) & ~3u));
+    use_psl = out.plan_cap > 0 && nparts + 1 <= FB_PSL_MAX;
+    if (use_psl) {
+      for (uint32_t q = tid; q <= nparts; q += blockDim.x) psl[q] = out.pstart[part0 + q];
+      __syncthreads();
+    }
+  }
   uint32_t jt = 0;                                              // tiles done by this workgroup
-  uint64_t item, next;
+  Item item, next;
   uint32_t j = 0;
   // FOLD: workgroup b takes tiles b, b + grid, ... and walks the parts of each in order
-  auto next_item = [&](const uint32_t jj, uint64_t& it) -> bool {
+  uint32_t fold_b = blockIdx.x;
+  if constexpr (FOLD) {
+    // tiles that share an X layout block (2^(logX3-logT3) of them) go to blocks b, b+8, ... : one XCD under the
+    // observed round-robin placement, at the same time, so the block's lines are fetched once (speed only)
+    const int lr = logX3 - logT3;
+    if (lr > 0 && (gridDim.x & ((8u << lr) - 1)) == 0)
+      fold_b = ((((fold_b >> (3 + lr)) << 3) | (fold_b & 7)) << lr) | ((fold_b >> 3) & ((1u << lr) - 1));
+  }
+  auto next_item = [&](const uint32_t jj, Item& it) -> bool {
     if constexpr (FOLD) {
-      // tiles that share an X layout block (2^(logX3-logT3) of them) go to blocks b, b+8, ... : one XCD under the
-      // observed round-robin placement, at the same time, so the block's lines are fetched once (speed only)
-      const int lr = logX3 - logT3;
-      uint32_t b = blockIdx.x;
-      if (lr > 0 && (gridDim.x & ((8u << lr) - 1)) == 0)
-        b = ((((b >> (3 + lr)) << 3) | (b & 7)) << lr) | ((b >> 3) & ((1u << lr) - 1));
-      const uint64_t tl = b + (uint64_t)(jj / nparts) * gridDim.x;
-      it = tl * nparts + jj % nparts;
-      return tl < ntile;
+      const uint32_t q = jj / nparts;                  // (32-bit; jj counts this workgroup's items)
+      it.tile = fold_b + q * gridDim.x;
+      it.lp = jj - q * nparts;
+      return it.tile < ntile;
     } else {
-      return persistent_item(blockIdx.x, gridDim.x, jj, run, total, it);
+      // XCD dealing as persistent_item (wgfft.h) with runs of `run` items; run == nparts (the default) makes the run
+      // index the tile and the position in the run the part, without a division by nparts
+      const uint32_t grid = gridDim.x, b = blockIdx.x;
+      uint32_t hi, lo;
+      if (grid & 7) {
+        const uint32_t lin = b + jj * grid;
+        hi = lin / run; lo = lin - hi * run;
+      } else {
+        const uint32_t q = jj * (grid >> 3) + (b >> 3);
+        const uint32_t qr = q / run;
+        hi = qr * 8 + (b & 7); lo = q - qr * run;
+      }
+      if (run == nparts) { it.tile = hi; it.lp = lo; }
+      else { const uint32_t lin = hi * run + lo; it.tile = lin / nparts; it.lp = lin - it.tile * nparts; }
+      return it.tile < ntile;                          // (lp < nparts by construction)
     }
   };
   if (!next_item(j, item)) return;
   Abk raw[PTS / 2];
   fetch(item, raw, -1);
+  cf kk[PTS / 2];                       // chirp of the current tile
+  uint32_t kk_tile = ~0u;
+  // FOLD: plan entry of this thread for the item about to be processed (tid < number of active bins of the part)
+  uint4 en_cur = make_uint4(0, 0, 0, 0);
+  uint32_t fe0_cur = 0, fn_cur = 0;
+  auto plan_fetch = [&](const Item it) {
+    if constexpr (FOLD) {
+      const uint32_t lp = it.lp;
+      if (use_psl) { fe0_cur = psl[lp]; fn_cur = psl[lp + 1] - fe0_cur; }
+      else { fe0_cur = out.pstart[part0 + lp]; fn_cur = out.pstart[part0 + lp + 1] - fe0_cur; }
+      if (FB_DBG(g) & 16) fn_cur = 0;
+      if (fn_cur <= out.plan_cap && tid < fn_cur) en_cur = fent_all[fe0_cur + tid];      // plan_cap <= blockDim
+    }
+  };
+
 #if defined(FB_STAMPS) && FB_STAMPS == 3
   unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, acc_s[6] = {0, 0, 0, 0, 0, 0};
   STAMP(ts5);
@@ -927,18 +980,17 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     STAMP(ts0);
 #endif
     {
-      cf kk[PTS / 2];
-      load_chirp(item, kk);
+      // FOLD: a workgroup walks the parts of ITS tile, so consecutive items share the chirp rows: they are loaded when
+      // the tile changes and stay in registers (the load and its latency were 22 % of the tile, profiles/r02c_*)
+      if (!FOLD || item.tile != kk_tile) {
+        load_chirp(item, kk);
+        kk_tile = item.tile;
+      }
       if constexpr (FOLD) {
-        // this part's active-bin entries travel with the chirp loads and are parked in LDS (double buffered:
-        // slower waves may still be folding the previous tile from the other half)
-        const uint64_t fpart = part0 + item % nparts;
-        const uint32_t fe0 = out.pstart[fpart], fn = out.pstart[fpart + 1] - fe0;
-        if (fn <= out.plan_cap && !(FB_DBG(g) & 16)) {
-          const uint4* __restrict__ fent = (const uint4*)(out.pstart + ((out.nparts_plan + 1 + 3) & ~3u)) + fe0;
-          uint4* pl = (uint4*)&lds[plan_off] + (jt & 1) * out.plan_cap;
-          for (uint32_t q = tid; q < fn; q += blockDim.x) pl[q] = fent[q];
-        }
+        // this part's active-bin entries travel with the chirp loads and are parked in LDS (double buffered: slower
+        // waves may still be folding the previous tile from the other half); their offsets come from the LDS copy
+        plan_fetch(item);
+        if (fn_cur <= out.plan_cap && tid < fn_cur) ((uint4*)&lds[plan_off] + (jt & 1) * out.plan_cap)[tid] = en_cur;
       }
       if constexpr (PAIR16) {
         if (pair16) {                       // hand the other channel's halves of the 16-byte pairs to the neighbour lane
@@ -961,23 +1013,24 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
           if ((tid >> 1) == 0) raw[0].b = special;
         }
       }
+      // (the uniform real/complex choice is made once, outside the unrolled loops: no branch per element)
+      if (g.real_input) {
 #pragma unroll
-      for (int g2 = 0; g2 < P::G1; g2 += 2)
-#pragma unroll
-        for (int i = 0; i < P::R1; i++) {
-          const Abk r = raw[(g2 / 2) * P::R1 + i];
-          const cf k = kk[(g2 / 2) * P::R1 + i];
-          cf x0, x1;
-          if (g.real_input) {
-            // W[k] = X0[k] + i X1[k] ; conj(W[L-k]) = X0[k] - i X1[k]
-            x0 = make_float2(0.5f * (r.a.x + r.b.x), 0.5f * (r.a.y - r.b.y));
-            x1 = make_float2(0.5f * (r.a.y + r.b.y), 0.5f * (r.b.x - r.a.x));
-          } else {
-            x0 = r.a;
-            x1 = g.npol == 2 ? r.b : make_float2(0.f, 0.f);
-          }
-          x[(g2 / 2) * P::R1 + i] = cmuls(make_cx2(x0, x1), k);          // Response::operate, Response.C:429-441
+        for (int q = 0; q < PTS / 2; q++) {
+          const Abk r = raw[q];
+          // W[k] = X0[k] + i X1[k] ; conj(W[L-k]) = X0[k] - i X1[k]
+          const cf x0 = make_float2(0.5f * (r.a.x + r.b.x), 0.5f * (r.a.y - r.b.y));
+          const cf x1 = make_float2(0.5f * (r.a.y + r.b.y), 0.5f * (r.b.x - r.a.x));
+          x[q] = cmuls(make_cx2(x0, x1), kk[q]);          // Response::operate, Response.C:429-441
         }
+      } else {
+        const bool two = g.npol == 2;
+#pragma unroll
+        for (int q = 0; q < PTS / 2; q++) {
+          const Abk r = raw[q];
+          x[q] = cmuls(make_cx2(r.a, two ? r.b : make_float2(0.f, 0.f)), kk[q]);
+        }
+      }
     }
 #if defined(FB_STAMPS) && FB_STAMPS == 3
     STAMP(ts1);
@@ -991,8 +1044,8 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     STAMP(ts2);
 #endif
 
-    const uint32_t tile = (uint32_t)(item / nparts);
-    const uint64_t part = part0 + item % nparts;
+    const uint32_t tile = item.tile;
+    const uint64_t part = part0 + item.lp;
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
       if constexpr (FOLD) {
@@ -1017,23 +1070,33 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       const int32_t t0 = (int32_t)p - (int32_t)g.nfilt_pos;
       float2* __restrict__ o2 = (float2*)(row + part * out.part_step) + t0;
       float4* __restrict__ o4 = (float4*)row + ((int64_t)(part * g.nkeep) + t0);
+      // the output kind / layout is uniform: chosen once, outside the unrolled element loop (no branch per element)
+      if (out.kind == 1) {
+        const bool two = g.npol == 2;
 #pragma unroll
-      for (int k = 0; k < R; k++) {
-        const int32_t ts = t0 + (int32_t)(k * pstride);
-        if ((uint32_t)ts >= g.nkeep) continue;
-        const uint32_t t = (uint32_t)ts;
-        const cf va = cx2_lo(v[k]), vb = cx2_hi(v[k]);
-        if (out.kind == 1) {
+        for (int k = 0; k < R; k++) {
+          if ((uint32_t)(t0 + (int32_t)(k * pstride)) >= g.nkeep) continue;
           float2* o = o2 + k * pstride;
-          st_stream(o, va);
-          if (g.npol == 2) st_stream((float2*)((float*)o + out.pol_stride), vb);
-        } else {
+          st_stream(o, cx2_lo(v[k]));
+          if (two) st_stream((float2*)((float*)o + out.pol_stride), cx2_hi(v[k]));
+        }
+      } else if (out.ndim == 4) {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          if ((uint32_t)(t0 + (int32_t)(k * pstride)) >= g.nkeep) continue;
           float r[4];
-          detect4(va, vb, out.state, r);
-          const uint64_t idat = part * g.nkeep + t;
-          if (out.ndim == 4) {
-            st_stream(o4 + k * pstride, make_float4(r[0], r[1], r[2], r[3]));
-          } else if (out.ndim == 2) {
+          detect4(cx2_lo(v[k]), cx2_hi(v[k]), out.state, r);
+          st_stream(o4 + k * pstride, make_float4(r[0], r[1], r[2], r[3]));
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          const int32_t ts = t0 + (int32_t)(k * pstride);
+          if ((uint32_t)ts >= g.nkeep) continue;
+          float r[4];
+          detect4(cx2_lo(v[k]), cx2_hi(v[k]), out.state, r);
+          const uint64_t idat = part * g.nkeep + (uint32_t)ts;
+          if (out.ndim == 2) {
             st_stream(&((float2*)row)[idat], make_float2(r[0], r[1]));
             st_stream(&((float2*)(row + out.pol_stride))[idat], make_float2(r[2], r[3]));
           } else {
@@ -1058,9 +1121,9 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     float4 acc_pre = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr bool PRE = FOLD && FftPlan<LOGF>::NS >= 2;
     if constexpr (FOLD) {
-      f_e0 = out.pstart[part];
-      f_nact = (FB_DBG(g) & 16) ? 0u : out.pstart[part + 1] - f_e0;
-      ent = (const uint4*)(out.pstart + ((out.nparts_plan + 1 + 3) & ~3u)) + f_e0;
+      f_e0 = fe0_cur;
+      f_nact = fn_cur;
+      ent = fent_all + f_e0;
       planl = (const uint4*)&lds[plan_off] + (jt & 1) * out.plan_cap;
       in_lds = f_nact <= out.plan_cap;
     }
@@ -1161,14 +1224,15 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
   const uint64_t L = 1ull << (g.logM + g.logR);
   const uint32_t nseq = g.real_input ? 1 : g.npol;
   const uint32_t ntile = 1u << (g.logMb - logTm);          // m2 tiles per channel
-  const uint64_t per_part = (uint64_t)ntile * g.C;
-  const uint64_t total = per_part * nparts;
+  const uint32_t per_part = ntile * g.C;
+  const uint32_t total = per_part * nparts;
+  const int logNt = g.logMb - logTm;        // ntile = 2^logNt
   struct Abk { cf a, b; };
 
-  auto fetch = [&](const uint64_t item, Abk (&raw)[PTS / 2]) {
-    const uint64_t part = item / per_part, r = item % per_part;
-    const uint32_t c = (uint32_t)(r / ntile), tile = (uint32_t)(r % ntile);
-    const cf* __restrict__ X0s = X + part * nseq * L;
+  auto fetch = [&](const uint32_t item, Abk (&raw)[PTS / 2]) {
+    const uint32_t part = item / per_part, r = item - part * per_part;
+    const uint32_t c = r >> logNt, tile = r & (ntile - 1);
+    const cf* __restrict__ X0s = X + (uint64_t)part * nseq * L;
     if (FB_DBG(g) & 2) {
 #pragma unroll
       for (int i = 0; i < NPAIR; i++) { raw[i].a = make_float2(tid, i); raw[i].b = raw[i].a; }
@@ -1199,15 +1263,15 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
-  uint64_t item, next;
+  uint32_t item, next;
   uint32_t jn = 0;
   if (!persistent_item(blockIdx.x, gridDim.x, jn, run, total, item)) return;
   Abk raw[PTS / 2];
   fetch(item, raw);
   for (;;) {
     asm volatile("" : "+v"(tid));
-    const uint64_t part = item / per_part, r = item % per_part;
-    const uint32_t c = (uint32_t)(r / ntile), tile = (uint32_t)(r % ntile);
+    const uint32_t part = item / per_part, r = item - part * per_part;
+    const uint32_t c = r >> logNt, tile = r & (ntile - 1);
     cx2 x[NPAIR];
     {
       cf kk[PTS / 2];
@@ -1242,7 +1306,7 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++jn, run, total, next);
     if (more) fetch(next, raw);
 
-    cf* __restrict__ Uc = U + (part * g.C + c) * (2ull << g.logMf);
+    cf* __restrict__ Uc = U + ((uint64_t)part * g.C + c) * (2ull << g.logMf);
     // staged image order [t1/Tt][j][t1%Tt][pol]: whole runs of Tm*Tt*2 elements go out with 16-byte stores
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
@@ -1283,13 +1347,14 @@ __global__ __launch_bounds__(512) void k_inv_b(const FbGeom g, const cf* __restr
   uint32_t tid = threadIdx.x;
   const int logTt = g.logTt, logT = logTt + 1;
   const uint32_t ntile = 1u << (g.logMa - logTt);          // t1 blocks per channel
-  const uint64_t per_part = (uint64_t)ntile * g.C;
-  const uint64_t total = per_part * nparts;
+  const uint32_t per_part = ntile * g.C;
+  const uint32_t total = per_part * nparts;
+  const int logNt = g.logMa - logTt;        // ntile = 2^logNt
 
-  auto fetch = [&](const uint64_t item, float4 (&y)[NPAIR]) {
-    const uint64_t part = item / per_part, r = item % per_part;
-    const uint32_t c = (uint32_t)(r / ntile), tile = (uint32_t)(r % ntile);
-    const cf* __restrict__ blk = U + (part * g.C + c) * (2ull << g.logMf) + (((uint64_t)tile << g.logMb) << logT);
+  auto fetch = [&](const uint32_t item, float4 (&y)[NPAIR]) {
+    const uint32_t part = item / per_part, r = item - part * per_part;
+    const uint32_t c = r >> logNt, tile = r & (ntile - 1);
+    const cf* __restrict__ blk = U + ((uint64_t)part * g.C + c) * (2ull << g.logMf) + (((uint64_t)tile << g.logMb) << logT);
     if (FB_DBG(g) & 2) {
 #pragma unroll
       for (int i = 0; i < NPAIR; i++) y[i] = make_float4(tid, i, 1.f, 1.f);
@@ -1304,7 +1369,7 @@ __global__ __launch_bounds__(512) void k_inv_b(const FbGeom g, const cf* __restr
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
-  uint64_t item, next;
+  uint32_t item, next;
   uint32_t jn = 0;
   if (!persistent_item(blockIdx.x, gridDim.x, jn, run, total, item)) return;
   float4 y[NPAIR];
@@ -1314,8 +1379,9 @@ __global__ __launch_bounds__(512) void k_inv_b(const FbGeom g, const cf* __restr
     cx2 x[NPAIR];
 #pragma unroll
     for (int i = 0; i < NPAIR; i++) x[i] = make_cx2(make_float2(y[i].x, y[i].y), make_float2(y[i].z, y[i].w));
-    const uint64_t part = part0 + item / per_part, r = item % per_part;
-    const uint32_t c = (uint32_t)(r / ntile), tile = (uint32_t)(r % ntile);
+    const uint32_t lpart = item / per_part, r = item - lpart * per_part;
+    const uint64_t part = part0 + lpart;
+    const uint32_t c = r >> logNt, tile = r & (ntile - 1);
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++jn, run, total, next);
     if (more) fetch(next, y);
 
@@ -1633,12 +1699,13 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
       fb->k3 = fb_pick3(g.logM, full3);
       fb->k3f = fb_pick3f(g.logM, full3);
       // fused fold: the LDS left over behind the twiddle tables holds the part's fold plan (two buffers)
-      const size_t spare = 160 * 1024 - 64 - fb->lds3 - 16;
-      uint32_t cap = fb->lds3 + 64 + 16 < 160 * 1024 ? (uint32_t)(spare / 32) : 0;
-      if (cap > 512) cap = 512;
+      const size_t psl_bytes = FB_PSL_MAX * sizeof(uint32_t);
+      const size_t spare = 160 * 1024 - 64 - fb->lds3 - 16 - psl_bytes;
+      uint32_t cap = fb->lds3 + 64 + 16 + psl_bytes < 160 * 1024 ? (uint32_t)(spare / 32) : 0;
+      if (cap > fb->nt3) cap = fb->nt3;           // one plan entry per thread of the workgroup (nt3 <= 512)
       if (cap < 16) cap = 0;
       fb->plan_cap = cap;
-      fb->lds3f = fb->lds3 + 16 + (size_t)cap * 32;
+      fb->lds3f = fb->lds3 + 16 + (size_t)cap * 32 + psl_bytes;
     }
     hipError_t e = hipSuccess;
     bool have = (fb->k1_w1 || fb->k1_w4) && fb->k2 && (g.four_pass ? (fb->k3a && fb->k3b) : (fb->k3 != nullptr));
@@ -1808,8 +1875,20 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
     FbOut co = out;
     co.chan0 = ichan * g.C;
     const cf* kern = fb->kernel ? fb->kernel + (uint64_t)ichan * fb->N : nullptr;
-    for (uint64_t part0 = 0; part0 < npart; part0 += fb->max_parts) {
-      const uint32_t nb = (uint32_t)((npart - part0) < fb->max_parts ? (npart - part0) : fb->max_parts);
+    uint32_t nb_step = 0;
+    for (uint64_t part0 = 0; part0 < npart; part0 += nb_step) {
+      uint32_t nb = (uint32_t)((npart - part0) < fb->max_parts ? (npart - part0) : fb->max_parts);
+      {  // the kernels count their work items in 32 bits: keep every pass of a launch group below 2^31 items
+        uint64_t per_part_items = (uint64_t)(Rr >> g.logT1) * fb->nseq;
+        const uint64_t i2 = (uint64_t)(M >> g.logT2) * fb->nseq, i3 = g.four_pass ? 0 : (uint64_t)(g.C >> g.logT3),
+                       i3a = g.four_pass ? ((uint64_t)g.C << (g.logMb - g.logTm)) : 0, i3b = g.four_pass ? ((uint64_t)g.C << (g.logMa - g.logTt)) : 0;
+        if (i2 > per_part_items) per_part_items = i2;
+        if (i3 > per_part_items) per_part_items = i3;
+        if (i3a > per_part_items) per_part_items = i3a;
+        if (i3b > per_part_items) per_part_items = i3b;
+        while (nb > 1 && per_part_items * nb >= (1ull << 31)) nb /= 2;
+        nb_step = nb;
+      }
       // persistent grids: one workgroup per CU (LDS-limited), a multiple of 8 so the XCD-aware item order applies
       const uint64_t n1 = (uint64_t)(Rr >> g.logT1) * fb->nseq * nb, n2 = (uint64_t)(M >> g.logT2) * fb->nseq * nb,
                      n3 = g.four_pass ? 0 : (uint64_t)(g.C >> g.logT3) * nb;

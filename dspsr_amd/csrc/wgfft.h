@@ -382,14 +382,17 @@ DEV void wgfft_passthrough(uint32_t tid, const int logT, cx2 (&x)[NPAIR], Out& o
 // consecutive items (blocks b and b+8 share an XCD under the observed round-robin placement;
 // a different placement only changes speed), so neighbouring items -- which share 128-byte
 // input lines (P1) or chirp rows (P3) -- are served by one XCD's L2.
-DEV bool persistent_item(uint32_t b, uint32_t grid, uint32_t j, uint32_t run, uint64_t total, uint64_t& item)
+// (32-bit arithmetic throughout: a launch holds fewer than 2^31 items -- the host sizes its launch groups accordingly --
+// and 64-bit divisions by a run-time value cost hundreds of instructions per tile)
+DEV bool persistent_item(uint32_t b, uint32_t grid, uint32_t j, uint32_t run, uint32_t total, uint32_t& item)
 {
   if (grid & 7) {
-    item = b + (uint64_t)j * grid;
+    item = b + j * grid;
   } else {
     const uint32_t nxl = grid >> 3;
-    const uint64_t q = (uint64_t)j * nxl + (b >> 3);
-    item = (q / run) * (8ull * run) + (uint64_t)(b & 7) * run + (q % run);
+    const uint32_t q = j * nxl + (b >> 3);
+    const uint32_t qr = q / run;
+    item = qr * (8u * run) + (b & 7) * run + (q - qr * run);
   }
   return item < total;
 }
