@@ -56,6 +56,7 @@ SYMBOLS = {
     "dspsr_amd_zero": (_i, [_vp, _vp, _sz]),
     "dspsr_amd_copy": (_i, [_vp, _vp, _vp, _sz, _i]),
     "dspsr_amd_copy_fpt": (_i, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u32, _u64]),
+    "dspsr_amd_add_fpt": (_i, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u32, _u64]),
     "dspsr_amd_filterbank_create": (_i, [_vp, C.POINTER(FilterbankConfig), _pp]),
     "dspsr_amd_filterbank_destroy": (None, [_vp]),
     "dspsr_amd_filterbank_set_kernel": (_i, [_vp, _vp, _u64]),
@@ -89,6 +90,7 @@ SYMBOLS = {
     "dspsr_amd_fold_set_ndat": (_i, [_vp, _u64, _u64]),
     "dspsr_amd_fold_set_bin": (_i, [_vp, _u64, _d, _d]),
     "dspsr_amd_fold_set_bins": (_i, [_vp, _d, _d, _u64, _u64, _vp, C.POINTER(_u64)]),
+    "dspsr_amd_fold_set_bins_weighted": (_i, [_vp, _d, _d, _u64, _u64, _vp, _u64, _u64, _u64, _vp, C.POINTER(_u64)]),
     "dspsr_amd_fold_fold": (_i, [_vp, _vp, _u64, _u64]),
     "dspsr_amd_fold_profiles_dev": (_vp, [_vp]),
     "dspsr_amd_fold_get_ndat_folded": (_u64, [_vp]),

@@ -144,3 +144,47 @@ extern "C" int dspsr_amd_copy_fpt(dspsr_amd_ctx* ctx, float* to_dev, uint64_t to
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_copy_fpt: %s", hipGetErrorString(e));
   return DSPSR_AMD_OK;
 }
+
+// dsp::TimeSeries::operator += on device rows (PhaseSeries::combine, PhaseSeries.C:442-484): one (chan, pol) row per
+// blockIdx.y/z, grid-stride over the row; plain float adds (the same sum the host loop of TimeSeries.C makes)
+__global__ __launch_bounds__(256) void k_add_fpt(float* __restrict__ to, const uint64_t tcs, const uint64_t tps,
+                                                 const float* __restrict__ from, const uint64_t fcs, const uint64_t fps,
+                                                 const uint64_t nfloat)
+{
+  float* __restrict__ t = to + blockIdx.z * tcs + blockIdx.y * tps;
+  const float* __restrict__ f = from + blockIdx.z * fcs + blockIdx.y * fps;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (((((uintptr_t)t) | ((uintptr_t)f)) & 15) == 0) {
+    const uint64_t n4 = nfloat >> 2;
+    for (uint64_t j = i; j < n4; j += stride) {
+      float4 a = ((float4*)t)[j];
+      const float4 b = ((const float4*)f)[j];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      ((float4*)t)[j] = a;
+    }
+    for (uint64_t j = (n4 << 2) + i; j < nfloat; j += stride) t[j] += f[j];
+  } else {
+    for (; i < nfloat; i += stride) t[i] += f[i];
+  }
+}
+
+extern "C" int dspsr_amd_add_fpt(dspsr_amd_ctx* ctx, float* to_dev, uint64_t to_chan_stride, uint64_t to_pol_stride,
+                                 const float* from_dev, uint64_t from_chan_stride, uint64_t from_pol_stride,
+                                 uint32_t nchan, uint32_t npol, uint64_t nfloat)
+{
+  if (!ctx || ((!to_dev || !from_dev) && nfloat)) return DSPSR_AMD_EINVAL;
+  if (!nfloat || !nchan || !npol) return DSPSR_AMD_OK;
+  if (npol > 65535 || nchan > 65535)
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_add_fpt: nchan=%u npol=%u exceed the grid limits", nchan, npol);
+  if (to_dev == from_dev)
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_add_fpt: a PhaseSeries cannot be combined with itself");
+  uint64_t bx = (nfloat / 4 + 255) / 256;
+  if (bx < 1) bx = 1;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(k_add_fpt, dim3((uint32_t)bx, npol, nchan), dim3(256), 0, ctx->stream, to_dev, to_chan_stride,
+                     to_pol_stride, from_dev, from_chan_stride, from_pol_stride, nfloat);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_add_fpt: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}

@@ -315,27 +315,60 @@ extern "C" int dspsr_amd_fold_set_bin(dspsr_amd_fold* f, uint64_t idat, double d
   return DSPSR_AMD_OK;
 }
 
-extern "C" int dspsr_amd_fold_set_bins(dspsr_amd_fold* f, double phi, double phase_per_sample, uint64_t ndat,
-                                       uint64_t idat_start, uint32_t* hits_host, uint64_t* ndat_folded)
+// The plan loop of Fold.C:744-787, the same double recurrence sample by sample (the sums are not associative, so nothing is
+// skipped), written so that the loop-carried chain is the one addition: phi -= floor(phi) changes phi only when phi is
+// outside [0, 1) (phi - 0.0 == phi), the run-length bookkeeping of set_bin (FoldCUDA.cu:84-113) is inlined and hits[] is
+// updated once per run.  At 6 MHz output rates the plan loop is what a block waits for.
+// Weights (Fold.C:686-716,746-763): sample idat belongs to weight (idat + weight_idat) / ndatperweight; samples of a zero
+// weight are dropped from the plan (binplan = folding_nbin in the reference: not folded, not counted in hits or
+// ndat_folded) -- the hook a weighted input (dropped packets, RFI flagging upstream) needs; weights == NULL: none.
+static int fold_set_bins_impl(dspsr_amd_fold* f, double phi, double phase_per_sample, uint64_t ndat, uint64_t idat_start,
+                              const uint32_t* weights, uint64_t nweights, uint64_t ndatperweight, uint64_t weight_idat,
+                              uint32_t* hits_host, uint64_t* ndat_folded)
 {
   if (!f) return DSPSR_AMD_EINVAL;
   if (!f->folding_nbin) return ctx_fail(f->ctx, DSPSR_AMD_ESTATE, "dsp::Fold::fold nbin not set");
   const double double_nbin = (double)f->folding_nbin;     // Fold.C:719
   const uint32_t nbin = f->folding_nbin;
-  // Fold.C:744-787, the same double recurrence sample by sample (the sums are not associative, so nothing is
-  // skipped), written so that the loop-carried chain is the one addition: phi -= floor(phi) changes phi only when
-  // phi is outside [0, 1) (phi - 0.0 == phi), the run-length bookkeeping of set_bin (FoldCUDA.cu:84-113) is inlined
-  // and hits[] is updated once per run.  At 6 MHz output rates the plan loop is what a block waits for.
   uint32_t cur_bin = f->current_bin, cur_hits = f->current_hits;
   uint32_t counted = cur_hits;          // hits of the open run already added to hits_host by an earlier call
   const uint64_t end = idat_start + ndat;
+  uint64_t folded = 0, iweight = 0, idat_nextweight = ~0ull;
+  bool bad = false;
+  if (weights && ndatperweight) {                         // Fold.C:686-716
+    iweight = (idat_start + weight_idat) / ndatperweight;
+    idat_nextweight = (iweight + 1) * ndatperweight - weight_idat;
+    if (iweight >= nweights)
+      return ctx_fail(f->ctx, DSPSR_AMD_ESTATE, "dsp::Fold::fold iweight=%llu >= nweight=%llu", (unsigned long long)iweight,
+                      (unsigned long long)nweights);
+    bad = weights[iweight] == 0;
+  }
+  auto close_run = [&]() {              // a dropped sample ends the open run: the next kept sample starts a new one
+    if (!f->binplan.empty()) f->binplan.back().hits = cur_hits;
+    if (hits_host && cur_bin < nbin) hits_host[cur_bin] += cur_hits - counted;
+    cur_bin = nbin; cur_hits = 0; counted = 0;
+  };
   for (uint64_t idat = idat_start; idat < end; idat++) {
+    if (idat >= idat_nextweight) {                        // Fold.C:746-763
+      iweight++;
+      if (iweight >= nweights) {
+        f->current_bin = cur_bin; f->current_hits = cur_hits;
+        return ctx_fail(f->ctx, DSPSR_AMD_ESTATE, "dsp::Fold::fold iweight=%llu >= nweight=%llu", (unsigned long long)iweight,
+                        (unsigned long long)nweights);
+      }
+      bad = weights[iweight] == 0;
+      idat_nextweight += ndatperweight;
+    }
     if (!(phi >= 0.0 && phi < 1.0)) phi -= floor(phi);
     const uint32_t ibin = (uint32_t)(phi * double_nbin);
     phi += phase_per_sample;
     if (ibin >= nbin) {
       f->current_bin = cur_bin; f->current_hits = cur_hits;
       return ctx_fail(f->ctx, DSPSR_AMD_EINVAL, "dsp::Fold::fold ibin=%u >= nbin=%u", ibin, nbin);
+    }
+    if (bad) {
+      if (cur_hits || cur_bin < nbin) close_run();
+      continue;
     }
     if (ibin != cur_bin) {                // set_bin: a new run starts
       if (!f->binplan.empty()) f->binplan.back().hits = cur_hits;
@@ -347,13 +380,30 @@ extern "C" int dspsr_amd_fold_set_bins(dspsr_amd_fold* f, double phi, double pha
       counted = 0;
     }
     cur_hits++;
+    folded++;
   }
   if (hits_host && cur_bin < nbin) hits_host[cur_bin] += cur_hits - counted;
-  f->ndat_fold += ndat;
+  f->ndat_fold += folded;
   f->current_bin = cur_bin;
   f->current_hits = cur_hits;
-  if (ndat_folded) *ndat_folded = ndat;
+  if (ndat_folded) *ndat_folded = folded;
   return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_fold_set_bins(dspsr_amd_fold* f, double phi, double phase_per_sample, uint64_t ndat,
+                                       uint64_t idat_start, uint32_t* hits_host, uint64_t* ndat_folded)
+{
+  return fold_set_bins_impl(f, phi, phase_per_sample, ndat, idat_start, nullptr, 0, 0, 0, hits_host, ndat_folded);
+}
+
+extern "C" int dspsr_amd_fold_set_bins_weighted(dspsr_amd_fold* f, double phi, double phase_per_sample, uint64_t ndat,
+                                                uint64_t idat_start, const uint32_t* weights_host, uint64_t nweights,
+                                                uint64_t ndatperweight, uint64_t weight_idat, uint32_t* hits_host,
+                                                uint64_t* ndat_folded)
+{
+  if (weights_host && !ndatperweight) return DSPSR_AMD_EINVAL;
+  return fold_set_bins_impl(f, phi, phase_per_sample, ndat, idat_start, weights_host, nweights, ndatperweight, weight_idat,
+                            hits_host, ndat_folded);
 }
 
 extern "C" uint64_t dspsr_amd_fold_get_ndat_folded(const dspsr_amd_fold* f) { return f ? f->ndat_fold : 0; }

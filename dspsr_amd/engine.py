@@ -296,6 +296,13 @@ def copy_data_fpt(ctx: Context, to, frm):
                                              frm.stride(1), nchan, npol, nfloat), "dspsr_amd_copy_fpt")
 
 
+def add_fpt(ctx: Context, to, frm):
+    """dsp::TimeSeries::operator += on device rows [nchan][npol][nfloat] (PhaseSeries::combine): to += frm."""
+    nchan, npol, nfloat = frm.shape
+    _check(ctx.handle, lib.dspsr_amd_add_fpt(ctx.handle, to.data_ptr(), to.stride(0), to.stride(1), frm.data_ptr(), frm.stride(0),
+                                            frm.stride(1), nchan, npol, nfloat), "dspsr_amd_add_fpt")
+
+
 def dedispersion_sample_delays(centre_frequency, bandwidth, dispersion_measure, nchan, rate_hz, swap=False, nsub_swap=0,
                                dc_centred=False):
     """Dedispersion::SampleDelay::match (DedispersionSampleDelay.C:24-75): int64 delay of each channel in samples."""
@@ -451,12 +458,22 @@ class FoldEngine:
         _check(self.ctx.handle, lib.dspsr_amd_fold_set_bin(self.handle, idat, ibin, bins_per_samp),
                "dspsr_amd_fold_set_bin")
 
-    def set_bins(self, phi, phase_per_sample, ndat, idat_start, hits: np.ndarray | None = None):
+    def set_bins(self, phi, phase_per_sample, ndat, idat_start, hits: np.ndarray | None = None, weights=None,
+                 ndatperweight=0, weight_idat=0):
+        """weights (uint32, one per ndatperweight samples; sample idat belongs to weight (idat + weight_idat) //
+        ndatperweight): samples of a zero weight are not folded (Fold.C:686-716,746-763)."""
         n = C.c_uint64()
         hp = hits.ctypes.data_as(C.c_void_p) if hits is not None else None
-        _check(self.ctx.handle,
-               lib.dspsr_amd_fold_set_bins(self.handle, phi, phase_per_sample, ndat, idat_start, hp, C.byref(n)),
-               "dspsr_amd_fold_set_bins")
+        if weights is None:
+            _check(self.ctx.handle,
+                   lib.dspsr_amd_fold_set_bins(self.handle, phi, phase_per_sample, ndat, idat_start, hp, C.byref(n)),
+                   "dspsr_amd_fold_set_bins")
+        else:
+            w = np.ascontiguousarray(weights, dtype=np.uint32)
+            _check(self.ctx.handle,
+                   lib.dspsr_amd_fold_set_bins_weighted(self.handle, phi, phase_per_sample, ndat, idat_start,
+                                                        w.ctypes.data_as(C.c_void_p), w.size, ndatperweight, weight_idat, hp,
+                                                        C.byref(n)), "dspsr_amd_fold_set_bins_weighted")
         return n.value
 
     def get_ndat_folded(self):

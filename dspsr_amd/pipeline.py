@@ -17,7 +17,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from .engine import (Context, Dedispersion, DspsrAmdError, FilterbankEngine, FoldEngine, Rescale, SampleDelay, copy_data_fpt,
+from .engine import (Context, Dedispersion, DspsrAmdError, FilterbankEngine, FoldEngine, Rescale, SampleDelay, add_fpt, copy_data_fpt,
                      dedispersion_sample_delays, eight_bit_scale, pscrunch_tfp, sigproc_digitize, tfp_filterbank)
 
 
@@ -30,6 +30,8 @@ class Config:
     folding_period: float = 0.0       # -c  (seconds); 0 => polyco
     freq_res: int = 0                 # -x  (0 => optimal)
     subint_seconds: float = 0.0       # -L  (0 => single integration)
+    subint_turns: float = 0.0         # -s (1 turn: single pulses) / -turns N: sub-integrations of N pulse periods
+    fractional_pulses: bool = False   # -fractional_pulses: start the first division at the first sample, not at phase 0
     stokes: bool = False              # -4? (default Coherence, LoadToFold1.C:1119-1134)
     ndim: int = 4                     # detected layout (CPU default 4, CUDA engine 2; LoadToFoldConfig.C:104)
     parts_per_block: int = 64         # block size in overlap-save parts (LoadToFold1.C:825-835 sizes blocks likewise)
@@ -91,6 +93,31 @@ class Polyco:
             d = d * dt + k * self.coef[k]
         return self.f0 + d / 60.0
 
+    def phase(self, day, sec):
+        """Absolute phase as (integer turns, fractional turns) -- Pulsar::Predictor::phase keeps the two apart because
+        the total (3.6e9 turns for vela.polyco) does not fit a double to 1e-6 turns."""
+        dt = self._dt(day, sec)
+        poly = 0.0
+        for c in reversed(self.coef):
+            poly = poly * dt + c
+        spin = 60.0 * dt * self.f0
+        si = math.floor(spin)
+        fr = self.rphase_frac + (spin - si) + poly
+        fi = math.floor(fr)
+        return int(self.rphase_int + si + fi), fr - fi
+
+    def iphase(self, phase, day, sec_guess):
+        """Pulsar::Predictor::iphase: the epoch (seconds of `day`) at which the phase is `phase` = (int, frac) turns,
+        by Newton iteration with slope frequency(t)."""
+        sec = sec_guess
+        for _ in range(20):
+            pi, pf = self.phase(day, sec)
+            step = ((pi - phase[0]) + (pf - phase[1])) / self.frequency(day, sec)
+            sec -= step
+            if abs(step) < 1e-12:
+                break
+        return sec
+
 
 def choose_nbin(folding_period, rate, requested_nbin=0, maximum_nbin=1024, minimum_bin_width=1.2,
                 power_of_two=True, force_sensible_nbin=False):
@@ -133,6 +160,62 @@ def subint_pieces(first_sample, ndat, division_seconds, rate):
         if pos == upper:
             k += 1
     return out
+
+
+class TurnsDivider:
+    """dsp::TimeDivide in turns mode (dspsr -s / -turns N; TimeDivide.C:360-436,461-500): division k spans pulse phases
+    [start_phase + k*D, start_phase + (k+1)*D), start_phase = the first phase at or after the observation start whose
+    fractional part is reference_phase (the leading partial turn is not folded) unless fractional_pulses.  Boundaries
+    are snapped to output samples like set_boundaries(mjd1, mjd2) (:503-540).  D >= 1 (phase-resolved divisions with
+    D < 1 are not built).  phase(t) -> (int, frac), iphase((int, frac), t_guess) -> t, t in seconds of the stream."""
+
+    def __init__(self, phase, iphase, period_guess, t_start, rate, division_turns, reference_phase=0.0,
+                 fractional_pulses=False):
+        if division_turns < 1.0:
+            raise DspsrAmdError("dsp::TimeDivide division_turns < 1 (phase-resolved divisions) is not built")
+        self.iphase, self.t_start, self.rate, self.D, self.pguess = iphase, t_start, rate, float(division_turns), period_guess
+        pi, pf = phase(t_start)
+        if not fractional_pulses and pf > reference_phase:
+            pi += 1
+        self.start_phase = (pi, reference_phase)
+        self.start_time = iphase(self.start_phase, t_start)
+        self._cache = {}
+
+    def _at(self, turns):
+        tot = self.start_phase[1] + turns
+        ti = math.floor(tot)
+        return self.iphase((self.start_phase[0] + int(ti), tot - ti), self.start_time + turns * self.pguess)
+
+    def bounds(self, k):
+        """[first, last) output sample of division k (sample 0 = first output sample of the stream)."""
+        if k not in self._cache:
+            mjd1, mjd2 = self._at(k * self.D), self._at((k + 1) * self.D)
+            lower = int(round((mjd1 - self.t_start) * self.rate))                      # lrint
+            ndat = int(round((mjd2 - (self.t_start + lower / self.rate)) * self.rate))
+            self._cache[k] = (lower, lower + ndat)
+            if len(self._cache) > 64:
+                self._cache.pop(next(iter(self._cache)))
+        return self._cache[k]
+
+    def pieces(self, first_sample, ndat):
+        """Subint<Fold> over one block: (idat_start, ndat_fold, division, division_complete) pieces; samples in front of
+        division 0 are skipped (TimeDivide::set_bounds, :196-246: idat_start = rint((lower - input_start) * rate))."""
+        out = []
+        pos, end = first_sample, first_sample + ndat
+        pos = max(pos, self.bounds(0)[0])
+        if pos >= end:
+            return out
+        k = max(int((pos - self.bounds(0)[0]) / (self.D * self.pguess * self.rate)) - 1, 0)
+        while self.bounds(k)[1] <= pos:
+            k += 1
+        while pos < end:
+            upper = self.bounds(k)[1]
+            stop = min(end, upper)
+            out.append((pos - first_sample, stop - pos, k, stop == upper))
+            pos = stop
+            if pos == upper:
+                k += 1
+        return out
 
 
 def normalise_profile(profile, hits, scale):
@@ -203,6 +286,87 @@ def read_phase_series(path):
             raise DspsrAmdError("read_phase_series: %s is truncated" % path)
         prof = np.frombuffer(body, dtype="<f4").reshape(nchan, npol, nbin, ndim).copy()
     return hdr, hits, prof
+
+
+class PhaseSeries:
+    """The product's dsp::PhaseSeries (Signal/Pulsar/dsp/PhaseSeries.h:163-200): profile sums resident on the device
+    ([nchan][npol][nbin*ndim] float32 tensor), hits[] and the integration bookkeeping on the host, plus the Observation
+    attributes `combinable` compares.  mixable / combine follow PhaseSeries.C:336-418,442-484; the profile half of
+    combine is TimeSeries::operator += on the device (dspsr_amd_add_fpt)."""
+
+    OBS_KEYS = ("centre_frequency", "bandwidth", "nchan", "npol", "ndim", "state", "rate")
+
+    def __init__(self, ctx, obs=None):
+        self.ctx = ctx
+        self.obs = dict(obs or {})
+        self.nbin = 0
+        self.profile = None
+        self.hits = np.zeros(0, np.uint32)
+        self.integration_length = 0.0
+        self.ndat_total = 0
+        self.start_time = self.end_time = 0.0
+
+    @classmethod
+    def from_subint(cls, ctx, sub, obs, start_time=0.0, end_time=0.0):
+        """Wrap a dict of LoadToFold.subints (the device copy `profile_dev`, hits, integration_length, ndat_total)."""
+        ps = cls(ctx, obs)
+        ps.nbin = len(sub["hits"])
+        ps.profile = sub["profile_dev"].view(obs["nchan"], obs["npol"], ps.nbin * obs["ndim"])
+        ps.hits = np.array(sub["hits"], dtype=np.uint32)
+        ps.integration_length, ps.ndat_total = float(sub["integration_length"]), int(sub["ndat_total"])
+        ps.start_time, ps.end_time = start_time, end_time
+        return ps
+
+    def zero(self):                                            # PhaseSeries::zero, PhaseSeries.C:239-256
+        self.integration_length, self.ndat_total = 0.0, 0
+        self.hits[:] = 0
+        if self.profile is not None:
+            self.profile.zero_()
+
+    def combinable(self, obs):                                 # Observation::combinable: the attributes that must agree
+        return all(self.obs.get(k) == obs.get(k) for k in self.OBS_KEYS)
+
+    def mixable(self, obs, nbin, start_time, end_time):
+        """PhaseSeries::mixable (PhaseSeries.C:336-418): an empty integration adopts `obs`, is resized and zeroed (the
+        count of dropped samples ndat_total survives); otherwise the observations must be combinable and nbin equal, and
+        the time span is extended."""
+        if self.integration_length == 0.0:
+            import torch
+            self.obs = {k: obs.get(k) for k in self.OBS_KEYS}
+            keep = self.ndat_total
+            self.nbin = nbin
+            shape = (obs["nchan"], obs["npol"], nbin * obs["ndim"])
+            if self.profile is None or tuple(self.profile.shape) != shape:
+                self.profile = torch.empty(shape, dtype=torch.float32, device="cuda:%d" % self.ctx.device)
+            self.hits = np.zeros(nbin, np.uint32)
+            self.zero()
+            self.ndat_total = keep
+            self.start_time, self.end_time = start_time, end_time
+            return True
+        if not self.combinable(obs) or self.nbin != nbin:
+            return False
+        self.end_time = max(self.end_time, end_time)
+        self.start_time = min(self.start_time, start_time)
+        return True
+
+    def combine(self, other):
+        """PhaseSeries::combine (PhaseSeries.C:442-484)."""
+        if other is None or other.nbin == 0:
+            return self
+        if not self.integration_length:                        # this is empty: *this = *prof
+            keep = self.ndat_total
+            self.mixable(other.obs, other.nbin, other.start_time, other.end_time)
+            self.profile.copy_(other.profile)
+            self.hits = other.hits.copy()
+            self.integration_length, self.ndat_total = other.integration_length, other.ndat_total + 0 * keep
+            return self
+        if not self.mixable(other.obs, other.nbin, other.start_time, other.end_time):
+            raise DspsrAmdError("PhaseSeries::combine PhaseSeries !mixable")
+        add_fpt(self.ctx, self.profile, other.profile)         # TimeSeries::operator +=
+        self.hits += other.hits
+        self.integration_length += other.integration_length
+        self.ndat_total += other.ndat_total
+        return self
 
 
 def combine_phase_series(a, b):
@@ -410,11 +574,8 @@ class LoadToFold:
         if self.sample_delay is not None:
             return self._process_block_interchan(raw, npart, ndat, state, events)
         # Subint<Fold>::transformation: fold piece by piece, emitting a sub-integration at every boundary
-        if self.cfg.subint_seconds > 0:
-            pieces = subint_pieces(self.ndat_out, ndat, self.cfg.subint_seconds, self.out_rate)
-        else:
-            pieces = [(0, ndat, 0, False)]
-        if self.fused_fold and len(pieces) == 1:
+        pieces = self._pieces(ndat)
+        if self.fused_fold and len(pieces) == 1 and pieces[0][:2] == (0, ndat):
             # one fold call covers the block: filterbank, detection and fold in one launch group.  Same sums in the
             # same order as the unfused chain below (blocks holding a sub-integration boundary take that chain).
             idat_start, ndat_fold, _division, complete = pieces[0]
@@ -456,11 +617,7 @@ class LoadToFold:
         rows = self.detected[:, :, off * nd:(off + nin) * nd]
         nout = self.sample_delay.transform(rows.unflatten(2, (nin, nd)))
         if nout:
-            if cfg.subint_seconds > 0:
-                pieces = subint_pieces(self.ndat_out, nout, cfg.subint_seconds, self.out_rate)
-            else:
-                pieces = [(0, nout, 0, False)]
-            for idat_start, ndat_fold, _division, complete in pieces:
+            for idat_start, ndat_fold, _division, complete in self._pieces(nout):
                 folded = self._set_plan(idat_start, ndat_fold)
                 self.fold.fold(rows)
                 self.integration_length += folded / self.out_rate
@@ -475,6 +632,30 @@ class LoadToFold:
         self.ndat_out += nout
         self.nsamples_in += npart * self.nsamp_step
 
+    def _pieces(self, ndat):
+        """Subint<Fold>::transformation (Subint.h:234-309): the pieces of the next `ndat` output samples, one per
+        sub-integration they touch -- seconds mode (-L), turns mode (-s / -turns) or one piece."""
+        cfg = self.cfg
+        if cfg.subint_seconds > 0:
+            return subint_pieces(self.ndat_out, ndat, cfg.subint_seconds, self.out_rate)
+        if cfg.subint_turns > 0:
+            if self._turns is None:
+                if cfg.folding_period > 0:
+                    p = cfg.folding_period
+                    phase = lambda t: (int(math.floor(t / p)), t / p - math.floor(t / p))
+                    iphase = lambda ph, guess: (ph[0] + ph[1]) * p
+                    pg = p
+                else:
+                    day, s0 = self.info.mjd_day, self.info.mjd_sec
+                    phase = lambda t: self.polyco.phase(day, s0 + t)
+                    iphase = lambda ph, guess: self.polyco.iphase(ph, day, s0 + guess) - s0
+                    pg = 1.0 / self.polyco.frequency(day, s0 + self.out_start)
+                self._turns = TurnsDivider(phase, iphase, pg, self.out_start, self.out_rate, cfg.subint_turns,
+                                           self.reference_phase, cfg.fractional_pulses)
+            return self._turns.pieces(self.ndat_out, ndat)
+        return [(0, ndat, 0, False)]
+
+    _turns = None
     _subint_comm = (None, 0, 1, None)     # (dist, rank, world, gather_buffer[, replicas]) used at sub-integration dumps
 
     def set_communicator(self, dist, rank, world, gather_buffer=None, replicas=False):

@@ -64,6 +64,12 @@ int dspsr_amd_copy(dspsr_amd_ctx* ctx, void* dst, const void* src, size_t nbytes
 int dspsr_amd_copy_fpt(dspsr_amd_ctx* ctx, float* to_dev, uint64_t to_chan_stride, uint64_t to_pol_stride,
                        const float* from_dev, uint64_t from_chan_stride, uint64_t from_pol_stride,
                        uint32_t nchan, uint32_t npol, uint64_t nfloat);
+/* dsp::TimeSeries::operator += on device rows (Kernel/Classes/TimeSeries.C, used by PhaseSeries::combine,
+ * Signal/Pulsar/PhaseSeries.C:442-484): to[row][i] += from[row][i]; same row geometry arguments as copy_fpt.  The profile
+ * half of combining two device-resident PhaseSeries (the hits / integration_length half stays with the host object). */
+int dspsr_amd_add_fpt(dspsr_amd_ctx* ctx, float* to_dev, uint64_t to_chan_stride, uint64_t to_pol_stride,
+                      const float* from_dev, uint64_t from_chan_stride, uint64_t from_pol_stride,
+                      uint32_t nchan, uint32_t npol, uint64_t nfloat);
 
 /* ---- dsp::Filterbank::Engine ------------------------------------------------------------
  * setup(Filterbank*)  -> dspsr_amd_filterbank_create + dspsr_amd_filterbank_set_kernel
@@ -189,6 +195,13 @@ int dspsr_amd_fold_set_bin(dspsr_amd_fold* fold, uint64_t idat, double ibin, dou
  * hits_host[nbin] (may be NULL) is incremented like Fold.C:783; returns ndat folded via *ndat_folded */
 int dspsr_amd_fold_set_bins(dspsr_amd_fold* fold, double phi, double phase_per_sample, uint64_t ndat,
                             uint64_t idat_start, uint32_t* hits_host, uint64_t* ndat_folded);
+/* the same with the weights of the input (Fold.C:686-716,746-763: WeightedTimeSeries, one weight per ndatperweight samples,
+ * sample idat belongs to weight (idat + weight_idat) / ndatperweight): samples of a zero weight are left out of the plan,
+ * of hits[] and of *ndat_folded.  The hook for flagged / dropped data; spectral kurtosis itself is not part of this path. */
+int dspsr_amd_fold_set_bins_weighted(dspsr_amd_fold* fold, double phi, double phase_per_sample, uint64_t ndat,
+                                     uint64_t idat_start, const uint32_t* weights_host, uint64_t nweights,
+                                     uint64_t ndatperweight, uint64_t weight_idat, uint32_t* hits_host,
+                                     uint64_t* ndat_folded);
 /* fold(): accumulate in_dev rows (get_datptr(ichan,ipol) = in_dev + ichan*in_chan_stride + ipol*in_pol_stride)
  * into the device profile using the plan built since the last set_nbin (FoldCUDA.cu:586-697) */
 int dspsr_amd_fold_fold(dspsr_amd_fold* fold, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride);

@@ -946,6 +946,30 @@ def fold_binplan(phi: float, phase_per_sample: float, nbin: int, ndat_fold: int)
     return plan
 
 
+def fold_binplan_weighted(phi: float, phase_per_sample: float, nbin: int, idat_start: int, ndat_fold: int,
+                          weights: np.ndarray, ndatperweight: int, weight_idat: int = 0) -> np.ndarray:
+    """Fold.C:686-716,744-787 with a WeightedTimeSeries input (not zeroed_samples): sample idat belongs to weight
+    (idat + weight_idat) / ndatperweight; samples of a zero weight get binplan = nbin (not folded, no hit)."""
+    plan = np.empty(ndat_fold, dtype=np.uint32)
+    double_nbin = float(nbin)
+    iweight = (idat_start + weight_idat) // ndatperweight
+    idat_nextweight = (iweight + 1) * ndatperweight - weight_idat
+    assert iweight < len(weights)
+    bad = weights[iweight] == 0
+    for idat in range(idat_start, idat_start + ndat_fold):
+        if idat >= idat_nextweight:
+            iweight += 1
+            assert iweight < len(weights)
+            bad = weights[iweight] == 0
+            idat_nextweight += ndatperweight
+        phi -= math.floor(phi)
+        ibin = int(phi * double_nbin)
+        phi += phase_per_sample
+        assert ibin < nbin
+        plan[idat - idat_start] = nbin if bad else ibin
+    return plan
+
+
 def fold(detected: np.ndarray, obs: Observation, cfg: FoldConfig, out: PhaseSeries,
          idat_start: int = 0, ndat_fold: int | None = None) -> np.ndarray:
     """dsp::Fold::fold (Fold.C:626-906), FPT order.  detected: [nchan][npol][ndat][ndim] float.
@@ -1043,6 +1067,81 @@ def subint_sample_bounds(obs: Observation, division_seconds: float, division: in
     lower = int(round(float(division) * division_seconds * rate))
     ndat = int(round((float(division + 1) * division_seconds - lower / rate) * rate))
     return lower, lower + ndat
+
+
+# --------------------------------------------------------------------------------------
+# Sub-integration division in turns (a12, dspsr -s / -turns)   TimeDivide.C:360-436,461-500
+# --------------------------------------------------------------------------------------
+# Pulsar::Predictor::phase / iphase are PSRCHIVE (ext, absent): phase(t) is the TEMPO polyco of class Polyco above with
+# integer and fractional turns carried separately, iphase its inverse by Newton iteration on phase(t) - target = 0 with
+# slope frequency(t) (the method PSRCHIVE's polyco uses).  "parity unpinned" for these two, like the polyco itself.
+
+def predictor_phase(cfg: "FoldConfig", obs: Observation, t_seconds: float) -> tuple[int, float]:
+    """Absolute pulse phase (integer turns, fractional turns in [0,1)) at t_seconds after obs.utc_start."""
+    if cfg.folding_period > 0.0:
+        turns = (t_seconds - cfg.reference_epoch_seconds) / cfg.folding_period
+        i = math.floor(turns)
+        return int(i), turns - i
+    day, sec = utc_to_mjd(obs.utc_start)
+    sec += t_seconds
+    pc = cfg.polyco
+    dt = pc._dt_min(day, sec)
+    poly = 0.0
+    for c in pc.coef[::-1]:
+        poly = poly * dt + c
+    spin = 60.0 * dt * pc.f0
+    si = math.floor(spin)
+    fr = pc.rphase_frac + (spin - si) + poly
+    fi = math.floor(fr)
+    return int(pc.rphase_int + si + fi), fr - fi
+
+
+def predictor_iphase(cfg: "FoldConfig", obs: Observation, phase: tuple[int, float], t_guess: float) -> float:
+    """Time (seconds after obs.utc_start) at which the phase equals `phase` = (int turns, frac turns)."""
+    if cfg.folding_period > 0.0:
+        return cfg.reference_epoch_seconds + (phase[0] + phase[1]) * cfg.folding_period
+    t = t_guess
+    for _ in range(20):
+        pi, pf = predictor_phase(cfg, obs, t)
+        dphi = (pi - phase[0]) + (pf - phase[1])
+        day, sec = utc_to_mjd(obs.utc_start)
+        f = cfg.polyco.frequency(day, sec + t)
+        step = dphi / f
+        t -= step
+        if abs(step) < 1e-12:
+            break
+    return t
+
+
+def subint_turns_start(cfg: "FoldConfig", obs: Observation, division_turns: float, fractional_pulses: bool = False):
+    """First call of TimeDivide::set_boundaries in turns mode (TimeDivide.C:360-436), division_turns >= 1: the divisions
+    start at the first epoch at or after the observation start where the fractional phase equals reference_phase
+    (unless fractional_pulses).  -> (start_phase (int, frac), start_time seconds)."""
+    if division_turns < 1.0:
+        raise OracleError("dsp::TimeDivide division_turns < 1 (phase-resolved divisions) is not restated")
+    pi, pf = predictor_phase(cfg, obs, obs.start_seconds)
+    if not fractional_pulses and pf > cfg.reference_phase:
+        pi += 1
+    start_phase = (pi, cfg.reference_phase)
+    return start_phase, predictor_iphase(cfg, obs, start_phase, obs.start_seconds)
+
+
+def subint_turns_sample_bounds(cfg: "FoldConfig", obs: Observation, division_turns: float, division: int,
+                               fractional_pulses: bool = False) -> tuple[int, int]:
+    """[first, last) output sample of division k in turns mode: boundaries iphase(start_phase + k*D) and
+    iphase(start_phase + (k+1)*D) (TimeDivide.C:461-500), snapped to samples like set_boundaries(mjd1, mjd2) (:503-540)."""
+    (pi, pf), t0 = subint_turns_start(cfg, obs, division_turns, fractional_pulses)
+    rate = obs.rate
+
+    def at(turns):
+        tot = pf + turns
+        ti = math.floor(tot)
+        return predictor_iphase(cfg, obs, (pi + int(ti), tot - ti), t0 + turns * (cfg.folding_period or 1.0 / cfg.polyco.f0))
+    mjd1, mjd2 = at(division * division_turns), at((division + 1) * division_turns)
+    samples = int(round((mjd1 - obs.start_seconds) * rate))
+    lower = obs.start_seconds + samples / rate
+    division_ndat = int(round((mjd2 - lower) * rate))
+    return samples, samples + division_ndat
 
 
 # --------------------------------------------------------------------------------------

@@ -611,6 +611,52 @@ def test_pipeline_subintegrations(oracle, gpu):
     lt.close()
 
 
+@pytest.mark.parametrize("turns", [1.0, 2.0])
+def test_pipeline_turns_mode_subintegrations(oracle, gpu, turns):
+    """dspsr -s / -turns N: sub-integrations of N pulse periods (TimeDivide.C:360-500) through the LoadToFold driver over
+    several blocks, against the oracle folding the same divisions: the leading partial turn is dropped, every division
+    holds N turns of samples, hits identical, profiles <= 1e-5."""
+    dspsr_amd, _ = gpu
+    from dspsr_amd import pipeline, synth
+    o = oracle
+    freq, bw, tsamp, dm, period, nchan, nbin = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004, 16, 64
+    cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=4,
+                          parts_per_block=3, max_parts=2, subint_turns=turns)
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
+    lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    nblocks = 5
+    step = cfg.parts_per_block * lt.nsamp_step
+    raw = synth.voltages(nblocks * step + lt.nsamp_overlap, freq, bw, tsamp, dm, period)
+    d_raw = torch.from_numpy(raw).cuda()
+    for b in range(nblocks):
+        lt.process_block(d_raw[2 * b * step: 2 * (b * step + step + lt.nsamp_overlap)])
+    lt.synchronize()
+    got = [(s["hits"], s["profile_dev"].cpu().numpy().reshape(nchan, 1, nbin, 4), s["ndat_total"]) for s in lt.subints]
+    assert len(got) >= 2
+    obs = o.Observation(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, dispersion_measure=dm)
+    resp = o.Dedispersion().match(obs, nchan)
+    plan = o.filterbank_plan(obs, nchan, resp)
+    fb = o.filterbank(o.unpack_8bit(raw, obs), plan, lt.response.kernel, dtype=np.float64)
+    det = o.detect_layout(o.detect_products(fb, "Coherence"), 4)
+    fobs = o.filterbank_output_observation(obs, plan)
+    fcfg = o.FoldConfig(nbin=nbin, folding_period=period)
+    block_out = cfg.parts_per_block * plan.nkeep
+    first = o.subint_turns_sample_bounds(fcfg, fobs, turns, 0)[0]
+    assert 0 < first <= round(period * fobs.rate)                  # the leading partial turn is not folded
+    for isub, (hits, prof, ndat_total) in enumerate(got):
+        ps = o.PhaseSeries(nchan, 1, 4, nbin, data=np.zeros((nchan, 1, nbin, 4), np.float64))
+        lo, hi = o.subint_turns_sample_bounds(fcfg, fobs, turns, isub)
+        assert abs((hi - lo) - turns * period * fobs.rate) <= 1 and ndat_total == hi - lo
+        pos = lo
+        while pos < hi:                                             # block boundaries restart the phase recurrence
+            stop = min(hi, (pos // block_out + 1) * block_out)
+            o.fold(det, fobs, fcfg, ps, idat_start=pos, ndat_fold=stop - pos)
+            pos = stop
+        assert np.array_equal(hits, ps.hits), isub
+        assert np.abs(prof - ps.data).max() <= 1e-5 * np.abs(ps.data).max(), isub
+    lt.close()
+
+
 @pytest.mark.parametrize("nchan,tscrunch,pscrunch,npart", [(4096, 16, True, 64), (4096, 16, False, 35), (256, 4, True, 130),
                                                            (64, 1, False, 300), (1024, 32, True, 96), (16, 2, False, 1024)])
 def test_tfp_filterbank_search_mode(oracle, gpu, nchan, tscrunch, pscrunch, npart):
@@ -886,3 +932,68 @@ def test_search_mode_and_delay_error_paths(gpu):
     z = torch.zeros_like(y)
     assert sd.transform(y, z) == 10 and torch.equal(y, z)
     sd.close()
+
+
+def test_fold_weights_drop_flagged_samples(oracle, gpu):
+    """Fold.C:686-716,746-763: samples whose weight is zero are left out of the plan, of hits[] and of ndat_folded; the
+    kept samples are summed in time order -- bit-identical to the CPU loop with binplan == nbin for the dropped ones."""
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(61)
+    nchan, npol, ndim, ndat, nbin = 3, 2, 2, 5000, 48
+    det = rng.standard_normal((nchan, npol, ndat, ndim)).astype(np.float32)
+    ndatperweight, weight_idat, idat_start, ndat_fold = 64, 17, 9, ndat - 30
+    nweights = (ndat + weight_idat) // ndatperweight + 2
+    weights = rng.integers(0, 4, nweights).astype(np.uint32)            # a quarter of the weights are zero
+    weights[3:6] = 0                                                    # a run of consecutive dropped weights
+    phi, pps = 0.21, 1.0 / 77.3
+    eng = dspsr_amd.FoldEngine(ctx)
+    eng.set_shape(nchan, npol, ndim, nbin)
+    eng.set_nbin(nbin)
+    eng.set_ndat(ndat_fold, idat_start)
+    hits = np.zeros(nbin, np.uint32)
+    n = eng.set_bins(phi, pps, ndat_fold, idat_start, hits, weights=weights, ndatperweight=ndatperweight, weight_idat=weight_idat)
+    eng.fold(torch.from_numpy(det.reshape(nchan, npol, ndat * ndim)).cuda())
+    plan = oracle.fold_binplan_weighted(phi, pps, nbin, idat_start, ndat_fold, weights, ndatperweight, weight_idat)
+    kept = plan != nbin
+    assert 0 < kept.sum() < ndat_fold and n == kept.sum() == eng.get_ndat_folded()
+    assert np.array_equal(hits, np.bincount(plan[kept], minlength=nbin).astype(np.uint32))
+    want = np.zeros((nchan, npol, nbin, ndim), np.float32)
+    for i in np.flatnonzero(kept):
+        want[:, :, plan[i], :] += det[:, :, idat_start + i, :]
+    assert np.array_equal(eng.synch(), want)
+    eng.close()
+
+
+def test_phase_series_mixable_and_device_combine(gpu):
+    """PhaseSeries::mixable / combine (PhaseSeries.C:336-418,442-484) on device-resident profiles: an empty integration
+    adopts the other one; combinable observations add (profiles on the device, hits / integration_length / ndat_total on
+    the host) and extend the time span; a different nbin or band is not mixable."""
+    dspsr_amd, ctx = gpu
+    from dspsr_amd import pipeline
+    obs = dict(centre_frequency=1382.0, bandwidth=-400.0, nchan=5, npol=2, ndim=2, state="Coherence", rate=390625.0)
+    rng = np.random.default_rng(62)
+
+    def make(nbin, t0, t1, o=obs):
+        sub = {"hits": rng.integers(1, 9, nbin).astype(np.uint32), "integration_length": t1 - t0, "ndat_total": int((t1 - t0) * o["rate"]),
+               "profile_dev": torch.from_numpy(rng.standard_normal(o["nchan"] * o["npol"] * nbin * o["ndim"]).astype(np.float32)).cuda()}
+        return pipeline.PhaseSeries.from_subint(ctx, sub, o, t0, t1)
+    a, b, c = make(32, 0.0, 1.0), make(32, 1.0, 2.5), make(32, 4.0, 4.5)
+    want_prof = (a.profile + b.profile).cpu().numpy()
+    want_hits = a.hits + b.hits
+    total = pipeline.PhaseSeries(ctx)
+    assert total.integration_length == 0.0
+    total.combine(a)                                            # empty: becomes a copy of a
+    assert np.array_equal(total.hits, a.hits) and torch.equal(total.profile, a.profile) and total.profile.data_ptr() != a.profile.data_ptr()
+    total.combine(b)
+    ctx.synchronize()
+    assert np.array_equal(total.profile.cpu().numpy(), want_prof) and np.array_equal(total.hits, want_hits)
+    assert total.integration_length == 2.5 and total.ndat_total == a.ndat_total + b.ndat_total
+    total.combine(c)
+    assert (total.start_time, total.end_time) == (0.0, 4.5) and total.integration_length == 3.0
+    with pytest.raises(dspsr_amd.DspsrAmdError, match="!mixable"):
+        total.combine(make(64, 5.0, 6.0))                       # nbin differs
+    with pytest.raises(dspsr_amd.DspsrAmdError, match="!mixable"):
+        total.combine(make(32, 5.0, 6.0, dict(obs, centre_frequency=1400.0)))
+    total.zero()
+    assert total.integration_length == 0.0 and not total.hits.any() and float(total.profile.abs().max()) == 0.0
+    assert total.mixable(dict(obs, nchan=2), 16, 7.0, 8.0) and tuple(total.profile.shape) == (2, 2, 32) and total.nbin == 16

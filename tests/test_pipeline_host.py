@@ -56,6 +56,55 @@ def test_subint_pieces_cover_block_and_match_oracle_boundaries(oracle):
                 assert abs(v - (hi - lo)) <= 1
 
 
+@pytest.mark.parametrize("use_polyco", [False, True])
+@pytest.mark.parametrize("turns,fractional", [(1.0, False), (3.0, False), (2.5, True)])
+def test_turns_mode_divisions_match_oracle(oracle, use_polyco, turns, fractional):
+    """dspsr -s / -turns N (TimeDivide.C:360-436,461-500): division boundaries from the pulse phase -- constant period and
+    the vela.polyco predictor (phase / iphase with integer and fractional turns apart) -- against the oracle's restatement;
+    the leading partial turn is skipped, every later sample lands in exactly one division."""
+    from dspsr_amd import pipeline
+    text = json.load(open(os.path.join(ROOT, "tests", "golden", "vela_polyco.json")))["text"]
+    rate, t_start = 390625.0, 0.00108
+    obs = oracle.Observation(tsamp_us=1e6 / rate)
+    obs.start_seconds = t_start
+    if use_polyco:
+        pc, opc = pipeline.Polyco(text), oracle.Polyco.parse(text)
+        ocfg = oracle.FoldConfig(nbin=64, polyco=opc)
+        assert pc.phase(55299, 7545.0 + 3.3) == oracle.predictor_phase(ocfg, obs, 3.3)
+        phase = lambda t: pc.phase(55299, 7545.0 + t)
+        iphase = lambda ph, guess: pc.iphase(ph, 55299, 7545.0 + guess) - 7545.0
+        pguess = 1.0 / pc.frequency(55299, 7545.0 + t_start)
+        # iphase inverts phase to well under a sample
+        ph = pc.phase(55299, 7545.0 + 1.2345)
+        assert abs(iphase(ph, 1.0) - 1.2345) < 1e-9
+    else:
+        period = 0.0893
+        ocfg = oracle.FoldConfig(nbin=64, folding_period=period)
+        phase = lambda t: (int(np.floor(t / period)), t / period - np.floor(t / period))
+        iphase = lambda ph, guess: (ph[0] + ph[1]) * period
+        pguess = period
+    div = pipeline.TurnsDivider(phase, iphase, pguess, t_start, rate, turns, 0.0, fractional)
+    for k in (0, 1, 2, 7):
+        assert div.bounds(k) == oracle.subint_turns_sample_bounds(ocfg, obs, turns, k, fractional), k
+    first = div.bounds(0)[0]
+    if fractional:
+        assert -int(pguess * rate) - 1 <= first <= 0                 # division 0 began before the data: nothing is skipped
+    else:
+        assert 0 < first <= int(pguess * rate) + 1                  # the leading partial turn is not folded
+    pos, per_div = 0, {}
+    for blk in (1000, 50000, 39070, 120000, 1, 200000):
+        for idat, n, k, complete in div.pieces(pos, blk):
+            lo, hi = div.bounds(k)
+            assert lo <= pos + idat and pos + idat + n <= hi and complete == (pos + idat + n == hi)
+            per_div[k] = per_div.get(k, 0) + n
+        pos += blk
+    for k, v in per_div.items():
+        lo, hi = div.bounds(k)
+        if k < max(per_div):
+            assert v == hi - max(lo, 0)
+            assert abs((hi - lo) - turns * pguess * rate) <= 2          # N turns long, to the sample
+
+
 def test_normalise_profile_matches_oracle(oracle):
     from dspsr_amd import pipeline
     rng = np.random.default_rng(3)
