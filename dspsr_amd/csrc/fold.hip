@@ -343,9 +343,13 @@ static int fold_set_bins_impl(dspsr_amd_fold* f, double phi, double phase_per_sa
                       (unsigned long long)nweights);
     bad = weights[iweight] == 0;
   }
+  // cur_bin == nbin (the value set_nbin leaves, FoldCUDA.cu:64-70) means "no run open": the last entry of the plan, if
+  // any, already has its final hits
   auto close_run = [&]() {              // a dropped sample ends the open run: the next kept sample starts a new one
-    if (!f->binplan.empty()) f->binplan.back().hits = cur_hits;
-    if (hits_host && cur_bin < nbin) hits_host[cur_bin] += cur_hits - counted;
+    if (cur_bin < nbin) {
+      if (!f->binplan.empty()) f->binplan.back().hits = cur_hits;
+      if (hits_host) hits_host[cur_bin] += cur_hits - counted;
+    }
     cur_bin = nbin; cur_hits = 0; counted = 0;
   };
   for (uint64_t idat = idat_start; idat < end; idat++) {
@@ -367,12 +371,14 @@ static int fold_set_bins_impl(dspsr_amd_fold* f, double phi, double phase_per_sa
       return ctx_fail(f->ctx, DSPSR_AMD_EINVAL, "dsp::Fold::fold ibin=%u >= nbin=%u", ibin, nbin);
     }
     if (bad) {
-      if (cur_hits || cur_bin < nbin) close_run();
+      close_run();
       continue;
     }
     if (ibin != cur_bin) {                // set_bin: a new run starts
-      if (!f->binplan.empty()) f->binplan.back().hits = cur_hits;
-      if (hits_host && cur_bin < nbin) hits_host[cur_bin] += cur_hits - counted;
+      if (cur_bin < nbin) {               // (an open run ends here)
+        if (!f->binplan.empty()) f->binplan.back().hits = cur_hits;
+        if (hits_host) hits_host[cur_bin] += cur_hits - counted;
+      }
       RunBin start; start.offset = idat; start.ibin = ibin; start.hits = 0;
       f->binplan.push_back(start);
       cur_bin = ibin;

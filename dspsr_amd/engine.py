@@ -143,9 +143,7 @@ class FilterbankEngine:
     def setup(self, nchan_subband, freq_res, nfilt_pos, nfilt_neg, input_nchan=1, npol=2, real_input=True,
               kernel: np.ndarray | None = None, max_parts: int = 1, force_four_pass: bool = False,
               fused_fold: int = _lib.FUSED_AUTO):
-        if self.handle:
-            lib.dspsr_amd_filterbank_destroy(self.handle)
-            self.handle = None
+        self.close()
         cfg = _lib.FilterbankConfig(nchan_subband, freq_res, nfilt_pos, nfilt_neg, input_nchan, npol,
                                     1 if real_input else 0, max_parts, 1 if force_four_pass else 0, fused_fold)
         h = C.c_void_p()
@@ -256,9 +254,9 @@ class FilterbankEngine:
         self.ctx.synchronize()
 
     def close(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:          # (a context closed first has already taken the device objects with it)
             lib.dspsr_amd_filterbank_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:
@@ -341,9 +339,9 @@ class SampleDelay:
         return n.value
 
     def close(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             lib.dspsr_amd_sample_delay_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
 
 class Rescale:
@@ -373,9 +371,9 @@ class Rescale:
         return off.reshape(self.nchan, self.npol), sc.reshape(self.nchan, self.npol)
 
     def close(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             lib.dspsr_amd_rescale_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
 
 def pscrunch_tfp(ctx: Context, inp, out, nchan, npol=2):
@@ -496,9 +494,9 @@ class FoldEngine:
         return out
 
     def close(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             lib.dspsr_amd_fold_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:

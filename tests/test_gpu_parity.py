@@ -624,7 +624,7 @@ def test_pipeline_turns_mode_subintegrations(oracle, gpu, turns):
                           parts_per_block=3, max_parts=2, subint_turns=turns)
     info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
     lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
-    nblocks = 5
+    nblocks = 8
     step = cfg.parts_per_block * lt.nsamp_step
     raw = synth.voltages(nblocks * step + lt.nsamp_overlap, freq, bw, tsamp, dm, period)
     d_raw = torch.from_numpy(raw).cuda()
