@@ -2,6 +2,7 @@
 #ifndef STUB_OwnStream_h
 #define STUB_OwnStream_h
 #include <iostream>
+#include "Reference.h"   // (PSRCHIVE headers reach ReferenceAble.h through one another)
 class OwnStream {
 public:
   OwnStream (); OwnStream (const OwnStream&); virtual ~OwnStream ();
