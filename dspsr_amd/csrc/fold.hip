@@ -56,20 +56,38 @@ __global__ void k_fold_direct(const float* __restrict__ in, const uint64_t chan_
 // is filled without touching the order of any sum.
 constexpr uint32_t FOLD_CHUNK = 2048;   // samples per chunk
 constexpr int FOLD_BPT = 4;             // bins per thread (nbin <= FOLD_BPT * blockDim)
+// LONG runs.  A sum in strict time order is one dependent chain of float adds per (chan, pol, bin, dim): with phase bins
+// hundreds of samples wide only a couple of chains are alive per row and the kernel is bound by the add latency (10 ms per
+// 4 M samples and row at -F 64:D, profiles/r02j).  When the plan holds a run of FOLD_LONG_RUN samples or more, the host
+// picks the LONG variant for the whole call: every chunk is first reduced, by all threads, to the sums of its aligned
+// FOLD_MB-sample micro-blocks (each summed in time order); a bin's owner then adds, in time order, single samples up to
+// the first micro-block boundary inside its run, whole micro-block sums, and single samples after the last boundary.
+// Deterministic (the association depends on the plan and the chunk grid only), no longer the association of the CPU
+// loop: it agrees with it to float rounding, like the reference's own GPU fold (FoldCUDA.cu:208-269 sums each
+// run from zero and adds the run sums atomically).  Plans of shorter runs keep the exact time-order kernel.
+constexpr uint32_t FOLD_MB = 32;
+constexpr uint32_t FOLD_LONG_RUN = FOLD_LONG_RUN_HOST;
 
-template <int NDIM>
+template <int NDIM, bool LONG>
 __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__ in, const uint64_t chan_stride,
                                                        const uint64_t pol_stride, float* __restrict__ prof,
                                                        const uint64_t prof_span, const uint32_t nbin,
                                                        const uint32_t* __restrict__ bin_start,
                                                        const Interval* __restrict__ iv, const uint64_t first,
-                                                       const uint64_t last /* [first,last): sample span of the plan */)
+                                                       const uint64_t last /* [first,last): sample span of the plan */,
+                                                       float* __restrict__ part /* LONG: [seg][row][nbin][NDIM] partial sums */,
+                                                       const uint32_t chunks_per_seg /* LONG: chunks per blockIdx.z */)
 {
-  extern __shared__ __attribute__((aligned(16))) float fold_lds[];   // FOLD_CHUNK * NDIM floats
+  extern __shared__ __attribute__((aligned(16))) float fold_lds[];   // FOLD_CHUNK * NDIM floats (+ micro-block sums, LONG)
   const uint32_t ipol = blockIdx.x, npol = gridDim.x, ichan = blockIdx.y;
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const float* __restrict__ row = in + ichan * chan_stride + ipol * pol_stride;
-  float* __restrict__ out = prof + ((uint64_t)ichan * npol + ipol) * prof_span;
+  // LONG: blockIdx.z is a TIME segment of the row (all bins), summed from zero into this segment's partial profile --
+  // every sample of the row is read once; k_fold_combine adds the partials to the profile in time order.
+  // exact: blockIdx.z deals the BINS of a row to gridDim.z workgroups, each streams the whole row and owns its sums.
+  float* __restrict__ out = LONG ? part + (((uint64_t)blockIdx.z * gridDim.y + ichan) * npol + ipol) * nbin * NDIM
+                                 : prof + ((uint64_t)ichan * npol + ipol) * prof_span;
+  const uint32_t bz = LONG ? 0u : blockIdx.z, nz = LONG ? 1u : gridDim.z;
   constexpr uint32_t NF4 = FOLD_CHUNK * NDIM / 4;        // float4 per chunk
   constexpr uint32_t MAXR = NF4 / 256;                    // float4 per thread at the minimum block size (256)
 
@@ -88,21 +106,34 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
   };
 #pragma unroll
   for (int j = 0; j < FOLD_BPT; j++) {
-    const uint32_t b = blockIdx.z + gridDim.z * (tid + j * nt);   // bins are dealt to the gridDim.z workgroups of a row
+    const uint32_t b = bz + nz * (tid + j * nt);   // bins are dealt to the nz workgroups of a row
     cur[j] = end[j] = 0;
     if (b < nbin) { cur[j] = bin_start[b]; end[j] = bin_start[b + 1]; }
-    touched[j] = cur[j] != end[j];
+    if constexpr (LONG) {
+      // first interval of the bin that reaches into this segment (intervals are time ordered: binary search)
+      const uint64_t seg0 = first + (uint64_t)blockIdx.z * chunks_per_seg * FOLD_CHUNK;
+      uint32_t lo_i = cur[j], hi_i = end[j];
+      while (lo_i < hi_i) {
+        const uint32_t mid = (lo_i + hi_i) >> 1;
+        const Interval t = iv[mid];
+        if (t.offset + t.hits <= seg0) lo_i = mid + 1; else hi_i = mid;
+      }
+      cur[j] = lo_i;
+    }
+    touched[j] = LONG ? (b < nbin) : (cur[j] != end[j]);
     v0[j] = load_iv(cur[j], cur[j] < end[j]);
     v1[j] = load_iv(cur[j] + 1, cur[j] + 1 < end[j]);
 #pragma unroll
-    for (int d = 0; d < NDIM; d++) acc[j][d] = (b < nbin && touched[j]) ? out[b * NDIM + d] : 0.f;
+    for (int d = 0; d < NDIM; d++) acc[j][d] = (!LONG && b < nbin && touched[j]) ? out[b * NDIM + d] : 0.f;
   }
 
   // chunk c covers samples [first + c*FOLD_CHUNK, ...); rows are 16-byte aligned when first*NDIM % 4 == 0,
   // the host guarantees it by rounding `first` down
   const float4* __restrict__ src = (const float4*)(row + first * NDIM);
   const uint64_t nfl_total = (last - first) * NDIM;      // floats in the span
-  const uint32_t nchunk = (uint32_t)((last - first + FOLD_CHUNK - 1) / FOLD_CHUNK);
+  const uint32_t nchunk_all = (uint32_t)((last - first + FOLD_CHUNK - 1) / FOLD_CHUNK);
+  const uint32_t cbeg = LONG ? blockIdx.z * chunks_per_seg : 0u;
+  const uint32_t nchunk = LONG ? (cbeg + chunks_per_seg < nchunk_all ? cbeg + chunks_per_seg : nchunk_all) : nchunk_all;
   float4 pre[MAXR];
   auto fetch = [&](uint32_t c) {
 #pragma unroll
@@ -124,14 +155,25 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
       pre[r] = v;
     }
   };
-  fetch(0);
-  for (uint32_t c = 0; c < nchunk; c++) {
+  if (cbeg < nchunk) fetch(cbeg);
+  for (uint32_t c = cbeg; c < nchunk; c++) {
     __syncthreads();                                    // previous chunk fully consumed
 #pragma unroll
     for (uint32_t r = 0; r < MAXR; r++)
       if (tid + r * nt < NF4) ((float4*)fold_lds)[tid + r * nt] = pre[r];
     if (c + 1 < nchunk) fetch(c + 1);
     __syncthreads();
+    if constexpr (LONG) {                                 // level 1: sums of the aligned micro-blocks of this chunk
+      float* mbs = fold_lds + FOLD_CHUNK * NDIM;
+      for (uint32_t q = tid; q < (FOLD_CHUNK / FOLD_MB) * NDIM; q += nt) {
+        const uint32_t mb = q / NDIM, d = q % NDIM;
+        float sacc = 0.f;
+#pragma unroll 8
+        for (uint32_t h = 0; h < FOLD_MB; h++) sacc += fold_lds[(mb * FOLD_MB + h) * NDIM + d];
+        mbs[q] = sacc;
+      }
+      __syncthreads();
+    }
     const uint64_t c0 = first + (uint64_t)c * FOLD_CHUNK, c1 = c0 + FOLD_CHUNK;
 #pragma unroll
     for (int j = 0; j < FOLD_BPT; j++) {
@@ -143,11 +185,33 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
         // whose vmcnt(0) wait also drains the chunk prefetch)
         const uint32_t x0 = (uint32_t)(lo - c0) * NDIM;
         const uint32_t n = (uint32_t)(hi - lo);
-#pragma unroll 4
-        for (uint32_t h = 0; h < n; h++)
+        if constexpr (LONG) {
+          const float* mbs = fold_lds + FOLD_CHUNK * NDIM;
+          const uint32_t s0 = (uint32_t)(lo - c0), s1 = s0 + n;                       // samples [s0, s1) of the chunk
+          const uint32_t a0 = (s0 + FOLD_MB - 1) / FOLD_MB * FOLD_MB;                // first micro-block boundary >= s0
+          const uint32_t a1 = s1 / FOLD_MB * FOLD_MB;                                // last boundary <= s1
+          if (a0 >= a1) {                                                            // no whole micro-block inside the run
+            for (uint32_t h = s0; h < s1; h++)
 #pragma unroll
-          for (int d = 0; d < NDIM; d++) acc[j][d] += fold_lds[x0 + h * NDIM + d];
-        if (v.offset + v.hits > c1) break;               // interval continues in the next chunk
+              for (int d = 0; d < NDIM; d++) acc[j][d] += fold_lds[h * NDIM + d];
+          } else {
+            for (uint32_t h = s0; h < a0; h++)
+#pragma unroll
+              for (int d = 0; d < NDIM; d++) acc[j][d] += fold_lds[h * NDIM + d];
+            for (uint32_t mb = a0 / FOLD_MB; mb < a1 / FOLD_MB; mb++)
+#pragma unroll
+              for (int d = 0; d < NDIM; d++) acc[j][d] += mbs[mb * NDIM + d];
+            for (uint32_t h = a1; h < s1; h++)
+#pragma unroll
+              for (int d = 0; d < NDIM; d++) acc[j][d] += fold_lds[h * NDIM + d];
+          }
+        } else {
+#pragma unroll 4
+          for (uint32_t h = 0; h < n; h++)
+#pragma unroll
+            for (int d = 0; d < NDIM; d++) acc[j][d] += fold_lds[x0 + h * NDIM + d];
+        }
+        if (v.offset + v.hits > c1) break;               // interval continues in the next chunk (or segment)
         cur[j]++;
         v0[j] = v1[j];
         v1[j] = load_iv(cur[j] + 1, cur[j] + 1 < end[j]);
@@ -156,10 +220,23 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
   }
 #pragma unroll
   for (int j = 0; j < FOLD_BPT; j++) {
-    const uint32_t b = blockIdx.z + gridDim.z * (tid + j * nt);   // bins are dealt to the gridDim.z workgroups of a row
+    const uint32_t b = bz + nz * (tid + j * nt);
     if (b < nbin && touched[j])
 #pragma unroll
       for (int d = 0; d < NDIM; d++) out[b * NDIM + d] = acc[j][d];
+  }
+}
+
+// LONG: profile[row][bin][dim] += partial sums of the time segments, in time order
+__global__ __launch_bounds__(256) void k_fold_combine(float* __restrict__ prof, const uint64_t prof_span, const float* __restrict__ part,
+                                                      const uint32_t nrow, const uint32_t row_floats, const uint32_t nseg)
+{
+  const uint64_t n = (uint64_t)nrow * row_floats;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = i / row_floats, k = i - r * row_floats;
+    float a = prof[r * prof_span + k];
+    for (uint32_t sg = 0; sg < nseg; sg++) a += part[(uint64_t)sg * n + i];
+    prof[r * prof_span + k] = a;
   }
 }
 
@@ -214,6 +291,7 @@ extern "C" void dspsr_amd_fold_destroy(dspsr_amd_fold* f)
   if (!f) return;
   (void)hipStreamSynchronize(f->ctx->stream);
   if (f->profile && !f->bound) (void)hipFree(f->profile);
+  if (f->part) (void)hipFree(f->part);
   slot_free(f->slot[0]);
   slot_free(f->slot[1]);
   delete f;
@@ -467,14 +545,18 @@ extern "C" int dspsr_amd_fold_fold(dspsr_amd_fold* f, const float* in_dev, uint6
     e = hipMemcpyAsync(sl.d_iv, sl.h_iv, niv * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: plan copy: %s", hipGetErrorString(e));
 
-  // rows x bin groups: at least two workgroups per CU when the band has few channels
-  uint32_t nsplit = 1;
-  while (nsplit < 8 && (uint64_t)f->npol * f->nchan * nsplit < 512 && nbin / (2 * nsplit) >= 64) nsplit *= 2;
-  dim3 grid(f->npol, f->nchan, nsplit);
   // sample span covered by the plan (intervals are time ordered)
   uint64_t first = f->binplan.front().offset, last = f->binplan.back().offset + f->binplan.back().hits;
   first -= first % 4;                                  // keeps 16-byte alignment of the chunk loads for any ndim
   const bool aligned = ((uintptr_t)in_dev % 16 == 0) && (in_chan_stride % 4 == 0) && (in_pol_stride % 4 == 0);
+  uint32_t max_run = 0;
+  for (const RunBin& r : f->binplan) if (r.hits > max_run) max_run = r.hits;
+  const bool lng = aligned && nbin <= (uint32_t)FOLD_BPT * 1024 && max_run >= FOLD_LONG_RUN;   // re-associated sums (see FOLD_LONG_RUN)
+  const uint32_t nrow = f->npol * f->nchan;
+  // exact mode: rows x bin groups, at least two workgroups per CU when the band has few channels
+  uint32_t nsplit = 1;
+  if (!lng)
+    while (nsplit < 8 && (uint64_t)nrow * nsplit < 512 && nbin / (2 * nsplit) >= 64) nsplit *= 2;
   uint32_t threads = nbin < 1024 ? ((nbin + 63) / 64) * 64 : 1024;
   if (aligned && nbin <= (uint32_t)FOLD_BPT * 1024) {
     // FOLD_BPT bins per thread: 256-thread workgroups for nbin <= 1024, so that four of them share a CU and
@@ -483,17 +565,43 @@ extern "C" int dspsr_amd_fold_fold(dspsr_amd_fold* f, const float* in_dev, uint6
     threads = ((bins_wg + FOLD_BPT - 1) / FOLD_BPT + 63) / 64 * 64;
     if (threads < 256) threads = 256;
     if (threads > 1024) threads = 1024;
-    const size_t lds = (size_t)FOLD_CHUNK * f->ndim * sizeof(float);
-    if (f->ndim == 4)
-      hipLaunchKernelGGL(k_fold_chunked<4>, grid, dim3(threads), lds, ctx->stream, in_dev, in_chan_stride,
-                         in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv, first, last);
-    else if (f->ndim == 2)
-      hipLaunchKernelGGL(k_fold_chunked<2>, grid, dim3(threads), lds, ctx->stream, in_dev, in_chan_stride,
-                         in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv, first, last);
-    else
-      hipLaunchKernelGGL(k_fold_chunked<1>, grid, dim3(threads), lds, ctx->stream, in_dev, in_chan_stride,
-                         in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv, first, last);
+    // LONG: rows x time segments (about four workgroups per CU), every sample read once
+    const uint32_t nchunk = (uint32_t)((last - first + FOLD_CHUNK - 1) / FOLD_CHUNK);
+    uint32_t nseg = 1, cps = nchunk;
+    if (lng) {
+      nseg = (4 * ctx->ncu + nrow - 1) / nrow;
+      if (nseg > nchunk) nseg = nchunk;
+      if (nseg > 65535) nseg = 65535;
+      if (nseg < 1) nseg = 1;
+      cps = (nchunk + nseg - 1) / nseg;
+      nseg = (nchunk + cps - 1) / cps;
+      const size_t need = (size_t)nseg * nrow * nbin * f->ndim;
+      if (need > f->part_floats) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (f->part) (void)hipFree(f->part);
+        f->part = nullptr; f->part_floats = 0;
+        if (hipMalloc((void**)&f->part, need * sizeof(float)) != hipSuccess)
+          return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_fold_fold: hipMalloc of %zu partial-sum floats failed", need);
+        f->part_floats = need;
+      }
+    }
+    dim3 grid(f->npol, f->nchan, lng ? nseg : nsplit);
+    const size_t lds = ((size_t)FOLD_CHUNK + (lng ? FOLD_CHUNK / FOLD_MB : 0)) * f->ndim * sizeof(float);
+#define FOLD_LAUNCH(ND, LG) hipLaunchKernelGGL((k_fold_chunked<ND, LG>), grid, dim3(threads), lds, ctx->stream, in_dev, \
+                                               in_chan_stride, in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv, first, last, \
+                                               f->part, cps)
+    if (f->ndim == 4) { if (lng) FOLD_LAUNCH(4, true); else FOLD_LAUNCH(4, false); }
+    else if (f->ndim == 2) { if (lng) FOLD_LAUNCH(2, true); else FOLD_LAUNCH(2, false); }
+    else { if (lng) FOLD_LAUNCH(1, true); else FOLD_LAUNCH(1, false); }
+#undef FOLD_LAUNCH
+    if (lng) {
+      const uint64_t n = (uint64_t)nrow * nbin * f->ndim;
+      uint32_t gx = (uint32_t)((n + 255) / 256);
+      if (gx > 4 * ctx->ncu) gx = 4 * ctx->ncu;
+      hipLaunchKernelGGL(k_fold_combine, dim3(gx), dim3(256), 0, ctx->stream, f->profile, f->span, f->part, nrow, nbin * f->ndim, nseg);
+    }
   } else {
+    dim3 grid(f->npol, f->nchan, nsplit);
     if (f->ndim == 4)
       hipLaunchKernelGGL(k_fold_direct<4>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride,
                          in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv);

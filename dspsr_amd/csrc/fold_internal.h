@@ -27,6 +27,8 @@ struct dspsr_amd_fold {
   float* profile = nullptr;     // [chan][pol] rows of nbin*ndim floats, `span` floats apart
   size_t profile_floats = 0;    // floats of the library-owned buffer (0 when the profile is bound to a caller's buffer)
   uint64_t span = 0;            // floats between consecutive (chan, pol) rows
+  float* part = nullptr;        // partial profiles of the time segments of a long-run fold (fold.hip, FOLD_LONG_RUN)
+  size_t part_floats = 0;
   bool bound = false;           // profile points into the engine-owned device PhaseSeries (dspsr_amd_fold_bind_profile)
   // run-length plan, as CUDA::FoldEngine (FoldCUDA.cu:64-113)
   std::vector<dspsr_amd::RunBin> binplan;
@@ -37,6 +39,17 @@ struct dspsr_amd_fold {
   std::vector<uint32_t> cursor;
 };
 
+
+// Longest run of the pending plan (samples that go to one phase bin in a row).  Runs of FOLD_LONG_RUN samples or more are
+// folded with re-associated sums (fold.hip, k_fold_chunked<., true>); the fused filterbank kernel only has the exact
+// time-order fold, so such plans take the separate Detection + Fold launches.
+constexpr uint32_t FOLD_LONG_RUN_HOST = 64;
+static inline uint32_t fold_plan_max_run(const dspsr_amd_fold* f)
+{
+  uint32_t m = f->current_hits;
+  for (const dspsr_amd::RunBin& r : f->binplan) if (r.hits > m) m = r.hits;
+  return m;
+}
 
 // Fused path (filterbank.hip): turns the pending run-length plan into a per-part plan on the device --
 // runs split at multiples of `nkeep`, bucketed by (part, bin), offsets relative to the start of the part.

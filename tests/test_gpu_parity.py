@@ -997,3 +997,33 @@ def test_phase_series_mixable_and_device_combine(gpu):
     total.zero()
     assert total.integration_length == 0.0 and not total.hits.any() and float(total.profile.abs().max()) == 0.0
     assert total.mixable(dict(obs, nchan=2), 16, 7.0, 8.0) and tuple(total.profile.shape) == (2, 2, 32) and total.nbin == 16
+
+
+@pytest.mark.parametrize("ndim,npol", [(4, 1), (2, 2), (1, 4)])
+def test_fold_long_runs_reassociated(oracle, gpu, ndim, npol):
+    """Phase bins hundreds of samples wide (-F 64:D: 1090 samples per bin): the plan holds runs >= 256 samples and the fold
+    sums aligned 32-sample micro-blocks first (fold.hip FOLD_LONG_RUN).  Same hits, deterministic, equal to the time-order
+    sum to float rounding (<= 2e-6 of the profile maximum against a float64 fold; the CPU float32 loop is no closer)."""
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(71)
+    nchan, ndat, nbin = 3, 50000, 16
+    det = (rng.standard_normal((nchan, npol, ndat, ndim)).astype(np.float32) ** 2 + 1).astype(np.float32)
+    phi, pps = 0.13, 1.0 / (nbin * 1090.7)
+    idat_start, ndat_fold = 37, ndat - 100
+    res = []
+    for rep in range(2):
+        eng = dspsr_amd.FoldEngine(ctx)
+        eng.set_shape(nchan, npol, ndim, nbin)
+        hits = np.zeros(nbin, np.uint32)
+        eng.set_nbin(nbin)
+        eng.set_ndat(ndat_fold, idat_start)
+        eng.set_bins(phi, pps, ndat_fold, idat_start, hits)
+        eng.fold(torch.from_numpy(det.reshape(nchan, npol, ndat * ndim)).cuda())
+        res.append(eng.synch())
+        eng.close()
+    assert np.array_equal(res[0], res[1])                                     # deterministic
+    plan = oracle.fold_binplan(phi, pps, nbin, ndat_fold)
+    assert np.array_equal(hits, np.bincount(plan, minlength=nbin).astype(np.uint32)) and np.diff(np.flatnonzero(np.diff(plan))).max() >= 256
+    want = np.zeros((nchan, npol, nbin, ndim), np.float64)
+    np.add.at(want, (slice(None), slice(None), plan), det[:, :, idat_start:idat_start + ndat_fold, :].astype(np.float64))
+    assert np.abs(res[0] - want).max() <= 2e-6 * np.abs(want).max()
