@@ -1456,7 +1456,11 @@ void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, con
 k1_t fb_pick1(int logf, int raww, bool full)
 {
   if (logf == 12 && raww == 2 && full) return k_fwd_cols<12, 2, 2>;
+#ifdef FB_P1_HALF_TILE   // experiment: 2^13-point tiles (two columns), two workgroups per CU, compile-time tile shape
+  return logf == 12 && raww == 1 ? (full ? k_fwd_cols<12, 1, 2> : k_fwd_cols<12, 1, 1>) : nullptr;
+#else
   return logf == 12 && raww == 1 ? (full ? k_fwd_cols<12, 1, 2> : k_fwd_cols<12, 1, -1>) : nullptr;
+#endif
 }
 #endif
 #if FB_HAS(2)
