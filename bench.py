@@ -371,8 +371,15 @@ def parity_gate(lt, raw, torch, dist, rank, world, sharded):
     lt.fused_fold = was
     hits, prof = res[False]
     fails = []
-    if was and not (np.array_equal(res[True][0], hits) and bool(torch.equal(res[True][1], prof))):
-        fails.append("fused fold differs from Detection + Fold")
+    exact = getattr(lt, "fused_mode", 1) != 2       # mode 2: the parts of a launch are folded in runs (re-associated sums)
+    if was:
+        same_hits = np.array_equal(res[True][0], hits)
+        if exact:
+            same = bool(torch.equal(res[True][1], prof))
+        else:
+            same = float((res[True][1].double() - prof.double()).abs().max()) <= 2e-6 * float(prof.abs().max())
+        if not (same_hits and same):
+            fails.append("fused fold differs from Detection + Fold")
     if int(hits.astype(np.int64).sum()) != ndat:
         fails.append("hits.sum()=%d != ndat=%d" % (int(hits.sum()), ndat))
     nd = lt.cfg.ndim
@@ -390,7 +397,7 @@ def parity_gate(lt, raw, torch, dist, rank, world, sharded):
             fails.append(str(e))
     if fails:
         raise ParityGateError("bench.py parity gate FAILED on rank %d: %s" % (rank, "; ".join(fails)))
-    return {"status": "ok", "checks": (["fused == Detection+Fold bit for bit"] if was else []) +
+    return {"status": "ok", "checks": (["fused == Detection+Fold " + ("bit for bit" if exact else "to 2e-6 (segmented fused fold)")] if was else []) +
             ["hits.sum() == ndat", "profile power == detected power (rel %.1e)" % res.get("power_rel", 0.0)] +
             (["identical hits on all sub-band ranks"] if sharded and world > 1 else [])}
 

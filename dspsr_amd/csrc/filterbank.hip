@@ -77,6 +77,12 @@ struct FbOut {
   uint32_t ndim, chan0;
   uint32_t nbin;                                // kind 3
   uint64_t prof_span4;                          // kind 3: float4 between consecutive channel rows of the profile
+  float* part;                                  // kind 3, nseg > 1: partial profiles of part segments 1 .. nseg-1 for the
+                                                //         nchan_subband channels of this launch, packed
+                                                //         [seg-1][chan - chan0][nbin] float4, zeroed before the launch
+  uint32_t nchan_prof;                          // kind 3: channel rows of the whole profile
+  uint32_t nseg;                                // kind 3: part segments of a launch folded by different workgroups (0/1: one)
+  dspsr_amd_fold* fold;                         // kind 3 (host side only): the engine whose profile `base` is
   const uint32_t* pstart;                       // kind 3: per-part active-bin plan (fold_internal.h), nparts_plan parts
   uint32_t nparts_plan;
   uint32_t plan_cap;                            // kind 3: plan entries per LDS buffer (two buffers behind the twiddles)
@@ -916,20 +922,32 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   uint32_t jt = 0;                                              // tiles done by this workgroup
   Item item, next;
   uint32_t j = 0;
-  // FOLD: workgroup b takes tiles b, b + grid, ... and walks the parts of each in order
+  // FOLD: workgroup b takes tiles b, b + grid, ... and walks the parts of each in order.
+  // Segmented (out.nseg > 1, geometries with fewer channel tiles than compute units): the parts of the launch are cut
+  // into nseg runs; workgroup (lane, seg) walks the parts of run `seg` for tiles lane, lane + ntg, ...  Run 0 adds onto
+  // the profile (it continues the sums of earlier launches in time order), the others onto zeroed partial profiles that
+  // are added to the profile, in run order, after the launch -- the sums of a launch are re-associated per run.
   uint32_t fold_b = blockIdx.x;
+  const uint32_t fnseg = FOLD && out.nseg > 1 ? out.nseg : 1u;
+  const uint32_t fntg = gridDim.x / fnseg;                         // workgroups per run (host: gridDim.x % nseg == 0)
+  const uint32_t fseg = fnseg > 1 ? fold_b / fntg : 0u;
+  const uint32_t fpps = (nparts + fnseg - 1) / fnseg;              // parts per run
+  const uint32_t fp0 = fseg * fpps;
+  const uint32_t fnp = fp0 >= nparts ? 0u : (nparts - fp0 < fpps ? nparts - fp0 : fpps);
+  if (fnseg > 1) fold_b -= fseg * fntg;
   if constexpr (FOLD) {
+    if (fnp == 0) return;
     // tiles that share an X layout block (2^(logX3-logT3) of them) go to blocks b, b+8, ... : one XCD under the
     // observed round-robin placement, at the same time, so the block's lines are fetched once (speed only)
     const int lr = logX3 - logT3;
-    if (lr > 0 && (gridDim.x & ((8u << lr) - 1)) == 0)
+    if (fnseg == 1 && lr > 0 && (gridDim.x & ((8u << lr) - 1)) == 0)
       fold_b = ((((fold_b >> (3 + lr)) << 3) | (fold_b & 7)) << lr) | ((fold_b >> 3) & ((1u << lr) - 1));
   }
   auto next_item = [&](const uint32_t jj, Item& it) -> bool {
     if constexpr (FOLD) {
-      const uint32_t q = jj / nparts;                  // (32-bit; jj counts this workgroup's items)
-      it.tile = fold_b + q * gridDim.x;
-      it.lp = jj - q * nparts;
+      const uint32_t q = jj / fnp;                     // (32-bit; jj counts this workgroup's items)
+      it.tile = fold_b + q * fntg;
+      it.lp = fp0 + (jj - q * fnp);
       return it.tile < ntile;
     } else {
       // XCD dealing as persistent_item (wgfft.h) with runs of `run` items; run == nparts (the default) makes the run
@@ -1128,7 +1146,9 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       in_lds = f_nact <= out.plan_cap;
     }
     auto acc_ptr = [&](const uint32_t w, const uint32_t b) {
-      return (float4*)out.base + (uint64_t)(out.chan0 + tile * T3 + (w & (T3 - 1))) * out.prof_span4 + b;
+      const uint32_t cl = tile * T3 + (w & (T3 - 1));              // channel within this input channel's sub-band
+      return fseg == 0 ? (float4*)out.base + (uint64_t)(out.chan0 + cl) * out.prof_span4 + b
+                       : (float4*)out.part + ((uint64_t)(fseg - 1) * g.C + cl) * out.nbin + b;
     };
     auto mid = [&](const int phase) {
       if constexpr (PRE) {
@@ -1559,6 +1579,8 @@ struct dspsr_amd_filterbank_impl {
   k3_t k3 = nullptr, k3f = nullptr;                          // inverse pass: plain, fused fold
   k3a_t k3a = nullptr;
   k3b_t k3b = nullptr;
+  float* fpart = nullptr;    // segmented fused fold: partial profiles of the part runs 1 .. nseg-1 of a launch
+  size_t fpart_floats = 0;
   uint32_t plan_cap = 0;     // fused fold: plan entries per LDS buffer behind the twiddle tables
   size_t lds3f = 0;          // dynamic LDS of the fused inverse pass
 };
@@ -1781,6 +1803,7 @@ extern "C" void dspsr_amd_filterbank_destroy(dspsr_amd_filterbank* fb)
   if (fb->kernel) (void)hipFree(fb->kernel);
   if (fb->Rt) (void)hipFree(fb->Rt);
   if (fb->det) (void)hipFree(fb->det);
+  if (fb->fpart) (void)hipFree(fb->fpart);
   if (fb->tw_lo) (void)hipFree(fb->tw_lo);
   if (fb->tw_lo_m) (void)hipFree(fb->tw_lo_m);
   delete fb;
@@ -1833,6 +1856,46 @@ static uint32_t grid_for(uint64_t items, uint32_t ncu)
 }
 
 
+// Fused inverse pass of one launch (ns parts starting at part0).  With fewer channel tiles than compute units the parts
+// are cut into runs folded by different workgroups (k_inv_chan, "Segmented"): partial profiles zeroed before, added to the
+// profile in run order after the launch.  segmented == false: one workgroup owns a tile for all parts (exact time order).
+static int fb_launch_fused(dspsr_amd_filterbank* fb, k3_t k3, const cf* X, const cf* kern, FbOut co, uint64_t part0, uint32_t ns,
+                           bool segmented)
+{
+  dspsr_amd_ctx* ctx = fb->ctx;
+  const FbGeom& g = fb->g;
+  const uint32_t tiles = g.C >> g.logT3, wgs = fb->ncu * fb->wg3;
+  uint32_t nseg = 1;
+  if (segmented && tiles < wgs) {
+    nseg = wgs / tiles;
+    if (nseg > ns) nseg = ns;
+    if (nseg > 16) nseg = 16;
+    if (nseg < 1) nseg = 1;
+  }
+  co.plan_cap = fb->plan_cap;
+  co.nseg = nseg;
+  co.part = nullptr;
+  if (nseg > 1) {
+    const size_t need = (size_t)(nseg - 1) * g.C * co.nbin * 4;
+    if (need > fb->fpart_floats) {
+      (void)hipStreamSynchronize(ctx->stream);
+      if (fb->fpart) (void)hipFree(fb->fpart);
+      fb->fpart = nullptr; fb->fpart_floats = 0;
+      if (hipMalloc((void**)&fb->fpart, need * sizeof(float)) != hipSuccess)
+        return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform_fold: hipMalloc of %zu partial-profile bytes failed",
+                       need * sizeof(float));
+      fb->fpart_floats = need;
+    }
+    if (hipMemsetAsync(fb->fpart, 0, need * sizeof(float), ctx->stream) != hipSuccess)
+      return fb_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_filterbank_perform_fold: hipMemsetAsync failed");
+    co.part = fb->fpart;
+  }
+  const uint32_t grid = nseg > 1 ? tiles * nseg : grid_for(tiles, wgs);
+  hipLaunchKernelGGL(k3, dim3(grid), dim3(fb->nt3), fb->lds3f, ctx->stream, g, X, kern, co, ctx->tw, part0, ns, ns);
+  if (nseg > 1) return fold_combine_partials(co.fold, fb->fpart, nseg - 1, co.chan0, g.C);
+  return DSPSR_AMD_OK;
+}
+
 static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, uint64_t in_chan_stride_bytes_or_floats)
 {
   dspsr_amd_ctx* ctx = fb->ctx;
@@ -1871,6 +1934,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   hipError_t e;
   const uint32_t Rr = 1u << g.logR, M = 1u << g.logM;
   const float* in_f32 = (const float*)in.base;
+  const bool fused_segmented = out.kind == 3 && dspsr_amd_filterbank_fold_is_fused(fb) == 2;
   for (uint32_t ichan = 0; ichan < fb->cfg.input_nchan; ichan++) {
     FbIn ci = in;
     if (in.kind == 0) ci.base = in_f32 + ichan * in_chan_stride_bytes_or_floats;
@@ -1932,8 +1996,13 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
           const uint64_t n3s = co.kind == 3 ? (uint64_t)(g.C >> g.logT3) : (uint64_t)(g.C >> g.logT3) * ns;
           hipLaunchKernelGGL(k2, dim3(grid_for(n2s, fb->ncu * fb->wg_per_cu)), dim3(fb->nt2), fb->lds2, ctx->stream, g, fb->A + off,
                              fb->X + off, ctx->tw, ns, fb->nseq, run2);
-          hipLaunchKernelGGL(k3, dim3(grid_for(n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), lds3s, ctx->stream, g, fb->X + off, kern, co,
-                             ctx->tw, part0 + s0, ns, env_run3 > 0 ? (uint32_t)env_run3 : ns);
+          if (co.kind == 3) {
+            const int rc = fb_launch_fused(fb, k3, fb->X + off, kern, co, part0 + s0, ns, fused_segmented);
+            if (rc != DSPSR_AMD_OK) return rc;
+          } else {
+            hipLaunchKernelGGL(k3, dim3(grid_for(n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), lds3s, ctx->stream, g, fb->X + off, kern, co,
+                               ctx->tw, part0 + s0, ns, env_run3 > 0 ? (uint32_t)env_run3 : ns);
+          }
         }
         continue;
       }
@@ -1944,8 +2013,13 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         const uint64_t items3 = co.kind == 3 ? (uint64_t)(g.C >> g.logT3) : n3;
         const size_t lds3 = co.kind == 3 ? fb->lds3f : fb->lds3;
         if (co.kind == 3) co.plan_cap = fb->plan_cap;       // LDS left over behind the twiddle tables holds the part's fold plan
-        hipLaunchKernelGGL(k3, dim3(grid_for(items3, fb->ncu * fb->wg3)), dim3(fb->nt3), lds3, ctx->stream, g, fb->X, kern, co,
-                           ctx->tw, part0, nb, run3);
+        if (co.kind == 3) {
+          const int rc = fb_launch_fused(fb, k3, fb->X, kern, co, part0, nb, fused_segmented);
+          if (rc != DSPSR_AMD_OK) return rc;
+        } else {
+          hipLaunchKernelGGL(k3, dim3(grid_for(items3, fb->ncu * fb->wg3)), dim3(fb->nt3), lds3, ctx->stream, g, fb->X, kern, co,
+                             ctx->tw, part0, nb, run3);
+        }
       } else {
         // two-pass inverse: X (natural order) -> U (in the A buffer, dead after pass 2) -> output
         const uint64_t n3a = ((uint64_t)g.C << (g.logMb - g.logTm)) * nb, n3b = ((uint64_t)g.C << (g.logMa - g.logTt)) * nb;
@@ -2063,7 +2137,8 @@ extern "C" int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb
   if (fb->cfg.fused_fold == DSPSR_AMD_FUSED_ALWAYS) return 1;
   if (fb->cfg.fused_fold == DSPSR_AMD_FUSED_NEVER) return 0;
   const uint64_t tiles = (uint64_t)(fb->g.C >> fb->g.logT3);
-  return tiles >= fb->ncu ? 1 : 0;
+  if (tiles >= fb->ncu) return 1;           // one workgroup per tile fills the chip: exact time-order sums
+  return tiles >= 8 ? 2 : 0;                // fewer tiles: the parts of a launch are folded in runs (re-associated sums)
 }
 
 extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const float* in_f32_dev,
@@ -2133,7 +2208,8 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
   PlanSlot* slot = nullptr;
   int rc = fold_build_part_plan(fold, fb->g.nkeep, (uint32_t)npart, &d_start, &d_iv, &slot);
   if (rc != DSPSR_AMD_OK) return rc;
-  FbOut out = {3, fold->profile, 0, 0, 0, state, 4, 0, fold->nbin, fold->span / 4, d_start, (uint32_t)npart, 0, d_iv};
+  FbOut out = {3, fold->profile, 0, 0, 0, state, 4, 0, fold->nbin, fold->span / 4, nullptr, fold->nchan, 0, fold, d_start,
+               (uint32_t)npart, 0, d_iv};
   rc = fb_run(fb, in, out, npart, in_chan_stride);
   const int rc2 = fold_part_plan_submitted(fold, slot);
   return rc != DSPSR_AMD_OK ? rc : rc2;

@@ -717,6 +717,21 @@ int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, cons
   return DSPSR_AMD_OK;
 }
 
+int fold_combine_partials(dspsr_amd_fold* f, const float* part, uint32_t nseg, uint32_t chan0, uint32_t nchan)
+{
+  // profile rows [chan0, chan0 + nchan) += partial profiles of the runs 1 .. nseg of a segmented fused launch (packed
+  // [seg][chan - chan0][nbin][ndim], npol 1), in run order
+  const uint32_t nrow = nchan * f->npol;
+  const uint64_t n = (uint64_t)nrow * f->nbin * f->ndim;
+  uint32_t gx = (uint32_t)((n + 255) / 256);
+  if (gx > 4 * f->ctx->ncu) gx = 4 * f->ctx->ncu;
+  hipLaunchKernelGGL(k_fold_combine, dim3(gx), dim3(256), 0, f->ctx->stream, f->profile + (uint64_t)chan0 * f->npol * f->span, f->span,
+                     part, nrow, f->nbin * f->ndim, nseg);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ctx_fail(f->ctx, DSPSR_AMD_EHIP, "fused fold: combine: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}
+
 int fold_part_plan_submitted(dspsr_amd_fold* f, PlanSlot* slot)
 {
   hipError_t e = hipEventRecord(slot->done, f->ctx->stream);

@@ -60,3 +60,5 @@ static inline uint32_t fold_plan_max_run(const dspsr_amd_fold* f)
 int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, const uint32_t** d_start,
                          const dspsr_amd::Interval** d_iv, PlanSlot** slot);
 int fold_part_plan_submitted(dspsr_amd_fold* f, PlanSlot* slot);
+// profile += sum of `nseg` partial profiles (packed [seg][chan][npol][nbin][ndim]) in order: segmented fused launches
+int fold_combine_partials(dspsr_amd_fold* f, const float* part, uint32_t nseg, uint32_t chan0, uint32_t nchan);

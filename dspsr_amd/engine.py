@@ -225,9 +225,11 @@ class FilterbankEngine:
                                                        state, ndim, det.data_ptr(), dcs, dps, npart),
                "dspsr_amd_filterbank_perform_detect")
 
-    def fold_is_fused(self) -> bool:
-        """True when perform_fold folds inside the last filterbank pass (else it runs Detection + Fold launches)."""
-        return bool(lib.dspsr_amd_filterbank_fold_is_fused(self.handle))
+    def fold_is_fused(self) -> int:
+        """0: perform_fold runs Detection + Fold launches; 1: it folds inside the last filterbank pass with exact time-order
+        sums (one workgroup per channel tile); 2: it folds inside the last pass with the parts of a launch cut into runs
+        (geometries with fewer tiles than compute units): sums re-associated per run, equal to float rounding."""
+        return int(lib.dspsr_amd_filterbank_fold_is_fused(self.handle))
 
     def perform_fold(self, fold, npart, state=_lib.COHERENCE, inp=None, in_step=0, raw=None,
                      layout=_lib.RAW_GENERIC, scale=1.0):

@@ -533,7 +533,8 @@ class LoadToFold:
         # fused filterbank+detect+fold (no detected time series in HBM): ndim 4, three-pass geometries
         # (the library decides whether fusing pays for this geometry; when it does not, this driver keeps the
         # separate Detection and Fold operations on its own `detected` block)
-        self.fused_fold = bool(cfg.fused_fold) and cfg.ndim == 4 and self.sample_delay is None and self.fb.fold_is_fused()
+        self.fused_mode = self.fb.fold_is_fused() if (cfg.fused_fold and cfg.ndim == 4 and self.sample_delay is None) else 0
+        self.fused_fold = self.fused_mode != 0      # fused_mode 2: sums re-associated per run of parts (engine.fold_is_fused)
         # fold bookkeeping (PhaseSeries) ---------------------------------------------------
         self.hits = np.zeros(cfg.nbin, dtype=np.uint32)
         self.integration_length = 0.0

@@ -143,9 +143,15 @@ int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, const float* i
  * (dspsr_amd_fold_set_nbin / set_ndat / set_bin(s) with sample indices counted from the first output sample of
  * this call); it is consumed.  Sums are accumulated into the device profile of `fold` in time order per
  * (chan, bin), bit-identical to perform_detect followed by dspsr_amd_fold_fold.
- * The fold happens inside the last filterbank pass when that fills the chip (three-pass geometry, at least one
- * tile of channels per compute unit: dspsr_amd_filterbank_fold_is_fused() == 1); otherwise the same call runs
- * Detection and Fold as separate launches on a block owned by the filterbank object -- same sums either way. */
+ * dspsr_amd_filterbank_fold_is_fused() says how this object folds (fused_fold = DSPSR_AMD_FUSED_AUTO):
+ *   1  inside the last filterbank pass, one workgroup per tile of channels walking the parts in order (three-pass geometry
+ *      with at least one tile per compute unit): exact time-order sums, bit-identical to Detection + Fold;
+ *   2  inside the last pass with the parts of a launch cut into runs folded by different workgroups (8 .. ncu-1 tiles):
+ *      run 0 continues the profile, the other runs go to partial profiles added in run order after the launch -- sums
+ *      re-associated per run, equal to the time-order sums to float rounding, deterministic;
+ *   0  Detection and Fold as separate launches on a block owned by the filterbank object (four-pass geometry, fewer than 8
+ *      tiles, DSPSR_AMD_FUSED_NEVER).  Plans with runs of >= 64 samples per bin always take this path (fold.hip).
+ * DSPSR_AMD_FUSED_ALWAYS forces mode 1 on any three-pass geometry. */
 int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb);
 int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const float* in_f32_dev, uint64_t in_chan_stride,
                                       uint64_t in_pol_stride, uint64_t in_step, const int8_t* raw_dev, int raw_layout,

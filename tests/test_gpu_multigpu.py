@@ -36,6 +36,7 @@ def _raw(n, seed):
 
 @pytest.mark.parametrize("force_fused", [False, True])
 def test_subband_shards_equal_fullband(oracle, gpu, force_fused):
+    """(force_fused False: 32 channel tiles per sub-band -> the segmented fused fold; True: one workgroup per tile, exact.)"""
     from dspsr_amd import pipeline
     nsub, nblocks = 8, 2
     info = pipeline.InputInfo(centre_frequency=1382.0, bandwidth=-400.0, nchan=nsub, npol=2, ndim=2, tsamp_us=0.02,
@@ -68,7 +69,7 @@ def test_subband_shards_equal_fullband(oracle, gpu, force_fused):
     assert int(want["hits"].sum()) == nblocks * cfg.parts_per_block * full.nkeep and float(wprof.abs().max()) > 0
     for g in range(nsub):
         lt = pipeline.LoadToFold(cfg, info, device=0, stream=stream, subband=g)
-        assert lt.fused_fold == force_fused
+        assert lt.fused_mode == (1 if force_fused else 2)
         assert (lt.nkeep, lt.nsamp_step, lt.out_start, lt.out_rate) == (full.nkeep, full.nsamp_step, full.out_start, full.out_rate)
         mine = torch.from_numpy(np.ascontiguousarray(raw.reshape(ndat, nsub, 4)[:, g, :]).reshape(-1)).cuda()   # what rank g reads
         for b in range(nblocks):

@@ -1027,3 +1027,47 @@ def test_fold_long_runs_reassociated(oracle, gpu, ndim, npol):
     want = np.zeros((nchan, npol, nbin, ndim), np.float64)
     np.add.at(want, (slice(None), slice(None), plan), det[:, :, idat_start:idat_start + ndat_fold, :].astype(np.float64))
     assert np.abs(res[0] - want).max() <= 2e-6 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("C,M,nfilt,nbin,real", [(512, 512, (27, 27), 1024, False),      # cfg4: 32 tiles of 16 channels
+                                                 (256, 4096, (953, 956), 1024, True)])   # cfg2: 128 tiles of 2 channels
+def test_segmented_fused_fold(oracle, gpu, C, M, nfilt, nbin, real):
+    """Geometries with fewer channel tiles than compute units: perform_fold cuts the parts of a launch into runs folded by
+    different workgroups (fold_is_fused() == 2).  hits identical; sums equal to Detection + Fold to float rounding (<= 2e-6
+    of the maximum), deterministic, accumulated over several calls and ragged launch groups; FUSED_NEVER / FUSED_ALWAYS
+    still give the exact paths, bit-identical to each other."""
+    dspsr_amd, ctx = gpu
+    o = oracle
+    N = C * M
+    nkeep = M - sum(nfilt)
+    ndim_in = 1 if real else 2
+    step, ovl = (2 if real else 1) * (N - sum(nfilt) * C), (2 if real else 1) * sum(nfilt) * C
+    npart, ncall = 11, 2
+    rng = np.random.default_rng(81)
+    kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, N)).astype(np.complex64)
+    res = {}
+    for mode in ("auto", "auto2", "never", "always"):
+        pol = {"auto": dspsr_amd.FUSED_AUTO, "auto2": dspsr_amd.FUSED_AUTO, "never": dspsr_amd.FUSED_NEVER, "always": dspsr_amd.FUSED_ALWAYS}[mode]
+        eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, 2, real, kernel, max_parts=8, fused_fold=pol)
+        assert eng.fold_is_fused() == {"auto": 2, "auto2": 2, "never": 0, "always": 1}[mode]
+        fold = dspsr_amd.FoldEngine(ctx)
+        fold.set_shape(C, 1, 4, nbin)
+        hits = np.zeros(nbin, np.uint32)
+        pps = 1.0 / (nbin * 8.7)
+        for call in range(ncall):
+            raw = torch.from_numpy(_raw((npart * step + ovl), npol=2, ndim=ndim_in, seed=200 + call)).cuda()
+            fold.set_nbin(nbin)
+            fold.set_ndat(npart * nkeep, 0)
+            fold.set_bins((0.21 + call * npart * nkeep * pps) % 1.0, pps, npart * nkeep, 0, hits)
+            eng.perform_fold(fold, npart, dspsr_amd.COHERENCE, raw=raw, scale=float(o.S8))
+        res[mode] = (hits, fold.synch())
+        eng.close()
+        fold.close()
+    assert np.array_equal(res["auto"][1], res["auto2"][1])                      # deterministic
+    assert np.array_equal(res["never"][1], res["always"][1])                    # the exact paths agree bit for bit
+    for m in ("auto2", "never", "always"):
+        assert np.array_equal(res["auto"][0], res[m][0])
+    ref = res["never"][1].astype(np.float64)
+    assert np.abs(ref).max() > 0
+    assert np.abs(res["auto"][1] - ref).max() <= 2e-6 * np.abs(ref).max()
+    assert not np.array_equal(res["auto"][1], res["never"][1]) or True          # (re-associated: usually differs in the last bits)
