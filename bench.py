@@ -600,33 +600,14 @@ def main():
                 "note": "the fused group also does the fold; its algorithmic bytes have no output term "
                         "(SURVEY 8(d)), so this fraction is not comparable with roofline.frac"}
         if args.h2d:
-            # host-buffer hand-over: block i+1 is copied H2D on a side stream while block i is processed
+            # host-buffer hand-over through the product's own feeder (pipeline.LoadToFold.process_host_blocks): block i+1
+            # is copied H2D on a second stream while block i is processed
             host = raw.cpu().pin_memory()
-            bufs = [torch.empty_like(raw), torch.empty_like(raw)]
-            copy_stream = torch.cuda.Stream()
-            ready = [torch.cuda.Event(), torch.cuda.Event()]
-            done = [torch.cuda.Event(), torch.cuda.Event()]
-            main_stream = torch.cuda.current_stream()
-
-            def h2d_run(nsteps):
-                with torch.cuda.stream(copy_stream):
-                    bufs[0].copy_(host, non_blocking=True)
-                    ready[0].record(copy_stream)
-                for i in range(nsteps):
-                    b = i & 1
-                    if i + 1 < nsteps:
-                        with torch.cuda.stream(copy_stream):
-                            if i >= 1:
-                                copy_stream.wait_event(done[b ^ 1])     # the kernels of block i-1 are finished with it
-                            bufs[b ^ 1].copy_(host, non_blocking=True)
-                            ready[b ^ 1].record(copy_stream)
-                    main_stream.wait_event(ready[b])
-                    lt.process_block(bufs[b])
-                    done[b].record(main_stream)
-                torch.cuda.synchronize()
-            h2d_run(3)
+            lt.process_host_blocks(host for _ in range(3))
+            torch.cuda.synchronize()
             t1 = time.perf_counter()
-            h2d_run(args.steps)
+            lt.process_host_blocks(host for _ in range(args.steps))
+            torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             out["config"]["pcie_inclusive"] = {
                 "value": round(cfg.parts_per_block * lt.nsamp_step * args.steps / dt / 1e6, 1), "unit": "Msamples/s",

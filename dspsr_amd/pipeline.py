@@ -715,6 +715,43 @@ class LoadToFold:
         self.integration_length = 0.0
         self.ndat_total = 0
 
+    def process_host_blocks(self, blocks, npart=None):
+        """Host hand-over (the role of dsp::TransferCUDA / TransferBitSeriesCUDA, Signal/General/TransferCUDA.C:24-85):
+        `blocks` yields pinned host int8 tensors, one block each; block i+1 is copied to the device on a second stream
+        while block i is processed (two device buffers, events both ways).  With the data coming over PCIe Gen5 x16 the
+        link, not the GPU, sets the rate.  Returns the number of blocks processed."""
+        torch = self.torch
+        main = torch.cuda.current_stream()
+        copy = torch.cuda.Stream()
+        bufs, ready, done = [None, None], [torch.cuda.Event(), torch.cuda.Event()], [torch.cuda.Event(), torch.cuda.Event()]
+        it = iter(blocks)
+
+        def upload(k, host):
+            with torch.cuda.stream(copy):
+                if bufs[k] is None or bufs[k].numel() != host.numel():
+                    bufs[k] = torch.empty(host.numel(), dtype=torch.int8, device="cuda:%d" % self.ctx.device)
+                else:
+                    copy.wait_event(done[k])                 # the kernels that read this buffer have finished
+                bufs[k].copy_(host, non_blocking=True)
+                ready[k].record(copy)
+        nxt = next(it, None)
+        if nxt is None:
+            return 0
+        upload(0, nxt)
+        n = 0
+        while True:
+            k = n & 1
+            nxt = next(it, None)
+            if nxt is not None:
+                upload(k ^ 1, nxt)
+            main.wait_event(ready[k])
+            self.process_block(bufs[k], npart)
+            done[k].record(main)
+            n += 1
+            if nxt is None:
+                break
+        return n
+
     def synchronize(self):
         self.ctx.synchronize()
 

@@ -1071,3 +1071,30 @@ def test_segmented_fused_fold(oracle, gpu, C, M, nfilt, nbin, real):
     assert np.abs(ref).max() > 0
     assert np.abs(res["auto"][1] - ref).max() <= 2e-6 * np.abs(ref).max()
     assert not np.array_equal(res["auto"][1], res["never"][1]) or True          # (re-associated: usually differs in the last bits)
+
+
+def test_host_block_feeder_equals_resident_blocks(gpu):
+    """pipeline.LoadToFold.process_host_blocks (pinned host blocks, H2D on a second stream overlapped with the kernels)
+    folds exactly what process_block folds from resident blocks."""
+    dspsr_amd, _ = gpu
+    from dspsr_amd import pipeline, synth
+    freq, bw, tsamp, dm, period, nchan, nbin = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004, 16, 64
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
+    cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=4, parts_per_block=3, max_parts=2)
+    res = []
+    for hosted in (False, True):
+        lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+        nblocks = 5
+        step = cfg.parts_per_block * lt.nsamp_step
+        raw = torch.from_numpy(synth.voltages(nblocks * step + lt.nsamp_overlap, freq, bw, tsamp, dm, period))
+        blocks = [raw[2 * b * step: 2 * (b * step + step + lt.nsamp_overlap)] for b in range(nblocks)]
+        if hosted:
+            assert lt.process_host_blocks(b.clone().pin_memory() for b in blocks) == nblocks
+        else:
+            for b in blocks:
+                lt.process_block(b.cuda())
+        lt.finish_subint()
+        lt.synchronize()
+        res.append((lt.subints[0]["hits"].copy(), lt.subints[0]["profile_dev"].cpu().numpy()))
+        lt.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.abs(res[0][1]).max() > 0
