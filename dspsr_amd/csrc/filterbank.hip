@@ -294,8 +294,8 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
 #ifndef FB_TABLE_TWIDDLES
 #define FB_TABLE_TWIDDLES 0   // 1: pass twiddles from the (coarse x fine) tables for every length (comparison builds)
 #endif
-template <int NT> DEV void twiddles_big(cf (&t)[NT], const uint64_t (&j)[NT], const int logL, const cf* __restrict__ tw,
-                                        const cf* __restrict__ tw_lo)
+template <int NT, typename IDX> DEV void twiddles_big(cf (&t)[NT], const IDX (&j)[NT], const int logL, const cf* __restrict__ tw,
+                                                      const cf* __restrict__ tw_lo)
 {
   if (logL <= 24 && !FB_TABLE_TWIDDLES) {      // uniform
     // v_cos_f32 / v_sin_f32 take their argument in revolutions: j / 2^logL is exact in float, and the measured
@@ -325,26 +325,43 @@ template <int NT> DEV void twiddles_big(cf (&t)[NT], const uint64_t (&j)[NT], co
 template <int R> DEV void apply_pass_twiddle(cx2 (&v)[R], const uint32_t nb, const uint32_t p, const uint32_t pstride,
                                              const int logL, const cf* __restrict__ tw, const cf* __restrict__ tw_lo)
 {
-  const uint64_t Lm = (1ull << logL) - 1;
-  const uint64_t a0 = ((uint64_t)nb * p) & Lm, d0 = ((uint64_t)nb * pstride) & Lm;
-  const uint64_t a1 = (a0 + p) & Lm, d1 = (d0 + pstride) & Lm;             // column nb + 1
+  // 32-bit index arithmetic: nb < Fb and k*pstride + p < Fa with both factors <= 2^MAX_LOGF = 2^13, so every product is
+  // below 2^26 and its multiples up to 8 below 2^29
+  const uint32_t Lm = (uint32_t)((1ull << logL) - 1);
+  const uint32_t a0 = (nb * p) & Lm, d0 = (nb * pstride) & Lm;
+  const uint32_t a1 = (a0 + p) & Lm, d1 = (d0 + pstride) & Lm;             // column nb + 1
   constexpr int NP = R >= 16 ? 4 : R >= 8 ? 3 : R >= 4 ? 2 : R >= 2 ? 1 : 0;   // powers 1, 2, 4, 8 of the step
-  uint64_t j[2 + 2 * (NP ? NP : 1)];
+  uint32_t j[2 + 2 * (NP ? NP : 1)];
   cf t[2 + 2 * (NP ? NP : 1)];
   j[0] = a0; j[1] = a1;
 #pragma unroll
   for (int q = 0; q < (NP ? NP : 1); q++) { j[2 + 2 * q] = (d0 << q) & Lm; j[3 + 2 * q] = (d1 << q) & Lm; }
   twiddles_big(t, j, logL, tw, tw_lo);
   const cx2 wa = make_cx2(t[0], t[1]);
-  if constexpr (R > 1) {
+  if constexpr (R == 1) {
+    v[0] = cmul(v[0], wa);
+  } else {
+    // u[k] = wa * w1^k by a ladder that starts from wa (15 products for R = 16) instead of w1^k (11 products) followed by
+    // a separate multiplication of every element by wa (16 more): 31 packed complex products per call instead of 42
     const cx2 w1 = make_cx2(t[2], t[3]);
     const cx2 w2 = NP >= 2 ? make_cx2(t[2 + 2 * (NP >= 2 ? 1 : 0)], t[3 + 2 * (NP >= 2 ? 1 : 0)]) : w1;
     const cx2 w4 = NP >= 3 ? make_cx2(t[2 + 2 * (NP >= 3 ? 2 : 0)], t[3 + 2 * (NP >= 3 ? 2 : 0)]) : w1;
     const cx2 w8 = NP >= 4 ? make_cx2(t[2 + 2 * (NP >= 4 ? 3 : 0)], t[3 + 2 * (NP >= 4 ? 3 : 0)]) : w1;
-    apply_powers2<R>(v, w1, w2, w4, w8);
-  }
+    cx2 u[R];
+    u[0] = wa;
+    u[1] = cmul(wa, w1);
+    if constexpr (R >= 4) { u[2] = cmul(wa, w2); u[3] = cmul(u[1], w2); }
+    if constexpr (R >= 8) {
 #pragma unroll
-  for (int k = 0; k < R; k++) v[k] = cmul(v[k], wa);
+      for (int k = 0; k < 4; k++) u[4 + k] = cmul(u[k], w4);
+    }
+    if constexpr (R >= 16) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) u[8 + k] = cmul(u[k], w8);
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) v[k] = cmul(v[k], u[k]);
+  }
 }
 
 // v[k] *= conj(W_L^{nb*(k*pstride + p)}) for BOTH columns of the pair (the two polarisations of one column
@@ -352,10 +369,10 @@ template <int R> DEV void apply_pass_twiddle(cx2 (&v)[R], const uint32_t nb, con
 template <int R> DEV void apply_pass_twiddle_inv(cx2 (&v)[R], const uint32_t nb, const uint32_t p, const uint32_t pstride,
                                                  const int logL, const cf* __restrict__ tw, const cf* __restrict__ tw_lo)
 {
-  const uint64_t Lm = (1ull << logL) - 1;
-  const uint64_t a0 = ((uint64_t)nb * p) & Lm, d0 = ((uint64_t)nb * pstride) & Lm;
+  const uint32_t Lm = (uint32_t)((1ull << logL) - 1);
+  const uint32_t a0 = (nb * p) & Lm, d0 = (nb * pstride) & Lm;      // (factors <= 2^13 each: see apply_pass_twiddle)
   constexpr int NP = R >= 16 ? 4 : R >= 8 ? 3 : R >= 4 ? 2 : R >= 2 ? 1 : 0;
-  uint64_t j[1 + (NP ? NP : 1)];
+  uint32_t j[1 + (NP ? NP : 1)];
   cf t[1 + (NP ? NP : 1)];
   j[0] = a0;
 #pragma unroll
