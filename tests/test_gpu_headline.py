@@ -209,3 +209,33 @@ def test_cfg3_pipeline_geometry(gpu):
     assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
     lt.close()
     ltu.close()
+
+
+def test_filterbank_very_long_response(oracle, gpu):
+    """Towards the upper end of the supported range: single-channel coherent dedispersion (dsp::Convolution geometry) with a
+    2^24-point response on real dual-pol input -- forward transform of 2^25 points (8192 x 4096), two-pass inverse
+    4096 x 4096."""
+    _fb(oracle, gpu, 1, 1 << 24, (700000, 650000), 1, layout="caspsr")
+
+
+def test_fold_many_bins_direct_kernel(oracle, gpu):
+    """nbin beyond what the chunked kernel's workgroup covers (4096 bins): the direct fold kernel, still bit-identical to
+    the CPU loop."""
+    ctx = gpu.Context(0, torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(91)
+    nchan, npol, ndim, ndat, nbin = 2, 1, 4, 30000, 6000
+    det = rng.standard_normal((nchan, npol, ndat, ndim)).astype(np.float32)
+    eng = gpu.FoldEngine(ctx)
+    eng.set_shape(nchan, npol, ndim, nbin)
+    eng.set_nbin(nbin)
+    eng.set_ndat(ndat, 0)
+    hits = np.zeros(nbin, np.uint32)
+    eng.set_bins(0.4, 1.0 / 7001.3, ndat, 0, hits)
+    eng.fold(torch.from_numpy(det.reshape(nchan, npol, ndat * ndim)).cuda())
+    plan = oracle.fold_binplan(0.4, 1.0 / 7001.3, nbin, ndat)
+    want = np.zeros((nchan, npol, nbin, ndim), np.float32)
+    for i in range(ndat):
+        want[:, :, plan[i], :] += det[:, :, i, :]
+    assert np.array_equal(hits, np.bincount(plan, minlength=nbin).astype(np.uint32)) and np.array_equal(eng.synch(), want)
+    eng.close()
+    ctx.close()
