@@ -110,6 +110,14 @@ def load() -> C.CDLL:
         raise ImportError(
             "dspsr_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process.  torch ships its own libamdhip64.so.7 / libhsa-runtime64 and the Python host side
+    # shares streams and device memory with it, so torch's copy must be the one the dynamic linker binds: import torch
+    # BEFORE the library (loading libdspsr_amd.so first binds /opt/rocm's runtime, and the context then finds no device
+    # once torch has initialised its own).  A C/C++ host such as DSPSR has no torch in the process and links /opt/rocm.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

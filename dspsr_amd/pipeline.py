@@ -717,39 +717,66 @@ class LoadToFold:
 
     def process_host_blocks(self, blocks, npart=None):
         """Host hand-over (the role of dsp::TransferCUDA / TransferBitSeriesCUDA, Signal/General/TransferCUDA.C:24-85):
-        `blocks` yields pinned host int8 tensors, one block each; block i+1 is copied to the device on a second stream
-        while block i is processed (two device buffers, events both ways).  With the data coming over PCIe Gen5 x16 the
-        link, not the GPU, sets the rate.  Returns the number of blocks processed."""
+        `blocks` yields one block each -- a pinned host int8 tensor (copied from where it lies; the caller must not touch
+        it again before the call returns), or any other host int8 tensor / numpy array (staged through two pinned buffers
+        owned by this call), optionally as a pair (block, npart) for a ragged last block.  Block i+1 is copied to the
+        device on a second stream while block i is processed (two device buffers, events both ways).  With the data
+        coming over PCIe Gen5 x16 the link, not the GPU, sets the rate.  Returns the number of
+        blocks processed."""
         torch = self.torch
         main = torch.cuda.current_stream()
         copy = torch.cuda.Stream()
-        bufs, ready, done = [None, None], [torch.cuda.Event(), torch.cuda.Event()], [torch.cuda.Event(), torch.cuda.Event()]
+        bufs, pins = [None, None], [None, None]
+        ready, done = [torch.cuda.Event(), torch.cuda.Event()], [torch.cuda.Event(), torch.cuda.Event()]
+        used = [False, False]
         it = iter(blocks)
 
+        def split(item):
+            if item is None:
+                return None, None
+            if isinstance(item, tuple):
+                return item[0], item[1]
+            return item, npart
+
         def upload(k, host):
+            if not (torch.is_tensor(host) and host.is_pinned()):
+                src = (host.numpy() if torch.is_tensor(host) else np.asarray(host)).reshape(-1).view(np.int8)
+                if used[k]:
+                    ready[k].synchronize()                   # host wait: the previous copy out of this pinned buffer is over
+                if pins[k] is None or pins[k].numel() < src.size:
+                    pins[k] = torch.empty(src.size, dtype=torch.int8).pin_memory()
+                host = pins[k][:src.size]
+                host.numpy()[:] = src                        # (a read-only memory map is fine as a source)
             with torch.cuda.stream(copy):
-                if bufs[k] is None or bufs[k].numel() != host.numel():
+                if bufs[k] is None or bufs[k].numel() < host.numel():
+                    if bufs[k] is not None:
+                        bufs[k].record_stream(main)          # still being read by kernels on the main stream
                     bufs[k] = torch.empty(host.numel(), dtype=torch.int8, device="cuda:%d" % self.ctx.device)
-                else:
+                    bufs[k].record_stream(main)
+                elif used[k]:
                     copy.wait_event(done[k])                 # the kernels that read this buffer have finished
-                bufs[k].copy_(host, non_blocking=True)
+                bufs[k][:host.numel()].copy_(host, non_blocking=True)
                 ready[k].record(copy)
-        nxt = next(it, None)
+            used[k] = True
+            return host.numel()
+        nxt, nxt_parts = split(next(it, None))
         if nxt is None:
             return 0
-        upload(0, nxt)
+        sizes = [upload(0, nxt), 0]
+        parts = [nxt_parts, None]
         n = 0
         while True:
             k = n & 1
-            nxt = next(it, None)
+            nxt, nxt_parts = split(next(it, None))
             if nxt is not None:
-                upload(k ^ 1, nxt)
+                sizes[k ^ 1], parts[k ^ 1] = upload(k ^ 1, nxt), nxt_parts
             main.wait_event(ready[k])
-            self.process_block(bufs[k], npart)
+            self.process_block(bufs[k][:sizes[k]], parts[k])
             done[k].record(main)
             n += 1
             if nxt is None:
                 break
+        main.synchronize()                                   # the staging buffers go out of scope with this call
         return n
 
     def synchronize(self):

@@ -1,0 +1,144 @@
+"""dspsr_amd.dada: the DADA header and file layout on the input side of the path (ascii_header.c:31-131,
+ASCIIObservation.C:82-415, DADAFile.C:33-180).  Host logic on the CPU; the GPU cases fold a synthetic file end to end and
+compare with the same bytes handed over as device-resident blocks."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+from dspsr_amd import dada, synth
+from dspsr_amd.engine import DspsrAmdError
+
+REF_HEADER = "/root/reference/Benchmark/header.dada"
+
+
+def test_header_find_semantics():
+    h = "HDR_VERSION 1.0\n# BW 999 in a comment\nXBW 5\nBWX 7\nBW\t-400   # bandwidth in MHz\nFREQ  1382\t\t# centre\nNDIM 1\nBW 64\n"
+    assert dada.header_get(h, "HDR_VERSION") == "1.0"            # first word of the header
+    assert dada.header_get(h, "BW") == "-400"                     # not the comment, not XBW / BWX, first real match wins
+    assert dada.header_get(h, "FREQ") == "1382"
+    assert dada.header_get(h, "NPOL") is None
+    assert dada.header_get("A 1\\B 2\n", "B") == "2"              # a backslash also counts as a line start
+    assert dada.header_get("NBIT 8bits\n", "NBIT") == "8bits" and dada._scan("NBIT 8bits\n", "NBIT", int, 2) == 8
+    assert dada.header_get("KEY\n", "KEY") is None                # keyword without the blank that must follow it
+
+
+def test_observation_defaults_and_errors():
+    info, ex = dada.observation("HDR_VERSION 1.0\nTSAMP 0.5\nFREQ 1400\nBW 16\n")
+    assert (info.nchan, info.npol, info.ndim, ex["nbit"], info.machine) == (1, 1, 1, 2, "DADA")   # ASCIIObservation defaults
+    assert info.rate == 2e6 and ex["ndat"] == 0 and ex["dual_sideband"] is None and info.start_seconds == 0.0
+    with pytest.raises(DspsrAmdError, match="invalid NDIM=3"):
+        dada.observation("TSAMP 1\nNDIM 3\n")
+    with pytest.raises(DspsrAmdError, match="strptime"):
+        dada.observation("TSAMP 1\nUTC_START yesterday\n")
+    with pytest.raises(DspsrAmdError, match="TSAMP"):
+        dada.observation("NDIM 1\n")
+
+
+def test_observation_matches_the_oracle(oracle):
+    raw = synth.dada_header(1382.0, -400.0, 8, 2, 2, 0.02, extra={"OBS_OFFSET": 64000, "DSB": 1, "DM": 67.99})
+    # OBS_OFFSET appears twice now (0 first): the first match wins, as in ascii_header_find
+    text = raw.split(b"\0", 1)[0].decode()
+    info, ex = dada.observation(text)
+    assert ex["offset_bytes"] == 0
+    text = text.replace("OBS_OFFSET 0\n", "")
+    info, ex = dada.observation(text)
+    obs = oracle.observation_from_header(oracle.parse_dada_header(text.encode()))
+    assert (info.centre_frequency, info.bandwidth, info.nchan, info.npol, info.ndim, ex["nbit"], info.machine) == \
+        (obs.centre_frequency, obs.bandwidth, obs.nchan, obs.npol, obs.ndim, obs.nbit, obs.machine)
+    assert info.rate == obs.rate and info.start_seconds == obs.start_seconds == 2000 * 0.02e-6
+    assert ex["dual_sideband"] is True and ex["dm"] == 67.99
+    assert (info.mjd_day, info.mjd_sec) == (55299, 7545.0)        # 2010-04-13-02:05:45
+
+
+def test_reference_benchmark_header():
+    if not os.path.exists(REF_HEADER):
+        pytest.skip("reference tree not present (GPU box)")
+    text = open(REF_HEADER, "rb").read().split(b"\0", 1)[0].decode("latin-1")
+    info, ex = dada.observation(text)
+    assert (info.centre_frequency, info.bandwidth, info.nchan, info.npol, info.ndim, ex["nbit"]) == (1382.0, -400.0, 1, 2, 1, 8)
+    assert info.machine == "CASPSR" and info.tsamp_us == 0.00125 and ex["source"] == "J0437-4715" and ex["telescope"] == "PKS"
+    assert (info.mjd_day, info.mjd_sec) == (55299, 7545.0) and ex["ndat"] == 1024000000000 and ex["resolution"] == 4
+
+
+def _fake_lt(step, overlap, ppb):
+    return types.SimpleNamespace(nsamp_step=step, nsamp_overlap=overlap, cfg=types.SimpleNamespace(parts_per_block=ppb))
+
+
+def test_file_layout_and_blocks(tmp_path):
+    # 2 input channels, complex, dual-pol: 8 bytes per time sample; HDR_SIZE larger than the first read
+    hdr = synth.dada_header(1400.0, 32.0, 2, 2, 2, 0.0625, size=8192)
+    ndat = 1000
+    data = (np.arange(ndat * 8) % 251 - 125).astype(np.int8)
+    p = tmp_path / "x.dada"
+    p.write_bytes(hdr + data.tobytes() + b"\x01\x02\x03")         # three stray bytes: not a whole sample
+    assert dada.is_valid(str(p))
+    f = dada.DadaFile(str(p))
+    assert (f.header_bytes, f.bytes_per_sample, f.ndat) == (8192, 8, ndat)
+    lt = _fake_lt(step=100, overlap=30, ppb=4)
+    assert f.nblocks(lt) == (2, 1)                                # (1000-30)//100 = 9 parts = 2 blocks of 4 + 1
+    got = list(f.blocks(lt))
+    assert [n for _, n in got] == [4, 4, 1]
+    for b, (blk, npart) in enumerate(got):
+        s0 = b * 400
+        assert np.array_equal(blk, data[s0 * 8:(s0 + npart * 100 + 30) * 8])          # consecutive blocks share the overlap
+    one = list(f.blocks(lt, channel=1))
+    assert np.array_equal(one[2][0], data.reshape(ndat, 2, 4)[800:930, 1, :].reshape(-1))
+    assert dada.DadaFile(str(p)).nblocks(_fake_lt(2000, 30, 4)) == (0, 0)
+    # header in a separate .hdr file (no HDR_SIZE): the data start at byte 0
+    q = tmp_path / "y.dada"
+    q.write_bytes(data.tobytes() + b"\0" * 4096)
+    text = hdr.split(b"\0", 1)[0].decode().replace("HDR_SIZE 8192\n", "")
+    (tmp_path / "y.hdr").write_text(text + "\n")
+    g = dada.DadaFile(str(q))
+    assert g.header_bytes == 0 and g.info.nchan == 2 and np.array_equal(np.asarray(g._map[:64]), data[:64])
+    r = tmp_path / "z.dada"
+    r.write_bytes(b"\0" * 100)
+    assert not dada.is_valid(str(r))
+    with pytest.raises(DspsrAmdError, match="fread"):
+        dada.read_header(str(r))
+    two = tmp_path / "two.dada"
+    two.write_bytes(synth.dada_header(1400.0, 32.0, 1, 2, 1, 0.0625).replace(b"NBIT 8", b"NBIT 2") + b"\0" * 64)
+    with pytest.raises(DspsrAmdError, match="NBIT=2"):
+        dada.DadaFile(str(two))
+
+
+@pytest.mark.gpu
+def test_fold_file_equals_resident_blocks(tmp_path):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    from dspsr_amd import pipeline
+    freq, bw, tsamp, dm, period = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004
+    cfg = pipeline.Config(nchan=16, dispersion_measure=dm, nbin=64, folding_period=period, ndim=4, parts_per_block=3,
+                          max_parts=2)
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA", mjd_day=55299, mjd_sec=7545.0)
+    stream = torch.cuda.current_stream().cuda_stream
+    ref = pipeline.LoadToFold(cfg, info, device=0, stream=stream)
+    step, ovl = ref.nsamp_step, ref.nsamp_overlap
+    nparts = 3 * 3 + 2                                             # three whole blocks and a ragged one of two parts
+    ndat = nparts * step + ovl + 17                                # 17 samples that no part uses
+    raw = synth.voltages(ndat, freq, bw, tsamp, dm, period)
+    path = tmp_path / "synthetic.dada"
+    path.write_bytes(synth.dada_header(freq, bw, 1, 2, 1, tsamp) + raw.tobytes())
+    dev = torch.from_numpy(raw.reshape(-1)).cuda()
+    for b in range(4):
+        npart = 3 if b < 3 else 2
+        s0 = b * 3 * step
+        ref.process_block(dev[2 * s0: 2 * (s0 + npart * step + ovl)], npart)
+    ref.finish_subint()
+    ref.synchronize()
+    want = ref.subints[0]
+    lt = dada.fold_file(str(path), cfg, device=0, stream=stream)
+    assert (lt.info.centre_frequency, lt.info.bandwidth, lt.info.machine, lt.info.mjd_day) == (freq, bw, "DADA", 55299)
+    got = lt.subints[0]
+    assert got["ndat_total"] == want["ndat_total"] == nparts * ref.nkeep
+    assert np.array_equal(got["hits"], want["hits"]) and torch.equal(got["profile_dev"], want["profile_dev"])
+    assert float(got["profile_dev"].abs().max()) > 0
+    lt.close()
+    ref.close()
+    short = tmp_path / "short.dada"
+    short.write_bytes(synth.dada_header(freq, bw, 1, 2, 1, tsamp) + raw.tobytes()[:2 * step])
+    with pytest.raises(DspsrAmdError, match="fewer than one overlap-save part"):
+        dada.fold_file(str(short), cfg, device=0, stream=stream)
