@@ -50,6 +50,12 @@ struct FbGeom {
   int logM, logR, logT1, logT2, logT3;   // four-pass mode: logM/logR are the forward factors Fa/Fb (L = Fa*Fb), logT3 = 0
   int logX3;                             // channels per block of the X layout (>= tile channels 2^logT3 of pass 3)
   int four_pass;                         // freq_res handled by a two-pass inverse (k_inv_a + k_inv_b)
+  int xblocked;                          // four-pass mode: spectrum element k = ka + Fa*kb lies at X[(ka >> logT2)*xblock + (kb << logT2
+                                         //   | (ka & (T2-1)))] -- every pass-2 tile is one contiguous block (see k_fwd_rows / k_inv_a)
+  uint32_t xblock;                       // elements from one block to the next: 2^(logR+logT2) + padding (power-of-two strides
+                                         //   between the pieces a k_inv_a tile reads would all fall on the same memory channels)
+  uint32_t kblock;                       // the same for the chirp on the device (k < N only, no padding): (N >> logM) << logT2
+  uint64_t xstride;                      // elements from one spectrum (sequence) to the next in X: L, or the padded size
   int logMf, logMa, logMb, logTm, logTt; // freq_res = Ma*Mb ; m2 columns per k_inv_a tile ; t1 columns per k_inv_b tile
   int real_input, npol;
   uint32_t C, nfilt_pos, nkeep;
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
 #endif
 
     const uint32_t tile = item & (ntile - 1);
-    cf* __restrict__ Xseq = X + seq_of(item) * L;
+    cf* __restrict__ Xseq = X + seq_of(item) * g.xstride;
     // last-stage outputs go to LDS in X-layout order [s'/T3][klo][s'%T3]; after a barrier the tile is
     // written out as whole runs of T2*T3 elements with 16-byte-per-lane stores.  XOR swizzle of the image
     // (bits 1,2 ^= bits 4,5) against bank conflicts of the 8-byte scatter (42 % of this pass's LDS cycles)
@@ -763,7 +769,11 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
         const uint32_t l = 2 * (tid + jj * nthr);
         const uint32_t blkX = l >> (logT + logT3), within = l & ((1u << (logT + logT3)) - 1);
         const float4 pr = *(const float4*)&lds[lds_pad(l ^ (((l >> 4) & swz) << 1))];
-        st_stream((float4*)&Xseq[((((uint64_t)blkX << g.logM) + tile * T2) << logT3) + within], pr);
+        // four-pass mode (xblocked): the tile's image [kb][ka % T2] IS its block of X -- one contiguous 2^14-element
+        // store instead of runs of T2 elements scattered over the natural order
+        const uint64_t xo = g.xblocked ? (uint64_t)tile * g.xblock + l
+                                       : ((((uint64_t)blkX << g.logM) + tile * T2) << logT3) + within;
+        st_stream((float4*)&Xseq[xo], pr);
       }
     }
 #if defined(FB_STAMPS) && FB_STAMPS == 2
@@ -1242,7 +1252,8 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 // ------------------------------------------------------------------------------------ P3a / P3b
 // Two-pass inverse transform for freq_res = Ma*Mb beyond one workgroup tile (and for nchan_subband = 1,
 // i.e. dsp::Convolution): bin m = m1*Mb + m2, output sample t = t1 + Ma*t2.
-//   P3a k_inv_a : spectrum X in natural order (k = c*freq_res + m) -> Hermitian split / pol select -> x chirp
+//   P3a k_inv_a : spectrum X (bin k = c*freq_res + m, blocked by pass-2 tile: FbGeom::xblocked) -> Hermitian split / pol
+//                 select -> x chirp
 //                 -> inverse Ma-point FFTs over m1 for Tm adjacent m2 -> x conj(W_M^{m2*t1})
 //                 -> U[c][t1/Tt][m2][t1%Tt][pol]
 //   P3b k_inv_b : inverse Mb-point FFTs over m2 for Tt adjacent t1 (one contiguous block of U)
@@ -1266,13 +1277,53 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
   const int logNt = g.logMb - logTm;        // ntile = 2^logNt
   struct Abk { cf a, b; };
 
+  // Blocked spectrum (FbGeom::xblocked, written by k_fwd_rows): bin k = ka + Fa*kb lies at
+  // (ka >> logT2)*xblock + (kb << logT2 | ka % T2).  The tile's Ma x Tm bins are enumerated in MEMORY order -- the low
+  // bits of m2 (inside a run of T2), then the bits of m1 that fall into kb (consecutive in memory), then the rest -- so a
+  // wave's load covers whole runs (1 KB at -F 64:D -x 262144) although a first-stage butterfly needs bins Ma/16 rows apart;
+  // the split and chirp-multiplied elements change to butterfly order through the exchange buffer (one extra LDS round trip).
+  // Loading in butterfly order instead touches 32-byte pieces 128 KB apart: +54 % on this pass (r02 experiments, item 18).
+  const int nlow = g.logT2 < logTm ? g.logT2 : logTm;
+  const int hs0 = g.logM - g.logMb, hs = hs0 < 0 ? 0 : (hs0 > LOGF ? LOGF : hs0);    // m1 bits below `hs` stay in ka
+  const int nhh = LOGF - hs, nlh = logTm - nlow;
+  const uint32_t maskA = (1u << g.logM) - 1, maskT = (1u << g.logT2) - 1;
+  auto tile_elem = [&](const uint32_t e, uint32_t& m1, uint32_t& j) {
+    const uint32_t w = e & ((1u << nlow) - 1), e1 = e >> nlow;
+    const uint32_t mhh = e1 & ((1u << nhh) - 1), e2 = e1 >> nhh;
+    j = ((e2 & ((1u << nlh) - 1)) << nlow) | w;
+    m1 = (mhh << hs) | (e2 >> nlh);
+  };
+  auto xa = [&](const uint32_t k) -> uint32_t {            // k < L
+    const uint32_t ka = k & maskA, kb = k >> g.logM;
+    return (ka >> g.logT2) * g.xblock + ((kb << g.logT2) | (ka & maskT));
+  };
+  auto xk = [&](const uint32_t k) -> uint32_t {            // the chirp, permuted likewise by set_kernel (no padding)
+    const uint32_t ka = k & maskA, kb = k >> g.logM;
+    return (ka >> g.logT2) * g.kblock + ((kb << g.logT2) | (ka & maskT));
+  };
+
   auto fetch = [&](const uint32_t item, Abk (&raw)[PTS / 2]) {
-    const uint32_t part = item / per_part, r = item - part * per_part;
+    const uint32_t r = (FB_DBG(g) & 256) ? item % per_part : item / nparts, part = (FB_DBG(g) & 256) ? item / per_part : item - r * nparts;
     const uint32_t c = r >> logNt, tile = r & (ntile - 1);
-    const cf* __restrict__ X0s = X + (uint64_t)part * nseq * L;
+    const cf* __restrict__ X0s = X + (uint64_t)part * nseq * g.xstride;
     if (FB_DBG(g) & 2) {
 #pragma unroll
       for (int i = 0; i < NPAIR; i++) { raw[i].a = make_float2(tid, i); raw[i].b = raw[i].a; }
+      return;
+    }
+    if (g.xblocked) {
+      const uint32_t kt = (c << g.logMf) + tile * Tm, Lw = (uint32_t)L, nthr = blockDim.x;
+#pragma unroll
+      for (int i = 0; i < PTS / 2; i++) {
+        uint32_t m1, j;
+        tile_elem(tid + i * nthr, m1, j);
+        const uint32_t k = kt + (m1 << g.logMb) + j;
+        Abk q;
+        q.a = ld_stream(X0s + xa(k));
+        if (g.real_input) q.b = ld_stream(X0s + (k == 0 ? 0u : xa(Lw - k)));
+        else q.b = g.npol == 2 ? ld_stream(X0s + g.xstride + xa(k)) : make_float2(0.f, 0.f);
+        raw[i] = q;
+      }
       return;
     }
     // element i of the first-stage butterfly is bin k0 + i*step (m1 advances by MS): base plus a multiple of a
@@ -1300,19 +1351,34 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
-  uint32_t item, next;
-  uint32_t jn = 0;
-  if (!persistent_item(blockIdx.x, gridDim.x, jn, run, total, item)) return;
+  // Items are (tile, part) pairs with the part running fastest, and every workgroup takes one contiguous range of them: it
+  // walks the parts of a tile one after the other, so the tile's chirp is loaded once and stays in registers
+  // (one chirp read per launch instead of one per part: -1/7 of this pass's traffic at 8 parts per launch).
+  uint32_t item = (uint32_t)(((uint64_t)total * blockIdx.x) / gridDim.x);
+  const uint32_t item_end = (uint32_t)(((uint64_t)total * (blockIdx.x + 1)) / gridDim.x);
+  if (item >= item_end) return;
+  uint32_t next;
   Abk raw[PTS / 2];
   fetch(item, raw);
+  cf kk[PTS / 2];
+  uint32_t kk_tile = 0xffffffffu;
   for (;;) {
     asm volatile("" : "+v"(tid));
-    const uint32_t part = item / per_part, r = item - part * per_part;
+    const uint32_t r = (FB_DBG(g) & 256) ? item % per_part : item / nparts, part = (FB_DBG(g) & 256) ? item / per_part : item - r * nparts;
     const uint32_t c = r >> logNt, tile = r & (ntile - 1);
     cx2 x[NPAIR];
     {
-      cf kk[PTS / 2];
-      if (kernel && !(FB_DBG(g) & 2)) {
+      if (r == kk_tile) {
+        // chirp of this tile already in registers
+      } else if (kernel && !(FB_DBG(g) & 2) && g.xblocked) {
+        const uint32_t kt = (c << g.logMf) + tile * Tm, nthr = blockDim.x;
+#pragma unroll
+        for (int i = 0; i < PTS / 2; i++) {
+          uint32_t m1, j;
+          tile_elem(tid + i * nthr, m1, j);
+          kk[i] = kernel[xk(kt + (m1 << g.logMb) + j)];
+        }
+      } else if (kernel && !(FB_DBG(g) & 2)) {
         constexpr uint32_t MS = 1u << (LOGF - P::LOGR1);
 #pragma unroll
         for (int g2 = 0; g2 < P::G1; g2 += 2) {
@@ -1326,6 +1392,7 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
 #pragma unroll
         for (int i = 0; i < PTS / 2; i++) kk[i] = make_float2(1.f, 0.f);
       }
+      kk_tile = r;
 #pragma unroll
       for (int i = 0; i < PTS / 2; i++) {
         const Abk q = raw[i];
@@ -1340,8 +1407,30 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
         x[i] = cmuls(make_cx2(x0, x1), kk[i]);
       }
     }
-    const bool more = persistent_item(blockIdx.x, gridDim.x, ++jn, run, total, next);
+    next = item + 1;
+    const bool more = next < item_end;
     if (more) fetch(next, raw);
+    if (g.xblocked) {
+      // memory order -> butterfly order: element (m1, j) of the tile (both polarisations, 16 bytes) at word pair m1*Tm + j
+      __syncthreads();                         // the previous tile's copy-out has finished with the buffer
+      const uint32_t nthr = blockDim.x;
+#pragma unroll
+      for (int i = 0; i < PTS / 2; i++) {
+        uint32_t m1, j;
+        tile_elem(tid + i * nthr, m1, j);
+        *(float4*)&lds[lds_pad(((m1 << logTm) + j) << 1)] = make_float4(x[i].x[0], x[i].x[1], x[i].y[0], x[i].y[1]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int g2 = 0; g2 < P::G1; g2 += 2)
+#pragma unroll
+        for (int i = 0; i < P::R1; i++) {
+          const float4 pr = *(const float4*)&lds[lds_pad(first_stage_elem<LOGF>(tid, logT, g2, i))];
+          x[(g2 / 2) * P::R1 + i].x = (v2f){pr.x, pr.y};
+          x[(g2 / 2) * P::R1 + i].y = (v2f){pr.z, pr.w};
+        }
+      __syncthreads();                         // before the first stage's exchange overwrites the buffer
+    }
 
     cf* __restrict__ Uc = U + ((uint64_t)part * g.C + c) * (2ull << g.logMf);
     // staged image order [t1/Tt][j][t1%Tt][pol]: whole runs of Tm*Tt*2 elements go out with 16-byte stores
@@ -1422,38 +1511,60 @@ __global__ __launch_bounds__(512) void k_inv_b(const FbGeom g, const cf* __restr
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++jn, run, total, next);
     if (more) fetch(next, y);
 
+    // (uniform output kind / ndim decided once per butterfly, not per element: the compiler does not unswitch them out of
+    //  the unrolled loop; the keep window is the only per-element test)
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
       if (out.kind == 0) return;
       const uint32_t chan = out.chan0 + c;
       const uint32_t t1 = (tile << logTt) + (col >> 1);
       float* __restrict__ row = out.base + chan * out.chan_stride;
+      auto each = [&](auto&& emit) {
 #pragma unroll
-      for (int k = 0; k < R; k++) {
-        const uint32_t pos = ((k * pstride + p) << g.logMa) + t1;
-        if (pos < g.nfilt_pos || pos >= g.nfilt_pos + g.nkeep) continue;
-        const uint32_t t = pos - g.nfilt_pos;
-        const cf va = cx2_lo(v[k]), vb = cx2_hi(v[k]);
-        if (out.kind == 1) {
-          float2* o = (float2*)(row + part * out.part_step) + t;
-          st_stream(o, va);
-          if (g.npol == 2) st_stream((float2*)((float*)o + out.pol_stride), vb);
-        } else {
+        for (int k = 0; k < R; k++) {
+          const uint32_t pos = ((k * pstride + p) << g.logMa) + t1;
+          if (pos < g.nfilt_pos || pos >= g.nfilt_pos + g.nkeep) continue;
+          emit(pos - g.nfilt_pos, cx2_lo(v[k]), cx2_hi(v[k]));
+        }
+      };
+      if (out.kind == 1) {
+        float2* __restrict__ o0 = (float2*)(row + part * out.part_step);
+        if (g.npol == 2)
+          each([&](const uint32_t t, const cf va, const cf vb) {
+            st_stream(o0 + t, va);
+            st_stream((float2*)((float*)(o0 + t) + out.pol_stride), vb);
+          });
+        else
+          each([&](const uint32_t t, const cf va, const cf) { st_stream(o0 + t, va); });
+        return;
+      }
+      const uint64_t idat0 = part * g.nkeep;
+      if (out.ndim == 4) {
+        float4* __restrict__ o = (float4*)row + idat0;
+        each([&](const uint32_t t, const cf va, const cf vb) {
           float q[4];
           detect4(va, vb, out.state, q);
-          const uint64_t idat = part * g.nkeep + t;
-          if (out.ndim == 4) {
-            st_stream(&((float4*)row)[idat], make_float4(q[0], q[1], q[2], q[3]));
-          } else if (out.ndim == 2) {
-            st_stream(&((float2*)row)[idat], make_float2(q[0], q[1]));
-            st_stream(&((float2*)(row + out.pol_stride))[idat], make_float2(q[2], q[3]));
-          } else {
-            row[idat] = q[0];
-            row[out.pol_stride + idat] = q[1];
-            row[2 * out.pol_stride + idat] = q[2];
-            row[3 * out.pol_stride + idat] = q[3];
-          }
-        }
+          st_stream(o + t, make_float4(q[0], q[1], q[2], q[3]));
+        });
+      } else if (out.ndim == 2) {
+        float2* __restrict__ o = (float2*)row + idat0;
+        float2* __restrict__ o1 = (float2*)(row + out.pol_stride) + idat0;
+        each([&](const uint32_t t, const cf va, const cf vb) {
+          float q[4];
+          detect4(va, vb, out.state, q);
+          st_stream(o + t, make_float2(q[0], q[1]));
+          st_stream(o1 + t, make_float2(q[2], q[3]));
+        });
+      } else {
+        float* __restrict__ o = row + idat0;
+        each([&](const uint32_t t, const cf va, const cf vb) {
+          float q[4];
+          detect4(va, vb, out.state, q);
+          o[t] = q[0];
+          o[out.pol_stride + t] = q[1];
+          o[2 * out.pol_stride + t] = q[2];
+          o[3 * out.pol_stride + t] = q[3];
+        });
       }
     };
     wgfft<LOGF, +1>(lds, ltw_off, tid, logT, x, store);
@@ -1651,6 +1762,9 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   g.logR = ilog2(Rr);
   g.logMf = logMf;
   g.four_pass = 0;
+  g.xblocked = 0;
+  g.xblock = g.kblock = 0;
+  g.xstride = fb->L;
   g.logMa = g.logMb = g.logTm = g.logTt = 0;
   g.tw_lo = g.tw_lo_m = nullptr;
   g.real_input = cfg->real_input ? 1 : 0;
@@ -1685,13 +1799,23 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     p1 = M << g.logT1; p2 = Rr << g.logT2; p3 = (M << g.logT3) << logPol;
     three_ok = !(p1 < 32 || p2 < 32 || p3 < 32 || p3 > (1u << LOG_POINTS) || g.logT1 < 1 || g.logT2 < 1);
   }
-  // ... otherwise four: L = Fa*Fb forward (spectrum in natural order), freq_res = Ma*Mb inverse in two passes.
+  // ... otherwise four: L = Fa*Fb forward (whole spectrum, blocked by pass-2 tile), freq_res = Ma*Mb inverse in two passes.
   // This also covers nchan_subband = 1 (dsp::Convolution) and freq_res up to 2^26.
   if (cfg->force_four_pass || !three_ok) {
     int la = (logL + 1) / 2;
     if (la > MAX_LOGF) la = MAX_LOGF;
     const int lb = logL - la;
+    // spectrum layout between pass 2 and the inverse: blocked (every pass-2 tile one contiguous block) when the natural
+    // order would leave pass 2 with runs of fewer than 16 elements (128 bytes); measured per geometry, blocked is then
+    // 15-40 % faster over the whole launch group, natural 3 % faster otherwise (profiles/r02x_inverse_split.txt)
+    const int logT2f = imin(la, LOG_POINTS - (logL - la));
+    const bool blocked = FB_ENV_SET("DSPSR_AMD_X_NATURAL") ? false : FB_ENV_SET("DSPSR_AMD_X_BLOCKED") ? true : logT2f < 4;
+    // freq_res = Ma*Mb: the split that measured fastest (same file).  The second inverse pass likes Mb = 256 (two
+    // radix-16 stages, 32 adjacent output samples per run), the first one Ma <= 2^11 (>= 4 columns per tile).
+    static const signed char lma_best[27] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, -1, 10, 11, 11, 11, 12, 12, 13};
     int lma = (logMf + 1) / 2;
+    if (logMf >= 14 && logMf <= 26) lma = lma_best[logMf] > 0 ? lma_best[logMf] : (blocked ? 11 : 9);
+    lma = FB_ENV_INT("DSPSR_AMD_LMA", lma);
     if (lma > MAX_LOGF) lma = MAX_LOGF;
     const int lmb = logMf - lma;
     g.logM = la; g.logR = lb; g.logT3 = g.logX3 = 0;
@@ -1712,6 +1836,12 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
                      "and factors <= 2^%d)", (unsigned long long)C, (unsigned long long)M, la, lb, lma, lmb, MAX_LOGF);
     }
     g.four_pass = 1;
+    g.xblocked = blocked ? 1 : 0;
+    if (g.xblocked) {
+      g.xblock = (1u << (lb + g.logT2)) + (uint32_t)FB_ENV_INT("DSPSR_AMD_XPAD", 0);     // padding: even (16-byte stores)
+      g.xstride = (uint64_t)g.xblock << (la - g.logT2);
+      g.kblock = (uint32_t)((fb->N >> la) << g.logT2);
+    }
   }
   fb->nt1 = (uint32_t)(p1 / PTS);
   fb->nt2 = (uint32_t)(p2 / PTS);
@@ -1770,7 +1900,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   }
   fb->max_parts = cfg->max_parts ? cfg->max_parts : 1;
   // per part: nseq sequences of L points; the two-pass inverse re-uses A for 2 polarisations x N bins
-  fb->part_elems = fb->nseq * fb->L;
+  fb->part_elems = fb->nseq * g.xstride;       // (A needs nseq*L; X the same or, blocked and padded, a little more)
   if (g.four_pass && fb->part_elems < 2 * fb->N) fb->part_elems = 2 * fb->N;
   const size_t scratch = (size_t)fb->max_parts * fb->part_elems * sizeof(cf);
   if (hipMalloc((void**)&fb->A, scratch) != hipSuccess || hipMalloc((void**)&fb->X, scratch) != hipSuccess) {
@@ -1841,7 +1971,21 @@ extern "C" int dspsr_amd_filterbank_set_kernel(dspsr_amd_filterbank* fb, const f
                    (unsigned long long)ncomplex, (unsigned long long)expect);
   if (!fb->kernel && hipMalloc((void**)&fb->kernel, expect * sizeof(cf)) != hipSuccess)
     return fb_fail(fb->ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_set_kernel: hipMalloc failed");
-  hipError_t e = hipMemcpyAsync(fb->kernel, kernel_host, expect * sizeof(cf), hipMemcpyHostToDevice, fb->ctx->stream);
+  const cf* src = (const cf*)kernel_host;
+  std::vector<cf> perm;
+  if (fb->g.xblocked) {
+    // four-pass geometries: the chirp lies on the device in the order of the blocked spectrum (k_inv_a loads both alike)
+    const FbGeom& g = fb->g;
+    const uint64_t N = fb->N, maskA = (1ull << g.logM) - 1, maskT = (1ull << g.logT2) - 1;
+    perm.resize(expect);
+    for (uint64_t ic = 0; ic < fb->cfg.input_nchan; ic++)
+      for (uint64_t k = 0; k < N; k++) {
+        const uint64_t ka = k & maskA, kb = k >> g.logM;
+        perm[ic * N + (ka >> g.logT2) * g.kblock + ((kb << g.logT2) | (ka & maskT))] = src[ic * N + k];
+      }
+    src = perm.data();
+  }
+  hipError_t e = hipMemcpyAsync(fb->kernel, src, expect * sizeof(cf), hipMemcpyHostToDevice, fb->ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(fb->ctx->stream);
   if (e != hipSuccess)
     return fb_fail(fb->ctx, DSPSR_AMD_EHIP, "dspsr_amd_filterbank_set_kernel: %s", hipGetErrorString(e));
@@ -2038,7 +2182,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
                              ctx->tw, part0, nb, run3);
         }
       } else {
-        // two-pass inverse: X (natural order) -> U (in the A buffer, dead after pass 2) -> output
+        // two-pass inverse: X (whole spectrum) -> U (in the A buffer, dead after pass 2) -> output
         const uint64_t n3a = ((uint64_t)g.C << (g.logMb - g.logTm)) * nb, n3b = ((uint64_t)g.C << (g.logMa - g.logTt)) * nb;
         hipLaunchKernelGGL(k3a, dim3(grid_for(n3a, fb->ncu * fb->wg_per_cu)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern,
                            fb->A, ctx->tw, nb, 8u);
