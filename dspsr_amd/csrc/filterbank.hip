@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 //   P3b k_inv_b : inverse Mb-point FFTs over m2 for Tt adjacent t1 (one contiguous block of U)
 //                 -> keep window on t = t1 + Ma*t2 -> complex output or fused detection
 // Columns of both tiles are (column, pol) pairs, so the thread's two butterflies are the two polarisations.
-template <int LOGF>
+template <int LOGF, bool BLOCKED>
 __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restrict__ X, const cf* __restrict__ kernel,
                                                cf* __restrict__ U, const cf* __restrict__ tw, const uint32_t nparts,
                                                const uint32_t run)
@@ -1301,6 +1301,39 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
     const uint32_t ka = k & maskA, kb = k >> g.logM;
     return (ka >> g.logT2) * g.kblock + ((kb << g.logT2) | (ka & maskT));
   };
+  // The enumeration is a permutation of index BITS, and the element index of a thread's i-th element is tid + i*nthr
+  // (nthr a power of two), so bin index, spectrum address, chirp address and staging address of that element all split
+  // into a part that depends on the thread, a part that depends on the item (uniform) and one uniform increment per
+  // bit of i: disjoint bit fields add.  16 elements then cost one vector add each instead of a full decode (the decode
+  // per element made this pass issue 2650 vector instructions per thread and tile, 42 % of them integer).
+  auto stg = [&](const uint32_t m1, const uint32_t j) { return lds_pad(((m1 << logTm) + j) << 1); };
+  uint32_t thr_k, thr_st, Dk[4], Dxa[4], Dxk[4], Dst[4];
+  {
+    uint32_t m1, j;
+    tile_elem(tid, m1, j);
+    thr_k = (m1 << g.logMb) + j;
+    thr_st = stg(m1, j);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      tile_elem((uint32_t)blockDim.x << b, m1, j);
+      Dk[b] = (m1 << g.logMb) + j;
+      Dxa[b] = xa(Dk[b]);
+      Dxk[b] = xk(Dk[b]);
+      Dst[b] = stg(m1, j);
+    }
+  }
+  const uint32_t thr_xa = xa(thr_k), thr_xk = xk(thr_k);
+  // Mirror bin L - k = ~k + 1 (real input).  ~k complements every bit field, so its address is xa(L-1) - xa(k); the + 1
+  // adds 1 when the low T2 bits of k are not all zero, else carries into the row-group field (+ xblock - (T2-1)), else
+  // into kb.  Which case applies is decided by the thread/item part of k unless the increment of element i reaches into
+  // ka (uniform test): one select and one subtraction per element instead of a second full address computation.
+  const uint32_t XAM = xa((uint32_t)L - 1), dCarryA = g.xblock - maskT,
+                 dCarryB = (1u << g.logT2) - maskT - (maskA >> g.logT2) * g.xblock;
+  // (the element increments never reach the low T2 bits of k: dspsr_amd_filterbank_create uses the blocked layout only
+  //  when Mb >= T2 and the workgroup has at least T2 threads)
+  auto inc = [&](const uint32_t (&D)[4], const int i) {
+    return ((i & 1) ? D[0] : 0u) + ((i & 2) ? D[1] : 0u) + ((i & 4) ? D[2] : 0u) + ((i & 8) ? D[3] : 0u);
+  };
 
   auto fetch = [&](const uint32_t item, Abk (&raw)[PTS / 2]) {
     const uint32_t r = (FB_DBG(g) & 256) ? item % per_part : item / nparts, part = (FB_DBG(g) & 256) ? item / per_part : item - r * nparts;
@@ -1311,17 +1344,32 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
       for (int i = 0; i < NPAIR; i++) { raw[i].a = make_float2(tid, i); raw[i].b = raw[i].a; }
       return;
     }
-    if (g.xblocked) {
-      const uint32_t kt = (c << g.logMf) + tile * Tm, Lw = (uint32_t)L, nthr = blockDim.x;
+    if constexpr (BLOCKED) {
+      const uint32_t kt = (c << g.logMf) + tile * Tm;
+      const uint32_t k0 = kt + thr_k, a0 = xa(kt) + thr_xa;
+      const cf* __restrict__ X1s = X0s + g.xstride;
+      if (g.real_input) {
+        const uint32_t lowT = k0 & maskT, lowA = k0 & maskA;
+        const uint32_t E1 = XAM + (lowT ? 1u : dCarryA);                               // increment reaches into ka
+        const uint32_t E2 = XAM + (lowT ? 1u : (lowA ? dCarryA : dCarryB));            // increment in kb only
+#pragma unroll
+        for (int i = 0; i < PTS / 2; i++) {
+          const uint32_t ia = a0 + inc(Dxa, i);
+          uint32_t ib = ((inc(Dk, i) & maskA) ? E1 : E2) - ia;
+          if (i == 0) ib = k0 == 0 ? 0u : ib;                                          // bin 0 is its own mirror
+          Abk q;
+          q.a = ld_stream(X0s + ia);
+          q.b = ld_stream(X0s + ib);
+          raw[i] = q;
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < PTS / 2; i++) {
-        uint32_t m1, j;
-        tile_elem(tid + i * nthr, m1, j);
-        const uint32_t k = kt + (m1 << g.logMb) + j;
+        const uint32_t ia = a0 + inc(Dxa, i);
         Abk q;
-        q.a = ld_stream(X0s + xa(k));
-        if (g.real_input) q.b = ld_stream(X0s + (k == 0 ? 0u : xa(Lw - k)));
-        else q.b = g.npol == 2 ? ld_stream(X0s + g.xstride + xa(k)) : make_float2(0.f, 0.f);
+        q.a = ld_stream(X0s + ia);
+        q.b = g.npol == 2 ? ld_stream(X1s + ia) : make_float2(0.f, 0.f);
         raw[i] = q;
       }
       return;
@@ -1360,24 +1408,20 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
   uint32_t next;
   Abk raw[PTS / 2];
   fetch(item, raw);
-  cf kk[PTS / 2];
-  uint32_t kk_tile = 0xffffffffu;
   for (;;) {
     asm volatile("" : "+v"(tid));
     const uint32_t r = (FB_DBG(g) & 256) ? item % per_part : item / nparts, part = (FB_DBG(g) & 256) ? item / per_part : item - r * nparts;
     const uint32_t c = r >> logNt, tile = r & (ntile - 1);
     cx2 x[NPAIR];
     {
-      if (r == kk_tile) {
-        // chirp of this tile already in registers
-      } else if (kernel && !(FB_DBG(g) & 2) && g.xblocked) {
-        const uint32_t kt = (c << g.logMf) + tile * Tm, nthr = blockDim.x;
+      // (the chirp is re-read for every part of the tile -- from the L2, the workgroup has just used it: keeping it in
+      //  registers across the parts costs 32 registers that the 256-register budget does not have; the spills then wait
+      //  on the in-order vector-memory counter behind the prefetched tile: 1379 -> 1767 us)
+      cf kk[PTS / 2];
+      if (BLOCKED && kernel && !(FB_DBG(g) & 2)) {
+        const uint32_t c0 = xk((c << g.logMf) + tile * Tm) + thr_xk;
 #pragma unroll
-        for (int i = 0; i < PTS / 2; i++) {
-          uint32_t m1, j;
-          tile_elem(tid + i * nthr, m1, j);
-          kk[i] = kernel[xk(kt + (m1 << g.logMb) + j)];
-        }
+        for (int i = 0; i < PTS / 2; i++) kk[i] = kernel[c0 + inc(Dxk, i)];
       } else if (kernel && !(FB_DBG(g) & 2)) {
         constexpr uint32_t MS = 1u << (LOGF - P::LOGR1);
 #pragma unroll
@@ -1392,7 +1436,6 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
 #pragma unroll
         for (int i = 0; i < PTS / 2; i++) kk[i] = make_float2(1.f, 0.f);
       }
-      kk_tile = r;
 #pragma unroll
       for (int i = 0; i < PTS / 2; i++) {
         const Abk q = raw[i];
@@ -1410,16 +1453,12 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
     next = item + 1;
     const bool more = next < item_end;
     if (more) fetch(next, raw);
-    if (g.xblocked) {
+    if constexpr (BLOCKED) {
       // memory order -> butterfly order: element (m1, j) of the tile (both polarisations, 16 bytes) at word pair m1*Tm + j
       __syncthreads();                         // the previous tile's copy-out has finished with the buffer
-      const uint32_t nthr = blockDim.x;
 #pragma unroll
-      for (int i = 0; i < PTS / 2; i++) {
-        uint32_t m1, j;
-        tile_elem(tid + i * nthr, m1, j);
-        *(float4*)&lds[lds_pad(((m1 << logTm) + j) << 1)] = make_float4(x[i].x[0], x[i].x[1], x[i].y[0], x[i].y[1]);
-      }
+      for (int i = 0; i < PTS / 2; i++)
+        *(float4*)&lds[thr_st + inc(Dst, i)] = make_float4(x[i].x[0], x[i].x[1], x[i].y[0], x[i].y[1]);
       __syncthreads();
 #pragma unroll
       for (int g2 = 0; g2 < P::G1; g2 += 2)
@@ -1595,7 +1634,7 @@ k1_t fb_pick1(int logf, int raww, bool full);
 k2_t fb_pick2(int logf, bool full);
 k3_t fb_pick3(int logf, bool full);       // plain
 k3_t fb_pick3f(int logf, bool full);      // fused fold
-k3a_t fb_pick3a(int logf);
+k3a_t fb_pick3a(int logf, bool blocked);
 k3b_t fb_pick3b(int logf);
 void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 
@@ -1621,7 +1660,7 @@ k3_t fb_pick3(int logf, bool full) { return logf != 12 ? nullptr : (full ? k_inv
 k3_t fb_pick3f(int logf, bool full) { return logf != 12 ? nullptr : (full ? k_inv_chan<12, true, 2> : k_inv_chan<12, true, -1>); }
 #endif
 #if FB_HAS(4)
-k3a_t fb_pick3a(int) { return nullptr; }
+k3a_t fb_pick3a(int, bool) { return nullptr; }
 k3b_t fb_pick3b(int) { return nullptr; }
 #endif
 #else
@@ -1664,9 +1703,14 @@ template <int... I> static k3_t pick3f(int logf, bool full, iseq<I...>)
 k3_t fb_pick3f(int logf, bool full) { return pick3f(logf, full, seq_t()); }
 #endif
 #if FB_HAS(4)
-template <int... I> static k3a_t pick3a(int logf, iseq<I...>) { static const k3a_t t[] = {k_inv_a<I>...}; return t[logf]; }
+template <int... I> static k3a_t pick3a(int logf, bool blocked, iseq<I...>)
+{
+  static const k3a_t tn[] = {k_inv_a<I, false>...};
+  static const k3a_t tb[] = {k_inv_a<I, true>...};
+  return blocked ? tb[logf] : tn[logf];
+}
 template <int... I> static k3b_t pick3b(int logf, iseq<I...>) { static const k3b_t t[] = {k_inv_b<I>...}; return t[logf]; }
-k3a_t fb_pick3a(int logf) { return pick3a(logf, seq_t()); }
+k3a_t fb_pick3a(int logf, bool blocked) { return pick3a(logf, blocked, seq_t()); }
 k3b_t fb_pick3b(int logf) { return pick3b(logf, seq_t()); }
 #endif
 #endif
@@ -1836,7 +1880,8 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
                      "and factors <= 2^%d)", (unsigned long long)C, (unsigned long long)M, la, lb, lma, lmb, MAX_LOGF);
     }
     g.four_pass = 1;
-    g.xblocked = blocked ? 1 : 0;
+    // (k_inv_a's address arithmetic assumes that a thread's 16 elements differ in bits of k above the low T2 ones)
+    g.xblocked = (blocked && lmb >= g.logT2 && (p3 / PTS) >= (1u << g.logT2)) ? 1 : 0;
     if (g.xblocked) {
       g.xblock = (1u << (lb + g.logT2)) + (uint32_t)FB_ENV_INT("DSPSR_AMD_XPAD", 0);     // padding: even (16-byte stores)
       g.xstride = (uint64_t)g.xblock << (la - g.logT2);
@@ -1866,7 +1911,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
 #endif
     fb->k2 = fb_pick2(g.logR, full2);
     if (g.four_pass) {
-      fb->k3a = fb_pick3a(g.logMa);
+      fb->k3a = fb_pick3a(g.logMa, g.xblocked != 0);
       fb->k3b = fb_pick3b(g.logMb);
     } else {
       fb->k3 = fb_pick3(g.logM, full3);

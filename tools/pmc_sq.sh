@@ -1,7 +1,7 @@
 # SQ issue/wait counters per kernel (one pass, 8 SQ slots)
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmc_sq
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d gpurun_out/pmc_sq -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_sq.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d gpurun_out/pmc_sq -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS > gpurun_out/pmc_sq.log 2>&1
 f=$(find gpurun_out/pmc_sq -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys,collections

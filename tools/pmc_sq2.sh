@@ -2,7 +2,7 @@
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for set in "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_SCA" "SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU"; do
 rm -rf gpurun_out/pmc_sq2
-timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_sq2 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_sq2.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_sq2 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS > gpurun_out/pmc_sq2.log 2>&1
 f=$(find gpurun_out/pmc_sq2 -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys,collections
