@@ -518,15 +518,25 @@ class LoadToFold:
             delays = dedispersion_sample_delays(info.centre_frequency, info.bandwidth, cfg.dispersion_measure, cfg.nchan,
                                                 self.out_rate, swap=dual and info.nchan == 1,
                                                 nsub_swap=info.nchan if dual and info.nchan > 1 else 0)
-            if subband is not None:
-                raise DspsrAmdError("dspsr_amd.LoadToFold: -K with sub-band sharding is not built (the shards would "
-                                    "need the delays of the whole band)")
-            self.sample_delay = SampleDelay(self.ctx, delays, self.npol_out)
-            head = self.sample_delay.total_delay
+            self.sd_short = 0
+            if subband is None:
+                self.sample_delay = SampleDelay(self.ctx, delays, self.npol_out)
+                head, zero = self.sample_delay.total_delay, self.sample_delay.zero_delay
+            else:
+                # a sub-band rank applies ITS channels' delays relative to the zero of the WHOLE band and gives up the
+                # whole band's total delay per block, so that every rank emits the same samples with the same start time
+                # (SampleDelay.C:75-99 on the full band; the rank's slice goes in as absolute delays)
+                d = np.asarray(delays, np.int64)
+                zero = int(d.max())
+                applied = zero - d
+                head = int(applied.max())
+                mine = applied[subband * nsub:(subband + 1) * nsub]
+                self.sample_delay = SampleDelay(self.ctx, mine, self.npol_out, absolute=True)
+                self.sd_short = head - self.sample_delay.total_delay       # samples this rank must NOT emit
             if head > cfg.parts_per_block * self.nkeep:
                 raise DspsrAmdError("dspsr_amd.LoadToFold: inter-channel delay of %d samples exceeds the block of %d"
                                     % (head, cfg.parts_per_block * self.nkeep))
-            self.out_start += self.sample_delay.zero_delay / self.out_rate       # SampleDelay.C:159
+            self.out_start += zero / self.out_rate                               # SampleDelay.C:159
         self.sd_head = head
         self.detected = torch.empty((self.nchan_out, self.npol_out, (head + cfg.parts_per_block * self.nkeep) * cfg.ndim),
                                     dtype=torch.float32, device="cuda:%d" % device)
@@ -616,7 +626,8 @@ class LoadToFold:
             events[1].record()
         off, nin = head - self.sd_carried, self.sd_carried + ndat
         rows = self.detected[:, :, off * nd:(off + nin) * nd]
-        nout = self.sample_delay.transform(rows.unflatten(2, (nin, nd)))
+        nuse = nin - self.sd_short              # (sub-band rank: the band's total delay, not just this rank's, is given up)
+        nout = self.sample_delay.transform(rows[:, :, :nuse * nd].unflatten(2, (nuse, nd))) if nuse > 0 else 0
         if nout:
             for idat_start, ndat_fold, _division, complete in self._pieces(nout):
                 folded = self._set_plan(idat_start, ndat_fold)

@@ -137,3 +137,46 @@ def test_bench_two_ranks_one_command(gpu, workload, extra):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["parity_gate"]["status"] == "ok"
     assert ("sub-band" if workload == "cfg4" else "replicas") in res["config"]["parallelism"]
+
+
+def test_subband_shards_with_interchannel_dedispersion(gpu):
+    """-K (SampleDelay + fractional-delay phase) on a sub-band sharded run: every rank applies its channels' delays relative
+    to the zero of the WHOLE band and gives up the band's total delay, so the ranks stay sample aligned -- profiles, hits and
+    start time equal one full-band run bit for bit."""
+    from dspsr_amd import pipeline
+    nsub, nblocks = 4, 3
+    info = pipeline.InputInfo(centre_frequency=1400.0, bandwidth=-64.0, nchan=nsub, npol=2, ndim=2, tsamp_us=1.0 / 16.0,
+                              machine="DADA")
+    cfg = pipeline.Config(nchan=64, dispersion_measure=3.0, nbin=128, folding_period=0.0123, freq_res=256, ndim=4,
+                          parts_per_block=5, max_parts=4, interchan_dedispersion=True)
+    stream = torch.cuda.current_stream().cuda_stream
+    full = pipeline.LoadToFold(cfg, info, device=0, stream=stream)
+    assert full.sample_delay is not None and full.sd_head > 8            # the band really is delayed by several samples
+    step = cfg.parts_per_block * full.nsamp_step
+    ndat = nblocks * step + full.nsamp_overlap
+    raw = _raw(ndat * nsub * 4, 5)
+    d_full = torch.from_numpy(raw).cuda()
+    bps = nsub * 4
+    for b in range(nblocks):
+        full.process_block(d_full[b * step * bps:(b * step + step + full.nsamp_overlap) * bps])
+    full.finish_subint()
+    full.synchronize()
+    want = full.subints[0]
+    wprof = want["profile_dev"].view(64, -1)
+    assert want["ndat_total"] == nblocks * cfg.parts_per_block * full.nkeep - full.sd_head and float(wprof.abs().max()) > 0
+    shorts = []
+    for g in range(nsub):
+        lt = pipeline.LoadToFold(cfg, info, device=0, stream=stream, subband=g)
+        assert (lt.sd_head, lt.out_start) == (full.sd_head, full.out_start)
+        shorts.append(lt.sd_short)
+        mine = torch.from_numpy(np.ascontiguousarray(raw.reshape(ndat, nsub, 4)[:, g, :]).reshape(-1)).cuda()
+        for b in range(nblocks):
+            lt.process_block(mine[b * step * 4:(b * step + step + lt.nsamp_overlap) * 4])
+        lt.finish_subint()
+        lt.synchronize()
+        got = lt.subints[0]
+        assert np.array_equal(got["hits"], want["hits"]) and got["ndat_total"] == want["ndat_total"], g
+        assert torch.equal(got["profile_dev"].view(16, -1), wprof[g * 16:(g + 1) * 16]), g
+        lt.close()
+    assert min(shorts) == 0 and max(shorts) > 0          # one rank holds the band's extreme channel, the others give up more
+    full.close()
