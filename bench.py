@@ -65,7 +65,107 @@ WORKLOADS = {
     "cfg5": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=4096, dm=0.0, freq_res=1,
                  nbin=0, machine="DADA", tscrunch=16, nparts=32768,
                  cmd="digifil -F 4096 -t 16 -b 8 (TFP filterbank + square law + tscrunch, Rescale, PScrunch, 8-bit digitizer; no fold)"),
+    # the reference's fold benchmark (Benchmark/fold.csh on Benchmark/fold_header.dada): already-detected input, 1024
+    # channels x 4 polarisation products at 32 us, folded with vela.polyco -- dsp::Fold alone
+    "fold": dict(freq=1382.0, bw=-400.0, in_nchan=1024, ndim=1, tsamp_us=32.0, nchan=1024, dm=0.0, freq_res=1, nbin=0,
+                 machine="Dummy", npol=4, ndat=1 << 17,
+                 cmd="dspsr -E vela.par -P vela.polyco fold_header.dada (Benchmark/fold.csh: NCHAN 1024, NPOL 4, STATE Coherence, "
+                     "TSAMP 32 us; fold only)"),
 }
+
+
+def bench_fold_only(args, wl, torch):
+    """Benchmark/fold.csh: one step = one block of `ndat` detected samples (1024 channels x 4 products, FPT floats resident
+    in HBM -- the reference's Dummy unpacker does not touch the data either) folded with the vela.polyco predictor:
+    phase and period from the polynomial at the block's first sample, the double-precision bin plan on the host
+    (Fold.C:718-787), k_fold_chunked on the device (Fold.C:835-891).  nbin as dsp::Fold::choose_nbin picks it."""
+    import dspsr_amd
+    from dspsr_amd import pipeline
+    nchan, npol, ndat = wl["nchan"], wl["npol"], wl["ndat"]
+    rate = 1e6 / wl["tsamp_us"]
+    text = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "vela_polyco.json")))["text"]
+    polyco = pipeline.Polyco(text)
+    day, sec0 = 55299, 7545.0                                  # UTC_START 2010-04-13-02:05:45 (fold_header.dada)
+    nbin = pipeline.choose_nbin(1.0 / polyco.frequency(day, sec0), rate)
+    ctx = dspsr_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    fold = dspsr_amd.FoldEngine(ctx)
+    fold.set_shape(nchan, npol, 1, nbin)
+    gen = torch.Generator(device="cuda").manual_seed(20100413)
+    det = torch.empty((nchan, npol, ndat), dtype=torch.float32, device="cuda")
+    for c0 in range(0, nchan, 64):
+        det[c0:c0 + 64] = torch.randn((min(64, nchan - c0), npol, ndat), generator=gen, device="cuda").square_()
+    hits = np.zeros(nbin, np.uint32)
+    state = {"blocks": 0, "length": 0.0}
+
+    def step(ev=None):
+        t0 = (state["blocks"] * ndat + 0.5) / rate
+        phi = polyco.phase_frac(day, sec0 + t0)
+        pfold = 1.0 / polyco.frequency(day, sec0 + t0)
+        fold.set_nbin(nbin)
+        fold.set_ndat(ndat, 0)
+        folded = fold.set_bins(phi, (1.0 / rate) / pfold, ndat, 0, hits)
+        if ev is not None:
+            ev[0].record()
+        fold.fold(det)
+        if ev is not None:
+            ev[1].record()
+        state["blocks"] += 1
+        state["length"] += folded / rate
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for e in ev:
+        step(e)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    # parity gate (one more block on a zeroed profile): every sample in exactly one bin; the profile equals the float64
+    # index_add of the same samples by the same plan to float rounding
+    fold.zero()
+    hits[:] = 0
+    step()
+    prof = torch.from_numpy(fold.synch()).cuda().view(nchan * npol, nbin).double()
+    plan, _ = dspsr_amd.fold_binplan(polyco.phase_frac(day, sec0 + ((state["blocks"] - 1) * ndat + 0.5) / rate),
+                                  (1.0 / rate) * polyco.frequency(day, sec0 + ((state["blocks"] - 1) * ndat + 0.5) / rate), nbin, ndat)
+    want = torch.zeros((nchan * npol, nbin), dtype=torch.float64, device="cuda")
+    want.index_add_(1, torch.from_numpy(plan.astype(np.int64)).cuda(), det.view(nchan * npol, ndat).double())
+    rel = float((prof - want).abs().max() / want.abs().max())
+    if int(hits.astype(np.int64).sum()) != ndat or not rel <= 2e-6:
+        raise ParityGateError("bench.py parity gate FAILED (fold): hits.sum()=%d ndat=%d, profile rel %.3g"
+                              % (int(hits.sum()), ndat, rel))
+    b_alg = det.numel() * 4
+    achieved = b_alg / (k_ms * 1e-3) / 1e9
+    res = {"metric": "Msamples/s folded", "value": round(ndat * args.steps / elapsed / 1e6, 3), "unit": "Msamples/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "fold", "command": wl["cmd"], "nchan": nchan, "npol": npol, "ndim": 1, "nbin": nbin,
+                      "ndat_per_block": ndat, "input": "detected float32 FPT rows, resident in HBM",
+                      "realtime_factor": round(ndat * args.steps / elapsed / rate, 1),
+                      "note": "time samples per second; every sample carries nchan*npol = %d floats" % (nchan * npol)},
+           "parity_gate": {"status": "ok", "checks": ["hits.sum() == ndat", "profile == float64 index_add (rel %.1e)" % rel]},
+           "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_fold_chunked<1,.>",
+                        "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(k_ms, 4)}}
+    if not args.no_cpu_baseline:
+        import oracle.dspsr_oracle as o
+        nc = nchan                                              # one whole block (about 1.5 s on one core)
+        x = det[:nc].cpu().numpy()
+        t1 = time.perf_counter()
+        acc = np.zeros((nc, npol, nbin), np.float32)
+        bins = o.fold_binplan(0.25, 1.0 / 2794.0, nbin, ndat)
+        for c in range(nc):
+            for q in range(npol):
+                np.add.at(acc[c, q], bins, x[c, q])
+        dt = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": round(ndat * nc / nchan / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                               "sample": "%d of %d channels of one block, numpy restatement of the Fold.C:835-891 loop, %.2f s"
+                                         % (nc, nchan, dt)}
+    print(json.dumps(res), flush=True)
+    fold.close()
+    ctx.close()
 
 
 def bench_search_mode(args, wl, torch):
@@ -450,10 +550,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
-    if args.workload == "cfg5":
+    if args.workload in ("cfg5", "fold"):
         if world > 1:
-            sys.exit("bench.py: the search-mode workload runs as independent replicas; use --gpus 1")
-        return bench_search_mode(args, wl, torch)
+            sys.exit("bench.py: the %s workload runs as independent replicas; use --gpus 1" % args.workload)
+        return bench_search_mode(args, wl, torch) if args.workload == "cfg5" else bench_fold_only(args, wl, torch)
     sharded = wl["in_nchan"] > 1                 # sub-band sharding; otherwise time-slice replicas
     if sharded and world > wl["in_nchan"]:
         sys.exit("bench.py: workload %s has %d sub-bands, --gpus %d is more" % (args.workload, wl["in_nchan"], world))

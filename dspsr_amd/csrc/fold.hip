@@ -68,7 +68,10 @@ constexpr int FOLD_BPT = 4;             // bins per thread (nbin <= FOLD_BPT * b
 constexpr uint32_t FOLD_MB = 32;
 constexpr uint32_t FOLD_LONG_RUN = FOLD_LONG_RUN_HOST;
 
-template <int NDIM, bool LONG>
+// NROW: polarisation rows of one channel folded by the same workgroup (detected data with ndim < 4 lie in 4/ndim planes:
+// the walk through the bin plan -- most of the work with 4-byte samples -- then serves all planes; the sums of every
+// (chan, pol, bin, dim) keep their order).
+template <int NDIM, bool LONG, int NROW>
 __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__ in, const uint64_t chan_stride,
                                                        const uint64_t pol_stride, float* __restrict__ prof,
                                                        const uint64_t prof_span, const uint32_t nbin,
@@ -78,15 +81,18 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
                                                        float* __restrict__ part /* LONG: [seg][row][nbin][NDIM] partial sums */,
                                                        const uint32_t chunks_per_seg /* LONG: chunks per blockIdx.z */)
 {
-  extern __shared__ __attribute__((aligned(16))) float fold_lds[];   // FOLD_CHUNK * NDIM floats (+ micro-block sums, LONG)
-  const uint32_t ipol = blockIdx.x, npol = gridDim.x, ichan = blockIdx.y;
+  extern __shared__ __attribute__((aligned(16))) float fold_lds[];   // NROW x FOLD_CHUNK * NDIM floats (+ micro-block sums, LONG)
+  const uint32_t ipol = blockIdx.x * NROW, npol = gridDim.x * NROW, ichan = blockIdx.y;
+  constexpr uint32_t RS = FOLD_CHUNK * NDIM;             // floats per row of the chunk image
+  constexpr uint32_t MS = (FOLD_CHUNK / FOLD_MB) * NDIM;  // micro-block sums per row (LONG)
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
-  const float* __restrict__ row = in + ichan * chan_stride + ipol * pol_stride;
+  const float* __restrict__ row = in + ichan * chan_stride + ipol * pol_stride;          // row r: + r * pol_stride
   // LONG: blockIdx.z is a TIME segment of the row (all bins), summed from zero into this segment's partial profile --
   // every sample of the row is read once; k_fold_combine adds the partials to the profile in time order.
   // exact: blockIdx.z deals the BINS of a row to gridDim.z workgroups, each streams the whole row and owns its sums.
   float* __restrict__ out = LONG ? part + (((uint64_t)blockIdx.z * gridDim.y + ichan) * npol + ipol) * nbin * NDIM
                                  : prof + ((uint64_t)ichan * npol + ipol) * prof_span;
+  const uint64_t out_rs = LONG ? (uint64_t)nbin * NDIM : prof_span;                        // row r: + r * out_rs
   const uint32_t bz = LONG ? 0u : blockIdx.z, nz = LONG ? 1u : gridDim.z;
   constexpr uint32_t NF4 = FOLD_CHUNK * NDIM / 4;        // float4 per chunk
   constexpr uint32_t MAXR = NF4 / 256;                    // float4 per thread at the minimum block size (256)
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
   // registers (loaded long before they are needed) so the chunk loop never waits on global memory
   uint32_t cur[FOLD_BPT], end[FOLD_BPT];
   Interval v0[FOLD_BPT], v1[FOLD_BPT];
-  float acc[FOLD_BPT][NDIM];
+  float acc[FOLD_BPT][NROW][NDIM];
   bool touched[FOLD_BPT];
   // "no interval" = offset ~0.  Always load through the global pointer with a clamped index: selecting
   // between &iv[i] and a local would make the load generic (flat_load + full vmcnt/lgkmcnt drain).
@@ -124,52 +130,60 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
     v0[j] = load_iv(cur[j], cur[j] < end[j]);
     v1[j] = load_iv(cur[j] + 1, cur[j] + 1 < end[j]);
 #pragma unroll
-    for (int d = 0; d < NDIM; d++) acc[j][d] = (!LONG && b < nbin && touched[j]) ? out[b * NDIM + d] : 0.f;
+    for (int r = 0; r < NROW; r++)
+#pragma unroll
+      for (int d = 0; d < NDIM; d++) acc[j][r][d] = (!LONG && b < nbin && touched[j]) ? out[r * out_rs + b * NDIM + d] : 0.f;
   }
 
   // chunk c covers samples [first + c*FOLD_CHUNK, ...); rows are 16-byte aligned when first*NDIM % 4 == 0,
   // the host guarantees it by rounding `first` down
-  const float4* __restrict__ src = (const float4*)(row + first * NDIM);
+  const float* __restrict__ src0 = row + first * NDIM;
   const uint64_t nfl_total = (last - first) * NDIM;      // floats in the span
   const uint32_t nchunk_all = (uint32_t)((last - first + FOLD_CHUNK - 1) / FOLD_CHUNK);
   const uint32_t cbeg = LONG ? blockIdx.z * chunks_per_seg : 0u;
   const uint32_t nchunk = LONG ? (cbeg + chunks_per_seg < nchunk_all ? cbeg + chunks_per_seg : nchunk_all) : nchunk_all;
-  float4 pre[MAXR];
+  float4 pre[NROW][MAXR];
   auto fetch = [&](uint32_t c) {
 #pragma unroll
-    for (uint32_t r = 0; r < MAXR; r++) {
-      const uint32_t q = tid + r * nt;
-      const uint64_t k = (uint64_t)c * NF4 + q;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q < NF4) {
-        if (4 * k + 4 <= nfl_total) {
-          v = src[k];
-        } else if (4 * k < nfl_total) {                  // ragged end of the span: never read past it
-          const float* t = (const float*)(src + k);
-          const uint32_t n = (uint32_t)(nfl_total - 4 * k);
-          v.x = t[0];
-          if (n > 1) v.y = t[1];
-          if (n > 2) v.z = t[2];
+    for (int rw = 0; rw < NROW; rw++) {
+      const float4* __restrict__ src = (const float4*)(src0 + rw * pol_stride);
+#pragma unroll
+      for (uint32_t r = 0; r < MAXR; r++) {
+        const uint32_t q = tid + r * nt;
+        const uint64_t k = (uint64_t)c * NF4 + q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < NF4) {
+          if (4 * k + 4 <= nfl_total) {
+            v = src[k];
+          } else if (4 * k < nfl_total) {                  // ragged end of the span: never read past it
+            const float* t = (const float*)(src + k);
+            const uint32_t n = (uint32_t)(nfl_total - 4 * k);
+            v.x = t[0];
+            if (n > 1) v.y = t[1];
+            if (n > 2) v.z = t[2];
+          }
         }
+        pre[rw][r] = v;
       }
-      pre[r] = v;
     }
   };
   if (cbeg < nchunk) fetch(cbeg);
   for (uint32_t c = cbeg; c < nchunk; c++) {
     __syncthreads();                                    // previous chunk fully consumed
 #pragma unroll
-    for (uint32_t r = 0; r < MAXR; r++)
-      if (tid + r * nt < NF4) ((float4*)fold_lds)[tid + r * nt] = pre[r];
+    for (int rw = 0; rw < NROW; rw++)
+#pragma unroll
+      for (uint32_t r = 0; r < MAXR; r++)
+        if (tid + r * nt < NF4) ((float4*)(fold_lds + rw * RS))[tid + r * nt] = pre[rw][r];
     if (c + 1 < nchunk) fetch(c + 1);
     __syncthreads();
     if constexpr (LONG) {                                 // level 1: sums of the aligned micro-blocks of this chunk
-      float* mbs = fold_lds + FOLD_CHUNK * NDIM;
-      for (uint32_t q = tid; q < (FOLD_CHUNK / FOLD_MB) * NDIM; q += nt) {
-        const uint32_t mb = q / NDIM, d = q % NDIM;
+      float* mbs = fold_lds + NROW * RS;
+      for (uint32_t q = tid; q < NROW * MS; q += nt) {
+        const uint32_t rw = q / MS, qr = q - rw * MS, mb = qr / NDIM, d = qr % NDIM;
         float sacc = 0.f;
 #pragma unroll 8
-        for (uint32_t h = 0; h < FOLD_MB; h++) sacc += fold_lds[(mb * FOLD_MB + h) * NDIM + d];
+        for (uint32_t h = 0; h < FOLD_MB; h++) sacc += fold_lds[rw * RS + (mb * FOLD_MB + h) * NDIM + d];
         mbs[q] = sacc;
       }
       __syncthreads();
@@ -186,30 +200,40 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
         const uint32_t x0 = (uint32_t)(lo - c0) * NDIM;
         const uint32_t n = (uint32_t)(hi - lo);
         if constexpr (LONG) {
-          const float* mbs = fold_lds + FOLD_CHUNK * NDIM;
+          const float* mbs = fold_lds + NROW * RS;
           const uint32_t s0 = (uint32_t)(lo - c0), s1 = s0 + n;                       // samples [s0, s1) of the chunk
           const uint32_t a0 = (s0 + FOLD_MB - 1) / FOLD_MB * FOLD_MB;                // first micro-block boundary >= s0
           const uint32_t a1 = s1 / FOLD_MB * FOLD_MB;                                // last boundary <= s1
           if (a0 >= a1) {                                                            // no whole micro-block inside the run
             for (uint32_t h = s0; h < s1; h++)
 #pragma unroll
-              for (int d = 0; d < NDIM; d++) acc[j][d] += fold_lds[h * NDIM + d];
+              for (int r = 0; r < NROW; r++)
+#pragma unroll
+                for (int d = 0; d < NDIM; d++) acc[j][r][d] += fold_lds[r * RS + h * NDIM + d];
           } else {
             for (uint32_t h = s0; h < a0; h++)
 #pragma unroll
-              for (int d = 0; d < NDIM; d++) acc[j][d] += fold_lds[h * NDIM + d];
+              for (int r = 0; r < NROW; r++)
+#pragma unroll
+                for (int d = 0; d < NDIM; d++) acc[j][r][d] += fold_lds[r * RS + h * NDIM + d];
             for (uint32_t mb = a0 / FOLD_MB; mb < a1 / FOLD_MB; mb++)
 #pragma unroll
-              for (int d = 0; d < NDIM; d++) acc[j][d] += mbs[mb * NDIM + d];
+              for (int r = 0; r < NROW; r++)
+#pragma unroll
+                for (int d = 0; d < NDIM; d++) acc[j][r][d] += mbs[r * MS + mb * NDIM + d];
             for (uint32_t h = a1; h < s1; h++)
 #pragma unroll
-              for (int d = 0; d < NDIM; d++) acc[j][d] += fold_lds[h * NDIM + d];
+              for (int r = 0; r < NROW; r++)
+#pragma unroll
+                for (int d = 0; d < NDIM; d++) acc[j][r][d] += fold_lds[r * RS + h * NDIM + d];
           }
         } else {
 #pragma unroll 4
           for (uint32_t h = 0; h < n; h++)
 #pragma unroll
-            for (int d = 0; d < NDIM; d++) acc[j][d] += fold_lds[x0 + h * NDIM + d];
+            for (int r = 0; r < NROW; r++)
+#pragma unroll
+              for (int d = 0; d < NDIM; d++) acc[j][r][d] += fold_lds[r * RS + x0 + h * NDIM + d];
         }
         if (v.offset + v.hits > c1) break;               // interval continues in the next chunk (or segment)
         cur[j]++;
@@ -223,7 +247,9 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
     const uint32_t b = bz + nz * (tid + j * nt);
     if (b < nbin && touched[j])
 #pragma unroll
-      for (int d = 0; d < NDIM; d++) out[b * NDIM + d] = acc[j][d];
+      for (int r = 0; r < NROW; r++)
+#pragma unroll
+        for (int d = 0; d < NDIM; d++) out[r * out_rs + b * NDIM + d] = acc[j][r][d];
   }
 }
 
@@ -585,14 +611,19 @@ extern "C" int dspsr_amd_fold_fold(dspsr_amd_fold* f, const float* in_dev, uint6
         f->part_floats = need;
       }
     }
-    dim3 grid(f->npol, f->nchan, lng ? nseg : nsplit);
-    const size_t lds = ((size_t)FOLD_CHUNK + (lng ? FOLD_CHUNK / FOLD_MB : 0)) * f->ndim * sizeof(float);
-#define FOLD_LAUNCH(ND, LG) hipLaunchKernelGGL((k_fold_chunked<ND, LG>), grid, dim3(threads), lds, ctx->stream, in_dev, \
+    // planes of one channel folded together (ndim < 4): 4 or 2 rows per workgroup when the channels alone fill the chip
+    const uint32_t nrw = (f->ndim * f->npol == 4 && f->ndim < 4 && (uint64_t)f->nchan * (lng ? nseg : nsplit) >= 2 * ctx->ncu)
+                             ? f->npol : 1u;
+    dim3 grid(f->npol / nrw, f->nchan, lng ? nseg : nsplit);
+    const size_t lds = ((size_t)FOLD_CHUNK + (lng ? FOLD_CHUNK / FOLD_MB : 0)) * f->ndim * nrw * sizeof(float);
+#define FOLD_LAUNCH(ND, LG, NR) hipLaunchKernelGGL((k_fold_chunked<ND, LG, NR>), grid, dim3(threads), lds, ctx->stream, in_dev, \
                                                in_chan_stride, in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv, first, last, \
                                                f->part, cps)
-    if (f->ndim == 4) { if (lng) FOLD_LAUNCH(4, true); else FOLD_LAUNCH(4, false); }
-    else if (f->ndim == 2) { if (lng) FOLD_LAUNCH(2, true); else FOLD_LAUNCH(2, false); }
-    else { if (lng) FOLD_LAUNCH(1, true); else FOLD_LAUNCH(1, false); }
+    if (f->ndim == 4) { if (lng) FOLD_LAUNCH(4, true, 1); else FOLD_LAUNCH(4, false, 1); }
+    else if (f->ndim == 2 && nrw == 2) { if (lng) FOLD_LAUNCH(2, true, 2); else FOLD_LAUNCH(2, false, 2); }
+    else if (f->ndim == 2) { if (lng) FOLD_LAUNCH(2, true, 1); else FOLD_LAUNCH(2, false, 1); }
+    else if (nrw == 4) { if (lng) FOLD_LAUNCH(1, true, 4); else FOLD_LAUNCH(1, false, 4); }
+    else { if (lng) FOLD_LAUNCH(1, true, 1); else FOLD_LAUNCH(1, false, 1); }
 #undef FOLD_LAUNCH
     if (lng) {
       const uint64_t n = (uint64_t)nrow * nbin * f->ndim;

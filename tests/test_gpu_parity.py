@@ -410,6 +410,49 @@ def test_fold_engine_bit_exact(oracle, gpu, ndim, npol, nbin):
     eng.close()
 
 
+@pytest.mark.parametrize("ndim,npol", [(2, 2), (1, 4)])
+@pytest.mark.parametrize("pps", [1.0 / 7.7, 1.0 / 90000.0])
+def test_fold_planes_of_a_channel_together_bit_exact(oracle, gpu, ndim, npol, pps):
+    """With enough channels to fill the chip the 4/ndim planes of a channel are folded by ONE workgroup (the walk through
+    the bin plan serves all planes; the reference's fold benchmark, Benchmark/fold.csh, is this shape: 1024 channels x 4
+    products).  Short runs: still bit-identical to the CPU loop; runs of thousands of samples: the re-associated long-run
+    fold, equal to rounding and identical to folding the planes one by one."""
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(18)
+    nchan, ndat, nbin = 600, 9000, 200
+    det = rng.standard_normal((nchan, npol, ndat, ndim)).astype(np.float32) ** 2
+    phi, idat_start, ndat_fold = 0.61, 4, ndat - 9
+    d = torch.from_numpy(det.reshape(nchan, npol, ndat * ndim)).cuda()
+    eng = dspsr_amd.FoldEngine(ctx)
+    eng.set_shape(nchan, npol, ndim, nbin)
+    hits = np.zeros(nbin, np.uint32)
+    eng.set_nbin(nbin)
+    eng.set_ndat(ndat_fold, idat_start)
+    eng.set_bins(phi, pps, ndat_fold, idat_start, hits)
+    eng.fold(d)
+    got = eng.synch()
+    plan = oracle.fold_binplan(phi, pps, nbin, ndat_fold)
+    assert np.array_equal(hits, np.bincount(plan, minlength=nbin).astype(np.uint32))
+    want = np.zeros((nchan, npol, nbin, ndim), np.float32)
+    for i in range(ndat_fold):
+        want[:, :, plan[i], :] += det[:, :, idat_start + i, :]
+    if pps > 1e-3:
+        assert np.array_equal(got, want)
+    else:
+        assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+        # the planes one by one (few channels -> one row per workgroup): the same re-associated sums
+        one = dspsr_amd.FoldEngine(ctx)
+        one.set_shape(4, npol, ndim, nbin)
+        one.set_nbin(nbin)
+        one.set_ndat(ndat_fold, idat_start)
+        one.set_bins(phi, pps, ndat_fold, idat_start, np.zeros(nbin, np.uint32))
+        one.fold(d[:4])
+        got4 = one.synch()
+        one.close()
+        assert np.abs(got[:4] - got4).max() <= 2e-6 * np.abs(want).max()
+    eng.close()
+
+
 def test_fold_set_bin_equals_set_bins(gpu):
     dspsr_amd, ctx = gpu
     rng = np.random.default_rng(9)
