@@ -46,7 +46,12 @@ template <bool CASPSR> DEV uint32_t tfp_pair(const TfpRaw<CASPSR>& r)
   else return r.w[0] & 0xffffu;
 }
 
-template <int LOGF, bool CASPSR>
+// COAL: the T parts of a group are ONE contiguous range of T*L*2 bytes.  Loading it in first-stage order means 32 two-byte
+// loads per thread (128 bytes per wave instruction: 13.7 us per 16384-point group, the pass was bound by the issue of its
+// loads); instead every thread loads 16-byte pieces of the range (prefetched one group ahead, 4 registers per piece), the
+// bytes go through the -- at that moment idle -- exchange buffer, and the thread picks its 32 samples from LDS.
+// Needs a 16-byte aligned block (the host checks; otherwise the element-wise kernel runs).
+template <int LOGF, bool CASPSR, bool COAL>
 __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __restrict__ tw)
 {
   typedef FftPlan<LOGF> P;
@@ -85,7 +90,21 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
   // the 8-bit samples of the next group are requested while the current one is transformed (register prefetch,
   // as in the filterbank passes); past the end the loads are skipped by the part bound inside fetch()
   TfpRaw<CASPSR> ra[NPAIR], rb[NPAIR];
-  if (blockIdx.x < nitem) fetch((uint64_t)blockIdx.x * groups_per_out, ra, rb);
+  constexpr uint32_t NCH = (PTS * 2) / 16;                 // 16-byte pieces per thread: 32 points x 2 bytes
+  uint4 piece[NCH];
+  const uint64_t raw_bytes = p.npart * (uint64_t)L * 2;
+  auto fetch_pieces = [&](const uint64_t group) {
+    const uint64_t base = (group << logT) * (uint64_t)L * 2;
+#pragma unroll
+    for (uint32_t r = 0; r < NCH; r++) {
+      const uint64_t off = base + 16ull * (tid + r * nt);
+      piece[r] = off + 16 <= raw_bytes ? *(const uint4*)(p.raw + off) : make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+    }
+  };
+  if (blockIdx.x < nitem) {
+    if constexpr (COAL) fetch_pieces((uint64_t)blockIdx.x * groups_per_out);
+    else fetch((uint64_t)blockIdx.x * groups_per_out, ra, rb);
+  }
   for (uint64_t item = blockIdx.x; item < nitem; item += gridDim.x) {
     float acc[NB][2];
 #pragma unroll
@@ -94,6 +113,40 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
       const uint64_t group = item * groups_per_out + gi;
       asm volatile("" : "+v"(tid));
       cx2 x[NPAIR];
+      if constexpr (COAL) {
+        // the group's bytes, in file order, into the exchange buffer (the previous group's read-back ended with a barrier)
+        uint8_t* img = (uint8_t*)lds;
+#pragma unroll
+        for (uint32_t r = 0; r < NCH; r++) *(uint4*)(img + 16u * (tid + r * nt)) = piece[r];
+        __syncthreads();
+#pragma unroll
+        for (int g2 = 0; g2 < P::G1; g2 += 2)
+#pragma unroll
+          for (int i = 0; i < P::R1; i++) {
+            const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
+            const uint32_t col = e & (T - 1), n = e >> logT;
+            const uint32_t sa = col * L + n, sb = sa + L;           // columns col and col + 1 (T >= 2)
+            uint32_t wa, wb;
+            if constexpr (CASPSR) {
+              const uint8_t* a = img + (sa >> 2) * 8 + (sa & 3);
+              const uint8_t* b = img + (sb >> 2) * 8 + (sb & 3);
+              wa = (uint32_t)a[0] | ((uint32_t)a[4] << 8);
+              wb = (uint32_t)b[0] | ((uint32_t)b[4] << 8);
+            } else {
+              wa = *(const uint16_t*)(img + 2 * sa);
+              wb = *(const uint16_t*)(img + 2 * sb);
+            }
+            ra[(g2 / 2) * P::R1 + i].w[0] = wa & 0xffu;
+            rb[(g2 / 2) * P::R1 + i].w[0] = wb & 0xffu;
+            if constexpr (CASPSR) {
+              ra[(g2 / 2) * P::R1 + i].w[1] = wa >> 8;
+              rb[(g2 / 2) * P::R1 + i].w[1] = wb >> 8;
+            } else {
+              ra[(g2 / 2) * P::R1 + i].w[0] = wa;
+              rb[(g2 / 2) * P::R1 + i].w[0] = wb;
+            }
+          }
+      }
 #pragma unroll
       for (int h = 0; h < NPAIR; h++) {
         const uint32_t w = tfp_pair<CASPSR>(ra[h]) | (tfp_pair<CASPSR>(rb[h]) << 16);
@@ -102,8 +155,12 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
       }
       {
         const uint64_t next = gi + 1 < groups_per_out ? group + 1 : (item + gridDim.x) * groups_per_out;
-        if (gi + 1 < groups_per_out || item + gridDim.x < nitem) fetch(next, ra, rb);
+        if (gi + 1 < groups_per_out || item + gridDim.x < nitem) {
+          if constexpr (COAL) fetch_pieces(next);
+          else fetch(next, ra, rb);
+        }
       }
+      if constexpr (COAL) __syncthreads();      // every thread has taken its samples: the exchanges may overwrite the image
       auto store = [&](const uint32_t col, const uint32_t pp, const uint32_t pstride, auto& v) {
         constexpr int R = sizeof(v) / sizeof(v[0]);
 #pragma unroll
@@ -118,6 +175,43 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
       const uint64_t part_first = group << logT, part_end = nout * p.sfactor;
       const uint32_t phase_first = (uint32_t)(part_first % p.sfactor);       // wave-uniform: no division per bin
       const uint64_t out_first = part_first / p.sfactor;
+      // Whole group inside one output sample (tscrunch >= T, all parts present): no per-column bookkeeping, the columns of
+      // a bin are read two at a time (16 bytes).  0 + p0 == p0, so starting an output sample from zero gives the sums of
+      // TScrunch.C:193-200 bit for bit.
+      const bool whole = p.sfactor >= T && T >= 2 && part_first + T <= part_end;
+      if (whole) {
+        const bool emit = phase_first + T == p.sfactor;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+          const uint32_t k = tid + j * nt;
+          if (k < nchan) {
+            const uint32_t km = (L - k) & (L - 1);
+            float s0 = phase_first == 0 ? 0.f : acc[j][0], s1 = phase_first == 0 ? 0.f : acc[j][1];
+            const uint32_t ia = lds_pad(k << logT), ib = lds_pad(km << logT);
+            for (uint32_t c = 0; c < T; c += 2) {
+              const uint32_t ca = c + ((c >> 6) << 2);          // lds_pad(e0 + c) for e0 a multiple of 64 (T >= 64) or c < 64
+              const float4 a2 = *(const float4*)&lds[T >= 64 ? ia + ca : ia + c];
+              const float4 b2 = *(const float4*)&lds[T >= 64 ? ib + ca : ib + c];
+#pragma unroll
+              for (int h = 0; h < 2; h++) {
+                const float ax = h ? a2.z : a2.x, ay = h ? a2.w : a2.y, bx = h ? b2.z : b2.x, by = h ? b2.w : b2.y;
+                const float x0r = 0.5f * (ax + bx), x0i = 0.5f * (ay - by);
+                const float x1r = 0.5f * (ay + by), x1i = 0.5f * (bx - ax);
+                float p0 = x0r * x0r; p0 += x0i * x0i;            // TFPFilterbank.C:56-59
+                float p1 = x1r * x1r; p1 += x1i * x1i;
+                if (p.pscrunch) { p0 += p1; p1 = 0.f; }
+                s0 += p0; s1 += p1;
+              }
+            }
+            acc[j][0] = s0; acc[j][1] = s1;
+            if (emit) {
+              float* o = p.out + (out_first * nchan + k) * npol_out;
+              o[0] = s0;
+              if (!p.pscrunch) o[1] = s1;
+            }
+          }
+        }
+      } else
 #pragma unroll
       for (int j = 0; j < NB; j++) {
         const uint32_t k = tid + j * nt;
@@ -155,11 +249,13 @@ typedef void (*ktfp_t)(TfpParams, const cf*);
 template <int... I> struct iseq_t {};
 template <int N, int... I> struct mkseq_t : mkseq_t<N - 1, N - 1, I...> {};
 template <int... I> struct mkseq_t<0, I...> { typedef iseq_t<I...> type; };
-template <int... I> static ktfp_t pick_tfp(int logf, bool caspsr, iseq_t<I...>)
+template <int... I> static ktfp_t pick_tfp(int logf, bool caspsr, bool coal, iseq_t<I...>)
 {
-  static const ktfp_t t[] = {k_tfp<I, false>...};
-  static const ktfp_t c[] = {k_tfp<I, true>...};
-  return caspsr ? c[logf] : t[logf];
+  static const ktfp_t t[] = {k_tfp<I, false, false>...};
+  static const ktfp_t c[] = {k_tfp<I, true, false>...};
+  static const ktfp_t tc[] = {k_tfp<I, false, true>...};
+  static const ktfp_t cc[] = {k_tfp<I, true, true>...};
+  return coal ? (caspsr ? cc[logf] : tc[logf]) : (caspsr ? c[logf] : t[logf]);
 }
 
 }  // namespace dspsr_amd
@@ -192,7 +288,9 @@ extern "C" int dspsr_amd_tfp_filterbank(dspsr_amd_ctx* ctx, const dspsr_amd_tfp_
   TfpParams p;
   p.raw = (const uint8_t*)raw_dev; p.out = out_dev; p.npart = npart; p.sfactor = sf; p.pscrunch = cfg->pscrunch ? 1 : 0;
   p.scale = scale; p.logT = logT; p.caspsr = raw_layout == DSPSR_AMD_RAW_CASPSR;
-  ktfp_t k = pick_tfp(logF, p.caspsr != 0, mkseq_t<14>::type());
+  // whole-range 16-byte loads need an aligned block, at least two columns per group (T >= 2) and full-size workgroups
+  const bool coal = ((uintptr_t)raw_dev & 15) == 0 && logT >= 1;
+  ktfp_t k = pick_tfp(logF, p.caspsr != 0, coal, mkseq_t<14>::type());
   const size_t lds = lds_total_words_host(16384, logF) * sizeof(cf);
   hipError_t e = dspsr_amd_allow_lds((const void*)k, lds);      // raised once per kernel, not per call
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_tfp_filterbank: %s", hipGetErrorString(e));

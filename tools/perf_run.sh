@@ -10,5 +10,5 @@ python tools/kstats.py gpurun_out/$T/prof | tee gpurun_out/$T/kstats.txt
 python - <<PY
 import json
 d=json.loads([l for l in open("gpurun_out/$T/bench.json") if l.startswith("{")][0])
-print("value %.0f  ms/step %.4f  frac %.4f  fused_frac %s  gate %s" % (d["value"], d["ms_per_step"], d["roofline"]["frac"], d.get("roofline_fused",{}).get("frac"), d["parity_gate"]["status"]))
+print("value %.0f  ms/step %.4f  frac %.4f  fused_frac %s  gate %s" % (d["value"], d["ms_per_step"], d["roofline"]["frac"], d.get("roofline_fused",{}).get("frac"), d.get("parity_gate",{}).get("status")))
 PY
