@@ -239,3 +239,20 @@ def test_fold_many_bins_direct_kernel(oracle, gpu):
     assert np.array_equal(hits, np.bincount(plan, minlength=nbin).astype(np.uint32)) and np.array_equal(eng.synch(), want)
     eng.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("C,M,nfilt,npart,kw", [
+    (1024, 4096, (422, 422), 2, dict(four_pass=True, max_parts=2)),          # the headline band through the four-pass path
+    (8, 1 << 19, (30000, 29000), 1, dict()),                                # freq_res 2^19: 2048 x 256 inverse split
+    (4, 1 << 20, (50000, 60000), 1, dict(real=False)),                      # complex dual-pol input: two sequences of L = N
+    (64, 1 << 15, (2000, 2100), 2, dict(npol=1)),                           # single polarisation
+    (32, 1 << 16, (4000, 4100), 3, dict(use_raw=False, max_parts=2)),       # float input, ragged launch groups
+    (32, 1 << 16, (4000, 4100), 1, dict(input_nchan=2)),                    # two input channels: kernel slice per channel
+    (4096, 512, (40, 41), 1, dict(four_pass=True)),                         # many channels, short inverse (32 x 16)
+    (1, 1 << 22, (100000, 90000), 1, dict(layout="caspsr")),                # one channel (dsp::Convolution), L = 2^23
+])
+def test_four_pass_blocked_spectrum_geometries(oracle, gpu, C, M, nfilt, npart, kw):
+    """L >= 2^22 in four-pass mode: the spectrum between pass 2 and the inverse is blocked by pass-2 tile, k_inv_a loads it in
+    memory order (thread / item / per-bit address parts, mirror bin from the complement), the chirp is permuted likewise on
+    upload.  Every variant of input the path takes, against the float64 oracle."""
+    _fb(oracle, gpu, C, M, nfilt, npart, **kw)
