@@ -1091,6 +1091,11 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 
     const uint32_t tile = item.tile;
     const uint64_t part = part0 + item.lp;
+    // FOLD: the tile's detected samples are staged UNPADDED, channel after channel (16 bytes per sample), so that the
+    // samples of a phase bin's run are read at constant offsets from one base (the padded image cost four integer
+    // instructions per sample in a phase that only three of eight waves work in).  The channel stride is nkeep rounded up
+    // so that the T3 channels a quarter wave writes at once fall on different LDS banks.
+    const uint32_t fcr = (16u >> logT3) & 15u, fcs = ((g.nkeep + 15u - fcr) & ~15u) + fcr;
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
       if constexpr (FOLD) {
@@ -1102,7 +1107,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
           if ((uint32_t)t >= g.nkeep) continue;           // outside the kept window (negative t wraps)
           float r[4];
           detect4(cx2_lo(v[k]), cx2_hi(v[k]), out.state, r);
-          *(float4*)&lds[lds_pad(2 * (slo * g.nkeep + (uint32_t)t))] = make_float4(r[0], r[1], r[2], r[3]);
+          *(float4*)&lds[2 * (slo * fcs + (uint32_t)t)] = make_float4(r[0], r[1], r[2], r[3]);
         }
         return;
       }
@@ -1210,17 +1215,17 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         float4* __restrict__ pp = acc_ptr(w, en.x);
         uint32_t off = en.w, hits = en.z & 0xffffu;
         for (uint32_t i = 0;;) {
-          const uint32_t l0 = slo * g.nkeep + off;
+          const float4* __restrict__ src = (const float4*)&lds[2 * (slo * fcs + off)];     // consecutive samples: constant offsets
           uint32_t h = 0;
           for (; h + 8 <= hits; h += 8) {
             float4 sm[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) sm[q] = *(const float4*)&lds[lds_pad(2 * (l0 + h + q))];
+            for (int q = 0; q < 8; q++) sm[q] = src[h + q];
 #pragma unroll
             for (int q = 0; q < 8; q++) { acc.x += sm[q].x; acc.y += sm[q].y; acc.z += sm[q].z; acc.w += sm[q].w; }
           }
           for (; h < hits; h++) {
-            const float4 sm = *(const float4*)&lds[lds_pad(2 * (l0 + h))];
+            const float4 sm = src[h];
             acc.x += sm.x; acc.y += sm.y; acc.z += sm.z; acc.w += sm.w;
           }
           if (++i >= nint) break;
