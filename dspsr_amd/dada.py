@@ -9,6 +9,7 @@ pipeline.LoadToFold.process_host_blocks, which copies them to the device while t
 from __future__ import annotations
 
 import calendar
+import math
 import os
 import time
 
@@ -135,12 +136,86 @@ def observation(header: str):
     dsb = header_get(header, "DSB")
     info = InputInfo(centre_frequency=_scan(header, "FREQ", float, 0.0), bandwidth=_scan(header, "BW", float, 0.0),
                      nchan=nchan, npol=npol, ndim=ndim, tsamp_us=tsamp, machine=machine, start_seconds=start,
-                     mjd_day=day, mjd_sec=sec)
+                     mjd_day=day, mjd_sec=sec, source=header_get(header, "SOURCE") or "unknown",
+                     telescope=header_get(header, "TELESCOPE") or "unknown")
     extras = {"nbit": nbit, "ndat": _scan(header, "NDAT", int, 0), "offset_bytes": offset_bytes,
               "source": header_get(header, "SOURCE") or "unknown", "telescope": header_get(header, "TELESCOPE") or "unknown",
               "dual_sideband": None if dsb is None else int(dsb) == 1, "dm": _scan(header, "DM", float, None),
               "resolution": _scan(header, "RESOLUTION", int, 1)}
     return info, extras
+
+
+def header_set(header: str, keyword: str, value) -> str:
+    """ascii_header_set (ascii_header.c:53-108): replace the value of an existing keyword (up to its comment or line end)
+    or append 'KEYWORD      value                  ' + newline (in front of a "DATA" line if there is one)."""
+    text = "%-12s %-20s   " % (keyword, value)
+    k = header_find(header, keyword)
+    if k >= 0:
+        e = k
+        while e < len(header) and header[e] not in "#\n":
+            e += 1
+        return header[:k] + text + header[e:]
+    d = header.find("DATA\n")
+    if d >= 0:
+        return header[:d] + text + "\n" + header[d:]
+    return header + text + "\n"
+
+
+def unload_header(*, centre_frequency, bandwidth, nchan, npol, ndim, nbit, state, rate, mjd_day, mjd_sec, machine="dspsr",
+                  telescope="unknown", receiver="unknown", source="unknown", size=DEFAULT_HEADER_SIZE) -> bytes:
+    """ASCIIObservation::unload (ASCIIObservation.C:423-582) + HDR_SIZE, as dsp::Dump::prepare writes it in front of a
+    binary dump (Dump.C:46-66): the keys in the reference's order, values in its printf formats, zero padded to `size`."""
+    whole = int(math.floor(mjd_sec))
+    day, sec = mjd_day + whole // 86400, whole % 86400
+    t = time.gmtime((day - 40587) * 86400 + sec)
+    frac = mjd_sec - whole
+    bits = nchan * npol * ndim * nbit
+    offset_bytes = (int(frac * rate) * bits) // 8                       # get_nbytes(offset_samples)
+    h = ""
+    for key, val in (("HDR_VERSION", "%f" % 1.0), ("TELESCOPE", telescope), ("RECEIVER", receiver), ("SOURCE", source),
+                     ("MODE", "PSR"), ("FREQ", "%f" % centre_frequency), ("BW", "%f" % bandwidth), ("NCHAN", "%d" % nchan),
+                     ("NPOL", "%d" % npol), ("NBIT", "%d" % nbit), ("NDIM", "%d" % ndim), ("STATE", state),
+                     ("TSAMP", "%f" % (1e6 / rate)), ("UTC_START", time.strftime("%Y-%m-%d-%H:%M:%S", t)),
+                     ("OBS_OFFSET", "%d" % offset_bytes), ("INSTRUMENT", machine), ("HDR_SIZE", "%d" % size)):
+        h = header_set(h, key, val)
+    raw = h.encode("ascii")
+    if len(raw) >= size:
+        raise DspsrAmdError("dspsr_amd.dada.unload_header: header of %d bytes does not fit HDR_SIZE %d" % (len(raw), size))
+    return raw + b"\0" * (size - len(raw))
+
+
+class Dump:
+    """dsp::Dump in binary mode (Dump.C:46-99; inserted by `dspsr --dump <Operation>`, SingleThread.C:315-346, as
+    pre_<Operation>.dump): a 4096-byte DADA header of the TimeSeries, then for every call the block's samples in TFP order
+    (for idat, ichan, ipol: ndim floats).  The reference's only stage-capture mechanism; the taps LoadToFold offers are the
+    same two, "Detection" (the filterbank's complex output) and "Fold" (the detected samples)."""
+
+    def __init__(self, path, **header_fields):
+        self.path = path
+        self.f = open(path, "wb")
+        self.f.write(unload_header(**header_fields))
+        self.ndat = 0
+
+    def write(self, rows, ndat, ndim):
+        """rows: torch tensor [nchan][npol][>= ndat*ndim] float32 (device or host), FPT order as in the TimeSeries."""
+        nchan, npol = rows.shape[0], rows.shape[1]
+        tfp = rows[:, :, :ndat * ndim].reshape(nchan, npol, ndat, ndim).permute(2, 0, 1, 3).contiguous()
+        tfp.cpu().numpy().tofile(self.f)
+        self.ndat += ndat
+
+    def close(self):
+        if self.f:
+            self.f.close()
+            self.f = None
+
+
+def read_dump(path):
+    """(header text, float32 array [ndat][nchan][npol][ndim]) of a binary dsp::Dump file."""
+    text, hb = read_header(path)
+    info, ex = observation(text)
+    data = np.fromfile(path, dtype=np.float32, offset=hb)
+    per = info.nchan * info.npol * info.ndim
+    return text, data[:(data.size // per) * per].reshape(-1, info.nchan, info.npol, info.ndim)
 
 
 class DadaFile:

@@ -12,6 +12,7 @@ Only plumbing lives here; all arithmetic on samples is done by libdspsr_amd.so.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -55,6 +56,8 @@ class InputInfo:
     start_seconds: float = 0.0        # of the first sample, relative to UTC_START
     mjd_day: int = 55299
     mjd_sec: float = 7545.0
+    source: str = "unknown"
+    telescope: str = "unknown"
 
     @property
     def rate(self):
@@ -455,7 +458,8 @@ class LoadToFold:
     separate Operation in the reference)."""
 
     def __init__(self, cfg: Config, info: InputInfo, device: int = 0, stream: int | None = None,
-                 polyco: Polyco | None = None, reference_phase: float = 0.0, subband: int | None = None):
+                 polyco: Polyco | None = None, reference_phase: float = 0.0, subband: int | None = None,
+                 dump_before=(), dump_dir="."):
         """subband = g: this instance is rank g of a sub-band sharded run.  `info`/`cfg` still describe the
         WHOLE band (info.nchan input channels, cfg.nchan output channels); the instance processes input channel g only:
         its block holds that channel's bytes alone ([t][pol][dim], what a rank reads from the NCHAN-interleaved file),
@@ -545,6 +549,29 @@ class LoadToFold:
         # separate Detection and Fold operations on its own `detected` block)
         self.fused_mode = self.fb.fold_is_fused() if (cfg.fused_fold and cfg.ndim == 4 and self.sample_delay is None) else 0
         self.fused_fold = self.fused_mode != 0      # fused_mode 2: sums re-associated per run of parts (engine.fold_is_fused)
+        # stage capture (dspsr --dump <Operation>, SingleThread.C:315-346): pre_Detection.dump / pre_Fold.dump ------------
+        self.dumps, self._dump_cplx = {}, None
+        for name in dump_before:
+            if name not in ("Detection", "Fold"):
+                raise DspsrAmdError("dsp::SingleThread::insert_dump_point no operation named '%s' on this path "
+                                    "(Detection, Fold)" % name)
+            if name == "Detection" and self.sample_delay is not None:
+                raise DspsrAmdError("dspsr_amd.LoadToFold: the pre_Detection tap is not built for -K (the delay is applied "
+                                    "to the detected rows here); tap pre_Fold instead")
+            from . import dada
+            chbw = info.bandwidth / info.nchan
+            fc = info.centre_frequency if subband is None else info.centre_frequency - 0.5 * info.bandwidth + (subband + 0.5) * chbw
+            bw = info.bandwidth if subband is None else chbw
+            det = name == "Fold"
+            path = os.path.join(dump_dir, "pre_%s%s.dump" % (name, "" if subband is None else ".%d" % subband))
+            self.dumps[name] = dada.Dump(
+                path, centre_frequency=fc, bandwidth=bw, nchan=self.nchan_out, npol=self.npol_out if det else 2,
+                ndim=cfg.ndim if det else 2, nbit=32, rate=self.out_rate, mjd_day=info.mjd_day,
+                mjd_sec=info.mjd_sec + self.out_start,
+                state=("Stokes" if cfg.stokes else "Coherence") if det else "Analytic",
+                source=getattr(info, "source", "unknown"), telescope=getattr(info, "telescope", "unknown"))
+        if "Fold" in self.dumps:
+            self.fused_mode, self.fused_fold = 0, False          # the detected samples must exist in HBM to be dumped
         # fold bookkeeping (PhaseSeries) ---------------------------------------------------
         self.hits = np.zeros(cfg.nbin, dtype=np.uint32)
         self.integration_length = 0.0
@@ -582,6 +609,12 @@ class LoadToFold:
                                 % (raw.numel(), self.block_bytes(npart)))
         ndat = npart * self.nkeep
         state = _lib.STOKES if cfg.stokes else _lib.COHERENCE
+        if "Detection" in self.dumps:                        # the filterbank's complex output: one extra pass, taps only
+            if self._dump_cplx is None:
+                self._dump_cplx = self.torch.empty((self.nchan_out, 2, 2 * cfg.parts_per_block * self.nkeep),
+                                                   dtype=self.torch.float32, device="cuda:%d" % self.ctx.device)
+            self.fb.perform_raw(raw, self.layout, self.scale8, self._dump_cplx, npart)
+            self.dumps["Detection"].write(self._dump_cplx, ndat, 2)
         if self.sample_delay is not None:
             return self._process_block_interchan(raw, npart, ndat, state, events)
         # Subint<Fold>::transformation: fold piece by piece, emitting a sub-integration at every boundary
@@ -608,6 +641,8 @@ class LoadToFold:
         self.fb.perform_detect(self.detected, npart, state, cfg.ndim, raw=raw, layout=self.layout, scale=self.scale8)
         if events is not None:
             events[1].record()
+        if "Fold" in self.dumps:
+            self.dumps["Fold"].write(self.detected, ndat, cfg.ndim)
         for idat_start, ndat_fold, _division, complete in pieces:
             self._fold_piece(idat_start, ndat_fold)
             if complete:
@@ -628,6 +663,8 @@ class LoadToFold:
         rows = self.detected[:, :, off * nd:(off + nin) * nd]
         nuse = nin - self.sd_short              # (sub-band rank: the band's total delay, not just this rank's, is given up)
         nout = self.sample_delay.transform(rows[:, :, :nuse * nd].unflatten(2, (nuse, nd))) if nuse > 0 else 0
+        if nout and "Fold" in self.dumps:
+            self.dumps["Fold"].write(rows, nout, nd)
         if nout:
             for idat_start, ndat_fold, _division, complete in self._pieces(nout):
                 folded = self._set_plan(idat_start, ndat_fold)
@@ -794,6 +831,8 @@ class LoadToFold:
         self.ctx.synchronize()
 
     def close(self):
+        for d in self.dumps.values():
+            d.close()
         if self.sample_delay is not None:
             self.sample_delay.close()
         self.fb.close()

@@ -142,3 +142,69 @@ def test_fold_file_equals_resident_blocks(tmp_path):
     short.write_bytes(synth.dada_header(freq, bw, 1, 2, 1, tsamp) + raw.tobytes()[:2 * step])
     with pytest.raises(DspsrAmdError, match="fewer than one overlap-save part"):
         dada.fold_file(str(short), cfg, device=0, stream=stream)
+
+
+def test_dump_header_round_trip():
+    h = dada.unload_header(centre_frequency=1382.0, bandwidth=-400.0, nchan=16, npol=2, ndim=2, nbit=32, state="Analytic",
+                           rate=25e6, mjd_day=55299, mjd_sec=7545.25, source="J0835-4510", telescope="PKS")
+    assert len(h) == 4096
+    text = h.split(b"\0", 1)[0].decode()
+    assert text.startswith("HDR_VERSION  1.000000               \nTELESCOPE    PKS ")       # "%-12s %-20s   " per key
+    info, ex = dada.observation(text)
+    assert (info.centre_frequency, info.bandwidth, info.nchan, info.npol, info.ndim, ex["nbit"]) == (1382.0, -400.0, 16, 2, 2, 32)
+    assert info.machine == "dspsr" and info.tsamp_us == 0.04 and (info.mjd_day, info.mjd_sec) == (55299, 7545.0)
+    assert info.start_seconds == 0.25 and info.source == "J0835-4510"                      # the fraction comes back as OBS_OFFSET
+    assert dada.header_set("A 1 # c\nB 2\n", "A", "77") == "A            77                     # c\nB 2\n"
+    assert dada.header_set("A 1\nDATA\n", "C", 3).endswith("C            3                      \nDATA\n")
+
+
+@pytest.mark.gpu
+def test_stage_capture_taps(oracle, tmp_path):
+    """dspsr --dump Detection --dump Fold: pre_Detection.dump holds the filterbank's complex output, pre_Fold.dump the
+    detected samples, both as dsp::Dump writes them (4096-byte header + TFP floats); the tapped run folds the same profile."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    from dspsr_amd import pipeline
+    freq, bw, tsamp, dm, period = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004
+    cfg = pipeline.Config(nchan=16, dispersion_measure=dm, nbin=64, folding_period=period, ndim=4, parts_per_block=3, max_parts=2,
+                          force_fused=True)
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA", source="J0835-4510")
+    stream = torch.cuda.current_stream().cuda_stream
+    plain = pipeline.LoadToFold(cfg, info, device=0, stream=stream)
+    tapped = pipeline.LoadToFold(cfg, info, device=0, stream=stream, dump_before=("Detection", "Fold"), dump_dir=str(tmp_path))
+    assert plain.fused_fold and not tapped.fused_fold
+    step, ovl, nkeep = plain.nsamp_step * 3, plain.nsamp_overlap, plain.nkeep
+    raw = synth.voltages(2 * step + ovl, freq, bw, tsamp, dm, period)
+    dev = torch.from_numpy(raw.reshape(-1)).cuda()
+    for lt in (plain, tapped):
+        for b in range(2):
+            lt.process_block(dev[2 * b * step: 2 * (b * step + step + ovl)])
+        lt.finish_subint()
+        lt.synchronize()
+    assert np.array_equal(plain.subints[0]["hits"], tapped.subints[0]["hits"])
+    assert torch.equal(plain.subints[0]["profile_dev"], tapped.subints[0]["profile_dev"])
+    detected_last = tapped.detected.clone()
+    out_rate, out_start = tapped.out_rate, tapped.out_start
+    tapped.close()
+    plain.close()
+    text, cplx = dada.read_dump(str(tmp_path / "pre_Detection.dump"))
+    hinfo, ex = dada.observation(text)
+    assert (hinfo.nchan, hinfo.npol, hinfo.ndim, ex["nbit"], hinfo.machine) == (16, 2, 2, 32, "dspsr")
+    assert dada.header_get(text, "STATE") == "Analytic" and hinfo.source == "J0835-4510"
+    assert abs(hinfo.rate - out_rate) <= 1e-6 * out_rate and abs(hinfo.start_seconds - out_start) <= 1.5 / out_rate   # OBS_OFFSET holds whole samples (truncated, ASCIIObservation.C:566-567)
+    assert cplx.shape == (2 * 3 * nkeep, 16, 2, 2)
+    text, det = dada.read_dump(str(tmp_path / "pre_Fold.dump"))
+    hinfo, ex = dada.observation(text)
+    assert (hinfo.nchan, hinfo.npol, hinfo.ndim) == (16, 1, 4) and dada.header_get(text, "STATE") == "Coherence"
+    assert det.shape == (2 * 3 * nkeep, 16, 1, 4)
+    # the second block of the detected dump is what the pipeline held in HBM; detection of the complex dump gives it back
+    last = detected_last.view(16, 1, 3 * nkeep, 4).permute(2, 0, 1, 3).cpu().numpy()
+    assert np.array_equal(det[3 * nkeep:], last)
+    z = cplx[..., 0].astype(np.float64) + 1j * cplx[..., 1]
+    prod = oracle.detect_products(np.moveaxis(z, 0, 2), "Coherence")             # [chan][4][ndat]
+    want = np.moveaxis(prod, 1, 2)                                                # [chan][ndat][4]
+    got = np.moveaxis(det[:, :, 0, :], 0, 1)
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    with pytest.raises(DspsrAmdError, match="no operation named"):
+        pipeline.LoadToFold(cfg, info, device=0, stream=stream, dump_before=("Filterbank",))
