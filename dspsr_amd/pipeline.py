@@ -41,6 +41,8 @@ class Config:
                                       # detected time series in HBM); False = Detection and Fold as separate ops
     force_fused: bool = False         # fuse also where the channel tiles do not fill the chip (slower there, same sums)
     interchan_dedispersion: bool = False   # -K: remove the inter-channel dispersion delay (LoadToFold1.C:605-624)
+    record_time: bool = False              # -r: time every operation (Operation.C:90-113); each one then ends with a stream
+                                           # synchronisation so that the wall times are honest (FilterbankCUDA.cu:302-303)
 
 
 @dataclass
@@ -550,6 +552,7 @@ class LoadToFold:
         self.fused_mode = self.fb.fold_is_fused() if (cfg.fused_fold and cfg.ndim == 4 and self.sample_delay is None) else 0
         self.fused_fold = self.fused_mode != 0      # fused_mode 2: sums re-associated per run of parts (engine.fold_is_fused)
         # stage capture (dspsr --dump <Operation>, SingleThread.C:315-346): pre_Detection.dump / pre_Fold.dump ------------
+        self.optime = {}                    # record_time: operation name -> [seconds, calls]
         self.dumps, self._dump_cplx = {}, None
         for name in dump_before:
             if name not in ("Detection", "Fold"):
@@ -579,6 +582,32 @@ class LoadToFold:
         self.nsamples_in = 0            # unique input samples consumed (per pol)
         self.ndat_out = 0               # output samples produced so far
         self.subints = []               # completed sub-integrations (host copies) on the writer rank
+
+    def _op(self, name, fn):
+        """Operation::operate with record_time (Operation.C:90-113): wall time of the operation including its stream
+        synchronisation, accumulated per name."""
+        if not self.cfg.record_time:
+            return fn()
+        import time as _time
+        self.ctx.synchronize()
+        t0 = _time.perf_counter()
+        r = fn()
+        self.ctx.synchronize()
+        e = self.optime.setdefault(name, [0.0, 0])
+        e[0] += _time.perf_counter() - t0
+        e[1] += 1
+        return r
+
+    def report(self, file=None):
+        """Operation::report (Operation.C:168-190): the table `dspsr -r` prints -- name, time spent, discarded weights."""
+        import sys
+        file = file or sys.stderr
+        if not self.optime:
+            return
+        pad = lambda t: ("%-25s" % t)
+        print(pad("Operation") + pad("Time Spent") + pad("Discarded"), file=file)
+        for name, (t, _n) in self.optime.items():
+            print(pad(name) + pad("%g" % t) + pad("0"), file=file)
 
     # bytes of one block of `npart` parts
     def block_bytes(self, npart=None):
@@ -626,7 +655,8 @@ class LoadToFold:
             folded = self._set_plan(idat_start, ndat_fold)
             if events is not None:
                 events[0].record()
-            self.fb.perform_fold(self.fold, npart, state, raw=raw, layout=self.layout, scale=self.scale8)
+            self._op("Filterbank+Detection+Fold", lambda: self.fb.perform_fold(self.fold, npart, state, raw=raw, layout=self.layout,
+                                                                            scale=self.scale8))
             if events is not None:
                 events[1].record()
             self.integration_length += folded / self.out_rate
@@ -638,7 +668,8 @@ class LoadToFold:
             return
         if events is not None:          # HIP events bracketing the FFT+chirp launch group (bench.py roofline)
             events[0].record()
-        self.fb.perform_detect(self.detected, npart, state, cfg.ndim, raw=raw, layout=self.layout, scale=self.scale8)
+        self._op("Filterbank+Detection", lambda: self.fb.perform_detect(self.detected, npart, state, cfg.ndim, raw=raw,
+                                                                        layout=self.layout, scale=self.scale8))
         if events is not None:
             events[1].record()
         if "Fold" in self.dumps:
@@ -655,20 +686,21 @@ class LoadToFold:
         cfg, nd, head = self.cfg, self.cfg.ndim, self.sd_head
         if events is not None:
             events[0].record()
-        self.fb.perform_detect(self.detected[:, :, head * nd:], npart, state, nd, raw=raw, layout=self.layout,
-                               scale=self.scale8)
+        self._op("Filterbank+Detection", lambda: self.fb.perform_detect(self.detected[:, :, head * nd:], npart, state, nd, raw=raw,
+                                                                        layout=self.layout, scale=self.scale8))
         if events is not None:
             events[1].record()
         off, nin = head - self.sd_carried, self.sd_carried + ndat
         rows = self.detected[:, :, off * nd:(off + nin) * nd]
         nuse = nin - self.sd_short              # (sub-band rank: the band's total delay, not just this rank's, is given up)
-        nout = self.sample_delay.transform(rows[:, :, :nuse * nd].unflatten(2, (nuse, nd))) if nuse > 0 else 0
+        nout = self._op("SampleDelay", lambda: self.sample_delay.transform(rows[:, :, :nuse * nd].unflatten(2, (nuse, nd)))) \
+            if nuse > 0 else 0
         if nout and "Fold" in self.dumps:
             self.dumps["Fold"].write(rows, nout, nd)
         if nout:
             for idat_start, ndat_fold, _division, complete in self._pieces(nout):
                 folded = self._set_plan(idat_start, ndat_fold)
-                self.fold.fold(rows)
+                self._op("Fold", lambda: self.fold.fold(rows))
                 self.integration_length += folded / self.out_rate
                 self.ndat_total += ndat_fold
                 if complete:
@@ -722,7 +754,7 @@ class LoadToFold:
     def _fold_piece(self, idat_start, ndat_fold):
         """Fold::fold (Fold.C:650-657,718-803) on detected[idat_start : idat_start+ndat_fold]."""
         folded = self._set_plan(idat_start, ndat_fold)
-        self.fold.fold(self.detected)                  # (no head room without -K)
+        self._op("Fold", lambda: self.fold.fold(self.detected))                  # (no head room without -K)
         self.integration_length += folded / self.out_rate
         self.ndat_total += ndat_fold
 

@@ -208,3 +208,38 @@ def test_stage_capture_taps(oracle, tmp_path):
     assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
     with pytest.raises(DspsrAmdError, match="no operation named"):
         pipeline.LoadToFold(cfg, info, device=0, stream=stream, dump_before=("Filterbank",))
+
+
+@pytest.mark.gpu
+def test_record_time_report(capsys):
+    """dspsr -r: every operation timed with a stream synchronisation behind it (Operation.C:90-113), the table of
+    Operation::report; the results do not change."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    import io
+    from dspsr_amd import pipeline
+    freq, bw, tsamp, dm, period = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
+    stream = torch.cuda.current_stream().cuda_stream
+    profs = []
+    for rec, fused in ((False, False), (True, False), (True, True)):
+        cfg = pipeline.Config(nchan=16, dispersion_measure=dm, nbin=64, folding_period=period, ndim=4, parts_per_block=3,
+                              max_parts=2, record_time=rec, fused_fold=fused, force_fused=fused)
+        lt = pipeline.LoadToFold(cfg, info, device=0, stream=stream)
+        raw = torch.from_numpy(synth.voltages(lt.nsamp_step * 3 + lt.nsamp_overlap, freq, bw, tsamp, dm, period)).cuda()
+        lt.process_block(raw)
+        lt.finish_subint()
+        profs.append(lt.subints[0]["profile_dev"].clone())
+        out = io.StringIO()
+        lt.report(out)
+        text = out.getvalue()
+        if not rec:
+            assert text == "" and lt.optime == {}
+        elif fused:
+            assert list(lt.optime) == ["Filterbank+Detection+Fold"] and lt.optime["Filterbank+Detection+Fold"][1] == 1
+        else:
+            assert list(lt.optime) == ["Filterbank+Detection", "Fold"] and all(t > 0 for t, _ in lt.optime.values())
+            assert text.splitlines()[0].split() == ["Operation", "Time", "Spent", "Discarded"] and "Fold" in text
+        lt.close()
+    assert torch.equal(profs[0], profs[1]) and torch.equal(profs[0], profs[2])
