@@ -259,13 +259,14 @@ class DadaFile:
             yield src, npart
 
 
-def fold_file(path, cfg, polyco=None, device=0, stream=None, reference_phase=0.0):
+def fold_file(path, cfg, polyco=None, device=0, stream=None, reference_phase=0.0, dump_before=(), dump_dir="."):
     """The reference's `dspsr file.dada -F nchan:D ...` on one GPU: open the file, build the pipeline from its header,
     feed every block, close the last sub-integration.  Returns the LoadToFold (its .subints hold the results; the caller
     closes it)."""
     from .pipeline import LoadToFold
     f = DadaFile(path)
-    lt = LoadToFold(cfg, f.info, device=device, stream=stream, polyco=polyco, reference_phase=reference_phase)
+    lt = LoadToFold(cfg, f.info, device=device, stream=stream, polyco=polyco, reference_phase=reference_phase,
+                    dump_before=dump_before, dump_dir=dump_dir)
     if f.nblocks(lt) == (0, 0):
         lt.close()
         raise DspsrAmdError("dspsr_amd.fold_file: %s holds %d samples, fewer than one overlap-save part (%d)"

@@ -598,6 +598,16 @@ class LoadToFold:
         e[1] += 1
         return r
 
+    def vitals(self):
+        """The lines `dspsr` prints while it prepares (report_vitals, LoadToFold1.C:773-792,874-879): dedispersion filter
+        length, what the filterbank requires, the block size."""
+        r, cfg = self.response, self.cfg
+        nsamp_fft = self.nsamp_step + self.nsamp_overlap
+        nblock = cfg.parts_per_block * self.nsamp_step + self.nsamp_overlap
+        return ["dspsr: dedispersion filter length=%d (minimum=%d) complex samples" % (r.ndat, r.minimum_ndat),
+                "dspsr: %d channel dedispersing filterbank requires %d samples" % (cfg.nchan, nsamp_fft),
+                "dspsr: blocksize=%d samples or %g MB" % (nblock, self.block_bytes() / (1024.0 * 1024.0))]
+
     def report(self, file=None):
         """Operation::report (Operation.C:168-190): the table `dspsr -r` prints -- name, time spent, discarded weights."""
         import sys

@@ -231,6 +231,7 @@ def test_record_time_report(capsys):
         lt.process_block(raw)
         lt.finish_subint()
         profs.append(lt.subints[0]["profile_dev"].clone())
+        assert lt.vitals()[0].startswith("dspsr: dedispersion filter length=%d (minimum=" % lt.response.ndat)
         out = io.StringIO()
         lt.report(out)
         text = out.getvalue()
@@ -243,3 +244,30 @@ def test_record_time_report(capsys):
             assert text.splitlines()[0].split() == ["Operation", "Time", "Spent", "Discarded"] and "Fold" in text
         lt.close()
     assert torch.equal(profs[0], profs[1]) and torch.equal(profs[0], profs[2])
+
+
+@pytest.mark.gpu
+def test_dspsr_spelled_driver(tmp_path):
+    """tools/dspsr_amd_fold.py with the reference's option spellings on a synthetic DADA file: sub-integrations of 2 ms land
+    in PhaseSeries hand-off files that read back with the right shape and sample counts."""
+    import subprocess
+    import sys
+    from dspsr_amd import pipeline
+    freq, bw, tsamp, dm, period = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004
+    raw = synth.voltages(400000, freq, bw, tsamp, dm, period)
+    path = tmp_path / "synthetic.dada"
+    path.write_bytes(synth.dada_header(freq, bw, 1, 2, 1, tsamp) + raw.tobytes())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "dspsr_amd_fold.py"), "-F", "16:D", "-D", str(dm), "-b", "64", "-c", str(period),
+           "-L", "0.002", "-r", "-O", str(tmp_path / "out"), str(path)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "dspsr: dedispersion filter length=" in p.stderr and "Time Spent" in p.stderr
+    files = sorted(f for f in os.listdir(tmp_path) if f.startswith("out_") and f.endswith(".ps"))
+    assert len(files) >= 5
+    total = 0
+    for f in files:
+        hdr, hits, prof = pipeline.read_phase_series(str(tmp_path / f))
+        assert prof.shape == (16, 1, 64, 4) and int(hits.sum()) == int(hdr["NDAT_TOTAL"])
+        total += int(hdr["NDAT_TOTAL"])
+    assert total > 0 and float(np.abs(prof).max()) > 0
