@@ -67,6 +67,7 @@ struct FbGeom {
 struct FbIn {
   int kind;  // 0: float32 rows, 1: int8 generic, 2: int8 caspsr, 3: (pol0,pol1) byte pairs pre-transposed per tile,
              // 4: 16-bit offset-binary complex in 2048-sample blocks per polarisation (UWB)
+             // 5: float32 pairs pre-transposed per tile ((pol0, pol1) of real input or (re, im) of one polarisation)
   const void* base;
   uint64_t pol_stride;  // float32: floats between pol rows
   uint64_t part_step;   // time samples between parts
@@ -184,7 +185,10 @@ template <int W> DEV RawW<W> fetch_pair(const FbGeom& g, const FbIn& in, const u
     r.w[0] = v.x; r.w[1] = v.y;
     return r;
   } else {
-  if (in.kind == 0) {                                   // float32 rows
+  if (in.kind == 5) {                                   // regrouped float32 pairs: columns t, t+1 are 16 contiguous bytes
+    const uint4 v = *(const uint4*)((const cf*)in.base + t);
+    r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+  } else if (in.kind == 0) {                            // float32 rows
     if (g.real_input) {
       const float* x = (const float*)in.base + t;
       r.w[0] = __float_as_uint(x[0]); r.w[1] = __float_as_uint(x[1]);
@@ -259,7 +263,10 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
     }
     return;
   } else {
-  if (in.kind == 0) {
+  if (in.kind == 5) {
+    a = make_float2(__uint_as_float(r.w[0]), __uint_as_float(r.w[1]));
+    b = make_float2(__uint_as_float(r.w[2]), __uint_as_float(r.w[3]));
+  } else if (in.kind == 0) {
     if (g.real_input) {
       a = make_float2(__uint_as_float(r.w[0]), g.npol == 2 ? __uint_as_float(r.w[2]) : 0.0f);
       b = make_float2(__uint_as_float(r.w[1]), g.npol == 2 ? __uint_as_float(r.w[3]) : 0.0f);
@@ -499,6 +506,53 @@ __global__ __launch_bounds__(256) void k_raw_transpose(const FbGeom g, const FbI
   }
 }
 
+// The same regrouping for float32 input -- what dsp::Filterbank::Engine::perform is handed by DSPSR (the input is unpacked
+// before the boundary): T1 adjacent samples of a row are 4*T1 bytes per polarisation row, 16-byte pieces 8 KB apart at the
+// headline geometry, and pass 1 reading them in place ran four times slower than from 8-bit data (2223 against 562 us per
+// 32 parts).  Elements are 8 bytes: (pol0, pol1) of a real sample pair, or (re, im) of one polarisation of complex input
+//   Rt[part][seq][tile][na][T1]   (lives in the X scratch, which is idle until pass 2 writes it)
+__global__ __launch_bounds__(256) void k_float_transpose(const FbGeom g, const FbIn in, cf* __restrict__ Rt, const uint64_t part0)
+{
+  constexpr uint32_t ROWS = 64, COLS = 64, PITCH = COLS + 1;
+  __shared__ cf sm[ROWS * PITCH];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t M = 1u << g.logM, Rr = 1u << g.logR;
+  const int logT = g.logT1;
+  const uint32_t nb0 = blockIdx.x * COLS, na0 = blockIdx.y * ROWS;
+  const uint32_t nsq = g.real_input ? 1u : g.npol;
+  const uint64_t part = blockIdx.z / nsq;
+  const uint32_t seq = blockIdx.z % nsq;
+  const uint64_t t0 = (part0 + part) * in.part_step;
+  const uint32_t ncol = Rr - nb0 < COLS ? Rr - nb0 : COLS, nrow = M - na0 < ROWS ? M - na0 : ROWS;   // ncol % 4 == 0 (host)
+  const float* __restrict__ x = (const float*)in.base;
+  if (g.real_input) {
+    for (uint32_t q = tid; q < nrow * (ncol / 4); q += 256) {            // 4 samples of both polarisations per step
+      const uint32_t r = q / (ncol / 4), c4 = (q % (ncol / 4)) * 4;
+      const uint64_t t = t0 + (((uint64_t)(na0 + r)) << g.logR) + nb0 + c4;
+      const float4 p0 = ld_stream((const float4*)(x + t)), p1 = ld_stream((const float4*)(x + in.pol_stride + t));
+      cf* d = &sm[r * PITCH + c4];
+      d[0] = make_float2(p0.x, p1.x); d[1] = make_float2(p0.y, p1.y); d[2] = make_float2(p0.z, p1.z); d[3] = make_float2(p0.w, p1.w);
+    }
+  } else {
+    for (uint32_t q = tid; q < nrow * (ncol / 2); q += 256) {            // 2 complex samples per step
+      const uint32_t r = q / (ncol / 2), c2 = (q % (ncol / 2)) * 2;
+      const uint64_t t = t0 + (((uint64_t)(na0 + r)) << g.logR) + nb0 + c2;
+      const float4 v = ld_stream((const float4*)(x + seq * in.pol_stride + 2 * t));
+      cf* d = &sm[r * PITCH + c2];
+      d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
+    }
+  }
+  __syncthreads();
+  cf* __restrict__ dst = Rt + (part * nsq + seq) * ((uint64_t)M << g.logR);
+  const uint32_t ntl = ncol >> logT, T = 1u << logT;                     // T >= 2: two elements (16 bytes) per lane
+  for (uint32_t q = tid; q < ntl * nrow * (T / 2); q += 256) {
+    const uint32_t h = q % (T / 2), r = (q / (T / 2)) % nrow, tl = q / ((T / 2) * nrow);
+    const cf* s0 = &sm[r * PITCH + (tl << logT) + 2 * h];
+    st_stream((float4*)&dst[((((uint64_t)((nb0 >> logT) + tl) << g.logM) + na0 + r) << logT) + 2 * h],
+              make_float4(s0[0].x, s0[0].y, s0[1].x, s0[1].y));
+  }
+}
+
 // ------------------------------------------------------------------------------------ P1
 // M-point forward FFTs down T1 adjacent stride-Rr columns of one sequence of one part.
 //   in : sample n = na*Rr + nb (8-bit or float32, converted on load), nb = tile*T1 + col
@@ -529,7 +583,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     const uint32_t tile = item & (ntile - 1);
     const uint32_t rest = item >> logNt;
     const uint32_t seq = seq_of(rest);
-    const bool pret = in.kind == 3;   // pre-transposed: [part][tile][na][T] pairs, contiguous per tile
+    const bool pret = in.kind == 3 || in.kind == 5;   // pre-transposed: [part][tile][na][T] pairs, contiguous per tile
     const uint64_t t0 = pret ? ((uint64_t)rest * ntile + tile) * ((uint64_t)T << LOGF)       // rest = part*nseq + seq
                              : (part0 + part_of(rest)) * in.part_step + tile * T;
     if (FB_DBG(g) & 2) {     // ablation only; hoisted so that the real path has no per-load branch
@@ -1642,6 +1696,7 @@ k3_t fb_pick3f(int logf, bool full);      // fused fold
 k3a_t fb_pick3a(int logf, bool blocked);
 k3b_t fb_pick3b(int logf);
 void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
+void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, cf* Rt, uint64_t part0);
 
 #ifdef FB_ONLY_HEADLINE   // experiment builds: only the kernels of the headline geometry (M = 4096, Rr = 2048, 8-bit)
 #if FB_HAS(1)
@@ -1723,6 +1778,10 @@ k3b_t fb_pick3b(int logf) { return pick3b(logf, seq_t()); }
 void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0)
 {
   hipLaunchKernelGGL(k_raw_transpose, grid, dim3(256), 0, stream, g, in, Rt, part0);
+}
+void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, cf* Rt, uint64_t part0)
+{
+  hipLaunchKernelGGL(k_float_transpose, grid, dim3(256), 0, stream, g, in, Rt, part0);
 }
 #endif
 
@@ -2128,6 +2187,10 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
     if (hipMalloc((void**)&fb->Rt, (size_t)fb->max_parts * fb->nseq * fb->L * sizeof(uint16_t)) != hipSuccess)
       return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of the 8-bit regroup buffer failed");
   }
+  // float32 rows (what Filterbank::Engine::perform is given): regrouped likewise, 8-byte elements, into the idle X scratch
+  const bool pretf = in.kind == 0 && g.npol == 2 && g.logR >= 6 && g.logM >= 1 && g.logT1 >= 1 && g.logT1 <= 4 &&
+                     ((uintptr_t)in.base % 16) == 0 && (in.part_step % 4) == 0 && (in.pol_stride % 4) == 0 &&
+                     (in_chan_stride_bytes_or_floats % 4) == 0 && !FB_ENV_SET("DSPSR_AMD_NO_PRETRANSPOSE");
   int raww = (pret || (fast8 && in.kind == 1)) ? 1 : 4;
 #ifdef FB_ONLY_HEADLINE
   if (fast8 && FB_ENV_SET("DSPSR_AMD_DIRECT8") && g.logT1 == 2 && (in.part_step % 4) == 0 && ((uintptr_t)in.base % 8) == 0) {
@@ -2179,6 +2242,10 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         fb_launch_raw_transpose(dim3((Rr + 255) / 256, (M + 63) / 64, nb * fb->nseq), ctx->stream, g, ci, fb->Rt, part0);
         ci.kind = 3;
         ci.base = fb->Rt;
+      } else if (pretf) {
+        fb_launch_float_transpose(dim3(Rr / 64, (M + 63) / 64, nb * fb->nseq), ctx->stream, g, ci, fb->X, part0);
+        ci.kind = 5;
+        ci.base = fb->X;
       }
       hipLaunchKernelGGL(k1, dim3(grid_for(n1, fb->ncu * fb->wg1)), dim3(fb->nt1), fb->lds1, ctx->stream, g, ci, fb->A, ctx->tw,
                          part0, nb, fb->nseq, run1);

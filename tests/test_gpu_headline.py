@@ -256,3 +256,18 @@ def test_four_pass_blocked_spectrum_geometries(oracle, gpu, C, M, nfilt, npart, 
     memory order (thread / item / per-bit address parts, mirror bin from the complement), the chirp is permuted likewise on
     upload.  Every variant of input the path takes, against the float64 oracle."""
     _fb(oracle, gpu, C, M, nfilt, npart, **kw)
+
+
+@pytest.mark.parametrize("C,M,nfilt,npart,kw", [
+    (64, 1024, (100, 101), 3, dict(max_parts=2)),                      # real dual-pol, three passes, 16-column tiles
+    (1024, 4096, (422, 422), 2, dict(max_parts=2)),                    # the headline geometry, 4-column tiles
+    (128, 512, (40, 30), 2, dict(real=False)),                         # complex dual-pol: one sequence per polarisation
+    (32, 2048, (100, 50), 2, dict(input_nchan=2)),                     # two input channels (channel stride)
+])
+def test_float_input_regrouped(oracle, gpu, C, M, nfilt, npart, kw):
+    """dsp::Filterbank::Engine::perform receives float32 rows (DSPSR unpacks before the boundary).  With rows of >= 64
+    columns the floats are first regrouped per pass-1 tile (k_float_transpose, 8-byte elements) exactly like the 8-bit
+    stream; same results as the 8-bit side channel to rounding, and within tolerance of the float64 oracle."""
+    a, _ = _fb(oracle, gpu, C, M, nfilt, npart, use_raw=False, **kw)
+    b, _ = _fb(oracle, gpu, C, M, nfilt, npart, use_raw=True, **kw)
+    assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max()
