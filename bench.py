@@ -511,7 +511,7 @@ def main():
     ap.add_argument("--parts-per-block", type=int, default=0,
                     help="overlap-save parts per block; 0 = 64 for the headline geometry (2^23 samples per part), "
                          "more for smaller parts so that a block stays near 5e8 samples (capped at 256)")
-    ap.add_argument("--max-parts", type=int, default=0, help="parts per launch group; 0 = parts_per_block/2, at most 64")
+    ap.add_argument("--max-parts", type=int, default=0, help="parts per launch group; 0 = parts_per_block/2, more for small parts (2 GB of scratch)")
     ap.add_argument("--dump-steps", type=int, default=8, help="steps per sub-integration dump")
     ap.add_argument("--ndim", type=int, default=4, choices=[1, 2, 4])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -564,7 +564,12 @@ def main():
         nsamp_fft = 2 * n_fft if wl["ndim"] == 1 else n_fft
         args.parts_per_block = max(16, min(256, (1 << 29) // nsamp_fft))
     if not args.max_parts:
-        args.max_parts = max(1, min(64, args.parts_per_block // 2))
+        # parts per launch group: half a block, or -- small parts -- as many as keep each scratch buffer near 2 GB
+        # (the persistent kernels amortise ramp-up and tail over the group and the launch gaps shrink: the 50 MHz sub-band
+        # geometry 42.1k / 45.6k / 46.0k Msamples/s at 64 / 128 / 256 parts per group)
+        n_fft = (wl["nchan"] // wl["in_nchan"]) * wl["freq_res"]
+        part_bytes = 2 * n_fft * 8          # L = 2N points of real input, or two sequences of N (complex dual-pol)
+        args.max_parts = max(1, args.parts_per_block // 2, min(args.parts_per_block, (2 << 30) // part_bytes))
     cfg = pipeline.Config(nchan=wl["nchan"], dispersion_measure=wl["dm"], nbin=wl["nbin"],
                           folding_period=0.0893, freq_res=wl["freq_res"], ndim=args.ndim,
                           parts_per_block=args.parts_per_block, max_parts=args.max_parts,
