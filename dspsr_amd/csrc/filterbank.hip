@@ -304,6 +304,9 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
 // table (the remaining low bits of j), both correctly rounded -> about 1.2e-7 relative error.
 // NT twiddles exp(-2*pi*i*j[q]/2^logL) at once: all table loads are issued back to back (one memory round trip)
 // and only then combined -- evaluating them one by one costs a dependent L1/L2 round trip each
+#ifndef FB_TWIDDLE_IN_P2
+#define FB_TWIDDLE_IN_P2 1     // 0: the inter-pass twiddle on pass 1's outputs (rounds 1-2a; A/B builds)
+#endif
 #ifndef FB_TABLE_TWIDDLES
 #define FB_TABLE_TWIDDLES 0   // 1: pass twiddles from the (coarse x fine) tables for every length (comparison builds)
 #endif
@@ -648,8 +651,10 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     const uint32_t swz = (PTS * blockDim.x) >= 256 ? 1u : 0u;
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
+#if !FB_TWIDDLE_IN_P2
       const uint32_t nb = tile * T + col;
       if (!(FB_DBG(g) & 8)) apply_pass_twiddle<R>(v, nb, p, pstride, logL, tw, g.tw_lo);
+#endif
       // image index of element k: l0 + k*(pstride << logT) (pstride is a multiple of T2), so when that step is a
       // multiple of 64 the swizzle and the padding of l0 carry over: one address per column, constant offsets
       auto img = [&](const uint32_t l) { return lds_pad(l ^ (((l >> 4) & swz) << 3)); };
@@ -770,6 +775,22 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
 #endif
 #pragma unroll
     for (int i = 0; i < NPAIR; i++) x[i] = make_cx2(make_float2(y[i].x, y[i].y), make_float2(y[i].z, y[i].w));
+#if FB_TWIDDLE_IN_P2
+    // The twiddle W_L^{nb*ka} between the two forward passes is applied HERE, to the elements pass 2 has just loaded, not
+    // to pass 1's outputs: pass 1 is bound by the vector instructions it issues (31 packed complex products and 10 sin/cos
+    // per thread and tile for this twiddle alone), pass 2 by the fabric with its vector unit two thirds idle.  The product
+    // nb*ka is symmetric: the column pair is (ka, ka + 1), the position nb = pos0 + i*S.
+    if (!(FB_DBG(g) & 8)) {
+      const uint32_t tile_t = item & (ntile - 1);
+      constexpr uint32_t S = 1u << (LOGF - P::LOGR1);
+#pragma unroll
+      for (int g2 = 0; g2 < P::G1; g2 += 2) {
+        const uint32_t eb = P::G1 * tid + g2;
+        cx2 (&xg)[P::R1] = *reinterpret_cast<cx2 (*)[P::R1]>(&x[(g2 / 2) * P::R1]);
+        apply_pass_twiddle<P::R1>(xg, tile_t * T2 + (eb & (T2 - 1)), eb >> logT, S, g.logM + LOGF, tw, g.tw_lo);
+      }
+    }
+#endif
 #if defined(FB_STAMPS) && FB_STAMPS == 2
     STAMP(ts1);
 #endif
