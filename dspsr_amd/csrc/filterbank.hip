@@ -919,9 +919,11 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   // chunk < 0: all elements; otherwise the elements i with i % NCHUNK == chunk (the prefetch of the next tile is
   // issued in NCHUNK groups spread over the transform, see wgfft_stage)
   constexpr int NCHUNK = P::NS + 1;
-  // T = 4 columns = 2 channels x 2 polarisations per tile.  Only where the pass is memory bound (detected or complex
-  // output written): -3.7 % there; the fused kernel is issue bound and loses 1.6 % to the exchange (r01g_experiments.txt)
-  constexpr bool PAIR16 = LOGT == 2 && P::G1 == 2 && !FOLD;
+  // T = 4 columns = 2 channels x 2 polarisations per tile: the two channels' elements are loaded as aligned 16-byte pairs and
+  // the halves exchanged between the lane pair.  -3.7 % where the detected or complex output is written; in the fused
+  // kernel it cost 1.6 % while the chirp was still loaded per part (round 1) and gains 5.7 % now that it stays in registers
+  // (profiles/r02_experiments.txt, item 23)
+  constexpr bool PAIR16 = LOGT == 2 && P::G1 == 2;
   const bool pair16 = PAIR16 && g.real_input && logX3 == 1 && !getenv_pair16_off(g);
   cf special = make_float2(0.f, 0.f);                   // mirror element of bin 0 (pair16 path)
   // a work item = (tile of channels, part of the launch), kept as two 32-bit numbers: a combined 64-bit index costs a
