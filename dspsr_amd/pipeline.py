@@ -770,7 +770,6 @@ class LoadToFold:
 
     def profiles_tensor(self):
         """Zero-copy torch view of the device-resident PhaseSeries (Fold::Engine::get_profiles)."""
-        import ctypes as C
         torch = self.torch
         n = self.nchan_out * self.npol_out * self.cfg.nbin * self.cfg.ndim
         ptr = self.fold.get_profiles_ptr()
