@@ -2486,7 +2486,7 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
   // internal block -- the sums are bit-identical either way.
   // (a bound profile whose rows are not float4 aligned also takes the separate launches: the fold kernel adds scalars)
   const bool prof_vec4 = fold->span % 4 == 0 && ((uintptr_t)fold->profile % 16) == 0;
-  if (!dspsr_amd_filterbank_fold_is_fused(fb) || !prof_vec4 || fold_plan_max_run(fold) >= FOLD_LONG_RUN_HOST) {
+  if (!dspsr_amd_filterbank_fold_is_fused(fb) || !prof_vec4 || fold_plan_max_run(fold) >= (uint32_t)FB_ENV_INT("DSPSR_AMD_FUSED_MAX_RUN", (int)FOLD_FUSED_MAX_RUN)) {
     const uint64_t row = npart * fb->g.nkeep * 4;                       // floats per channel
     const size_t need = (size_t)row * nchan;
     if (!need) return DSPSR_AMD_OK;

@@ -44,6 +44,11 @@ struct dspsr_amd_fold {
 // folded with re-associated sums (fold.hip, k_fold_chunked<., true>); the fused filterbank kernel only has the exact
 // time-order fold, so such plans take the separate Detection + Fold launches.
 constexpr uint32_t FOLD_LONG_RUN_HOST = 64;
+// The fused kernel adds a bin's samples one after the other (exact time order): a run of n samples is a dependent chain of n
+// float4 adds on one thread, about 16 cycles each.  Up to this length that still costs less than the detected round trip
+// through HBM (headline geometry, ms per block fused / separate: 34-sample runs 4.99 / 5.93, 136: 5.14 / 6.01, 545: 5.42 /
+// 5.85, 1090: 6.39 / 5.98; tools/exp_fused_runs.py); beyond it the plan takes the separate launches and the long-run fold.
+constexpr uint32_t FOLD_FUSED_MAX_RUN = 640;
 static inline uint32_t fold_plan_max_run(const dspsr_amd_fold* f)
 {
   uint32_t m = f->current_hits;

@@ -271,3 +271,35 @@ def test_float_input_regrouped(oracle, gpu, C, M, nfilt, npart, kw):
     a, _ = _fb(oracle, gpu, C, M, nfilt, npart, use_raw=False, **kw)
     b, _ = _fb(oracle, gpu, C, M, nfilt, npart, use_raw=True, **kw)
     assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max()
+
+
+def test_fused_fold_of_wide_bins(oracle, gpu):
+    """Phase bins 64 ... 640 samples wide are still folded inside the last filterbank pass (exact time order: one dependent
+    chain per bin), the separate Fold takes them as long runs (re-associated micro-block sums): the two agree to rounding,
+    hits are identical, and the fused sums equal the CPU loop's order on the detected samples bit for bit."""
+    from dspsr_amd import pipeline
+    info = pipeline.InputInfo(machine="CASPSR")
+    res = {}
+    for fused in (True, False):
+        cfg = pipeline.Config(nchan=1024, dispersion_measure=1000.0, nbin=128, folding_period=0.0893, freq_res=4096,
+                              parts_per_block=8, max_parts=4, fused_fold=fused)
+        lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+        assert lt.fused_fold == fused and 34883 // 128 > 64
+        raw = _noise_block(lt.block_bytes(), seed=11)
+        lt.process_block(raw)
+        lt.finish_subint()
+        lt.synchronize()
+        sub = lt.subints[0]
+        res[fused] = (sub["hits"].copy(), sub["profile_dev"].cpu().numpy().reshape(1024, 128, 4))
+        if not fused:
+            det = lt.detected.view(1024, -1, 4)[:3].cpu().numpy()                 # three channels, all samples
+            t0 = lt.out_start + 0.5 / lt.out_rate
+            plan = oracle.fold_binplan(math.fmod(t0, 0.0893) / 0.0893, (1.0 / lt.out_rate) / 0.0893, 128, det.shape[1])
+        lt.close()
+    assert np.array_equal(res[True][0], res[False][0]) and int(res[True][0].sum()) == 8 * 3252
+    scale = np.abs(res[False][1]).max()
+    assert np.abs(res[True][1] - res[False][1]).max() <= 2e-6 * scale
+    want = np.zeros((3, 128, 4), np.float32)
+    for i in range(det.shape[1]):                                                  # Fold.C:844-852: strict time order
+        want[:, plan[i], :] += det[:, i, :]
+    assert np.array_equal(res[True][1][:3], want)
