@@ -1172,7 +1172,9 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     // samples of a phase bin's run are read at constant offsets from one base (the padded image cost four integer
     // instructions per sample in a phase that only three of eight waves work in).  The channel stride is nkeep rounded up
     // so that the T3 channels a quarter wave writes at once fall on different LDS banks.
-    const uint32_t fcr = (16u >> logT3) & 15u, fcs = ((g.nkeep + 15u - fcr) & ~15u) + fcr;
+    // (many channels of a short transform: the rounded stride would not fit the exchange buffer -- 2*T3*nkeep words always do)
+    const uint32_t fcr = (16u >> logT3) & 15u, fcs_r = ((g.nkeep + 15u - fcr) & ~15u) + fcr;
+    const uint32_t fcs = ((2u * fcs_r) << logT3) <= PTS * blockDim.x ? fcs_r : g.nkeep;
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
       if constexpr (FOLD) {

@@ -1141,3 +1141,31 @@ def test_host_block_feeder_equals_resident_blocks(gpu):
         res.append((lt.subints[0]["hits"].copy(), lt.subints[0]["profile_dev"].cpu().numpy()))
         lt.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.abs(res[0][1]).max() > 0
+
+
+def test_fused_fold_many_channels_short_transform(gpu):
+    """256 channels of an 8-point inverse transform (nkeep 6) are ONE pass-3 tile: the fused fold's staging of the detected
+    tile must fit the exchange buffer (a channel stride rounded up to 16 samples did not: found by tools/fuzz_fold.py, which
+    it crashed).  Fused (forced) == Detection + Fold, with sub-integration boundaries every 131 samples."""
+    from dspsr_amd import pipeline, synth
+    dspsr_amd, ctx = gpu
+    freq, bw, tsamp, dm, period = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
+    res = []
+    for fused in (True, False):
+        cfg = pipeline.Config(nchan=256, dispersion_measure=dm, nbin=64, folding_period=period, ndim=4, parts_per_block=3,
+                              max_parts=2, fused_fold=fused, force_fused=fused, subint_seconds=0.0021)
+        lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+        assert (lt.response.ndat, lt.nkeep) == (8, 6) and lt.fused_fold == fused
+        step = 3 * lt.nsamp_step
+        raw = torch.from_numpy(synth.voltages(12 * step + lt.nsamp_overlap, freq, bw, tsamp, dm, period)).cuda()
+        for b in range(12):
+            lt.process_block(raw[2 * b * step: 2 * (b * step + step + lt.nsamp_overlap)])
+        if lt.ndat_total:
+            lt.finish_subint()
+        lt.synchronize()
+        res.append([(s["hits"].copy(), s["profile_dev"].cpu().numpy(), s["ndat_total"]) for s in lt.subints])
+        lt.close()
+    assert len(res[0]) == len(res[1]) >= 1
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a[0], b[0]) and a[2] == b[2] and np.array_equal(a[1], b[1])

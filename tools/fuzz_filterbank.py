@@ -1,0 +1,59 @@
+"""tools/fuzz_filterbank.py [ncases] [seed] : random filterbank geometries against the float64 oracle (test infrastructure:
+uses tests/test_gpu_parity._fb_case).  Every combination the C-ABI accepts is fair game: 1 or 2 polarisations, real or complex
+input, 8-bit or float32 input, generic or CASPSR byte order, 1-3 input channels, three- or four-pass, 1-3 parts per launch."""
+import os
+import sys
+import traceback
+
+import numpy as np
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import importlib.util
+
+spec = importlib.util.spec_from_file_location("oracle_mod", os.path.join(ROOT, "oracle", "dspsr_oracle.py"))
+oracle = importlib.util.module_from_spec(spec)
+sys.modules["oracle_mod"] = oracle
+spec.loader.exec_module(oracle)
+import dspsr_amd
+from test_gpu_parity import _fb_case
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = dspsr_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+bad = 0
+for i in range(ncases):
+    logN = int(rng.integers(7, 22))
+    logM = int(rng.integers(2, min(logN, 19) + 1))
+    C, M = 1 << (logN - logM), 1 << logM
+    real = bool(rng.integers(0, 4) != 0)
+    npol = 2 if not real or rng.integers(0, 5) else 1
+    pos = int(rng.integers(0, max(1, M // 3)))
+    neg = int(rng.integers(0, max(1, M // 3)))
+    if pos + neg >= M:
+        pos, neg = 0, 0
+    kw = dict(npol=npol, real=real, use_raw=bool(rng.integers(0, 3) != 0), max_parts=int(rng.integers(1, 4)),
+              four_pass=bool(rng.integers(0, 3) == 0), seed=int(rng.integers(1, 1000)))
+    if real and npol == 2 and kw["use_raw"] and rng.integers(0, 2):
+        kw["layout"] = "caspsr"
+    if rng.integers(0, 4) == 0 and logN <= 18 and "layout" not in kw:      # (the CASPSR byte order is single channel)
+        kw["input_nchan"] = int(rng.integers(2, 4))
+    npart = int(rng.integers(1, 4)) if logN <= 19 else 1
+    desc = "C=%d M=%d nfilt=(%d,%d) npart=%d %s" % (C, M, pos, neg, npart, kw)
+    try:
+        _fb_case(oracle, (dspsr_amd, ctx), C, M, (pos, neg), npart, **kw)
+        print("ok   ", desc, flush=True)
+    except dspsr_amd.DspsrAmdError as e:
+        print("refused", desc, "--", str(e)[:100], flush=True)
+    except AssertionError as e:
+        bad += 1
+        print("FAIL ", desc, "--", str(e)[:200], flush=True)
+    except Exception:
+        bad += 1
+        print("ERROR", desc, flush=True)
+        traceback.print_exc()
+ctx.close()
+print("%d cases, %d failures" % (ncases, bad))
+sys.exit(1 if bad else 0)
