@@ -166,9 +166,14 @@ class FilterbankEngine:
         if have < need:
             raise DspsrAmdError("dspsr_amd.FilterbankEngine: %s holds %d elements per row, %d needed" % (what, have, need))
 
-    def _raw_bytes(self, npart):
+    def _raw_bytes(self, npart, layout=_lib.RAW_GENERIC):
         c = self.cfg
-        return (npart * self.nsamp_step + self.nsamp_overlap) * c.input_nchan * c.npol * (1 if c.real_input else 2)
+        nsamp = npart * self.nsamp_step + self.nsamp_overlap
+        if layout == _lib.RAW_CASPSR:
+            # 4 samples of pol0 then 4 of pol1: the block must hold WHOLE 8-byte groups (its last samples' pol1 bytes lie
+            # up to 4 bytes behind their pol0 bytes; CASPSRUnpacker.C:132-187 unpacks group by group)
+            return ((nsamp + 3) // 4) * 8
+        return nsamp * c.input_nchan * c.npol * (1 if c.real_input else 2)
 
     def perform(self, inp, out, npart, in_step, out_step):
         ics, ips = _strides3(inp)
@@ -193,7 +198,7 @@ class FilterbankEngine:
             out_step = 2 * self.nkeep
         if npart:
             if layout != _lib.RAW_UWB16:
-                self._need("raw block", raw.numel(), self._raw_bytes(npart))
+                self._need("raw block", raw.numel(), self._raw_bytes(npart, layout))
             if out is not None:
                 self._need("output", out.shape[2], (npart - 1) * out_step + 2 * self.nkeep)
         _check(self.ctx.handle,
@@ -210,7 +215,7 @@ class FilterbankEngine:
                 raise DspsrAmdError("dspsr_amd.FilterbankEngine.perform_detect: ndim=%d needs %d planes, the block has %d"
                                     % (ndim, 4 // ndim, det.shape[1]))
             if raw is not None and layout != _lib.RAW_UWB16:
-                self._need("raw block", raw.numel(), self._raw_bytes(npart))
+                self._need("raw block", raw.numel(), self._raw_bytes(npart, layout))
             if inp is not None:
                 self._need("input", inp.shape[2], (npart - 1) * in_step + self.nsamp_fft * (1 if self.cfg.real_input else 2))
         if inp is not None:
@@ -237,7 +242,7 @@ class FilterbankEngine:
         npart*nkeep output samples must already have been given to `fold` (set_nbin/set_ndat/set_bins)."""
         if npart:
             if raw is not None and layout != _lib.RAW_UWB16:
-                self._need("raw block", raw.numel(), self._raw_bytes(npart))
+                self._need("raw block", raw.numel(), self._raw_bytes(npart, layout))
             if inp is not None:
                 self._need("input", inp.shape[2], (npart - 1) * in_step + self.nsamp_fft * (1 if self.cfg.real_input else 2))
         if inp is not None:

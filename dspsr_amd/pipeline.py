@@ -623,6 +623,8 @@ class LoadToFold:
     def block_bytes(self, npart=None):
         npart = npart or self.cfg.parts_per_block
         nsamp = npart * self.nsamp_step + self.nsamp_overlap
+        if self.layout == _lib.RAW_CASPSR:
+            return ((nsamp + 3) // 4) * 8          # whole 4-sample groups (4 B pol0 | 4 B pol1)
         return nsamp * self.in_nchan * self.info.npol * self.info.ndim
 
     def seek_block(self, k):

@@ -115,7 +115,8 @@ int dspsr_amd_filterbank_perform(dspsr_amd_filterbank* fb, const float* in_dev, 
  * unpack kernels GenericEightBitUnpackerCUDA.cu:24-45 / CASPSRUnpackerCUDA.cu:44-82 + perform).
  * raw_dev points at the first byte of the block (BitSeries::get_rawptr()); value = (int8+0.5)*scale. */
 #define DSPSR_AMD_RAW_GENERIC 0  /* byte ((t*nchan+c)*npol+p)*ndim+d   BitUnpacker.C:48-80 */
-#define DSPSR_AMD_RAW_CASPSR 1   /* 4 B pol0, 4 B pol1 repeating       CASPSRUnpacker.C:132-187 */
+#define DSPSR_AMD_RAW_CASPSR 1   /* 4 B pol0, 4 B pol1 repeating       CASPSRUnpacker.C:132-187; the block starts on a group
+                                    boundary and holds whole 8-byte groups: ceil(nsamp/4)*8 bytes */
 #define DSPSR_AMD_RAW_UWB16 2    /* 16-bit offset-binary complex, 2048-sample blocks per polarisation, single channel;
                                     value = float(int16(x ^ 0x8000)) * scale   uwb/UWBUnpackerCUDA.cu:24-75,
                                     uwb/UWBUnpacker.C:196-207 (the reference applies no scale: pass 1.0) */

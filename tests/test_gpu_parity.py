@@ -49,7 +49,8 @@ def _fb_case(oracle, gpu, C, M, nfilt, npart, npol=2, real=True, input_nchan=1, 
                             M - nfilt_pos - nfilt_neg, float(N) * M, real)
     plan.nsamp_step = plan.nsamp_fft - plan.nsamp_overlap
     ndat = npart * plan.nsamp_step + plan.nsamp_overlap
-    raw = _raw(ndat, npol, obs.ndim, input_nchan, seed)
+    # (the CASPSR byte order comes in whole groups of 4 samples: 4 B pol0 | 4 B pol1)
+    raw = _raw(-(-ndat // 4) * 4 if layout == "caspsr" else ndat, npol, obs.ndim, input_nchan, seed)
     scale = float(o.S8)
     unpacked = o.unpack_8bit(raw, obs)
     ref = o.filterbank(unpacked, plan, kernel, npart=npart, dtype=np.float64)

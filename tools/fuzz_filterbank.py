@@ -36,7 +36,7 @@ for i in range(ncases):
         pos, neg = 0, 0
     kw = dict(npol=npol, real=real, use_raw=bool(rng.integers(0, 3) != 0), max_parts=int(rng.integers(1, 4)),
               four_pass=bool(rng.integers(0, 3) == 0), seed=int(rng.integers(1, 1000)))
-    if real and npol == 2 and kw["use_raw"] and rng.integers(0, 2):
+    if real and npol == 2 and kw["use_raw"] and rng.integers(0, 2):      # (whole 4-sample groups: _fb_case pads the stream)
         kw["layout"] = "caspsr"
     if rng.integers(0, 4) == 0 and logN <= 18 and "layout" not in kw:      # (the CASPSR byte order is single channel)
         kw["input_nchan"] = int(rng.integers(2, 4))

@@ -51,7 +51,7 @@ for i in range(ncases):
     ok_hits = np.array_equal(hits, want_hits)
     exact = np.array_equal(got, want)
     # (float32 sums of n samples in two association orders differ by about eps*sqrt(n): the bound grows with the run length)
-    close = np.abs(got - want).max() <= 2e-6 * max(1.0, (spb / 100.0) ** 0.5) * max(np.abs(want).max(), 1e-30)
+    close = np.abs(got - want).max() <= 2e-6 * max(1.0, (float(hits.max()) / 100.0) ** 0.5) * max(np.abs(want).max(), 1e-30)
     long_runs = spb >= 60
     if ok_hits and (exact or (long_runs and close)):
         print("ok   ", desc, "exact" if exact else "rounding", flush=True)
