@@ -59,31 +59,46 @@ for i in range(ncases):
         bad += 1
         print("FAIL ", desc, "hits", ok_hits, "exact", exact, "close", close, flush=True)
 # pipeline: fused against separate launches
-freq, bw, tsamp, dm = 1382.0, -16.0, 1.0 / 32.0, 30.0
-for i in range(max(4, ncases // 6)):
-    nchan = int(rng.choice([16, 64, 256]))
+for i in range(max(4, ncases // 3)):
+    freq = float(rng.choice([1382.0, 400.0, 3100.0]))
+    bw = float(rng.choice([-16.0, 16.0, -64.0, 8.0]))
+    tsamp = 1.0 / (2.0 * abs(bw))                      # real sampling of the band
+    dm = float(rng.choice([0.0, 3.0, 30.0, 120.0]))
+    nchan = int(2 ** rng.integers(1, 10))
     nbin = int(rng.choice([16, 64, 256, 1024]))
     period = float(rng.choice([0.0007, 0.004, 0.0371]))
     ppb, mp = int(rng.integers(1, 6)), int(rng.integers(1, 4))
     sub = float(rng.choice([0.0, 0.0, 0.0021]))
     info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
     res = []
+    refused = None
     for fused in (True, False):
         cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=4, parts_per_block=ppb,
                               max_parts=mp, fused_fold=fused, force_fused=fused, subint_seconds=sub)
-        lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+        try:
+            lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+            if 3 * ppb * lt.nsamp_step + lt.nsamp_overlap > (1 << 25):
+                lt.close()
+                raise dspsr_amd.DspsrAmdError("block too long for a sweep")
+        except dspsr_amd.DspsrAmdError as e:
+            refused = str(e)
+            break
         step = ppb * lt.nsamp_step
-        raw = torch.from_numpy(synth.voltages(3 * step + lt.nsamp_overlap, freq, bw, tsamp, dm, period, seed=7 + i)).cuda()
+        raw = torch.from_numpy(synth.voltages(3 * step + lt.nsamp_overlap, freq, bw, tsamp, max(dm, 1.0), period, seed=7 + i)).cuda()
         for b in range(3):
             lt.process_block(raw[2 * b * step: 2 * (b * step + step + lt.nsamp_overlap)])
         if lt.ndat_total:
             lt.finish_subint()
         lt.synchronize()
         res.append([(s["hits"].copy(), s["profile_dev"].cpu().numpy(), s["ndat_total"]) for s in lt.subints])
-        mode = lt.fused_mode
+        mode = lt.fused_mode if fused else mode
+        freq_res = lt.response.ndat
         lt.close()
-    desc = "pipeline nchan=%d nbin=%d period=%g parts/block=%d max_parts=%d subint=%g (%d sub-integrations)" % (
-        nchan, nbin, period, ppb, mp, sub, len(res[0]))
+    if refused is not None:
+        print("refused pipeline freq=%g bw=%g DM=%g nchan=%d -- %s" % (freq, bw, dm, nchan, refused[:90]), flush=True)
+        continue
+    desc = "pipeline freq=%g bw=%g DM=%g nchan=%d freq_res=%d nbin=%d period=%g parts/block=%d max_parts=%d subint=%g (%d sub-integrations, mode %d)" % (
+        freq, bw, dm, nchan, freq_res, nbin, period, ppb, mp, sub, len(res[0]), mode)
     good = len(res[0]) == len(res[1])
     for a, b in zip(res[0], res[1]):
         scale = max(np.abs(b[1]).max(), 1e-30)
