@@ -135,13 +135,11 @@ extern "C" int dspsr_amd_dedispersion_prepare(const dspsr_amd_dedispersion_confi
       return fail(errbuf, errlen,
                   "Response::set_optimal_ndat specified maximum ndat (%d) < required minimum ndat (%d)",
                   cfg->ndat_max, info->minimum_ndat);
-    if (info->impulse_pos + info->impulse_neg == 0) {
-      info->ndat = 1;   // DM = 0: no smearing; caller should pass an explicit resolution
-    } else {
-      const uint64_t n = dspsr_amd_optimal_fft_length(info->impulse_pos + info->impulse_neg, cfg->ndat_max);
-      if (n == (uint64_t)-1) return fail(errbuf, errlen, "Response::set_optimal_ndat optimal_fft_length failed%s", 0, 0);
-      info->ndat = (uint32_t)n;
-    }
+    // (DM = 0: no smearing, nbadperfft == 0 -- optimal_fft_length fails and the reference throws, Response.C:300-305;
+    //  an explicit resolution, -x, is the way through there as here)
+    const uint64_t n = dspsr_amd_optimal_fft_length(info->impulse_pos + info->impulse_neg, cfg->ndat_max);
+    if (n == (uint64_t)-1) return fail(errbuf, errlen, "Response::set_optimal_ndat optimal_fft_length failed%s", 0, 0);
+    info->ndat = (uint32_t)n;
   }
   return DSPSR_AMD_OK;
 }

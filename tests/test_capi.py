@@ -168,3 +168,17 @@ def test_dedispersion_sample_delays_match_oracle(oracle, f0, bw, dm, nchan, swap
         assert got.max() > 0 > got.min()                     # relative to the centre frequency
     with pytest.raises(dspsr_amd.DspsrAmdError):
         dspsr_amd.dedispersion_sample_delays(f0, 0.0, dm, nchan, rate)
+
+
+def test_zero_dm_needs_an_explicit_resolution(oracle):
+    """DM = 0: no smearing, optimal_fft_length(0) fails and the reference throws (Response.C:300-305); same here, and -x works."""
+    import dspsr_amd
+    r = dspsr_amd.Dedispersion(1382.0, -16.0, 0.0, input_nchan=1, ndim=1)
+    with pytest.raises(dspsr_amd.DspsrAmdError, match="Response::set_optimal_ndat optimal_fft_length failed"):
+        r.match(16)
+    obs = oracle.Observation(centre_frequency=1382.0, bandwidth=-16.0, tsamp_us=1 / 32, dispersion_measure=0.0)
+    with pytest.raises(oracle.OracleError, match="optimal_fft_length failed"):
+        oracle.Dedispersion().match(obs, 16)
+    r.set_frequency_resolution(64)
+    r.match(16)
+    assert (r.ndat, r.impulse_pos, r.impulse_neg) == (64, 0, 0)
