@@ -182,3 +182,46 @@ def test_zero_dm_needs_an_explicit_resolution(oracle):
     r.set_frequency_resolution(64)
     r.match(16)
     assert (r.ndat, r.impulse_pos, r.impulse_neg) == (64, 0, 0)
+
+
+def test_host_preparation_random_bands_against_the_oracle(oracle):
+    """Random bands / DMs / channel counts / -x: dspsr_amd_dedispersion_prepare + build agree with the restated
+    Dedispersion::prepare / build / match (impulse_pos, impulse_neg, ndat, kernel), and refuse exactly where it refuses
+    (smearing beyond the threshold, -x below the minimum, DM 0 without -x)."""
+    import dspsr_amd
+    rng = np.random.default_rng(5)
+    agree = refuse = 0
+    for _ in range(24):
+        freq = float(rng.choice([150.0, 400.0, 1382.0, 3100.0]))
+        bw = float(rng.choice([-64, -16, 8, 32]))
+        dm = float(rng.choice([0.0, 0.5, 3, 30, 300]))
+        in_nchan = int(rng.choice([1, 1, 2, 8]))
+        ndim = 1 if in_nchan == 1 and rng.integers(0, 2) else 2
+        nchan = in_nchan * int(2 ** rng.integers(0, 5))
+        fr = int(rng.choice([0, 0, 64, 4096]))
+        obs = oracle.Observation(centre_frequency=freq, bandwidth=bw, nchan=in_nchan, npol=2, ndim=ndim,
+                                 tsamp_us=(0.5 if ndim == 1 else 1.0) / abs(bw / in_nchan), dispersion_measure=dm)
+        rp = dspsr_amd.Dedispersion(freq, bw, dm, input_nchan=in_nchan, ndim=ndim)
+        ro = oracle.Dedispersion()
+        if fr:
+            rp.set_frequency_resolution(fr)
+            ro.set_frequency_resolution(fr)
+        ep = eo = None
+        try:
+            rp.match(nchan)
+        except dspsr_amd.DspsrAmdError as e:
+            ep = str(e)
+        if ep is None and rp.kernel.size > (1 << 20):
+            continue                                        # (the Python restatement builds big kernels slowly)
+        try:
+            ro.match(obs, nchan)
+        except oracle.OracleError as e:
+            eo = str(e)
+        assert (ep is None) == (eo is None), (freq, bw, dm, in_nchan, ndim, nchan, fr, ep, eo)
+        if ep is None:
+            assert (rp.impulse_pos, rp.impulse_neg, rp.ndat) == (ro.impulse_pos, ro.impulse_neg, ro.ndat)
+            assert np.abs(rp.kernel - ro.buffer).max() <= 2e-7
+            agree += 1
+        else:
+            refuse += 1
+    assert agree >= 8 and refuse >= 2
