@@ -41,7 +41,7 @@ def _worker(rank, world, port, nfloat, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])          # 8: the node the sub-band config is written for
 def test_subband_reduce_gloo(tmp_path, world):
     nfloat = 4 * 3 * 16 * 4          # nchan*npol*nbin*ndim of one sub-band
     out = str(tmp_path / "res.npy")
@@ -83,7 +83,7 @@ def _replica_worker(rank, world, port, nbin, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_time_slice_replica_reduce_gloo(tmp_path, world):
     """PhaseSeries::combine semantics over the collective (PhaseSeries.C:442-484): profiles, hits, integration_length and
     ndat_total of all replicas ADD onto rank 0."""
