@@ -1,4 +1,4 @@
-"""tools/fuzz_filterbank.py [ncases] [seed] : random filterbank geometries against the float64 oracle (test infrastructure:
+"""tools/fuzz_filterbank.py [ncases] [seed] [log2 N min] [log2 N max] : random filterbank geometries against the float64 oracle (test infrastructure:
 uses tests/test_gpu_parity._fb_case).  Every combination the C-ABI accepts is fair game: 1 or 2 polarisations, real or complex
 input, 8-bit or float32 input, generic or CASPSR byte order, 1-3 input channels, three- or four-pass, 1-3 parts per launch."""
 import os
@@ -21,12 +21,13 @@ import dspsr_amd
 from test_gpu_parity import _fb_case
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+lo, hi = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (7, 21)     # log2 of N = nchan_subband * freq_res
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = dspsr_amd.Context(0, torch.cuda.current_stream().cuda_stream)
 bad = 0
 for i in range(ncases):
-    logN = int(rng.integers(7, 22))
-    logM = int(rng.integers(2, min(logN, 19) + 1))
+    logN = int(rng.integers(lo, hi + 1))
+    logM = int(rng.integers(2, min(logN, 22) + 1))
     C, M = 1 << (logN - logM), 1 << logM
     real = bool(rng.integers(0, 4) != 0)
     npol = 2 if not real or rng.integers(0, 5) else 1
@@ -40,7 +41,7 @@ for i in range(ncases):
         kw["layout"] = "caspsr"
     if rng.integers(0, 4) == 0 and logN <= 18 and "layout" not in kw:      # (the CASPSR byte order is single channel)
         kw["input_nchan"] = int(rng.integers(2, 4))
-    npart = int(rng.integers(1, 4)) if logN <= 19 else 1
+    npart = int(rng.integers(1, 4)) if logN <= 19 else int(rng.integers(1, 3))
     desc = "C=%d M=%d nfilt=(%d,%d) npart=%d %s" % (C, M, pos, neg, npart, kw)
     try:
         _fb_case(oracle, (dspsr_amd, ctx), C, M, (pos, neg), npart, **kw)
