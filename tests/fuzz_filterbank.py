@@ -1,4 +1,4 @@
-"""tools/fuzz_filterbank.py [ncases] [seed] [log2 N min] [log2 N max] : random filterbank geometries against the float64 oracle (test infrastructure:
+"""tests/fuzz_filterbank.py [ncases] [seed] [log2 N min] [log2 N max] : random filterbank geometries against the float64 oracle (test infrastructure:
 uses tests/test_gpu_parity._fb_case).  Every combination the C-ABI accepts is fair game: 1 or 2 polarisations, real or complex
 input, 8-bit or float32 input, generic or CASPSR byte order, 1-3 input channels, three- or four-pass, 1-3 parts per launch."""
 import os

@@ -1,4 +1,4 @@
-"""tools/fuzz_fold.py [ncases] [seed] : random fold shapes and bin plans against the CPU loop (Fold.C:835-891 restated with
+"""tests/fuzz_fold.py [ncases] [seed] : random fold shapes and bin plans against the CPU loop (Fold.C:835-891 restated with
 numpy, strict time order): bit-identical for plans without long runs, <= 2e-6 of the profile maximum otherwise; hits identical.
 Also random LoadToFold configurations, fused against Detection + Fold."""
 import os

@@ -1,4 +1,4 @@
-"""tools/fuzz_misc.py [ncases] [seed] : invariants between code paths that must give the SAME bits.
+"""tests/fuzz_misc.py [ncases] [seed] : invariants between code paths that must give the SAME bits.
   * search-mode front end: a 16-byte aligned block (whole-range loads through LDS) against the same bytes at an offset of
     2 bytes (element-wise loads); random nchan / tscrunch / parts / byte order / pscrunch;
   * filterbank on float32 rows: aligned rows (regrouped per tile first) against rows shifted by one float (read in place);
@@ -12,6 +12,12 @@ import torch
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
+import importlib.util
+
+spec = importlib.util.spec_from_file_location("oracle_mod", os.path.join(ROOT, "oracle", "dspsr_oracle.py"))
+oracle = importlib.util.module_from_spec(spec)
+sys.modules["oracle_mod"] = oracle
+spec.loader.exec_module(oracle)
 import dspsr_amd
 from dspsr_amd import pipeline, synth
 
@@ -50,8 +56,14 @@ for i in range(ncases):
         dspsr_amd.tfp_filterbank(ctx, raw, nchan, npart, out, psc, sf, dspsr_amd.RAW_CASPSR if caspsr else dspsr_amd.RAW_GENERIC, 0.01)
         outs.append(out)
     torch.cuda.synchronize()
-    report(bool(torch.equal(outs[0], outs[1])) and float(outs[0].abs().max()) > 0 or npart < sf,
-           "tfp nchan=%d tscrunch=%d npart=%d caspsr=%s pscrunch=%s" % (nchan, sf, npart, caspsr, psc))
+    good = bool(torch.equal(outs[0], outs[1])) and float(outs[0].abs().max()) > 0 or npart < sf
+    if good and npart >= sf and npart * L <= (1 << 20):      # and against the float64 restatement (TFPFilterbank.C:27-101, TScrunch.C:180-206)
+        obs = oracle.Observation(machine="CASPSR" if caspsr else "DADA")
+        un = oracle.unpack_8bit(buf[16:16 + nbytes].cpu().numpy(), obs, scale=0.01)
+        want = oracle.tscrunch_tfp(oracle.tfp_filterbank(un, nchan, psc, dtype=np.float64), sf)
+        got = outs[0].cpu().numpy().astype(np.float64)[:want.shape[0]]
+        good = np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+    report(good, "tfp nchan=%d tscrunch=%d npart=%d caspsr=%s pscrunch=%s" % (nchan, sf, npart, caspsr, psc))
 
 for i in range(max(3, ncases // 4)):
     logN = int(rng.integers(10, 19))

@@ -1,4 +1,4 @@
-"""Randomised sweeps (tools/fuzz_filterbank.py, tools/fuzz_fold.py) with fixed seeds: filterbank geometries against the
+"""Randomised sweeps (tests/fuzz_filterbank.py, tests/fuzz_fold.py, tests/fuzz_misc.py: scripts, not collected) with fixed seeds: filterbank geometries against the
 float64 oracle, fold shapes and bin plans against the CPU loop, pipeline configurations fused against Detection + Fold; code paths that must agree bit for bit (fuzz_misc.py).
 (The long sweeps that found the round-2 staging overflow run from the command line; these are the regression-sized ones.)"""
 import os
@@ -16,7 +16,7 @@ def test_randomised_sweep(tool, ncases, seed):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no HIP device is visible")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(ncases), str(seed)], capture_output=True, text=True,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", tool), str(ncases), str(seed)], capture_output=True, text=True,
                        timeout=600)
     tail = "\n".join((p.stdout + p.stderr).splitlines()[-15:])
     assert p.returncode == 0 and "GPU core dump" not in p.stdout + p.stderr, tail

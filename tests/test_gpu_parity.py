@@ -1146,7 +1146,7 @@ def test_host_block_feeder_equals_resident_blocks(gpu):
 
 def test_fused_fold_many_channels_short_transform(gpu):
     """256 channels of an 8-point inverse transform (nkeep 6) are ONE pass-3 tile: the fused fold's staging of the detected
-    tile must fit the exchange buffer (a channel stride rounded up to 16 samples did not: found by tools/fuzz_fold.py, which
+    tile must fit the exchange buffer (a channel stride rounded up to 16 samples did not: found by tests/fuzz_fold.py, which
     it crashed).  Fused (forced) == Detection + Fold, with sub-integration boundaries every 131 samples."""
     from dspsr_amd import pipeline, synth
     dspsr_amd, ctx = gpu
