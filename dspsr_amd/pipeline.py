@@ -171,18 +171,28 @@ class TurnsDivider:
     """dsp::TimeDivide in turns mode (dspsr -s / -turns N; TimeDivide.C:360-436,461-500): division k spans pulse phases
     [start_phase + k*D, start_phase + (k+1)*D), start_phase = the first phase at or after the observation start whose
     fractional part is reference_phase (the leading partial turn is not folded) unless fractional_pulses.  Boundaries
-    are snapped to output samples like set_boundaries(mjd1, mjd2) (:503-540).  D >= 1 (phase-resolved divisions with
-    D < 1 are not built).  phase(t) -> (int, frac), iphase((int, frac), t_guess) -> t, t in seconds of the stream."""
+    are snapped to output samples like set_boundaries(mjd1, mjd2) (:503-540).  D < 1 (phase-resolved divisions): the first
+    boundary reference_phase + N*D after the start (:374-425).  phase(t) -> (int, frac), iphase((int, frac), t_guess) -> t, t in seconds of the stream."""
 
     def __init__(self, phase, iphase, period_guess, t_start, rate, division_turns, reference_phase=0.0,
                  fractional_pulses=False):
-        if division_turns < 1.0:
-            raise DspsrAmdError("dsp::TimeDivide division_turns < 1 (phase-resolved divisions) is not built")
+        if division_turns <= 0.0:
+            raise DspsrAmdError("dsp::TimeDivide division_turns must be positive")
         self.iphase, self.t_start, self.rate, self.D, self.pguess = iphase, t_start, rate, float(division_turns), period_guess
         pi, pf = phase(t_start)
-        if not fractional_pulses and pf > reference_phase:
-            pi += 1
-        self.start_phase = (pi, reference_phase)
+        if division_turns < 1.0:
+            # phase-resolved divisions (:374-425): X = R + N*D, the first division boundary after the current phase
+            x_minus_r = pf - reference_phase
+            if pf < reference_phase:
+                x_minus_r += 1.0
+                pi -= 1
+            x = reference_phase + int(math.ceil(x_minus_r / division_turns)) * division_turns
+            xi = math.floor(x)
+            self.start_phase = (pi + int(xi), x - xi)
+        else:
+            if not fractional_pulses and pf > reference_phase:
+                pi += 1
+            self.start_phase = (pi, reference_phase)
         self.start_time = iphase(self.start_phase, t_start)
         self._cache = {}
 

@@ -1114,15 +1114,25 @@ def predictor_iphase(cfg: "FoldConfig", obs: Observation, phase: tuple[int, floa
 
 
 def subint_turns_start(cfg: "FoldConfig", obs: Observation, division_turns: float, fractional_pulses: bool = False):
-    """First call of TimeDivide::set_boundaries in turns mode (TimeDivide.C:360-436), division_turns >= 1: the divisions
+    """First call of TimeDivide::set_boundaries in turns mode (TimeDivide.C:360-436): with division_turns >= 1 the divisions
     start at the first epoch at or after the observation start where the fractional phase equals reference_phase
-    (unless fractional_pulses).  -> (start_phase (int, frac), start_time seconds)."""
-    if division_turns < 1.0:
-        raise OracleError("dsp::TimeDivide division_turns < 1 (phase-resolved divisions) is not restated")
+    (unless fractional_pulses); with division_turns < 1 at the first boundary reference_phase + N*division_turns after
+    the current phase.  -> (start_phase (int, frac), start_time seconds)."""
     pi, pf = predictor_phase(cfg, obs, obs.start_seconds)
-    if not fractional_pulses and pf > cfg.reference_phase:
-        pi += 1
-    start_phase = (pi, cfg.reference_phase)
+    if division_turns < 1.0:
+        # phase-resolved divisions (TimeDivide.C:374-425): X = R + N*D, the first division boundary after the current phase
+        x_minus_r = pf - cfg.reference_phase
+        if pf < cfg.reference_phase:
+            x_minus_r += 1.0
+            pi -= 1
+        n = int(math.ceil(x_minus_r / division_turns))
+        x = cfg.reference_phase + n * division_turns
+        xi = math.floor(x)                                    # Pulsar::Phase (turns, fracturns) settles the carry
+        start_phase = (pi + int(xi), x - xi)
+    else:
+        if not fractional_pulses and pf > cfg.reference_phase:
+            pi += 1
+        start_phase = (pi, cfg.reference_phase)
     return start_phase, predictor_iphase(cfg, obs, start_phase, obs.start_seconds)
 
 

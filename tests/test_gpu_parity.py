@@ -655,7 +655,7 @@ def test_pipeline_subintegrations(oracle, gpu):
     lt.close()
 
 
-@pytest.mark.parametrize("turns", [1.0, 2.0])
+@pytest.mark.parametrize("turns", [1.0, 2.0, 0.5])             # 0.5: phase-resolved divisions (half turns)
 def test_pipeline_turns_mode_subintegrations(oracle, gpu, turns):
     """dspsr -s / -turns N: sub-integrations of N pulse periods (TimeDivide.C:360-500) through the LoadToFold driver over
     several blocks, against the oracle folding the same divisions: the leading partial turn is dropped, every division
@@ -686,7 +686,7 @@ def test_pipeline_turns_mode_subintegrations(oracle, gpu, turns):
     fcfg = o.FoldConfig(nbin=nbin, folding_period=period)
     block_out = cfg.parts_per_block * plan.nkeep
     first = o.subint_turns_sample_bounds(fcfg, fobs, turns, 0)[0]
-    assert 0 < first <= round(period * fobs.rate)                  # the leading partial turn is not folded
+    assert 0 <= first <= round(min(turns, 1.0) * period * fobs.rate) + 1     # the leading partial turn (division) is not folded
     for isub, (hits, prof, ndat_total) in enumerate(got):
         ps = o.PhaseSeries(nchan, 1, 4, nbin, data=np.zeros((nchan, 1, nbin, 4), np.float64))
         lo, hi = o.subint_turns_sample_bounds(fcfg, fobs, turns, isub)

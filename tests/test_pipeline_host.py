@@ -216,3 +216,47 @@ def test_sigproc_header_matches_the_reference_writer(tmp_path):
         f2 = io.BytesIO()
         pipeline.write_sigproc_header(f2, **v2)
         assert f2.getvalue() == ref
+
+
+@pytest.mark.parametrize("use_polyco", [False, True])
+@pytest.mark.parametrize("turns,ref", [(0.25, 0.0), (0.1, 0.35), (0.5, 0.9)])
+def test_phase_resolved_divisions(oracle, use_polyco, turns, ref):
+    """Divisions shorter than one turn (TimeDivide.C:374-425): they start at the first boundary reference_phase + N*D after
+    the phase of the first sample, and follow each other every D turns; against the oracle's restatement, and every sample
+    after the start lands in exactly one division."""
+    from dspsr_amd import pipeline
+    text = json.load(open(os.path.join(ROOT, "tests", "golden", "vela_polyco.json")))["text"]
+    rate, t_start = 390625.0, 0.00108
+    obs = oracle.Observation(tsamp_us=1e6 / rate)
+    obs.start_seconds = t_start
+    if use_polyco:
+        pc, opc = pipeline.Polyco(text), oracle.Polyco.parse(text)
+        ocfg = oracle.FoldConfig(nbin=64, polyco=opc, reference_phase=ref)
+        phase = lambda t: pc.phase(55299, 7545.0 + t)
+        iphase = lambda ph, guess: pc.iphase(ph, 55299, 7545.0 + guess) - 7545.0
+        pguess = 1.0 / pc.frequency(55299, 7545.0 + t_start)
+    else:
+        period = 0.0893
+        ocfg = oracle.FoldConfig(nbin=64, folding_period=period, reference_phase=ref)
+        phase = lambda t: (int(np.floor(t / period)), t / period - np.floor(t / period))
+        iphase = lambda ph, guess: (ph[0] + ph[1]) * period
+        pguess = period
+    div = pipeline.TurnsDivider(phase, iphase, pguess, t_start, rate, turns, ref)
+    (spi, spf), st = oracle.subint_turns_start(ocfg, obs, turns)
+    assert div.start_phase[0] == spi and abs(div.start_phase[1] - spf) < 1e-12 and abs(div.start_time - st) < 1e-9
+    # the start is a division boundary (fractional phase = ref + N*D) less than one division after the first sample
+    n = (spf - ref) / turns
+    assert abs(n - round(n)) < 1e-9 or abs((spf + 1 - ref) / turns - round((spf + 1 - ref) / turns)) < 1e-9
+    assert 0 <= div.bounds(0)[0] <= int(turns * pguess * rate) + 1
+    for k in (0, 1, 5, 40):
+        assert div.bounds(k) == oracle.subint_turns_sample_bounds(ocfg, obs, turns, k), k
+        lo, hi = div.bounds(k)
+        assert abs((hi - lo) - turns * pguess * rate) <= 1.5
+    pos, seen = 0, 0
+    for blk in (700, 30000, 12345, 1, 60000):
+        for idat, cnt, k, complete in div.pieces(pos, blk):
+            lo, hi = div.bounds(k)
+            assert lo <= pos + idat and pos + idat + cnt <= hi and complete == (pos + idat + cnt == hi)
+            seen += cnt
+        pos += blk
+    assert seen == pos - div.bounds(0)[0]
