@@ -1047,8 +1047,12 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     if (fnseg == 1 && lr > 0 && (gridDim.x & ((8u << lr) - 1)) == 0)
       fold_b = ((((fold_b >> (3 + lr)) << 3) | (fold_b & 7)) << lr) | ((fold_b >> 3) & ((1u << lr) - 1));
   }
+  // Without the fold the order of the items is free.  When every workgroup gets the same number of tiles it also walks the
+  // parts of a tile one after the other, so that the tile's chirp stays in registers (one chirp read per launch, not per
+  // part); otherwise the items are dealt XCD-wise as in the other passes.
+  const bool tile_major = FOLD || (ntile >= gridDim.x && ntile % gridDim.x == 0 && !(FB_DBG(g) & 512));
   auto next_item = [&](const uint32_t jj, Item& it) -> bool {
-    if constexpr (FOLD) {
+    if (FOLD || tile_major) {
       const uint32_t q = jj / fnp;                     // (32-bit; jj counts this workgroup's items)
       it.tile = fold_b + q * fntg;
       it.lp = fp0 + (jj - q * fnp);
@@ -1104,7 +1108,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     {
       // FOLD: a workgroup walks the parts of ITS tile, so consecutive items share the chirp rows: they are loaded when
       // the tile changes and stay in registers (the load and its latency were 22 % of the tile, profiles/r02c_*)
-      if (!FOLD || item.tile != kk_tile) {
+      if (item.tile != kk_tile) {
         load_chirp(item, kk);
         kk_tile = item.tile;
       }
