@@ -1267,8 +1267,12 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     };
     auto mid = [&](const int phase) {
       if constexpr (PRE) {
-        if (phase == 2 && tid < (f_nact << logT3)) {
-          en_pre = in_lds ? planl[tid >> logT3] : ent[tid >> logT3];
+        // only when the part's plan entries are in LDS: the accumulator's address then depends on an LDS read alone.  With
+        // the entry possibly coming from global memory (a select, or two branches that the compiler merges again) the
+        // load below sat behind s_waitcnt vmcnt(0) -- a wait for the whole prefetch of the next tile, in the middle of the
+        // transform, on exactly the three waves that also fold
+        if (phase == 2 && in_lds && tid < (f_nact << logT3)) {
+          en_pre = planl[tid >> logT3];
           acc_pre = *acc_ptr(tid, en_pre.x);
         }
       }
@@ -1282,7 +1286,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       __syncthreads();                       // the tile's detected samples are staged
       // the samples of an interval are fetched from LDS eight at a time (independent loads) and then added one after
       // the other, so the sum keeps the time order
-      const bool pre = PRE && !(FB_DBG(g) & 4);
+      const bool pre = PRE && in_lds && !(FB_DBG(g) & 4);
       for (uint32_t w = tid; w < (f_nact << logT3); w += blockDim.x) {
         const uint32_t slo = w & (T3 - 1);
         uint4 en;
