@@ -84,6 +84,10 @@ struct FbOut {
   uint32_t ndim, chan0;
   uint32_t nbin;                                // kind 3
   uint64_t prof_span4;                          // kind 3: float4 between consecutive channel rows of the profile
+  uint32_t prof_planes;                         // kind 3: 1 = one float4 (PP, QQ, Re, Im) per bin (npol 1, ndim 4); 2 = two rows of
+                                                //         float2 per channel, (PP, QQ) and (Re, Im) (npol 2, ndim 2: the layout
+                                                //         the reference's GPU pipeline folds, LoadToFold1.C:1105-1109)
+  uint64_t plane_stride;                        // kind 3, prof_planes 2: floats from the (PP, QQ) row to the (Re, Im) row
   float* part;                                  // kind 3, nseg > 1: partial profiles of part segments 1 .. nseg-1 for the
                                                 //         nchan_subband channels of this launch, packed
                                                 //         [seg-1][chan - chan0][nbin] float4, zeroed before the launch
@@ -1260,10 +1264,29 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       planl = (const uint4*)&lds[plan_off] + (jt & 1) * out.plan_cap;
       in_lds = f_nact <= out.plan_cap;
     }
-    auto acc_ptr = [&](const uint32_t w, const uint32_t b) {
+    // accumulator of (work item w, phase bin b): one float4, or -- profile of npol 2 x ndim 2 -- a float2 in each of the
+    // channel's two rows; the partial profiles of a segmented launch are packed in the same shape (rows of nbin bins)
+    const bool planes2 = FOLD && out.prof_planes == 2;                       // uniform
+    const uint64_t plane = fseg == 0 ? out.plane_stride : 2ull * out.nbin;   // floats between the two rows of a channel
+    auto acc_row = [&](const uint32_t w) -> float* {
       const uint32_t cl = tile * T3 + (w & (T3 - 1));              // channel within this input channel's sub-band
-      return fseg == 0 ? (float4*)out.base + (uint64_t)(out.chan0 + cl) * out.prof_span4 + b
-                       : (float4*)out.part + ((uint64_t)(fseg - 1) * g.C + cl) * out.nbin + b;
+      return (float*)(fseg == 0 ? (float4*)out.base + (uint64_t)(out.chan0 + cl) * out.prof_span4
+                                : (float4*)out.part + ((uint64_t)(fseg - 1) * g.C + cl) * out.nbin);
+    };
+    auto acc_load = [&](float* row, const uint32_t b) -> float4 {
+      if (planes2) {
+        const float2 u = *(const float2*)(row + 2 * b), v = *(const float2*)(row + plane + 2 * b);
+        return make_float4(u.x, u.y, v.x, v.y);
+      }
+      return *(const float4*)(row + 4 * b);
+    };
+    auto acc_store = [&](float* row, const uint32_t b, const float4 a) {
+      if (planes2) {
+        *(float2*)(row + 2 * b) = make_float2(a.x, a.y);
+        *(float2*)(row + plane + 2 * b) = make_float2(a.z, a.w);
+      } else {
+        *(float4*)(row + 4 * b) = a;
+      }
     };
     auto mid = [&](const int phase) {
       if constexpr (PRE) {
@@ -1273,7 +1296,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         // transform, on exactly the three waves that also fold
         if (phase == 2 && in_lds && tid < (f_nact << logT3)) {
           en_pre = planl[tid >> logT3];
-          acc_pre = *acc_ptr(tid, en_pre.x);
+          acc_pre = acc_load(acc_row(tid), en_pre.x);
         }
       }
     };
@@ -1296,10 +1319,10 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
           acc = acc_pre;
         } else {
           en = in_lds ? planl[w >> logT3] : ent[w >> logT3];
-          acc = *acc_ptr(w, en.x);
+          acc = acc_load(acc_row(w), en.x);
         }
         const uint32_t nint = en.z >> 16;
-        float4* __restrict__ pp = acc_ptr(w, en.x);
+        float* __restrict__ pp = acc_row(w);
         uint32_t off = en.w, hits = en.z & 0xffffu;
         for (uint32_t i = 0;;) {
           const float4* __restrict__ src = (const float4*)&lds[2 * (slo * fcs + off)];     // consecutive samples: constant offsets
@@ -1319,7 +1342,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
           const Interval iv = out.piv[en.y + i];           // further intervals of the bin in this part (rare)
           off = (uint32_t)iv.offset; hits = iv.hits;
         }
-        *pp = acc;
+        acc_store(pp, en.x, acc);
       }
       // the barrier in front of the next tile's first exchange write also ends this read phase
     }
@@ -2464,10 +2487,13 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
   if (state != DSPSR_AMD_COHERENCE && state != DSPSR_AMD_STOKES)
     return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_fold: invalid state=%d", state);
   const uint32_t nchan = fb->cfg.input_nchan * fb->g.C;
-  if (!fold->profile || fold->nchan != nchan || fold->npol != 1 || fold->ndim != 4)
+  // profile shapes: npol 1 x ndim 4 (one float4 per bin, the CPU default, LoadToFoldConfig.C:104) or npol 2 x ndim 2 (rows
+  // (PP, QQ) and (Re, Im): what the reference's GPU pipeline detects and folds, LoadToFold1.C:1105-1109)
+  const bool planes2 = fold->npol == 2 && fold->ndim == 2;
+  if (!fold->profile || fold->nchan != nchan || !((fold->npol == 1 && fold->ndim == 4) || planes2))
     return fb_fail(ctx, DSPSR_AMD_EINVAL,
-                   "dspsr_amd_filterbank_perform_fold: fold shape must be nchan=%u npol=1 ndim=4 (is %u/%u/%u)", nchan,
-                   fold->nchan, fold->npol, fold->ndim);
+                   "dspsr_amd_filterbank_perform_fold: fold shape must be nchan=%u with npol=1 ndim=4 or npol=2 ndim=2 (is %u/%u/%u)",
+                   nchan, fold->nchan, fold->npol, fold->ndim);
   if (fold->folding_nbin != fold->nbin)
     return fb_fail(ctx, DSPSR_AMD_EINVAL, "dsp::Fold::fold folding_nbin != output->nbin (%u != %u)",
                    fold->folding_nbin, fold->nbin);
@@ -2495,7 +2521,8 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
   // Below the threshold, and for the four-pass geometry, Detection and Fold run as separate launches on an
   // internal block -- the sums are bit-identical either way.
   // (a bound profile whose rows are not float4 aligned also takes the separate launches: the fold kernel adds scalars)
-  const bool prof_vec4 = fold->span % 4 == 0 && ((uintptr_t)fold->profile % 16) == 0;
+  const bool prof_vec4 = planes2 ? (fold->span % 2 == 0 && ((uintptr_t)fold->profile % 16) == 0)
+                                 : (fold->span % 4 == 0 && ((uintptr_t)fold->profile % 16) == 0);
   if (!dspsr_amd_filterbank_fold_is_fused(fb) || !prof_vec4 || fold_plan_max_run(fold) >= (uint32_t)FB_ENV_INT("DSPSR_AMD_FUSED_MAX_RUN", (int)FOLD_FUSED_MAX_RUN)) {
     const uint64_t row = npart * fb->g.nkeep * 4;                       // floats per channel
     const size_t need = (size_t)row * nchan;
@@ -2509,18 +2536,20 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
         return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform_fold: hipMalloc of %zu bytes failed", need * sizeof(float));
       fb->det_floats = need;
     }
-    FbOut dout = {2, fb->det, row, 0, 0, state, 4, 0};
+    // (ndim 2: the channel's two rows of npart*nkeep float2 one after the other)
+    FbOut dout = {2, fb->det, row, planes2 ? row / 2 : 0, 0, state, planes2 ? 2u : 4u, 0};
     const int rc = fb_run(fb, in, dout, npart, in_chan_stride);
     if (rc != DSPSR_AMD_OK) return rc;
-    return dspsr_amd_fold_fold(fold, fb->det, row, 0);
+    return dspsr_amd_fold_fold(fold, fb->det, row, planes2 ? row / 2 : 0);
   }
   const uint32_t* d_start = nullptr;
   const Interval* d_iv = nullptr;
   PlanSlot* slot = nullptr;
   int rc = fold_build_part_plan(fold, fb->g.nkeep, (uint32_t)npart, &d_start, &d_iv, &slot);
   if (rc != DSPSR_AMD_OK) return rc;
-  FbOut out = {3, fold->profile, 0, 0, 0, state, 4, 0, fold->nbin, fold->span / 4, nullptr, fold->nchan, 0, fold, d_start,
-               (uint32_t)npart, 0, d_iv};
+  // (float4 from one channel to the next: span/4, or both rows of the channel, 2*span/4)
+  FbOut out = {3, fold->profile, 0, 0, 0, state, 4, 0, fold->nbin, planes2 ? fold->span / 2 : fold->span / 4, planes2 ? 2u : 1u,
+               fold->span, nullptr, fold->nchan, 0, fold, d_start, (uint32_t)npart, 0, d_iv};
   rc = fb_run(fb, in, out, npart, in_chan_stride);
   const int rc2 = fold_part_plan_submitted(fold, slot);
   return rc != DSPSR_AMD_OK ? rc : rc2;

@@ -9,6 +9,28 @@
 //   HIP::DetectionEngine   <- CUDA::DetectionEngine   Signal/General/DetectionCUDA.cu:127-322
 //   HIP::FoldEngine        <- CUDA::FoldEngine        Signal/Pulsar/FoldCUDA.cu:64-697
 // Errors: every non-zero C-ABI status is rethrown as the reference's `Error` with the library's message.
+//
+// DEFERRED MODE (HIP::Chain).  The three operations of the hot path are separate Engine calls in DSPSR, made in this order
+// per block: Filterbank::Engine::perform (Filterbank.C:547-553), Detection::Engine::polarimetry (Detection.C:325-334),
+// Fold::Engine::set_nbin / set_ndat / set_bins (Fold.C:724-741) and Fold::Engine::fold (Fold.C:817-829).  Run one by one
+// ("eager") the channelised block makes three round trips through HBM.  When the adaptors of one pipeline thread share a
+// HIP::Chain with set_deferred(true), perform() and polarimetry() only RECORD their arguments; FoldEngine::fold(), which
+// arrives last and with the bin plan complete, launches dspsr_amd_filterbank_perform_fold: filterbank, detection and fold
+// in one launch group, the detected time series never leaves the chip.  DSPSR's call order is untouched.  The chain falls
+// back to eager execution, block by block, whenever the fusion would change what another caller sees:
+//   * Filterbank::Engine::finish() (Operation::record_time, Filterbank.C:551,664) or any synch executes what is pending;
+//   * Fold folds only a piece of the block (a sub-integration boundary inside it, Subint.h:234-309), a Fold input that is
+//     not the Detection output, a detected shape other than (npol 2, ndim 2) / (npol 1, ndim 4), square-law detection;
+//   * TimeSeriesEngine::copy_data_fpt reads the pending output (a second consumer that goes through an engine).
+// A consumer of the intermediate TimeSeries that bypasses the engines (dsp::Dump, a TransferCUDA to the host) cannot be
+// seen from here: deferred mode is for pipelines in which Detection is the only reader of the Filterbank output and Fold
+// the only reader of the Detection output (dspsr's default fold pipeline); it is opt-in for that reason.
+//
+// RAW INPUT (FilterbankEngine::set_raw_input).  The reference unpacks 8-bit data to float32 in front of the Filterbank (4x
+// the bytes).  The twin of dsp::TransferBitSeriesCUDA (Signal/General/TransferBitSeriesCUDA.C:23-70) hands the packed
+// device block to the engine; perform() then reads the bytes instead of the floats whenever the TimeSeries it is given
+// is exactly the unpacked image of that block (same first input sample and length: dspsr -overlap, i.e.
+// config->input_buffering == false, LoadToFold1.C:813-821), and the float rows otherwise.
 #ifndef DSPSR_AMD_ENGINES_H
 #define DSPSR_AMD_ENGINES_H
 
@@ -29,6 +51,84 @@ namespace HIP
       throw Error (status == DSPSR_AMD_EINVAL ? InvalidParam : InvalidState, method,
                    dspsr_amd_last_error (ctx));
   }
+
+  //! What the adaptors of one pipeline thread share in deferred mode (see the top of this file)
+  class Chain : public Reference::Able
+  {
+  public:
+    Chain (dspsr_amd_ctx* _ctx) : ctx (_ctx), deferred (false), fused_blocks (0), eager_blocks (0), dropped_blocks (0)
+    { fbk.pending = false; det.pending = false; fbk.raw = 0; }
+
+    void set_deferred (bool flag) { if (!flag) flush (); deferred = flag; }
+    bool get_deferred () const { return deferred; }
+
+    //! blocks that went through the fused launch group / through the separate launches / recorded and never consumed
+    uint64_t get_fused_blocks () const { return fused_blocks; }
+    uint64_t get_eager_blocks () const { return eager_blocks; }
+    uint64_t get_dropped_blocks () const { return dropped_blocks; }
+
+    //! execute, as the separate launches DSPSR asked for, whatever has only been recorded
+    void flush ()
+    {
+      if (fbk.pending)
+      {
+        fbk.pending = false;
+        run_filterbank ();
+        eager_blocks ++;
+      }
+      if (det.pending)
+      {
+        det.pending = false;
+        run_detection ();
+      }
+    }
+    //! the same if `series` is the output of a recorded call (a second reader)
+    void flush_if (const dsp::TimeSeries* series)
+    { if ((fbk.pending && series == fbk.out) || (det.pending && (series == det.out || series == det.in))) flush (); }
+
+    // ---- arguments recorded by FilterbankEngine::perform
+    struct FilterbankCall
+    {
+      bool pending;
+      dspsr_amd_filterbank* fb;
+      const dsp::TimeSeries* in;
+      dsp::TimeSeries* out;
+      const float* ibase; uint64_t ics, ips;      // float input rows (device)
+      float* obase; uint64_t ocs, ops;            // complex output rows (device)
+      uint64_t npart, in_step, out_step;
+      const int8_t* raw; int raw_layout; float raw_scale;   // raw != 0: the packed block holds the same samples
+    } fbk;
+    // ---- arguments recorded by DetectionEngine::polarimetry
+    struct DetectionCall
+    {
+      bool pending;
+      unsigned ndim; int state;
+      const dsp::TimeSeries* in;
+      dsp::TimeSeries* out;
+      const float* ibase; uint64_t ics, ips;
+      float* obase; uint64_t ocs, ops;
+      unsigned nchan; uint64_t ndat;
+    } det;
+
+    void run_filterbank ()
+    {
+      if (fbk.raw)
+        check (ctx, dspsr_amd_filterbank_perform_raw (fbk.fb, fbk.raw, fbk.raw_layout, fbk.raw_scale, fbk.obase, fbk.ocs, fbk.ops,
+                                                     fbk.npart, fbk.out_step), "HIP::FilterbankEngine::perform");
+      else
+        check (ctx, dspsr_amd_filterbank_perform (fbk.fb, fbk.ibase, fbk.ics, fbk.ips, fbk.obase, fbk.ocs, fbk.ops, fbk.npart,
+                                                 fbk.in_step, fbk.out_step), "HIP::FilterbankEngine::perform");
+    }
+    void run_detection ()
+    {
+      check (ctx, dspsr_amd_detect_polarimetry (ctx, det.state, det.ndim, det.ibase, det.ics, det.ips, det.obase, det.ocs,
+                                                det.ops, det.nchan, det.ndat), "HIP::DetectionEngine::polarimetry");
+    }
+
+    dspsr_amd_ctx* ctx;
+    bool deferred;
+    uint64_t fused_blocks, eager_blocks, dropped_blocks;
+  };
 
   //! dsp::Memory on the MI355X: allocation bound to one context/stream (SingleThread.C:237-244)
   class DeviceMemory : public dsp::Memory
@@ -52,7 +152,7 @@ namespace HIP
   class TimeSeriesEngine : public dsp::TimeSeries::Engine
   {
   public:
-    TimeSeriesEngine (dspsr_amd_ctx* _ctx) : ctx (_ctx), to (0) { }
+    TimeSeriesEngine (dspsr_amd_ctx* _ctx, Chain* _chain = 0) : ctx (_ctx), to (0), chain (_chain) { }
     void prepare (dsp::TimeSeries* parent) { to = parent; }
     void prepare_buffer (unsigned) { }           // no staging buffer: rows are copied directly
 
@@ -60,6 +160,7 @@ namespace HIP
     //! `from`, starting at idat_start, to the start of the rows of the parent
     void copy_data_fpt (const dsp::TimeSeries* from, uint64_t idat_start = 0, uint64_t ndat = 0)
     {
+      if (chain) { chain->flush_if (from); chain->flush_if (to); }   // a reader of a recorded block: execute it first
       const unsigned nchan = to->get_nchan (), npol = to->get_npol (), ndim = to->get_ndim ();
       float* obase = to->get_datptr (0, 0);
       const float* ibase = from->get_datptr (0, 0);
@@ -71,14 +172,29 @@ namespace HIP
   protected:
     dspsr_amd_ctx* ctx;
     dsp::TimeSeries* to;
+    Reference::To<Chain> chain;
   };
 
   //! dsp::Filterbank::Engine (FilterbankEngine.h:15-44)
   class FilterbankEngine : public dsp::Filterbank::Engine
   {
   public:
-    FilterbankEngine (dspsr_amd_ctx* _ctx) : ctx (_ctx), fb (0) { }
-    ~FilterbankEngine () { dspsr_amd_filterbank_destroy (fb); }
+    FilterbankEngine (dspsr_amd_ctx* _ctx, Chain* _chain = 0)
+      : ctx (_ctx), fb (0), chain (_chain), fused_fold (DSPSR_AMD_FUSED_AUTO), max_parts (0)
+    { raw.ptr = 0; }
+    ~FilterbankEngine () { if (chain) chain->fbk.pending = false; dspsr_amd_filterbank_destroy (fb); }
+
+    //! before setup: DSPSR_AMD_FUSED_AUTO / _ALWAYS / _NEVER (dspsr_amd_filterbank_config::fused_fold) and the number of
+    //! overlap-save parts per launch group (0 = library default; the scratch is sized for it)
+    void set_fused_fold (int mode) { fused_fold = mode; }
+    void set_max_parts (unsigned parts) { max_parts = parts; }
+
+    //! Raw-input side channel, the hand-over a dsp::TransferBitSeriesCUDA twin makes per block: `raw_dev` = device copy of
+    //! BitSeries::get_rawptr(), holding `ndat` time samples that start at input sample `input_sample`
+    //! (BitSeries::get_input_sample, Kernel/Classes/dsp/BitSeries.h:83-86); layout / scale as dspsr_amd_filterbank_perform_raw.
+    //! One shot: consumed (or discarded) by the next perform().
+    void set_raw_input (const void* raw_dev, uint64_t ndat, int64_t input_sample, int layout, float scale)
+    { raw.ptr = (const int8_t*) raw_dev; raw.ndat = ndat; raw.input_sample = input_sample; raw.layout = layout; raw.scale = scale; }
 
     //! reads exactly what CUDA::FilterbankEngine::setup reads (FilterbankCUDA.cu:73-168)
     void setup (dsp::Filterbank* filterbank)
@@ -91,11 +207,12 @@ namespace HIP
       cfg.npol = filterbank->get_input()->get_npol ();
       cfg.real_input = filterbank->get_input()->get_state () == Signal::Nyquist;
       cfg.nfilt_pos = cfg.nfilt_neg = 0;
-      cfg.max_parts = 0;
+      cfg.max_parts = max_parts;
       cfg.force_four_pass = 0;
-      cfg.fused_fold = DSPSR_AMD_FUSED_AUTO;
+      cfg.fused_fold = fused_fold;
       const float* kernel = 0;
       uint64_t ncomplex = 0;
+      if (chain) chain->flush ();
       if (filterbank->has_response ())
       {
         const dsp::Response* response = filterbank->get_response ();
@@ -121,13 +238,42 @@ namespace HIP
       float* obase = out ? out->get_datptr (0, 0) : 0;      // out == NULL: benchmark only (:265)
       const uint64_t ocs = out && out->get_nchan () > 1 ? out->get_datptr (1, 0) - obase : 0;
       const uint64_t ops = out && out->get_npol () > 1 ? out->get_datptr (0, 1) - obase : 0;
-      check (ctx, dspsr_amd_filterbank_perform (fb, ibase, ics, ips, obase, ocs, ops, npart, in_step, out_step),
-             "HIP::FilterbankEngine::perform");
+      // the packed block may stand in for the float rows only if `in` is exactly its unpacked image
+      uint64_t step = 0;
+      dspsr_amd_filterbank_sizes (fb, 0, 0, &step, 0);
+      const bool use_raw = raw.ptr && in->get_input_sample () == raw.input_sample && in->get_ndat () == raw.ndat
+                           && in_step == step * in->get_ndim ();
+      const int8_t* rawp = use_raw ? raw.ptr : 0;
+      raw.ptr = 0;
+      if (chain && out)
+      {
+        Chain::FilterbankCall& c = chain->fbk;
+        if (c.pending) { c.pending = false; chain->det.pending = false; chain->dropped_blocks ++; }   // never asked for
+        c.fb = fb; c.in = in; c.out = out;
+        c.ibase = ibase; c.ics = ics; c.ips = ips; c.obase = obase; c.ocs = ocs; c.ops = ops;
+        c.npart = npart; c.in_step = in_step; c.out_step = out_step;
+        c.raw = rawp; c.raw_layout = raw.layout; c.raw_scale = raw.scale;
+        if (chain->get_deferred ()) { c.pending = true; return; }
+        chain->run_filterbank ();
+        chain->eager_blocks ++;
+        return;
+      }
+      if (rawp && out)
+        check (ctx, dspsr_amd_filterbank_perform_raw (fb, rawp, raw.layout, raw.scale, obase, ocs, ops, npart, out_step),
+               "HIP::FilterbankEngine::perform");
+      else
+        check (ctx, dspsr_amd_filterbank_perform (fb, ibase, ics, ips, obase, ocs, ops, npart, in_step, out_step),
+               "HIP::FilterbankEngine::perform");
     }
 
-    void finish () { check (ctx, dspsr_amd_stream_sync (ctx), "HIP::FilterbankEngine::finish"); }
+    //! Filterbank.C:551,664 (Operation::record_time): what was only recorded runs now, as its own launches
+    void finish ()
+    {
+      if (chain) chain->flush ();
+      check (ctx, dspsr_amd_stream_sync (ctx), "HIP::FilterbankEngine::finish");
+    }
 
-    //! optional side channel: 8-bit input straight from the BitSeries (fused unpack)
+    //! direct form of the side channel: 8-bit input straight from the BitSeries (fused unpack), always eager
     void perform_raw (const int8_t* raw, int layout, float scale, dsp::TimeSeries* out, uint64_t npart, uint64_t out_step)
     {
       float* obase = out->get_datptr (0, 0);
@@ -140,7 +286,25 @@ namespace HIP
   protected:
     dspsr_amd_ctx* ctx;
     dspsr_amd_filterbank* fb;
+    Reference::To<Chain> chain;
+    int fused_fold;
+    unsigned max_parts;
+    struct { const int8_t* ptr; uint64_t ndat; int64_t input_sample; int layout; float scale; } raw;
   };
+
+  //! Twin of dsp::TransferBitSeriesCUDA::transformation (Signal/General/TransferBitSeriesCUDA.C:23-70) with the hand-over
+  //! added: the packed block goes host -> device as it is (asynchronous, on the context's stream) and is announced to the
+  //! filterbank engine.  BitSeriesT = dsp::BitSeries (a template only so that this header does not pull in
+  //! dsp/BitSeries.h); `device` must have been resized by the caller through a HIP::DeviceMemory
+  //! (output->internal_match (input), as TransferBitSeriesCUDA::prepare does).
+  template <class BitSeriesT>
+  void transfer_bitseries (dspsr_amd_ctx* ctx, const BitSeriesT* host, BitSeriesT* device, FilterbankEngine* engine,
+                           int layout, float scale)
+  {
+    check (ctx, dspsr_amd_copy (ctx, device->get_rawptr (), host->get_rawptr (), host->get_size (), DSPSR_AMD_H2D),
+           "HIP::transfer_bitseries");
+    engine->set_raw_input (device->get_rawptr (), host->get_ndat (), host->get_input_sample (), layout, scale);
+  }
 
   //! dsp::Convolution::Engine (Convolution.h:158-167): the same library object with nchan_subband = 1,
   //! i.e. one forward FFT, response multiply and backward FFT of response->get_ndat() points per
@@ -204,7 +368,12 @@ namespace HIP
   class DetectionEngine : public dsp::Detection::Engine
   {
   public:
-    DetectionEngine (dspsr_amd_ctx* _ctx) : ctx (_ctx) { }
+    DetectionEngine (dspsr_amd_ctx* _ctx, Chain* _chain = 0) : ctx (_ctx), chain (_chain), stokes (-1) { }
+
+    //! Detection::Engine::polarimetry carries no output state, and an in-place Detection only sets it on the TimeSeries
+    //! AFTER the engine call (Detection.C:113-138,203): tell the engine (Detection::set_output_state) -- otherwise the
+    //! state is read from `out`, which is right for out-of-place use
+    void set_output_state (Signal::State state) { stokes = state == Signal::Stokes ? 1 : 0; }
 
     void polarimetry (unsigned ndim, const dsp::TimeSeries* in, dsp::TimeSeries* out)
     {
@@ -212,16 +381,33 @@ namespace HIP
         throw Error (InvalidParam, "HIP::DetectionEngine::polarimetry", "input ndat != output ndat");
       const float* ibase = in->get_datptr (0, 0);
       float* obase = out->get_datptr (0, 0);
-      const int state = out->get_state () == Signal::Stokes ? DSPSR_AMD_STOKES : DSPSR_AMD_COHERENCE;
+      const int state = (stokes >= 0 ? stokes == 1 : out->get_state () == Signal::Stokes) ? DSPSR_AMD_STOKES : DSPSR_AMD_COHERENCE;
+      if (chain)
+      {
+        Chain::DetectionCall& c = chain->det;
+        if (c.pending) chain->flush ();
+        c.ndim = ndim; c.state = state; c.in = in; c.out = out;
+        c.ibase = ibase; c.ics = in->get_nchan () > 1 ? in->get_datptr (1, 0) - ibase : 0; c.ips = in->get_datptr (0, 1) - ibase;
+        c.obase = obase; c.ocs = out->get_nchan () > 1 ? out->get_datptr (1, 0) - obase : 0;
+        // (the planes of an in-place detection lie where the polarisation rows were, DetectionCUDA.cu:145-149)
+        c.ops = in == out ? c.ips : (out->get_npol () > 1 ? out->get_datptr (0, 1) - obase : 0);
+        c.nchan = in->get_nchan (); c.ndat = in->get_ndat ();
+        // recorded only behind a recorded filterbank block whose output this is, in a shape the fused fold writes
+        if (chain->fbk.pending && in == chain->fbk.out && (ndim == 2 || ndim == 4)) { c.pending = true; return; }
+        chain->flush ();
+        chain->run_detection ();
+        return;
+      }
       check (ctx, dspsr_amd_detect_polarimetry (ctx, state, ndim, ibase,
                in->get_nchan () > 1 ? in->get_datptr (1, 0) - ibase : 0, in->get_datptr (0, 1) - ibase,
                obase, out->get_nchan () > 1 ? out->get_datptr (1, 0) - obase : 0,
-               out->get_npol () > 1 ? out->get_datptr (0, 1) - obase : 0,
+               in == out ? uint64_t (in->get_datptr (0, 1) - ibase) : (out->get_npol () > 1 ? out->get_datptr (0, 1) - obase : 0),
                in->get_nchan (), in->get_ndat ()), "HIP::DetectionEngine::polarimetry");
     }
 
     void square_law (const dsp::TimeSeries* in, dsp::TimeSeries* out)
     {
+      if (chain) chain->flush ();
       const float* ibase = in->get_datptr (0, 0);
       float* obase = out->get_datptr (0, 0);
       check (ctx, dspsr_amd_detect_square_law (ctx, out->get_state () == Signal::Intensity, ibase,
@@ -234,6 +420,8 @@ namespace HIP
 
   protected:
     dspsr_amd_ctx* ctx;
+    Reference::To<Chain> chain;
+    int stokes;
   };
 
   //! dsp::Fold::Engine (Fold.h:249-312), the twin of CUDA::FoldEngine (FoldCUDA.cu:31-198, dsp/FoldCUDA.h:27-80).
@@ -245,7 +433,7 @@ namespace HIP
   class FoldEngine : public dsp::Fold::Engine
   {
   public:
-    FoldEngine (dspsr_amd_ctx* _ctx) : ctx (_ctx), fold_handle (0)
+    FoldEngine (dspsr_amd_ctx* _ctx, Chain* _chain = 0) : ctx (_ctx), fold_handle (0), chain (_chain), plan_ndat (0), plan_idat_start (0)
     {
       use_set_bins = true;                       // plan built inside the library (Fold.C:730-740)
       check (ctx, dspsr_amd_fold_create (ctx, &fold_handle), "HIP::FoldEngine");
@@ -258,7 +446,10 @@ namespace HIP
     void set_nbin (unsigned nbin)
     { nbin_hits.assign (nbin, 0); check (ctx, dspsr_amd_fold_set_nbin (fold_handle, nbin), "HIP::FoldEngine::set_nbin"); }
     void set_ndat (uint64_t ndat, uint64_t idat_start)
-    { check (ctx, dspsr_amd_fold_set_ndat (fold_handle, ndat, idat_start), "HIP::FoldEngine::set_ndat"); }
+    {
+      plan_ndat = ndat; plan_idat_start = idat_start;
+      check (ctx, dspsr_amd_fold_set_ndat (fold_handle, ndat, idat_start), "HIP::FoldEngine::set_ndat");
+    }
     void set_bin (uint64_t idat, double ibin, double bins_per_samp)
     { check (ctx, dspsr_amd_fold_set_bin (fold_handle, idat, ibin, bins_per_samp), "HIP::FoldEngine::set_bin"); }
     //! the double recurrence of Fold.C:744-787 inside the library; Fold::fold adds get_bin_hits to hits[] (:733-736)
@@ -278,6 +469,30 @@ namespace HIP
       setup ();                                  // Fold.C:968-1011: input, input_span, output, output_span, nchan, npol, ndim
       check (ctx, dspsr_amd_fold_bind_profile (fold_handle, output, output_span, nchan, npol, ndim, d_profiles->get_nbin ()),
              "HIP::FoldEngine::fold");
+      if (chain && chain->fbk.pending)
+      {
+        // Deferred mode: the filterbank and the detection of this block have only been recorded.  If this call folds the
+        // WHOLE detected block (no sub-integration boundary inside it: Subint.h:234-309 would fold it in pieces) in a shape
+        // the fused kernel writes, the three operations run as ONE launch group and the channelised data stay on the chip;
+        // otherwise they run now as the separate launches DSPSR asked for and the fold below reads their output.
+        const Chain::FilterbankCall& f = chain->fbk;
+        const Chain::DetectionCall& d = chain->det;
+        const dsp::TimeSeries* in = parent->get_input ();
+        const bool whole = d.pending && in == d.out && plan_idat_start == 0 && plan_ndat == in->get_ndat ()
+                           && in->get_ndat () == d.ndat && ((npol == 2 && ndim == 2 && d.ndim == 2) || (npol == 1 && ndim == 4 && d.ndim == 4));
+        if (whole)
+        {
+          chain->fbk.pending = false; chain->det.pending = false;
+          check (ctx, dspsr_amd_filterbank_perform_fold (f.fb, f.raw ? 0 : f.ibase, f.ics, f.ips, f.in_step, f.raw, f.raw_layout,
+                                                        f.raw_scale, d.state, fold_handle, f.npart), "HIP::FoldEngine::fold");
+          chain->fused_blocks ++;
+          synchronized = false;
+          return;
+        }
+        chain->flush ();
+      }
+      else if (chain)
+        chain->flush ();
       // rows of the input are input_span floats apart, (ichan*npol + ipol)-th row, as fold1bin* index them
       check (ctx, dspsr_amd_fold_fold (fold_handle, input, uint64_t (npol) * input_span, input_span),
              "HIP::FoldEngine::fold");
@@ -304,6 +519,8 @@ namespace HIP
     dspsr_amd_fold* fold_handle;
     Reference::To<dsp::PhaseSeries> d_profiles;
     std::vector<unsigned> nbin_hits;
+    Reference::To<Chain> chain;
+    uint64_t plan_ndat, plan_idat_start;
   };
 }
 

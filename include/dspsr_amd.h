@@ -137,8 +137,10 @@ int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, const float* i
                                         int raw_layout, float scale, int state, uint32_t ndim, float* det_dev,
                                         uint64_t det_chan_stride, uint64_t det_pol_stride, uint64_t npart);
 
-/* Fused Filterbank -> Detection -> Fold (ndim 4, npol 1 profile): the detected time series never leaves the
- * chip.  Replaces the chain Filterbank::Engine::perform (FilterbankCUDA.cu:181-304) + Detection::Engine::polarimetry
+/* Fused Filterbank -> Detection -> Fold: the detected time series never leaves the chip.  The profile of `fold` is
+ * either npol 1 x ndim 4 (one (PP, QQ, Re, Im) float4 per bin: Detection's CPU default, LoadToFoldConfig.C:104) or
+ * npol 2 x ndim 2 (rows (PP, QQ) and (Re, Im) per channel: what the reference's GPU pipeline detects and folds,
+ * LoadToFold1.C:1105-1109, DetectionCUDA.cu:145-149) -- the same sums in either shape.  Replaces the chain Filterbank::Engine::perform (FilterbankCUDA.cu:181-304) + Detection::Engine::polarimetry
  * (DetectionCUDA.cu:127-177) + Fold::Engine::fold (FoldCUDA.cu:586-697) for one block of `npart` parts.
  * The bin plan of the npart*nkeep output samples of this call must have been handed to `fold` beforehand
  * (dspsr_amd_fold_set_nbin / set_ndat / set_bin(s) with sample indices counted from the first output sample of

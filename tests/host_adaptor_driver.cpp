@@ -26,6 +26,140 @@ static void d2h (dspsr_amd_ctx* ctx, dsp::TimeSeries& host, const dsp::TimeSerie
   HIP::check (ctx, dspsr_amd_stream_sync (ctx), "d2h");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Deferred mode (HIP::Chain) and the raw-input side channel: the SAME reference call order -- Filterbank::Engine::perform
+// (Filterbank.C:547-553), Detection::Engine::polarimetry in place (Detection.C:325-334, LoadToFold1.C:545-546), then
+// Fold::fold's set_nbin / set_ndat / set_bins / Engine::fold (Fold.C:724-741,817-829) -- through eager adaptors, deferred
+// adaptors on float32 rows and deferred adaptors on the packed 8-bit block must give the same PhaseSeries bit for bit.
+struct Variant { const char* name; bool chain, deferred, raw; int fused_mode; bool pieces, finish_each; };
+
+static int run_variant (dspsr_amd_ctx* ctx, dsp::Memory* dmem, const Variant& v, const std::vector<signed char>& raw_h, float scale,
+                        unsigned C, unsigned M, unsigned pos, unsigned neg, unsigned npart, unsigned nblock, const dsp::Response& resp,
+                        unsigned nbin, std::vector<float>& profile, std::vector<unsigned>& hits, double& length, uint64_t counters[3])
+{
+  const unsigned nkeep = M - pos - neg;
+  const uint64_t N = uint64_t (C) * M, nsamp_fft = 2 * N, overlap = 2 * (pos + neg) * C, step = nsamp_fft - overlap;
+  const uint64_t ndat_in = npart * step + overlap, ndat = uint64_t (npart) * nkeep;
+  HIP::Chain* chain = v.chain ? new HIP::Chain (ctx) : 0;
+  if (chain) chain->set_deferred (v.deferred);
+  dsp::TimeSeries in_h, in_d, out_d;
+  in_h.set_nchan (1); in_h.set_npol (2); in_h.set_ndim (1); in_h.set_state (Signal::Nyquist); in_h.set_rate (1e6);
+  in_h.resize (ndat_in);
+  in_d.set_memory (dmem); in_d.internal_match (&in_h);
+  dsp::BitSeries bits_h, bits_d;
+  bits_d.set_memory (dmem);
+  dsp::Filterbank fbk;
+  fbk.nchan_subband = C; fbk.freq_res = M; fbk.input = &in_d; fbk.response = &resp;
+  HIP::FilterbankEngine fbe (ctx, chain);
+  fbe.set_fused_fold (v.fused_mode);
+  fbe.setup (&fbk);
+  HIP::DetectionEngine dete (ctx, chain);
+  out_d.set_nchan (C); out_d.set_npol (2); out_d.set_ndim (2); out_d.set_rate (1e6 / (2 * C));
+  out_d.set_memory (dmem); out_d.resize (ndat);
+  dsp::Fold fold;
+  HIP::FoldEngine* eng = new HIP::FoldEngine (ctx, chain);
+  fold.set_input (&out_d); fold.set_engine (eng); fold.set_nbin (nbin);
+  const double pfold = 37.7 / out_d.get_rate ();
+  for (unsigned b = 0; b < nblock; b++)
+  {
+    // block b of the stream: packed bytes ((t*nchan + c)*npol + p)*ndim + d = 2*t + p, and their unpacked image
+    const signed char* rb = &raw_h[size_t (b) * step * 2];
+    for (unsigned p = 0; p < 2; p++) for (uint64_t t = 0; t < ndat_in; t++) in_h.get_datptr (0, p)[t] = (float (rb[2 * t + p]) + 0.5f) * scale;
+    const int64_t input_sample = int64_t (b) * step;
+    in_d.set_input_sample (input_sample);
+    h2d (ctx, in_d, in_h);
+    if (v.raw)
+    {
+      bits_h.resize (ndat_in, 2); bits_h.set_input_sample (input_sample);
+      memcpy (bits_h.get_rawptr (), rb, ndat_in * 2);
+      bits_d.resize (ndat_in, 2);
+      HIP::transfer_bitseries (ctx, &bits_h, &bits_d, &fbe, DSPSR_AMD_RAW_GENERIC, scale);
+      // the float rows must then be dead weight: poison them (a pipeline that hands over the BitSeries does not unpack)
+      for (unsigned p = 0; p < 2; p++) for (uint64_t t = 0; t < ndat_in; t++) in_h.get_datptr (0, p)[t] = 1e30f;
+      h2d (ctx, in_d, in_h);
+    }
+    out_d.set_state (Signal::Analytic); out_d.reshape (2, 2);
+    fbe.perform (&in_d, &out_d, npart, step, 2 * nkeep);
+    if (v.finish_each) fbe.finish ();                              // Operation::record_time: Filterbank.C:551
+    dete.polarimetry (2, &out_d, &out_d);                          // in place, LoadToFold1.C:545-546
+    out_d.reshape (2, 2); out_d.set_state (Signal::Coherence);     // Detection::resize_output AFTER the engine call (:136-138)
+    fold.prepare_output ();
+    const double phi = 0.11 + 0.37 * b;
+    if (v.pieces && b == 1) {                                      // a sub-integration boundary inside block 1 (Subint.h:234-309)
+      fold.fold (phi, pfold, 0, 700);
+      fold.fold (phi + 0.5, pfold, 700, ndat - 700);
+    } else
+      fold.fold (phi, pfold, 0, ndat);
+  }
+  dsp::PhaseSeries* res = fold.get_result ();
+  REQUIRE (res->get_nbin () == nbin && res->get_nchan () == C && res->get_npol () == 2 && res->get_ndim () == 2, "%s: result shape", v.name);
+  profile.resize (size_t (C) * 2 * nbin * 2);
+  for (unsigned c = 0; c < C; c++) for (unsigned p = 0; p < 2; p++)
+    memcpy (&profile[(size_t (c) * 2 + p) * nbin * 2], res->get_datptr (c, p), nbin * 2 * sizeof (float));
+  hits.assign (res->get_hits (), res->get_hits () + nbin);
+  length = res->integration_length;
+  counters[0] = chain ? chain->get_fused_blocks () : 0;
+  counters[1] = chain ? chain->get_eager_blocks () : 0;
+  counters[2] = chain ? chain->get_dropped_blocks () : 0;
+  return 0;
+}
+
+static int deferred_section (dspsr_amd_ctx* ctx, dsp::Memory* dmem)
+{
+  const unsigned C = 64, M = 256, pos = 5, neg = 7, npart = 5, nblock = 3, nbin = 32;
+  const uint64_t N = uint64_t (C) * M, step = 2 * N - 2 * (pos + neg) * C, ndat_in = npart * step + 2 * (pos + neg) * C;
+  std::vector<signed char> raw_h ((size_t (nblock - 1) * step + ndat_in) * 2);
+  for (size_t i = 0; i < raw_h.size (); i++) { lcg = lcg * 1664525u + 1013904223u; raw_h[i] = (signed char) ((int) (lcg >> 24) - 128); }
+  dsp::Response resp;
+  resp.impulse_pos = pos; resp.impulse_neg = neg; resp.nchan = C; resp.ndat = M;
+  resp.kernel.resize (2 * N);
+  for (uint64_t k = 0; k < N; k++) { const float a = 3.0f * rnd (); resp.kernel[2 * k] = cosf (a); resp.kernel[2 * k + 1] = sinf (a); }
+  const float scale = 0.0123f;
+  const Variant variants[] = {
+    // name                                                           chain  deferred raw    fused mode               pieces finish
+    {"eager adaptors, no chain",                                       false, false,   false, DSPSR_AMD_FUSED_AUTO,   false, false},
+    {"chain, not deferred",                                            true,  false,   false, DSPSR_AMD_FUSED_AUTO,   false, false},
+    {"deferred, float32 rows, fused kernel (one workgroup per tile)",  true,  true,    false, DSPSR_AMD_FUSED_ALWAYS, false, false},
+    {"deferred, packed 8-bit block, fused kernel",                     true,  true,    true,  DSPSR_AMD_FUSED_ALWAYS, false, false},
+    {"deferred, packed 8-bit block, library's choice of launches",     true,  true,    true,  DSPSR_AMD_FUSED_AUTO,   false, false},
+    {"eager, packed 8-bit block (perform_raw inside perform)",         true,  false,   true,  DSPSR_AMD_FUSED_AUTO,   false, false},
+    {"deferred + finish() after every perform (record_time)",          true,  true,    true,  DSPSR_AMD_FUSED_ALWAYS, false, true},
+  };
+  std::vector<float> want, got;
+  std::vector<unsigned> whits, ghits;
+  double wlen = 0, glen = 0;
+  uint64_t cnt[3];
+  for (size_t i = 0; i < sizeof variants / sizeof variants[0]; i++)
+  {
+    const Variant& v = variants[i];
+    if (run_variant (ctx, dmem, v, raw_h, scale, C, M, pos, neg, npart, nblock, resp, nbin, i ? got : want, i ? ghits : whits, i ? glen : wlen, cnt)) return 1;
+    if (i == 0) {
+      double power = 0;
+      for (size_t k = 0; k < want.size (); k++) power += double (want[k]) * want[k];
+      REQUIRE (power > 0, "deferred section: the eager profile is all zero");
+      continue;
+    }
+    REQUIRE (ghits == whits && glen == wlen, "%s: hits / integration_length differ from the eager run", v.name);
+    for (size_t k = 0; k < want.size (); k++)
+      REQUIRE (got[k] == want[k], "%s: profile[%zu] = %.9g != %.9g (eager)", v.name, k, got[k], want[k]);
+    if (v.deferred && !v.finish_each) REQUIRE (cnt[0] == nblock && cnt[1] == 0 && cnt[2] == 0, "%s: %llu fused / %llu eager / %llu dropped blocks",
+                                              v.name, (unsigned long long) cnt[0], (unsigned long long) cnt[1], (unsigned long long) cnt[2]);
+    if (v.chain && (!v.deferred || v.finish_each)) REQUIRE (cnt[0] == 0 && cnt[1] == nblock, "%s: %llu fused / %llu eager blocks", v.name,
+                                                            (unsigned long long) cnt[0], (unsigned long long) cnt[1]);
+    printf ("deferred section: %-66s == eager  (%llu fused, %llu eager)\n", v.name, (unsigned long long) cnt[0], (unsigned long long) cnt[1]);
+  }
+  // a sub-integration boundary inside a block: that block falls back to the separate launches, the others stay fused
+  const Variant pe = {"eager, block 1 folded in two pieces", false, false, false, DSPSR_AMD_FUSED_AUTO, true, false};
+  const Variant pd = {"deferred, block 1 folded in two pieces", true, true, true, DSPSR_AMD_FUSED_ALWAYS, true, false};
+  if (run_variant (ctx, dmem, pe, raw_h, scale, C, M, pos, neg, npart, nblock, resp, nbin, want, whits, wlen, cnt)) return 1;
+  if (run_variant (ctx, dmem, pd, raw_h, scale, C, M, pos, neg, npart, nblock, resp, nbin, got, ghits, glen, cnt)) return 1;
+  REQUIRE (ghits == whits && glen == wlen, "pieces: hits / integration_length differ");
+  for (size_t k = 0; k < want.size (); k++) REQUIRE (got[k] == want[k], "pieces: profile[%zu] = %.9g != %.9g", k, got[k], want[k]);
+  REQUIRE (cnt[0] == nblock - 1 && cnt[1] == 1 && cnt[2] == 0, "pieces: %llu fused / %llu eager blocks", (unsigned long long) cnt[0], (unsigned long long) cnt[1]);
+  printf ("deferred section: block with a sub-integration boundary falls back to eager, result identical\n");
+  return 0;
+}
+
 int main ()
 {
   dspsr_amd_ctx* ctx = 0;
@@ -146,6 +280,9 @@ int main ()
     want.assign (want.size (), 0.0f); whits.assign (nbin, 0); wtotal = 0;
     fold.fold (0.5, pfold, 10, 100);  cpu_fold (0.5, 10, 100);
     if (check_result ("after reset")) return 1;
+
+    // ---------------------------------------------------------------- deferred mode + raw side channel
+    if (deferred_section (ctx, dmem)) return 1;
 
     // ---------------------------------------------------------------- TimeSeries::Engine::copy_data_fpt
     HIP::TimeSeriesEngine tse (ctx);

@@ -63,10 +63,37 @@ namespace dsp {
     { Observation::copy_configuration (other); resize (other->get_ndat ()); }
     virtual void zero () { if (buffer) memory->do_zero (buffer, size); }           // TimeSeries::zero
     bool get_zeroed_data () const { return false; }
+    int64_t get_input_sample () const { return input_sample; }                     // TimeSeries.h:122-125
+    void set_input_sample (uint64_t sample) { input_sample = (int64_t) sample; }
+    //! TimeSeries::reshape (used by an in-place Detection, Detection.C:190-200): same buffer, other (npol, ndim) split
+    void reshape (unsigned new_npol, unsigned new_ndim) { span = span * npol / new_npol; npol = new_npol; ndim = new_ndim; }
   protected:
     Reference::To<Memory> memory;
     unsigned char* buffer;
     uint64_t size, span;
+    int64_t input_sample = -1;
+  };
+  class BitSeries : public Observation {                    // Kernel/Classes/dsp/BitSeries.h:30-125: the packed block
+  public:
+    BitSeries () : memory (new Memory), data (0), size (0), input_sample (-1) {}
+    void set_memory (Memory* m) { memory = m; }
+    void resize (uint64_t nsamples, unsigned nbyte_per_sample)
+    {
+      ndat = nsamples;
+      const uint64_t need = nsamples * nbyte_per_sample;
+      if (need > size) { if (data) memory->do_free (data); data = (unsigned char*) memory->do_allocate (need); size = need; }
+      used = need;
+    }
+    unsigned char* get_rawptr () { return data; }                                   // BitSeries.h:58-62
+    const unsigned char* get_rawptr () const { return data; }
+    uint64_t get_size () const { return used; }                                     // DataSeries.h: bytes in use
+    int64_t get_input_sample (void* = 0) const { return input_sample; }             // BitSeries.h:83-86
+    void set_input_sample (int64_t sample) { input_sample = sample; }
+  protected:
+    Reference::To<Memory> memory;
+    unsigned char* data;
+    uint64_t size, used = 0;
+    int64_t input_sample;
   };
   class TimeSeries::Engine : public Reference::Able {      // Kernel/Classes/dsp/TimeSeries.h:211-223
   public:

@@ -27,6 +27,19 @@ dsp::Filterbank::Engine* d (dspsr_amd_ctx* c) { return new HIP::FilterbankEngine
 dsp::Convolution::Engine* e (dspsr_amd_ctx* c) { return new HIP::ConvolutionEngine (c); }
 dsp::Detection::Engine* f (dspsr_amd_ctx* c) { return new HIP::DetectionEngine (c); }
 dsp::Fold::Engine* g (dspsr_amd_ctx* c) { return new HIP::FoldEngine (c); }
+// deferred mode: the adaptors of one pipeline thread share a HIP::Chain; the raw-input hand-over against the REAL dsp::BitSeries
+#include "dsp/BitSeries.h"
+void h (dspsr_amd_ctx* c, const dsp::BitSeries* host, dsp::BitSeries* device)
+{
+  HIP::Chain* chain = new HIP::Chain (c);
+  chain->set_deferred (true);
+  HIP::FilterbankEngine* fb = new HIP::FilterbankEngine (c, chain);
+  dsp::Detection::Engine* det = new HIP::DetectionEngine (c, chain);
+  dsp::Fold::Engine* fold = new HIP::FoldEngine (c, chain);
+  dsp::TimeSeries::Engine* ts = new HIP::TimeSeriesEngine (c, chain);
+  HIP::transfer_bitseries (c, host, device, fb, DSPSR_AMD_RAW_GENERIC, 1.0f);
+  (void) det; (void) fold; (void) ts;
+}
 '''
 
 
