@@ -163,9 +163,9 @@ def bench_fold_only(args, wl, torch):
         res["cpu_baseline"] = {"value": round(ndat * nc / nchan / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
                                "sample": "%d of %d channels of one block, numpy restatement of the Fold.C:835-891 loop, %.2f s"
                                          % (nc, nchan, dt)}
-    print(json.dumps(res), flush=True)
     fold.close()
     ctx.close()
+    return res
 
 
 def bench_search_mode(args, wl, torch):
@@ -232,8 +232,8 @@ def bench_search_mode(args, wl, torch):
         dt = time.perf_counter() - t1
         res["cpu_baseline"] = {"value": n * 2 * nchan / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
                                "sample": "%d FFT blocks of the same workload, numpy oracle, %.1f s" % (n, dt)}
-    print(json.dumps(res), flush=True)
     lf.close()
+    return res
 
 
 def algorithmic_bytes_per_part(npol, nsamp_fft, nbit, N, nchan_subband, nkeep):
@@ -505,12 +505,272 @@ def parity_gate(lt, raw, torch, dist, rank, world, sharded):
             (["identical hits on all sub-band ranks"] if sharded and world > 1 else [])}
 
 
+def engine_boundary(torch):
+    """The headline geometry through the C++ Engine adaptors in DSPSR's own call order (tools/engine_boundary_bench.cpp,
+    built by dspsr_amd/csrc/Makefile): a child process, started after this process has finished its own timing."""
+    import subprocess
+    exe = os.path.join(ROOT, "dspsr_amd", "host", "engine_boundary_bench")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "dspsr_amd", "csrc"), "../host/engine_boundary_bench"], capture_output=True)
+    try:
+        p = subprocess.run([exe, "64", "6", "32"], capture_output=True, text=True, timeout=300)
+        rec = json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as e:  # a reported companion figure only
+        return {"error": repr(e)}
+    rec["how"] = ("C++ adaptors dspsr_amd/host/dspsr_amd_engines.h driven as Filterbank.C:547-553 -> Detection.C:325-334 (ndim 2, in "
+                  "place) -> Fold.C:724-741,817-829 per block; eager = every Engine call launches at once, deferred = HIP::Chain "
+                  "(one fused launch group at Fold::Engine::fold); float = unpacked float32 rows, raw = the packed 8-bit "
+                  "BitSeries handed over (set_raw_input)")
+    return rec
+
+
+def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, steps, warmup, full=True):
+    """One filterbank + detect + fold workload on this process group: the timed region (barrier, `steps` steps with a
+    sub-integration dump every args.dump_steps, barrier), then -- outside it -- the unfused roofline blocks and the
+    parity gate.  Returns the result record on rank 0 (None elsewhere).  full: cpu_baseline / --h2d companions too."""
+    import dspsr_amd
+    from dspsr_amd import pipeline
+    wl = WORKLOADS[name]
+    sharded = wl["in_nchan"] > 1                 # sub-band sharding; otherwise time-slice replicas
+    if sharded and world > wl["in_nchan"]:
+        sys.exit("bench.py: workload %s has %d sub-bands, --gpus %d is more" % (name, wl["in_nchan"], world))
+    info = pipeline.InputInfo(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=wl["in_nchan"], npol=2,
+                              ndim=wl["ndim"], tsamp_us=wl["tsamp_us"], machine=wl["machine"])
+    parts_per_block, max_parts = args.parts_per_block, args.max_parts
+    n_fft = (wl["nchan"] // wl["in_nchan"]) * wl["freq_res"]
+    if not parts_per_block:
+        nsamp_fft = 2 * n_fft if wl["ndim"] == 1 else n_fft
+        parts_per_block = max(16, min(256, (1 << 29) // nsamp_fft))
+    if not max_parts:
+        # parts per launch group: half a block, or -- small parts -- as many as keep each scratch buffer near 2 GB
+        # (the persistent kernels amortise ramp-up and tail over the group and the launch gaps shrink: the 50 MHz sub-band
+        # geometry 42.1k / 45.6k / 46.0k Msamples/s at 64 / 128 / 256 parts per group)
+        part_bytes = 2 * n_fft * 8          # L = 2N points of real input, or two sequences of N (complex dual-pol)
+        max_parts = max(1, parts_per_block // 2, min(parts_per_block, (2 << 30) // part_bytes))
+    cfg = pipeline.Config(nchan=wl["nchan"], dispersion_measure=wl["dm"], nbin=wl["nbin"],
+                          folding_period=0.0893, freq_res=wl["freq_res"], ndim=args.ndim,
+                          parts_per_block=parts_per_block, max_parts=max_parts,
+                          fused_fold=not args.no_fused_fold)
+    lt = pipeline.LoadToFold(cfg, info, device=local_rank, stream=torch.cuda.current_stream().cuda_stream,
+                             subband=rank if sharded else None)
+
+    # synthetic block resident in HBM: seeded Gaussian noise, sigma = 24 LSB (content does not change the work; the
+    # oracle comparisons on a dispersed pulsed signal are the -m gpu tests, tests/test_gpu_headline.py)
+    nbytes = lt.block_bytes()
+    gen = torch.Generator(device="cuda").manual_seed(20100413 + rank)
+    raw = torch.empty(nbytes, dtype=torch.int8, device="cuda")
+    chunk = 1 << 26
+    for s in range(0, nbytes, chunk):
+        e = min(nbytes, s + chunk)
+        raw[s:e] = torch.randn(e - s, generator=gen, device="cuda").mul_(24.0).round_().clamp_(-128, 127).to(torch.int8)
+
+    # the exchange: RCCL behind the C-ABI (dspsr_amd_comm_*), one communicator per pipeline context; the unique id travels
+    # over the launcher's process group.  One-device rehearsals (gloo) keep the torch.distributed form of the same exchange.
+    gather, rccl = None, None
+    if world > 1 and not single:
+        ids = [dspsr_amd.Communicator.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        rccl = dspsr_amd.Communicator(lt.ctx, world, rank, ids[0])
+        lt.set_rccl_communicator(rccl)
+    elif world > 1 and sharded:
+        gather = torch.zeros(world * lt.nchan_out * lt.npol_out * cfg.nbin * cfg.ndim, dtype=torch.float32, device="cuda")
+    comm = dist if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def dump(wait=False, check=False):
+        # (the dump of block i overlaps the kernels of block i+1: snapshot on the compute stream, collective on the
+        #  communicator's stream; hits are checked in the parity gate and in the timed dumps of `reduce_ms_per_dump`)
+        lt.finish_subint(comm, rank, world, gather, replicas=not sharded, check_hits=check, wait=wait)
+        lt.subints.clear()
+
+    blocks_done = [0]
+
+    def step(i, ev=None):
+        if not sharded:
+            lt.seek_block(blocks_done[0] * world + rank)       # replica r takes blocks r, r + N, ... of the stream
+        blocks_done[0] += 1
+        lt.process_block(raw, events=ev)
+        if (i + 1) % args.dump_steps == 0:
+            dump()
+
+    for i in range(warmup):
+        step(i)
+    lt.collect_subint()
+    barrier()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    nsamp0 = lt.nsamples_in
+    t_start = time.perf_counter()
+    for i in range(steps):
+        step(i, events[i])
+    dump()
+    lt.collect_subint()                                                   # the last exchange has arrived on the root
+    lt.subints.clear()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    samples = float((lt.nsamples_in - nsamp0) * lt.in_nchan)          # this rank's own samples (per pol)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        t = torch.tensor([samples], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        samples = float(t.item())
+    value = samples / elapsed / 1e6
+
+    # ---- outside the timed region: the dump alone, roofline blocks, parity gate, baselines ---------------------
+    reduce_ms, hits_ok = None, None
+    if world > 1:
+        # the exchange by itself, start to arrival on the root, with the hits check in the same group (max over ranks)
+        lt.process_block(raw)
+        barrier()
+        nd = 4
+        t1 = time.perf_counter()
+        for _ in range(nd):
+            dump(wait=True, check=True)                                   # raises if the ranks disagree on hits[]
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t1) / nd * 1e3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        reduce_ms, hits_ok = float(t.item()), True
+        lt.fold.zero()
+        lt.hits[:] = 0
+        lt.integration_length, lt.ndat_total = 0.0, 0
+    timed_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)   # launch group of the timed region
+    fused = lt.fused_fold
+    fb_ms = timed_ms
+    extra = 0
+    if fused:
+        # The timed region ran the fused kernels (the detected time series never reaches HBM).  The roofline
+        # of the FFT+chirp(+detect) pass as SURVEY 8(d) defines it -- input once, chirp once, kept output once --
+        # is measured on extra blocks right after the timed region, with Detection and Fold as separate
+        # operations; the fused launch group is reported beside it with its own (smaller) algorithmic bytes.
+        lt.fused_fold = False
+        extra = max(4, steps // 4)
+        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(extra)]
+        lt.process_block(raw)
+        for e in ev2:
+            lt.process_block(raw, events=e)
+        torch.cuda.synchronize()
+        fb_ms = sum(a.elapsed_time(b) for a, b in ev2) / len(ev2)
+        lt.fused_fold = True
+        lt.fold.zero()
+        lt.hits[:] = 0
+        lt.integration_length, lt.ndat_total = 0.0, 0
+    lt.set_rccl_communicator(None)                                       # the gate's hits check goes through the process group
+    gate = parity_gate(lt, raw, torch, dist, rank, world, sharded)       # every rank; raises on failure
+    out = None
+    if rank == 0:
+        r = lt.response
+        nchan_subband = cfg.nchan // info.nchan
+        N = nchan_subband * r.ndat
+        nsamp_fft = 2 * N if info.ndim == 1 else N
+        b_alg = algorithmic_bytes_per_part(2, nsamp_fft * info.ndim, 8, N, nchan_subband, lt.nkeep)
+        achieved = b_alg * cfg.parts_per_block * lt.in_nchan / (fb_ms * 1e-3) / 1e9
+        exch = ("dspsr_amd_reduce_profiles_* (RCCL behind the C-ABI, csrc/comm.hip), snapshot on the compute stream, collective "
+                "on its own stream" if rccl is not None else
+                "torch.distributed (gloo rehearsal on one device)" if world > 1 else "one rank: no exchange")
+        par = ("sub-band per GPU x%d (input channel g of %d, slice g of the full-band kernel; per dump ONE ncclGather of the "
+               "ranks' slices; %s)" % (world, info.nchan, exch)) if sharded else \
+              ("time-slice replicas x%d (blocks dealt round robin; per dump ONE packed ncclReduce(SUM) of profile + hits + "
+               "lengths; %s)" % (world, exch) if world > 1 else "single GPU")
+        out = {
+            "metric": "Msamples/s dedispersed+folded", "value": round(value, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "command": wl["cmd"], "nchan": cfg.nchan, "freq_res": r.ndat,
+                       "n_fft": N, "nfilt_pos": r.impulse_pos, "nfilt_neg": r.impulse_neg, "nkeep": lt.nkeep,
+                       "nsamp_step": lt.nsamp_step, "dm": cfg.dispersion_measure, "nbin": cfg.nbin,
+                       "parts_per_block": cfg.parts_per_block, "max_parts": cfg.max_parts,
+                       "input": "8-bit dual-pol, resident in HBM",
+                       "detected_ndim": cfg.ndim, "fused_fold": bool(fused), "parallelism": par,
+                       "realtime_factor": round(value / world / (info.rate / 1e6), 3)},
+            "parity_gate": gate,
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": measured_traffic(name, cfg.max_parts),
+                         "traffic_unit": "HBM bytes per launch group of %d parts (PMC counters of a separate rocprofv3 run on the "
+                                         "commit named in %s -- not measured in this run); "
+                                         "algorithmic bytes for the same group: %d"
+                                         % (cfg.max_parts, measured_traffic.source or "profiles/r*_traffic.json: none for this shape",
+                                            b_alg * cfg.max_parts),
+                         "kernel": "filterbank launch group k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,false> "
+                                   "(FFT+chirp+detect, detected output written)",
+                         "algorithmic_bytes_per_part": b_alg, "group_ms_per_block": round(fb_ms, 4),
+                         "region": ("%d extra blocks right after the timed region with Detection and Fold as "
+                                    "separate operations (HIP events on the launch stream)" % extra) if fused
+                                   else "the timed region (HIP events on the launch stream)"},
+        }
+        if world > 1:
+            out["config"]["reduce_ms_per_dump"] = round(reduce_ms, 4)
+            out["config"]["identical_hits"] = hits_ok
+        if fused:
+            b_fused = b_alg - 2 * nchan_subband * lt.nkeep * 8         # no detected output: input once + chirp once
+            ach_f = b_fused * cfg.parts_per_block * lt.in_nchan / (timed_ms * 1e-3) / 1e9
+            out["roofline_fused"] = {
+                "bound": "hbm", "achieved": round(ach_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach_f / HBM_PEAK_GBS, 4),
+                "traffic": measured_traffic(name, cfg.max_parts, "hbm_bytes_per_launch_group_fused"),
+                "kernel": "k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,true> (FFT+chirp+detect+fold in one "
+                          "launch group, the timed region)",
+                "algorithmic_bytes_per_part": b_fused, "group_ms_per_block": round(timed_ms, 4),
+                "note": "the fused group also does the fold; its algorithmic bytes have no output term "
+                        "(SURVEY 8(d)), so this fraction is not comparable with roofline.frac"}
+        if full and args.h2d:
+            # host-buffer hand-over through the product's own feeder (pipeline.LoadToFold.process_host_blocks): block i+1
+            # is copied H2D on a second stream while block i is processed
+            host = raw.cpu().pin_memory()
+            lt.process_host_blocks(host for _ in range(3))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            lt.process_host_blocks(host for _ in range(steps))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            out["config"]["pcie_inclusive"] = {
+                "value": round(cfg.parts_per_block * lt.nsamp_step * steps / dt / 1e6, 1), "unit": "Msamples/s",
+                "note": "blocks copied from pinned host memory (%.1f MB each) on a second stream, double buffered"
+                        % (raw.numel() / 1e6)}
+        if full and world == 1 and not args.no_cpu_baseline:
+            geom = {"freq_res": r.ndat, "nkeep": lt.nkeep, "nsamp_step": lt.nsamp_step, "nsamp_overlap": lt.nsamp_overlap,
+                    "nfilt_pos": r.impulse_pos, "kernel": r.kernel, "scale8": lt.scale8, "out_rate": lt.out_rate}
+            try:
+                out["cpu_baseline"] = cpu_baseline(wl, geom)
+            except Exception as e:  # the oracle is only a reported baseline
+                out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+    if rccl is not None:
+        rccl.close()
+    lt.close()
+    del raw, gather
+    torch.cuda.empty_cache()
+    return out
+
+
+def brief(rec):
+    """One line of `other_workloads` / `subband_shard` from a full result record."""
+    b = {"workload": rec["config"]["workload"], "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"],
+         "steps": rec["steps"], "roofline_frac": rec["roofline"]["frac"], "roofline_kernel": rec["roofline"]["kernel"].split(" (")[0],
+         "command": rec["config"]["command"]}
+    for k in ("parts_per_block", "max_parts", "fused_fold", "parallelism", "reduce_ms_per_dump", "identical_hits"):
+        if k in rec["config"]:
+            b[k] = rec["config"][k]
+    if "parity_gate" in rec:
+        b["parity_gate"] = rec["parity_gate"]["status"]
+    return b
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="one workload only.  Default: the headline (`target`) as the result line, plus -- companions in the same "
+                         "line -- the sub-band sharded run of cfg4 (the north-star scaling curve), and at --gpus 1 the other "
+                         "BASELINE configurations in short runs and the headline through the C++ Engine adaptors")
     ap.add_argument("--parts-per-block", type=int, default=0,
                     help="overlap-save parts per block; 0 = 64 for the headline geometry (2^23 samples per part), "
                          "more for smaller parts so that a block stays near 5e8 samples (capped at 256)")
@@ -518,6 +778,7 @@ def main():
     ap.add_argument("--dump-steps", type=int, default=8, help="steps per sub-integration dump")
     ap.add_argument("--ndim", type=int, default=4, choices=[1, 2, 4])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-companions", action="store_true", help="default run without the companion measurements")
     ap.add_argument("--h2d", action="store_true",
                     help="also measure the PCIe-inclusive rate: every block copied from pinned host memory on a second "
                          "stream, double buffered, overlapped with the kernels (reported as config.pcie_inclusive)")
@@ -530,7 +791,6 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from dspsr_amd import pipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -552,188 +812,45 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    wl = WORKLOADS[args.workload]
-    if args.workload in ("cfg5", "fold"):
-        if world > 1:
-            sys.exit("bench.py: the %s workload runs as independent replicas; use --gpus 1" % args.workload)
-        return bench_search_mode(args, wl, torch) if args.workload == "cfg5" else bench_fold_only(args, wl, torch)
-    sharded = wl["in_nchan"] > 1                 # sub-band sharding; otherwise time-slice replicas
-    if sharded and world > wl["in_nchan"]:
-        sys.exit("bench.py: workload %s has %d sub-bands, --gpus %d is more" % (args.workload, wl["in_nchan"], world))
-    info = pipeline.InputInfo(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=wl["in_nchan"], npol=2,
-                              ndim=wl["ndim"], tsamp_us=wl["tsamp_us"], machine=wl["machine"])
-    if not args.parts_per_block:
-        n_fft = (wl["nchan"] // wl["in_nchan"]) * wl["freq_res"]
-        nsamp_fft = 2 * n_fft if wl["ndim"] == 1 else n_fft
-        args.parts_per_block = max(16, min(256, (1 << 29) // nsamp_fft))
-    if not args.max_parts:
-        # parts per launch group: half a block, or -- small parts -- as many as keep each scratch buffer near 2 GB
-        # (the persistent kernels amortise ramp-up and tail over the group and the launch gaps shrink: the 50 MHz sub-band
-        # geometry 42.1k / 45.6k / 46.0k Msamples/s at 64 / 128 / 256 parts per group)
-        n_fft = (wl["nchan"] // wl["in_nchan"]) * wl["freq_res"]
-        part_bytes = 2 * n_fft * 8          # L = 2N points of real input, or two sequences of N (complex dual-pol)
-        args.max_parts = max(1, args.parts_per_block // 2, min(args.parts_per_block, (2 << 30) // part_bytes))
-    cfg = pipeline.Config(nchan=wl["nchan"], dispersion_measure=wl["dm"], nbin=wl["nbin"],
-                          folding_period=0.0893, freq_res=wl["freq_res"], ndim=args.ndim,
-                          parts_per_block=args.parts_per_block, max_parts=args.max_parts,
-                          fused_fold=not args.no_fused_fold)
-    lt = pipeline.LoadToFold(cfg, info, device=local_rank, stream=torch.cuda.current_stream().cuda_stream,
-                             subband=rank if sharded else None)
-
-    # synthetic block resident in HBM: seeded Gaussian noise, sigma = 24 LSB (content does not change the work)
-    nbytes = lt.block_bytes()
-    gen = torch.Generator(device="cuda").manual_seed(20100413 + rank)
-    raw = torch.empty(nbytes, dtype=torch.int8, device="cuda")
-    chunk = 1 << 26
-    for s in range(0, nbytes, chunk):
-        e = min(nbytes, s + chunk)
-        raw[s:e] = torch.randn(e - s, generator=gen, device="cuda").mul_(24.0).round_().clamp_(-128, 127).to(torch.int8)
-
-    gather = None
-    if world > 1 and sharded:
-        gather = torch.zeros(world * lt.nchan_out * lt.npol_out * cfg.nbin * cfg.ndim, dtype=torch.float32, device="cuda")
-    comm = dist if world > 1 else None
-
-    def barrier():
+    def finish(rec):
+        if rank == 0 and rec is not None:
+            print(json.dumps(rec), flush=True)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            dist.destroy_process_group()
 
-    def dump():
-        lt.finish_subint(comm, rank, world, gather, replicas=not sharded)
-        lt.subints.clear()
-
-    blocks_done = [0]
-
-    def step(i, ev=None):
-        if not sharded:
-            lt.seek_block(blocks_done[0] * world + rank)       # replica r takes blocks r, r + N, ... of the stream
-        blocks_done[0] += 1
-        lt.process_block(raw, events=ev)
-        if (i + 1) % args.dump_steps == 0:
-            dump()
-
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    nsamp0 = lt.nsamples_in
-    t_start = time.perf_counter()
-    for i in range(args.steps):
-        step(i, events[i])
-    dump()
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    samples = float((lt.nsamples_in - nsamp0) * lt.in_nchan)          # this rank's own samples (per pol)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        t = torch.tensor([samples], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        samples = float(t.item())
-    value = samples / elapsed / 1e6
-
-    # ---- outside the timed region: roofline blocks, parity gate, baselines ------------------------------------
-    timed_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)   # launch group of the timed region
-    fused = lt.fused_fold
-    fb_ms = timed_ms
-    extra = 0
-    if fused:
-        # The timed region ran the fused kernels (the detected time series never reaches HBM).  The roofline
-        # of the FFT+chirp(+detect) pass as SURVEY 8(d) defines it -- input once, chirp once, kept output once --
-        # is measured on extra blocks right after the timed region, with Detection and Fold as separate
-        # operations; the fused launch group is reported beside it with its own (smaller) algorithmic bytes.
-        lt.fused_fold = False
-        extra = max(4, args.steps // 4)
-        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(extra)]
-        lt.process_block(raw)
-        for e in ev2:
-            lt.process_block(raw, events=e)
-        torch.cuda.synchronize()
-        fb_ms = sum(a.elapsed_time(b) for a, b in ev2) / len(ev2)
-        lt.fused_fold = True
-        lt.fold.zero()
-        lt.hits[:] = 0
-        lt.integration_length, lt.ndat_total = 0.0, 0
-    gate = parity_gate(lt, raw, torch, dist, rank, world, sharded)       # every rank; raises on failure
-    if rank == 0:
-        r = lt.response
-        nchan_subband = cfg.nchan // info.nchan
-        N = nchan_subband * r.ndat
-        nsamp_fft = 2 * N if info.ndim == 1 else N
-        b_alg = algorithmic_bytes_per_part(2, nsamp_fft * info.ndim, 8, N, nchan_subband, lt.nkeep)
-        achieved = b_alg * cfg.parts_per_block * lt.in_nchan / (fb_ms * 1e-3) / 1e9
-        par = ("sub-band per GPU x%d (input channel g of %d, slice g of the full-band kernel, one reduce per dump)"
-               % (world, info.nchan)) if sharded else \
-              ("time-slice replicas x%d (blocks dealt round robin, SUM reduce of profiles+hits per dump)" % world
-               if world > 1 else "single GPU")
-        out = {
-            "metric": "Msamples/s dedispersed+folded", "value": round(value, 2), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "command": wl["cmd"], "nchan": cfg.nchan, "freq_res": r.ndat,
-                       "n_fft": N, "nfilt_pos": r.impulse_pos, "nfilt_neg": r.impulse_neg, "nkeep": lt.nkeep,
-                       "nsamp_step": lt.nsamp_step, "dm": cfg.dispersion_measure, "nbin": cfg.nbin,
-                       "parts_per_block": cfg.parts_per_block, "max_parts": cfg.max_parts,
-                       "input": "8-bit dual-pol, resident in HBM",
-                       "detected_ndim": cfg.ndim, "fused_fold": bool(fused), "parallelism": par,
-                       "realtime_factor": round(value / world / (info.rate / 1e6), 3)},
-            "parity_gate": gate,
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(args.workload, cfg.max_parts),
-                         "traffic_unit": "HBM bytes per launch group of %d parts (PMC, %s); "
-                                         "algorithmic bytes for the same group: %d"
-                                         % (cfg.max_parts, measured_traffic.source or "profiles/r*_traffic.json: none for this shape",
-                                            b_alg * cfg.max_parts),
-                         "kernel": "filterbank launch group k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,false> "
-                                   "(FFT+chirp+detect, detected output written)",
-                         "algorithmic_bytes_per_part": b_alg, "group_ms_per_block": round(fb_ms, 4),
-                         "region": ("%d extra blocks right after the timed region with Detection and Fold as "
-                                    "separate operations (HIP events on the launch stream)" % extra) if fused
-                                   else "the timed region (HIP events on the launch stream)"},
-        }
-        if fused:
-            b_fused = b_alg - 2 * nchan_subband * lt.nkeep * 8         # no detected output: input once + chirp once
-            ach_f = b_fused * cfg.parts_per_block * lt.in_nchan / (timed_ms * 1e-3) / 1e9
-            out["roofline_fused"] = {
-                "bound": "hbm", "achieved": round(ach_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach_f / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic(args.workload, cfg.max_parts, "hbm_bytes_per_launch_group_fused"),
-                "kernel": "k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,true> (FFT+chirp+detect+fold in one "
-                          "launch group, the timed region)",
-                "algorithmic_bytes_per_part": b_fused, "group_ms_per_block": round(timed_ms, 4),
-                "note": "the fused group also does the fold; its algorithmic bytes have no output term "
-                        "(SURVEY 8(d)), so this fraction is not comparable with roofline.frac"}
-        if args.h2d:
-            # host-buffer hand-over through the product's own feeder (pipeline.LoadToFold.process_host_blocks): block i+1
-            # is copied H2D on a second stream while block i is processed
-            host = raw.cpu().pin_memory()
-            lt.process_host_blocks(host for _ in range(3))
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            lt.process_host_blocks(host for _ in range(args.steps))
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            out["config"]["pcie_inclusive"] = {
-                "value": round(cfg.parts_per_block * lt.nsamp_step * args.steps / dt / 1e6, 1), "unit": "Msamples/s",
-                "note": "blocks copied from pinned host memory (%.1f MB each) on a second stream, double buffered"
-                        % (raw.numel() / 1e6)}
-        if world == 1 and not args.no_cpu_baseline:
-            geom = {"freq_res": r.ndat, "nkeep": lt.nkeep, "nsamp_step": lt.nsamp_step, "nsamp_overlap": lt.nsamp_overlap,
-                    "nfilt_pos": r.impulse_pos, "kernel": r.kernel, "scale8": lt.scale8, "out_rate": lt.out_rate}
-            try:
-                out["cpu_baseline"] = cpu_baseline(wl, geom)
-            except Exception as e:  # the oracle is only a reported baseline
-                out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 1, "kind": "port",
-                                       "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)
-    lt.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    name = args.workload or "target"
+    if name in ("cfg5", "fold"):
+        if world > 1:
+            sys.exit("bench.py: the %s workload runs as independent replicas; use --gpus 1" % name)
+        return finish(bench_search_mode(args, WORKLOADS[name], torch) if name == "cfg5" else bench_fold_only(args, WORKLOADS[name], torch))
+    ctx = (torch, dist, rank, world, local_rank, single)
+    out = run_fold_workload(name, args, *ctx, steps=args.steps, warmup=args.warmup, full=True)
+    if args.workload is None and not args.no_companions and not (args.parts_per_block or args.max_parts):
+        # ---- companions of the default line (the scaling curve is quoted on the sub-band sharded
+        #      configuration; every BASELINE configuration gets a driver-run number) ---------------------------------
+        short = argparse.Namespace(**vars(args))
+        ssteps, swarm = max(5, min(args.steps, 10)), 3
+        if world <= WORKLOADS["cfg4"]["in_nchan"]:
+            shard = run_fold_workload("cfg4", short, *ctx, steps=max(ssteps, 2 * args.dump_steps), warmup=swarm, full=False)
+            if rank == 0:
+                out["subband_shard"] = brief(shard)
+                out["subband_shard"]["note"] = ("the north-star scaling curve: rank g = sub-band g of the NCHAN-8 band (weak scaling, "
+                                                "%d of 8 sub-bands in this run); `value` above stays the headline geometry as time-slice "
+                                                "replicas so that N = 1 agrees with the single-GPU record" % world)
+        if world == 1:
+            others = []
+            for w in ("cfg1", "cfg1opt", "cfg2", "cfg3"):
+                others.append(brief(run_fold_workload(w, short, *ctx, steps=5, warmup=2, full=False)))
+            sm = argparse.Namespace(**vars(args))
+            sm.steps, sm.warmup, sm.no_cpu_baseline = 5, 2, True
+            rec5 = bench_search_mode(sm, WORKLOADS["cfg5"], torch)
+            others.append({"workload": "cfg5", "value": rec5["value"], "unit": rec5["unit"], "ms_per_step": rec5["ms_per_step"], "steps": 5,
+                           "roofline_frac": rec5["roofline"]["frac"], "roofline_kernel": rec5["roofline"]["kernel"],
+                           "command": rec5["config"]["command"]})
+            out["other_workloads"] = others
+            out["config"]["engine_boundary"] = engine_boundary(torch)
+    finish(out)
 
 
 if __name__ == "__main__":

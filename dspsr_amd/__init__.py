@@ -4,8 +4,8 @@ Importing the package loads libdspsr_amd.so (hand-written HIP for gfx950); it ra
 library has not been built -- there is no CPU fallback."""
 from ._lib import (lib, LIB_PATH, RAW_GENERIC, RAW_CASPSR, RAW_UWB16, COHERENCE, STOKES,  # noqa: F401
                    FUSED_AUTO, FUSED_ALWAYS, FUSED_NEVER)
-from .engine import (Context, ConvolutionEngine, Dedispersion, DetectionEngine, DspsrAmdError, FilterbankEngine, FoldEngine, Rescale, SampleDelay, add_fpt, copy_data_fpt, dedispersion_sample_delays, pscrunch_tfp, sigproc_digitize,  # noqa: F401
+from .engine import (Communicator, Context, ConvolutionEngine, Dedispersion, DetectionEngine, DspsrAmdError, FilterbankEngine, FoldEngine, Rescale, SampleDelay, add_fpt, copy_data_fpt, dedispersion_sample_delays, pscrunch_tfp, sigproc_digitize,  # noqa: F401
                      eight_bit_scale, fold_binplan, optimal_fft_length, tfp_filterbank)
 
-__all__ = ["Context", "ConvolutionEngine", "Dedispersion", "DetectionEngine", "DspsrAmdError", "FilterbankEngine", "FoldEngine", "Rescale", "SampleDelay", "add_fpt", "copy_data_fpt", "dedispersion_sample_delays", "pscrunch_tfp", "sigproc_digitize",
+__all__ = ["Communicator", "Context", "ConvolutionEngine", "Dedispersion", "DetectionEngine", "DspsrAmdError", "FilterbankEngine", "FoldEngine", "Rescale", "SampleDelay", "add_fpt", "copy_data_fpt", "dedispersion_sample_delays", "pscrunch_tfp", "sigproc_digitize",
            "eight_bit_scale", "fold_binplan", "optimal_fft_length", "tfp_filterbank", "lib", "LIB_PATH"]

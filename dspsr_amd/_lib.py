@@ -16,6 +16,8 @@ H2D, D2H, D2D = 1, 2, 3
 RAW_GENERIC, RAW_CASPSR, RAW_UWB16 = 0, 1, 2
 COHERENCE, STOKES = 0, 1
 FUSED_AUTO, FUSED_ALWAYS, FUSED_NEVER = 0, 1, 2
+REDUCE_SUM, REDUCE_GATHER = 0, 1
+UNIQUE_ID_BYTES = 128
 
 
 class FilterbankConfig(C.Structure):
@@ -96,6 +98,14 @@ SYMBOLS = {
     "dspsr_amd_fold_get_ndat_folded": (_u64, [_vp]),
     "dspsr_amd_fold_zero": (_i, [_vp]),
     "dspsr_amd_fold_synch": (_i, [_vp, _vp]),
+    "dspsr_amd_comm_set_library": (_i, [C.c_char_p]),
+    "dspsr_amd_comm_unique_id": (_i, [_vp]),
+    "dspsr_amd_comm_create": (_i, [_vp, _i, _i, _vp, _pp]),
+    "dspsr_amd_comm_destroy": (None, [_vp]),
+    "dspsr_amd_comm_rank": (_i, [_vp]),
+    "dspsr_amd_comm_size": (_i, [_vp]),
+    "dspsr_amd_reduce_profiles_start": (_i, [_vp, _i, _i, _vp, _u64, _u64, _u64, _vp, _u32, _d, _u64, _i]),
+    "dspsr_amd_reduce_profiles_finish": (_i, [_vp, _vp, _vp, C.POINTER(_d), C.POINTER(_u64), C.POINTER(_i)]),
     "dspsr_amd_dedispersion_prepare": (_i, [C.POINTER(DedispersionConfig), C.POINTER(DedispersionInfo), C.c_char_p,
                                             _sz]),
     "dspsr_amd_dedispersion_build": (_i, [C.POINTER(DedispersionConfig), _u32, _vp]),

@@ -15,6 +15,7 @@ libdspsr_amd.so (hand-written HIP).  TimeSeries are torch tensors in FPT order:
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -503,6 +504,80 @@ class FoldEngine:
     def close(self):
         if self.handle and self.ctx.handle:
             lib.dspsr_amd_fold_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Communicator:
+    """The sub-integration exchange over RCCL / xGMI behind the C-ABI (dspsr_amd_comm_*, csrc/comm.hip): the same entry
+    points DSPSR's C++ host calls.  One per pipeline context.  `unique_id` = the 128 bytes of `Communicator.unique_id()`
+    made on rank 0 and handed to every rank by the host (bench.py: torch.distributed's store; DSPSR: its MPI transport).
+    The Python host shares PyTorch's ROCm runtime (see _lib.load), so the RCCL opened is the one PyTorch ships."""
+
+    SUM, GATHER = _lib.REDUCE_SUM, _lib.REDUCE_GATHER
+
+    @staticmethod
+    def _use_torch_rccl():
+        try:
+            import torch
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if os.path.exists(path):
+                lib.dspsr_amd_comm_set_library(path.encode())
+        except ImportError:
+            pass
+
+    @staticmethod
+    def unique_id() -> bytes:
+        Communicator._use_torch_rccl()
+        buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        if lib.dspsr_amd_comm_unique_id(buf) != 0:
+            raise DspsrAmdError("dspsr_amd_comm_unique_id: RCCL not available")
+        return buf.raw
+
+    def __init__(self, ctx: Context, nranks: int, rank: int, unique_id: bytes):
+        Communicator._use_torch_rccl()
+        assert len(unique_id) == _lib.UNIQUE_ID_BYTES
+        self.ctx = ctx
+        h = C.c_void_p()
+        _check(ctx.handle, lib.dspsr_amd_comm_create(ctx.handle, nranks, rank, unique_id, C.byref(h)), "dspsr_amd_comm_create")
+        self.handle = h
+        self.nranks, self.rank = nranks, rank
+        self._shape = None
+
+    def start(self, mode, profile_ptr, span, nrow, row_floats, hits, integration_length, ndat_total, root=0, check_hits=False):
+        """Snapshot + collective, asynchronous: the caller may zero the profile and go on at once."""
+        hits = np.ascontiguousarray(hits, dtype=np.uint32)
+        _check(self.ctx.handle,
+               lib.dspsr_amd_reduce_profiles_start(self.handle, mode, root, profile_ptr, span, nrow, row_floats,
+                                                   hits.ctypes.data_as(C.c_void_p), hits.size, float(integration_length),
+                                                   int(ndat_total), 1 if check_hits else 0), "dspsr_amd_reduce_profiles_start")
+        self._shape = (mode, root, nrow * row_floats, hits.size)
+
+    def finish(self):
+        """Waits.  Returns (profile, hits, integration_length, ndat_total, hits_identical): numpy arrays on the root
+        (profile flat: the SUM, or the nranks slices in rank order), None for the first four elsewhere."""
+        mode, root, n, nbin = self._shape
+        same = C.c_int(1)
+        if self.rank != root:
+            _check(self.ctx.handle, lib.dspsr_amd_reduce_profiles_finish(self.handle, None, None, None, None, C.byref(same)),
+                   "dspsr_amd_reduce_profiles_finish")
+            return None, None, None, None, bool(same.value)
+        prof = np.empty(n * (self.nranks if mode == self.GATHER else 1), np.float32)
+        hits = np.empty(nbin, np.uint32)
+        length, ndat = C.c_double(), C.c_uint64()
+        _check(self.ctx.handle,
+               lib.dspsr_amd_reduce_profiles_finish(self.handle, prof.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p),
+                                                    C.byref(length), C.byref(ndat), C.byref(same)), "dspsr_amd_reduce_profiles_finish")
+        return prof, hits, length.value, ndat.value, bool(same.value)
+
+    def close(self):
+        if self.handle and self.ctx.handle:
+            lib.dspsr_amd_comm_destroy(self.handle)
         self.handle = None
 
     def __del__(self):

@@ -408,22 +408,24 @@ def combine_phase_series(a, b):
 
 
 def reduce_subbands(prof, dist=None, rank=0, world=1, gather_buffer=None):
-    """The ONE collective of the path.  Each rank holds the folded profile of its own frequency sub-band
-    (flat [nchan*npol*nbin*ndim] float32).  The full-band buffer [world][...] is zero outside the rank's
-    slice, so a single reduce(SUM, dst=0) -- RCCL over xGMI on GPUs, gloo in the CPU tests -- delivers
-    the concatenated band to the writer rank with exactly PhaseSeries::combine semantics
-    (PhaseSeries.C:442-484: float add of profiles).  hits / integration_length are identical on all
-    ranks (channel-independent bin plan, Fold.C:744-787) and are taken from rank 0.
+    """torch.distributed form of the sub-band exchange (the product's own is dspsr_amd_reduce_profiles_*, csrc/comm.hip,
+    DSPSR_AMD_REDUCE_GATHER; this one serves the gloo CPU tests and one-device rehearsals, where RCCL cannot run).
+    Each rank holds the folded profile of its own frequency sub-band (flat [nchan*npol*nbin*ndim] float32); a gather
+    delivers the slices to rank 0 in rank order = the concatenated band, which is what PhaseSeries::combine of
+    disjoint channel ranges amounts to (PhaseSeries.C:442-484).  hits / integration_length are identical on all ranks
+    (channel-independent bin plan, Fold.C:744-787) and are taken from rank 0.
     Returns the full-band tensor on rank 0, None elsewhere; with world == 1 returns `prof` itself."""
     if world <= 1:
         return prof
     if gather_buffer is None or gather_buffer.numel() != world * prof.numel():
         raise DspsrAmdError("reduce_subbands: gather buffer must hold world*profile = %d floats"
                             % (world * prof.numel()))
-    gather_buffer.zero_()
-    gather_buffer.view(world, -1)[rank].copy_(prof.reshape(-1))
-    dist.reduce(gather_buffer, dst=0, op=dist.ReduceOp.SUM)
-    return gather_buffer if rank == 0 else None
+    mine = prof.reshape(-1).contiguous()
+    if rank == 0:
+        dist.gather(mine, list(gather_buffer.view(world, -1).unbind(0)), dst=0)
+        return gather_buffer
+    dist.gather(mine, None, dst=0)
+    return None
 
 
 def check_identical_hits(hits, dist, rank, world):
@@ -793,11 +795,50 @@ class LoadToFold:
                                       "strides": None}
         return torch.as_tensor(h, device="cuda:%d" % self.ctx.device)
 
-    def finish_subint(self, dist=None, rank=0, world=1, gather_buffer=None, replicas=False, check_hits=False):
+    comm = None                 # dspsr_amd.Communicator (RCCL behind the C-ABI): the product's exchange
+    _comm_pending = None
+
+    def set_rccl_communicator(self, comm):
+        """The exchange of a multi-GPU run: a dspsr_amd.Communicator (dspsr_amd_comm_*, csrc/comm.hip -- the same C entry
+        points DSPSR's host calls).  Without one, finish_subint falls back to the torch.distributed calls below, which
+        exist for the gloo CPU tests and for rehearsing several ranks on one device (RCCL needs one GPU per rank)."""
+        self.comm = comm
+
+    def collect_subint(self):
+        """Wait for the exchange finish_subint(wait=False) started and append its result to `subints` (root only)."""
+        if self._comm_pending is None:
+            return
+        check = self._comm_pending
+        self._comm_pending = None
+        prof, hits, length, ndat_total, same = self.comm.finish()
+        if check and not same:
+            raise DspsrAmdError("sub-band ranks disagree on hits[]: the shards are not sample aligned "
+                                "(different nfilt_pos/neg, start time or rate)")
+        if prof is not None:
+            self.subints.append({"hits": hits, "integration_length": length, "ndat_total": ndat_total, "profile": prof})
+
+    def finish_subint(self, dist=None, rank=0, world=1, gather_buffer=None, replicas=False, check_hits=True, wait=True):
         """Subint<Fold>: emit the finished sub-integration and zero the profile (Subint.h:291-303).  With world > 1 this
-        is the one exchange of the path: sub-band shards (gather_buffer given) deliver their slice of the full band to
-        rank 0, hits / integration_length taken from rank 0 (identical everywhere; check_hits asserts it);
-        time-slice replicas (replicas=True) SUM profiles, hits, integration_length and ndat_total."""
+        is the one exchange of the path: sub-band shards deliver their slice of the full band to rank 0, hits /
+        integration_length taken from rank 0 (identical everywhere; check_hits asserts it); time-slice replicas
+        (replicas=True) SUM profiles, hits, integration_length and ndat_total.
+        With an RCCL communicator (set_rccl_communicator) the exchange is dspsr_amd_reduce_profiles_start/finish: a
+        snapshot on the compute stream, the collective on the communicator's stream -- the next block's kernels overlap
+        it; wait=False leaves it in flight until collect_subint() or the next dump."""
+        if self.comm is not None:
+            self.collect_subint()                                       # one exchange in flight per communicator
+            n = self.npol_out * self.cfg.nbin * self.cfg.ndim           # floats per channel: rows are packed
+            self.comm.start(self.comm.SUM if replicas else self.comm.GATHER, self.fold.get_profiles_ptr(), n, self.nchan_out, n,
+                            self.hits, self.integration_length, self.ndat_total, root=0,
+                            check_hits=check_hits and not replicas)
+            self._comm_pending = bool(check_hits and not replicas)
+            self.fold.zero()                                            # stream ordered behind the snapshot
+            self.hits[:] = 0
+            self.integration_length = 0.0
+            self.ndat_total = 0
+            if wait:
+                self.collect_subint()
+            return
         prof = self.profiles_tensor()
         if replicas:
             res = reduce_replicas(prof, self.hits, self.integration_length, self.ndat_total, dist, rank, world)
@@ -884,6 +925,8 @@ class LoadToFold:
         self.ctx.synchronize()
 
     def close(self):
+        if self._comm_pending is not None:
+            self.collect_subint()
         for d in self.dumps.values():
             d.close()
         if self.sample_delay is not None:

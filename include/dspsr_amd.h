@@ -219,6 +219,43 @@ uint64_t dspsr_amd_fold_get_ndat_folded(const dspsr_amd_fold* fold);
 int dspsr_amd_fold_zero(dspsr_amd_fold* fold);                                            /* Engine::zero */
 int dspsr_amd_fold_synch(dspsr_amd_fold* fold, float* profile_host);                      /* FoldCUDA.cu:127-152 (blocks) */
 
+/* ---- the sub-integration dump over RCCL / xGMI: the ONE exchange of the path -----------------------------------------
+ * Reference hook: dsp::Subint<Fold>::transformation emits the finished sub-integration (Signal/Pulsar/dsp/Subint.h:291-303);
+ * merging semantics = PhaseSeries::combine (Signal/Pulsar/PhaseSeries.C:442-484); the reference merges its threads' pieces
+ * on the host today (Signal/General/MultiThread.C:274-379).  One process per GPU, one communicator per pipeline context.
+ *   dspsr_amd_comm_unique_id : ncclGetUniqueId -- rank 0 calls it and hands the 128 bytes to every rank by any host means
+ *                              (MPI, a file, a socket; dspsr's own MPI transport, Kernel/Classes/mpi)
+ *   dspsr_amd_comm_create    : ncclCommInitRank on the context's device (collective: every rank calls it)
+ *   dspsr_amd_reduce_profiles_start : snapshot of this rank's device profile rows (`nrow` rows of `row_floats` floats,
+ *       `span_floats` apart -- Fold::Engine::get_profiles()) on the context's stream, then ONE collective on the
+ *       communicator's own stream, so the caller may zero the profile and launch the next block at once:
+ *         DSPSR_AMD_REDUCE_SUM    time-slice replicas: profile, hits[], ndat_total and integration_length all SUMMED onto
+ *                                 `root` in one packed ncclReduce
+ *         DSPSR_AMD_REDUCE_GATHER sub-band shards (rank g = input channel g): the ranks' slices delivered to `root` in rank
+ *                                 order (ncclGather); hits[] / lengths are identical on every rank and are the root's own.
+ *                                 check_hits != 0 adds a MIN/MAX all-reduce of hits[] to the same group.
+ *   dspsr_amd_reduce_profiles_finish : waits for the exchange.  On `root`: profile_host receives nrow*row_floats floats
+ *       (SUM) or nranks*nrow*row_floats floats (GATHER), packed; hits_host[nbin], *integration_length, *ndat_total the
+ *       merged values.  Other ranks receive nothing.  *hits_identical (every rank; may be NULL) = 0 if check_hits found
+ *       ranks that disagree. */
+typedef struct dspsr_amd_comm dspsr_amd_comm;
+#define DSPSR_AMD_UNIQUE_ID_BYTES 128
+#define DSPSR_AMD_REDUCE_SUM 0
+#define DSPSR_AMD_REDUCE_GATHER 1
+/* optional, before the first communicator: the RCCL shared object to open (default: librccl.so.1 from the loader path,
+ * then /opt/rocm/lib).  A host process that carries its own ROCm runtime (PyTorch) names the RCCL built against it. */
+int dspsr_amd_comm_set_library(const char* path);
+int dspsr_amd_comm_unique_id(void* id_out);
+int dspsr_amd_comm_create(dspsr_amd_ctx* ctx, int nranks, int rank, const void* unique_id, dspsr_amd_comm** comm);
+void dspsr_amd_comm_destroy(dspsr_amd_comm* comm);
+int dspsr_amd_comm_rank(const dspsr_amd_comm* comm);
+int dspsr_amd_comm_size(const dspsr_amd_comm* comm);
+int dspsr_amd_reduce_profiles_start(dspsr_amd_comm* comm, int mode, int root, const float* profile_dev, uint64_t span_floats,
+                                    uint64_t nrow, uint64_t row_floats, const uint32_t* hits_host, uint32_t nbin,
+                                    double integration_length, uint64_t ndat_total, int check_hits);
+int dspsr_amd_reduce_profiles_finish(dspsr_amd_comm* comm, float* profile_host, uint32_t* hits_host, double* integration_length,
+                                     uint64_t* ndat_total, int* hits_identical);
+
 /* ---- integer-sample inter-channel delay (-K): dsp::SampleDelay (Signal/General/SampleDelay.C:52-195) --------------
  * create    : SampleDelay::build (:52-102) from the delay of each row, delays_host[ichan*npol+ipol] (the values
  *             SampleDelayFunction::get_delay returns); absolute = function->get_absolute()

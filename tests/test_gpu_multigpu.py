@@ -120,23 +120,92 @@ def test_time_slice_replicas_combine(gpu):
     one.close()
 
 
+def test_rccl_communicator_world1(gpu):
+    """The product's exchange (dspsr_amd_comm_* / dspsr_amd_reduce_profiles_*, csrc/comm.hip) through RCCL with a one-rank
+    communicator -- what a single GPU can execute of it: library load, ncclCommInitRank, the snapshot on the compute stream,
+    ncclGather / the packed ncclReduce on the communicator's stream, the MIN/MAX hits check, the copy to pinned memory.
+    (i) engine level, padded profile rows, both modes, profile zeroed right after start() (the snapshot must already hold);
+    (ii) pipeline level: finish_subint through the communicator == finish_subint without, asynchronous dumps collected in
+    order."""
+    import dspsr_amd
+    from dspsr_amd import pipeline, synth
+    ctx = dspsr_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    uid = dspsr_amd.Communicator.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = dspsr_amd.Communicator(ctx, 1, 0, uid)
+    assert dspsr_amd.lib.dspsr_amd_comm_size(comm.handle) == 1 and dspsr_amd.lib.dspsr_amd_comm_rank(comm.handle) == 0
+    rng = np.random.default_rng(5)
+    nrow, row, span, nbin = 24, 40, 48, 10
+    prof = torch.from_numpy(rng.standard_normal((nrow, span)).astype(np.float32)).cuda()
+    want = prof[:, :row].cpu().numpy().reshape(-1).copy()
+    hits = rng.integers(0, 1 << 31, nbin).astype(np.uint32)
+    for mode in (comm.SUM, comm.GATHER):
+        p = prof.clone()
+        comm.start(mode, p.data_ptr(), span, nrow, row, hits, 12.625, (1 << 40) + 7, check_hits=True)
+        p.zero_()                                                    # stream ordered behind the snapshot
+        got, h, length, ndat, same = comm.finish()
+        assert same and np.array_equal(got, want) and np.array_equal(h, hits) and length == 12.625 and ndat == (1 << 40) + 7
+    with pytest.raises(dspsr_amd.DspsrAmdError):
+        comm.finish()                                                # nothing in flight
+    # ---- pipeline level
+    freq, bw, tsamp, dm, period, nchan, nbin = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004, 16, 64
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
+    cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=4, parts_per_block=3, max_parts=2)
+    stream = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for replicas in (False, True):
+        for use_comm in (False, True):
+            lt = pipeline.LoadToFold(cfg, info, device=0, stream=stream)
+            step = cfg.parts_per_block * lt.nsamp_step
+            raw = torch.from_numpy(synth.voltages(4 * step + lt.nsamp_overlap, freq, bw, tsamp, dm, period)).cuda()
+            c2 = dspsr_amd.Communicator(lt.ctx, 1, 0, dspsr_amd.Communicator.unique_id()) if use_comm else None
+            if use_comm:
+                lt.set_rccl_communicator(c2)
+            for b in range(4):
+                lt.process_block(raw[2 * b * step: 2 * (b * step + step + lt.nsamp_overlap)])
+                if b % 2 == 1:
+                    lt.finish_subint(None, 0, 1, None, replicas=replicas, wait=False)     # in flight while the next block runs
+            lt.collect_subint()
+            lt.synchronize()
+            assert len(lt.subints) == 2
+            res[use_comm] = [(s_["hits"].copy(), s_["integration_length"], s_["ndat_total"],
+                              s_["profile"].reshape(-1) if "profile" in s_ else s_["profile_dev"].cpu().numpy().reshape(-1)) for s_ in lt.subints]
+            if c2 is not None:
+                c2.close()
+            lt.close()
+        for a, b in zip(res[False], res[True]):
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2] and np.array_equal(a[3], b[3])
+            assert int(a[0].sum()) == a[2] and float(np.abs(a[3]).max()) > 0
+    comm.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("workload,extra", [("cfg4", ["--parts-per-block", "16"]),
-                                            ("target", ["--parts-per-block", "4", "--max-parts", "2"])])
+                                            ("target", ["--parts-per-block", "4", "--max-parts", "2"]),
+                                            (None, [])])
 def test_bench_two_ranks_one_command(gpu, workload, extra):
     """bench.py --gpus 2 without a launcher: it spawns its own ranks (gloo, both on this GPU), runs the sub-integration
-    exchange inside the timed region, passes the parity gate and prints ONE JSON line."""
+    exchange inside the timed region, passes the parity gate and prints ONE JSON line.  workload None = the driver's own
+    command (no --workload): the headline as time-slice replicas in `value` AND the sub-band sharded cfg4 run -- the
+    north-star scaling curve -- in `subband_shard`, both from the one process group."""
     env = dict(os.environ, DSPSR_AMD_SINGLE_DEVICE="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dump-steps", "2",
-           "--workload", workload, "--no-cpu-baseline"] + extra
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+           "--no-cpu-baseline"] + (["--workload", workload] if workload else []) + extra
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["parity_gate"]["status"] == "ok"
     assert ("sub-band" if workload == "cfg4" else "replicas") in res["config"]["parallelism"]
+    assert res["config"]["reduce_ms_per_dump"] > 0
+    if workload is None:
+        assert res["config"]["workload"] == "target"
+        sh = res["subband_shard"]
+        assert sh["workload"] == "cfg4" and sh["value"] > 0 and sh["ms_per_step"] > 0 and sh["reduce_ms_per_dump"] > 0
+        assert sh["identical_hits"] is True and sh["parity_gate"] == "ok" and "sub-band" in sh["parallelism"]
 
 
 def test_subband_shards_with_interchannel_dedispersion(gpu):
