@@ -111,9 +111,22 @@ extern "C" int dspsr_amd_debug_stamps(unsigned long long* out_host, int zero)   
 }
 #endif
 
+// Experiment (-DFB_STAGGER=n): the persistent workgroups of a launch start n*8128 cycles apart in four phases, so that
+// the compute units are not all in their load / store phases at the same time
+DEV void fb_stagger()
+{
+#ifdef FB_STAGGER
+  const uint32_t ph = (blockIdx.x >> 3) & 3u;
+  for (uint32_t i = 0; i < ph * FB_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+#endif
+}
+
 [[maybe_unused]] constexpr uint32_t FB_PSL_MAX = 128;   // fused fold: part offsets of one launch kept in LDS (launches hold <= 64 parts)
 
-DEV float cvt8(int v, float scale) { return ((float)v + 0.5f) * scale; }
+// (int8 + 0.5) * scale (GenericEightBitUnpackerCUDA.cu:45).  int8 + 0.5 is exact in float, so the one rounding of the product
+// is the rounding of the exact value (v + 0.5)*scale -- which fma(v, scale, scale/2) rounds likewise (scale/2 is exact):
+// bit-identical, one instruction less per pair of samples
+DEV float cvt8(int v, float scale) { return __builtin_fmaf((float)v, scale, 0.5f * scale); }
 
 // streaming accesses: scratch and output data are written once and read once by another pass, so the
 // stores/loads may carry the non-temporal hint (build-time experiment switches FB_NT_STORE / FB_NT_LOAD)
@@ -613,6 +626,14 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
+  fb_stagger();
+  // copy-out of the staged tile (see the end of the tile loop): thread part of the addresses, once per kernel
+  const uint32_t co_swz = (PTS * blockDim.x) >= 256 ? 1u : 0u;
+  const uint32_t co_l0 = 2 * threadIdx.x, co_n2 = LOGT >= 0 ? (2u << (LOGF + LOGT - LOG_PTS)) : 2 * blockDim.x;   // full tiles: a constant
+  const bool co_fast = (co_n2 & 63) == 0 && (co_n2 >> (logT + logT2)) != 0 && (co_n2 & ((1u << (logT + logT2)) - 1)) == 0;   // uniform
+  const uint32_t co_lds = lds_pad(co_l0 ^ (((co_l0 >> 4) & co_swz) << 3)), co_lstep = co_n2 + ((co_n2 >> 6) << 2);
+  const uint32_t co_goff = (uint32_t)(((((uint64_t)(co_l0 >> (logT + logT2)) << g.logR) << logT2) + (co_l0 & ((1u << (logT + logT2)) - 1))) * sizeof(cf));
+  const uint64_t co_gstep = ((uint64_t)(co_n2 >> (logT + logT2)) << g.logR) << logT2;       // elements of A per pair step
   uint32_t item, next;
   uint32_t j = 0;
   if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
@@ -684,6 +705,24 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
         }
       }
     };
+#ifdef FB_P1_DIRECT   // experiment: the last stage stores its outputs straight from registers (8 bytes per lane, 64-byte runs),
+                      // no staging exchange through LDS
+    auto store_direct = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
+      constexpr int R = sizeof(v) / sizeof(v[0]);
+      cf* __restrict__ ab = Aseq + ((uint64_t)(tile * T + col) << logT2);
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const uint32_t ka = k * pstride + p;
+        cf* o = ab + (((uint64_t)(ka >> logT2) << g.logR) << logT2) + (ka & (T2 - 1));
+        st_stream(o, cx2_lo(v[k]));
+        st_stream(o + T2, cx2_hi(v[k]));
+      }
+    };
+    wgfft<LOGF, -1, false>(lds, ltw_off, tid, logT, x, store_direct);
+    if (!more) break;
+    item = next;
+    continue;
+#endif
     if (FB_DBG(g) & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
     else wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
     __syncthreads();
@@ -692,12 +731,30 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
 #endif
     if (!(FB_DBG(g) & 1)) {
       const uint32_t nthr = blockDim.x;
+      if (co_fast) {
+        // pair jj of a thread is pair 0 plus jj*2*nthr elements: a constant step in the padded image (co_lstep) and a
+        // uniform step in A (co_gstep) -- one LDS address and one 32-bit global offset per THREAD, computed before the
+        // tile loop; the per-pair part is an immediate / a scalar-register base (this loop issued 23 % of the pass's
+        // vector instructions as per-pair address arithmetic, 64-bit shifts included)
+        const char* __restrict__ gb = (const char*)(Aseq + ((uint64_t)(tile * T) << logT2));
+#pragma unroll
+        for (int j4 = 0; j4 < PTS / 2; j4 += 4) {                  // four LDS reads in flight, then their stores
+          float4 pr[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) pr[q] = *(const float4*)&lds[co_lds + (j4 + q) * co_lstep];
+          __builtin_amdgcn_sched_barrier(0);                         // (the min-register scheduler would pair every read with its store)
+#pragma unroll
+          for (int q = 0; q < 4; q++) st_stream((float4*)(gb + (uint64_t)(j4 + q) * co_gstep * sizeof(cf) + co_goff), pr[q]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll 4
-      for (int jj = 0; jj < PTS / 2; jj++) {
-        const uint32_t l = 2 * (tid + jj * nthr);                  // element index inside the staged tile
-        const uint32_t blkA = l >> (logT + logT2), within = l & ((1u << (logT + logT2)) - 1);
-        const float4 pr = *(const float4*)&lds[lds_pad(l ^ (((l >> 4) & swz) << 3))];
-        st_stream((float4*)&Aseq[((((uint64_t)blkA << g.logR) + tile * T) << logT2) + within], pr);
+        for (int jj = 0; jj < PTS / 2; jj++) {
+          const uint32_t l = 2 * (tid + jj * nthr);                  // element index inside the staged tile
+          const uint32_t blkA = l >> (logT + logT2), within = l & ((1u << (logT + logT2)) - 1);
+          const float4 pr = *(const float4*)&lds[lds_pad(l ^ (((l >> 4) & swz) << 3))];
+          st_stream((float4*)&Aseq[((((uint64_t)blkA << g.logR) + tile * T) << logT2) + within], pr);
+        }
       }
     }
 #if defined(FB_STAMPS) && FB_STAMPS == 1
@@ -761,6 +818,16 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
+  fb_stagger();
+  // copy-out of the staged tile (end of the tile loop): thread part of the addresses, once per kernel
+  const uint32_t co_swz = (PTS * blockDim.x) >= 256 ? 3u : 0u;
+  const uint32_t co_l0 = 2 * threadIdx.x, co_n2 = LOGT >= 0 ? (2u << (LOGF + LOGT - LOG_PTS)) : 2 * blockDim.x;   // full tiles: a constant
+  const int co_sh = logT + logT3;
+  const bool co_fast = (co_n2 & 63) == 0 && (g.xblocked || ((co_n2 >> co_sh) != 0 && (co_n2 & ((1u << co_sh) - 1)) == 0));   // uniform
+  const uint32_t co_lds = lds_pad(co_l0 ^ (((co_l0 >> 4) & co_swz) << 1)), co_lstep = co_n2 + ((co_n2 >> 6) << 2);
+  const uint32_t co_goff = (uint32_t)((g.xblocked ? (uint64_t)co_l0
+                                                   : ((((uint64_t)(co_l0 >> co_sh) << g.logM) << logT3) + (co_l0 & ((1u << co_sh) - 1)))) * sizeof(cf));
+  const uint64_t co_gstep = g.xblocked ? (uint64_t)co_n2 : (((uint64_t)(co_n2 >> co_sh) << g.logM) << logT3);   // elements of X per pair step
   uint32_t item, next;
   uint32_t j = 0;
   if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
@@ -843,16 +910,31 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
 #endif
     if (!(FB_DBG(g) & 1)) {
       const uint32_t nthr = blockDim.x;
+      if (co_fast) {
+        // thread part of the addresses computed once per kernel, per-pair part an immediate / a uniform step (see pass 1)
+        const char* __restrict__ gb = (const char*)(Xseq + (g.xblocked ? (uint64_t)tile * g.xblock : ((uint64_t)(tile * T2) << logT3)));
+#pragma unroll
+        for (int j4 = 0; j4 < PTS / 2; j4 += 4) {
+          float4 pr[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) pr[q] = *(const float4*)&lds[co_lds + (j4 + q) * co_lstep];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 4; q++) st_stream((float4*)(gb + (uint64_t)(j4 + q) * co_gstep * sizeof(cf) + co_goff), pr[q]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll 4
-      for (int jj = 0; jj < PTS / 2; jj++) {
-        const uint32_t l = 2 * (tid + jj * nthr);
-        const uint32_t blkX = l >> (logT + logT3), within = l & ((1u << (logT + logT3)) - 1);
-        const float4 pr = *(const float4*)&lds[lds_pad(l ^ (((l >> 4) & swz) << 1))];
-        // four-pass mode (xblocked): the tile's image [kb][ka % T2] IS its block of X -- one contiguous 2^14-element
-        // store instead of runs of T2 elements scattered over the natural order
-        const uint64_t xo = g.xblocked ? (uint64_t)tile * g.xblock + l
-                                       : ((((uint64_t)blkX << g.logM) + tile * T2) << logT3) + within;
-        st_stream((float4*)&Xseq[xo], pr);
+        for (int jj = 0; jj < PTS / 2; jj++) {
+          const uint32_t l = 2 * (tid + jj * nthr);
+          const uint32_t blkX = l >> (logT + logT3), within = l & ((1u << (logT + logT3)) - 1);
+          const float4 pr = *(const float4*)&lds[lds_pad(l ^ (((l >> 4) & swz) << 1))];
+          // four-pass mode (xblocked): the tile's image [kb][ka % T2] IS its block of X -- one contiguous 2^14-element
+          // store instead of runs of T2 elements scattered over the natural order
+          const uint64_t xo = g.xblocked ? (uint64_t)tile * g.xblock + l
+                                         : ((((uint64_t)blkX << g.logM) + tile * T2) << logT3) + within;
+          st_stream((float4*)&Xseq[xo], pr);
+        }
       }
     }
 #if defined(FB_STAMPS) && FB_STAMPS == 2
@@ -1011,6 +1093,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
+  fb_stagger();
   // FOLD: two buffers of out.plan_cap plan entries behind the twiddle tables (cf index, 16-byte aligned), followed by
   // a copy of the launch's nparts + 1 part offsets into the plan (PSL_MAX words): a part's entries are then found
   // without a dependent pair of global loads, and are fetched one item ahead (registers) like the tile itself
@@ -1604,12 +1687,31 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
     {
       const uint32_t nthr = blockDim.x;
       const int logRun = logTm + logTt + 1;
+      const uint32_t n2 = 2 * nthr;
+      if ((n2 & 63) == 0 && (n2 >> logRun) != 0 && (n2 & ((1u << logRun) - 1)) == 0) {      // uniform
+        // pair jj = pair 0 + jj*2*nthr elements: constant step in the padded image, uniform step in U (see pass 1)
+        const uint32_t l0 = 2 * tid, lstep = n2 + ((n2 >> 6) << 2), lb = lds_pad(l0);
+        const uint32_t goff = (uint32_t)(((((uint64_t)(l0 >> logRun) << g.logMb) << (logTt + 1)) + (l0 & ((1u << logRun) - 1))) * sizeof(cf));
+        const uint64_t gstep = (((uint64_t)(n2 >> logRun) << g.logMb) << (logTt + 1)) * sizeof(cf);
+        const char* __restrict__ gb = (const char*)(Uc + ((uint64_t)(tile * Tm) << (logTt + 1)));
+#pragma unroll
+        for (int j4 = 0; j4 < PTS / 2; j4 += 4) {
+          float4 pr[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) pr[q] = *(const float4*)&lds[lb + (j4 + q) * lstep];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 4; q++) st_stream((float4*)(gb + (uint64_t)(j4 + q) * gstep + goff), pr[q]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll 4
-      for (int jj = 0; jj < PTS / 2; jj++) {
-        const uint32_t l = 2 * (tid + jj * nthr);
-        const uint32_t tb = l >> logRun, within = l & ((1u << logRun) - 1);
-        const float4 pr = *(const float4*)&lds[lds_pad(l)];
-        st_stream((float4*)&Uc[((((uint64_t)tb << g.logMb) + tile * Tm) << (logTt + 1)) + within], pr);
+        for (int jj = 0; jj < PTS / 2; jj++) {
+          const uint32_t l = 2 * (tid + jj * nthr);
+          const uint32_t tb = l >> logRun, within = l & ((1u << logRun) - 1);
+          const float4 pr = *(const float4*)&lds[lds_pad(l)];
+          st_stream((float4*)&Uc[((((uint64_t)tb << g.logMb) + tile * Tm) << (logTt + 1)) + within], pr);
+        }
       }
     }
     if (!more) break;

@@ -52,7 +52,7 @@ def _noise_block(nbytes, seed=20100413):
     return raw
 
 
-def _oracle_detected(o, raw_host, plan, kernel, chans, npart, batch=4):
+def _oracle_detected(o, raw_host, plan, kernel, chans, npart, batch=4, state="Coherence"):
     """float64 oracle of the detected (Coherence, ndim 4) samples of `chans` for all parts:
     Filterbank.C:561-662 + Response.C:385-444 + cross_detect.ic restated -- only the selected channels are
     inverse-transformed (the forward transforms are the cost: 2 x npart real FFTs of 2^23 points, batched over cores)."""
@@ -73,7 +73,7 @@ def _oracle_detected(o, raw_host, plan, kernel, chans, npart, batch=4):
             t = np.fft.ifft(spec[:, :, c * M:(c + 1) * M] * k64[c * M:(c + 1) * M], axis=2) * M   # unnormalised bcc1d
             t = t[:, :, nfp:nfp + nk]
             for j in range(nb):
-                prod = o.detect_products(t[j][None, :, :], "Coherence")      # [1][4][nkeep], float64 in -> float64
+                prod = o.detect_products(t[j][None, :, :], state)            # [1][4][nkeep], float64 in -> float64
                 out[ci, 0, (p0 + j) * nk:(p0 + j + 1) * nk, :] = o.detect_layout(prod, 4)[0, 0]
     return out
 
@@ -165,6 +165,79 @@ def test_headline_ragged_groups_and_stokes(gpu):
     for h, p in res[1:]:
         assert np.array_equal(h, res[0][0]) and np.array_equal(p, res[0][1])
     assert int(res[0][0].sum()) == 2 * 45 * 3252 and np.abs(res[0][1]).max() > 0
+
+
+def test_headline_stokes_against_oracle(oracle, gpu):
+    """dspsr -4 (Stokes I, Q, U, V: stokes_detect.ic:21-44) at the headline geometry through the fused launch group, against
+    the float64 oracle on five channels: hits identical, folded Stokes profile <= 1e-5 of the profile maximum."""
+    o = oracle
+    npart = 8
+    lt = _headline(gpu, 8, True, parts_per_block=npart, stokes=True)
+    assert lt.fused_fold
+    raw = _noise_block(lt.block_bytes(), seed=11)
+    lt.process_block(raw)
+    lt.finish_subint()
+    lt.synchronize()
+    sub = lt.subints[0]
+    prof = sub["profile_dev"].cpu().numpy().reshape(1024, 1024, 4)
+    obs = o.Observation(centre_frequency=1382.0, bandwidth=-400.0, tsamp_us=0.00125, machine="CASPSR", dispersion_measure=1000.0)
+    resp = o.Dedispersion()
+    resp.set_frequency_resolution(4096)
+    resp.match(obs, 1024)
+    plan = o.filterbank_plan(obs, 1024, resp)
+    det = _oracle_detected(o, raw.cpu().numpy(), plan, lt.response.kernel, CHANS, npart, state="Stokes")
+    fobs = o.filterbank_output_observation(obs, plan)
+    ps = o.PhaseSeries(len(CHANS), 1, 4, 1024, data=np.zeros((len(CHANS), 1, 1024, 4), np.float64))
+    o.fold(det, fobs, o.FoldConfig(nbin=1024, folding_period=0.0893), ps)
+    assert np.array_equal(sub["hits"], ps.hits) and int(ps.hits.sum()) == npart * lt.nkeep
+    # Stokes I is positive; Q, U, V are differences / cross terms of noise: every product against the I scale
+    err = np.abs(prof[CHANS] - ps.data[:, 0]).max() / np.abs(ps.data[..., 0]).max()
+    assert err <= 1e-5, err
+    assert np.abs(prof[CHANS][..., 1:]).max() > 0
+    lt.close()
+
+
+def test_cfg1_pipeline_against_oracle(oracle, gpu):
+    """BASELINE configuration 1 as the pipeline really runs it: dspsr -F 64:D -x 16384 on the header.dada band, vela.par DM,
+    512 phase bins, vela.polyco -- the FOUR-pass path (two-pass inverse, Convolution.C:338-461 geometry), Detection, and
+    the long-run fold (1090 samples per phase bin: re-associated micro-block sums, Fold.C:835-891 to rounding).
+    Against the float64 oracle on five channels: hits identical, folded profile <= 1e-5 of the profile maximum."""
+    o = oracle
+    from dspsr_amd import pipeline
+    polyco_text = json.load(open(os.path.join(ROOT, "tests", "golden", "vela_polyco.json")))["text"]
+    info = pipeline.InputInfo(centre_frequency=1382.0, bandwidth=-400.0, nchan=1, npol=2, ndim=1, tsamp_us=0.00125, machine="CASPSR")
+    cfg = pipeline.Config(nchan=64, dispersion_measure=67.99, nbin=512, folding_period=0.0, freq_res=16384, ndim=4,
+                          parts_per_block=6, max_parts=4)
+    lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream, polyco=pipeline.Polyco(polyco_text))
+    assert not lt.fused_fold                                   # four-pass geometry: Detection + Fold as separate launches
+    nblocks, chans = 2, [0, 1, 31, 62, 63]
+    step = cfg.parts_per_block * lt.nsamp_step
+    raw = _noise_block(2 * (nblocks * step + lt.nsamp_overlap), seed=23)
+    for b in range(nblocks):
+        lt.process_block(raw[2 * b * step: 2 * (b * step + step + lt.nsamp_overlap)])
+    lt.finish_subint()
+    lt.synchronize()
+    sub = lt.subints[0]
+    prof = sub["profile_dev"].cpu().numpy().reshape(64, 512, 4)
+    obs = o.Observation(centre_frequency=1382.0, bandwidth=-400.0, tsamp_us=0.00125, machine="CASPSR", dispersion_measure=67.99)
+    resp = o.Dedispersion()
+    resp.set_frequency_resolution(16384)
+    resp.match(obs, 64)
+    plan = o.filterbank_plan(obs, 64, resp)
+    assert (plan.nkeep, plan.nsamp_step) == (lt.nkeep, lt.nsamp_step)
+    npart = nblocks * cfg.parts_per_block
+    det = _oracle_detected(o, raw.cpu().numpy(), plan, lt.response.kernel, chans, npart)
+    fobs = o.filterbank_output_observation(obs, plan)
+    ps = o.PhaseSeries(len(chans), 1, 4, 512, data=np.zeros((len(chans), 1, 512, 4), np.float64))
+    # the pipeline folds block by block (phase and period from the polynomial at each block's first sample, Fold.C:943-958)
+    nblk = cfg.parts_per_block * lt.nkeep
+    for b in range(nblocks):
+        o.fold(det, fobs, o.FoldConfig(nbin=512, polyco=o.Polyco.parse(polyco_text)), ps, idat_start=b * nblk, ndat_fold=nblk)
+    assert np.array_equal(sub["hits"], ps.hits) and int(ps.hits.sum()) == npart * lt.nkeep
+    assert ps.hits.max() > 64                                  # wide phase bins (1090 samples each): the long-run fold is what ran
+    err = np.abs(prof[chans] - ps.data[:, 0]).max() / np.abs(ps.data[..., :2]).max()
+    assert err <= 1e-5, err
+    lt.close()
 
 
 def _fb(oracle, gpu_mod, *a, **k):

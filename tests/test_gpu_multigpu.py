@@ -67,6 +67,27 @@ def test_subband_shards_equal_fullband(oracle, gpu, force_fused):
     want = full.subints[0]
     wprof = want["profile_dev"].view(4096, -1)
     assert int(want["hits"].sum()) == nblocks * cfg.parts_per_block * full.nkeep and float(wprof.abs().max()) > 0
+    # the folded profile of the full-band run (== the concatenated shards, below) against the float64 oracle on a few channels
+    # of three sub-bands: Filterbank.C:561-662 on the NCHAN-8 complex input, cross_detect, Fold.C:835-891; hits identical
+    import dataclasses
+    oplan = oracle.filterbank_plan(obs, 4096, oresp)
+    fobs = oracle.filterbank_output_observation(obs, oplan)
+    assert (oplan.nkeep, oplan.nsamp_step, fobs.rate, fobs.start_seconds) == (full.nkeep, full.nsamp_step, full.out_rate, full.out_start)
+    unpacked = oracle.unpack_8bit(raw, obs)                               # [8][2][ndat*2]
+    npart = nblocks * cfg.parts_per_block
+    nblk = cfg.parts_per_block * full.nkeep
+    for g, chans in ((0, [0, 1, 255]), (3, [17, 511]), (7, [0, 510, 511])):
+        sub_plan = dataclasses.replace(oplan, nchan=512, input_nchan=1)
+        fbk = oracle.filterbank(unpacked[g:g + 1].astype(np.float64), sub_plan, full.response.kernel[g * 512 * 512:(g + 1) * 512 * 512],
+                                npart=npart, dtype=np.float64)
+        det = oracle.detect_layout(oracle.detect_products(fbk[chans], "Coherence"), 4)       # [chan][1][ndat][4] float64
+        ps = oracle.PhaseSeries(len(chans), 1, 4, 1024, data=np.zeros((len(chans), 1, 1024, 4), np.float64))
+        for b in range(nblocks):
+            oracle.fold(det, fobs, oracle.FoldConfig(nbin=1024, folding_period=0.0893), ps, idat_start=b * nblk, ndat_fold=nblk)
+        assert np.array_equal(want["hits"], ps.hits), g
+        got = wprof.view(4096, 1024, 4)[[g * 512 + c for c in chans]].cpu().numpy()
+        err = np.abs(got - ps.data[:, 0]).max() / np.abs(ps.data[..., :2]).max()
+        assert err <= 1e-5, (g, err)
     for g in range(nsub):
         lt = pipeline.LoadToFold(cfg, info, device=0, stream=stream, subband=g)
         assert lt.fused_mode == (1 if force_fused else 2)

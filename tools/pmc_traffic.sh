@@ -8,7 +8,7 @@ mkdir -p $R/gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp && cd $R
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/$T/pmc_$c
-  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/$T/pmc_$c -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/$T/pmc_$c.log 2>&1 || { echo "pass $c failed"; tail -5 gpurun_out/$T/pmc_$c.log; exit 1; }
+  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/$T/pmc_$c -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-companions > gpurun_out/$T/pmc_$c.log 2>&1 || { echo "pass $c failed"; tail -5 gpurun_out/$T/pmc_$c.log; exit 1; }
 done
 python - "$T" <<'PY'
 import collections, csv, glob, json, sys
