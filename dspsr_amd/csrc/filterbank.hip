@@ -321,6 +321,9 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
 // table (the remaining low bits of j), both correctly rounded -> about 1.2e-7 relative error.
 // NT twiddles exp(-2*pi*i*j[q]/2^logL) at once: all table loads are issued back to back (one memory round trip)
 // and only then combined -- evaluating them one by one costs a dependent L1/L2 round trip each
+#ifndef FB_SPLIT
+#define FB_SPLIT 0             // 1: pass 1 with two staggered four-wave groups per workgroup (see k_fwd_cols): correct (the whole
+#endif                         //    GPU suite passes with it) and exactly as fast -- profiles/r03_experiments.txt item 5; off
 #ifndef FB_TWIDDLE_IN_P2
 #define FB_TWIDDLE_IN_P2 1     // 0: the inter-pass twiddle on pass 1's outputs (rounds 1-2a; A/B builds)
 #endif
@@ -588,9 +591,19 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
 {
   typedef FftPlan<LOGF> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
-  uint32_t tid = threadIdx.x;
+  // SPLIT (full-size tiles of >= 4 columns): the 512 threads work as TWO GROUPS of four waves (one wave per SIMD each), each
+  // transforming half the columns of the tile in its own half of the exchange buffer, one barrier phase apart.  Every
+  // s_barrier is still the whole workgroup's, but between two barriers one group runs a butterfly phase (vector unit)
+  // while the other runs an exchange-write phase (LDS store path): the phases of a transform alternate V, L, V, L, V, L.
+  // With all eight waves in lockstep the two kinds of phase ran one after the other -- about 6.3k cycles of butterflies
+  // plus 6.4k cycles of LDS transfers per 2^14-point tile.
+  constexpr bool SPLIT = FB_SPLIT && LOGT >= 2;
+  const uint32_t grp = SPLIT ? threadIdx.x >> 8 : 0u;                         // wave-uniform
+  uint32_t tid = SPLIT ? (threadIdx.x & 255u) : threadIdx.x;                 // thread of the group
   const int logT = LOGT >= 0 ? LOGT : g.logT1, logT2 = g.logT2;
-  const uint32_t T = 1u << logT, T2 = 1u << logT2;
+  const int logTw = SPLIT ? logT - 1 : logT;                                  // columns a group transforms
+  const uint32_t T = 1u << logT, T2 = 1u << logT2, Tw = 1u << logTw;
+  const uint32_t cofs = grp << logTw;                                         // first column of the group inside the tile
   const int logL = LOGF + g.logR;          // g.logM == LOGF
   const uint64_t L = 1ull << logL;
   const uint32_t ntile = 1u << (g.logR - logT);
@@ -617,23 +630,30 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     const uint64_t step = pret ? ((uint64_t)MS << logT) : ((uint64_t)MS << g.logR);
 #pragma unroll
     for (int g2 = 0; g2 < P::G1; g2 += 2) {
-      const uint32_t eb = P::G1 * tid + g2;
-      const uint64_t tb = t0 + (pret ? (uint64_t)eb : ((((uint64_t)(eb >> logT)) << g.logR) + (eb & (T - 1))));
+      const uint32_t eb = P::G1 * tid + g2;               // element of the group's half tile: row eb >> logTw, column eb % Tw
+      const uint64_t tb = t0 + cofs + (eb & (Tw - 1)) + (pret ? (uint64_t)((eb >> logTw) << logT) : (((uint64_t)(eb >> logTw)) << g.logR));
 #pragma unroll
       for (int i = 0; i < P::R1; i++) raw[(g2 / 2) * P::R1 + i] = fetch_pair<RAWW>(g, in, seq, tb + i * step);
     }
   };
 
-  const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
-  ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
+  // exchange buffer(s), then the stage twiddle tables (16-byte aligned)
+  const uint32_t nthr_w = SPLIT ? 256u : blockDim.x;             // threads of a group
+  const uint32_t ldsH = lds_pad(PTS * nthr_w) + 8;               // words of one exchange buffer
+  const uint32_t ltw_off = SPLIT ? 2 * ldsH : ldsH;
+  ltw_fill<LOGF>(lds, ltw_off, tw, threadIdx.x, blockDim.x);
+  cf* const lw = lds + grp * ldsH;                               // this group's exchange buffer
+  const uint32_t ltw_w = ltw_off - grp * ldsH;                   // the shared tables, relative to it
   fb_stagger();
   // copy-out of the staged tile (see the end of the tile loop): thread part of the addresses, once per kernel
   const uint32_t co_swz = (PTS * blockDim.x) >= 256 ? 1u : 0u;
-  const uint32_t co_l0 = 2 * threadIdx.x, co_n2 = LOGT >= 0 ? (2u << (LOGF + LOGT - LOG_PTS)) : 2 * blockDim.x;   // full tiles: a constant
-  const bool co_fast = (co_n2 & 63) == 0 && (co_n2 >> (logT + logT2)) != 0 && (co_n2 & ((1u << (logT + logT2)) - 1)) == 0;   // uniform
+  const uint32_t co_l0 = 2 * (SPLIT ? (threadIdx.x & 255u) : threadIdx.x);
+  const uint32_t co_n2 = SPLIT ? 512u : LOGT >= 0 ? (2u << (LOGF + LOGT - LOG_PTS)) : 2 * blockDim.x;   // full tiles: a constant
+  const int co_sh = logTw + logT2;
+  const bool co_fast = (co_n2 & 63) == 0 && (co_n2 >> co_sh) != 0 && (co_n2 & ((1u << co_sh) - 1)) == 0;   // uniform
   const uint32_t co_lds = lds_pad(co_l0 ^ (((co_l0 >> 4) & co_swz) << 3)), co_lstep = co_n2 + ((co_n2 >> 6) << 2);
-  const uint32_t co_goff = (uint32_t)(((((uint64_t)(co_l0 >> (logT + logT2)) << g.logR) << logT2) + (co_l0 & ((1u << (logT + logT2)) - 1))) * sizeof(cf));
-  const uint64_t co_gstep = ((uint64_t)(co_n2 >> (logT + logT2)) << g.logR) << logT2;       // elements of A per pair step
+  const uint32_t co_goff = (uint32_t)(((((uint64_t)(co_l0 >> co_sh) << g.logR) << logT2) + (co_l0 & ((1u << co_sh) - 1))) * sizeof(cf));
+  const uint64_t co_gstep = ((uint64_t)(co_n2 >> co_sh) << g.logR) << logT2;       // elements of A per pair step
   uint32_t item, next;
   uint32_t j = 0;
   if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
@@ -643,6 +663,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
   unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, acc_s[6] = {0, 0, 0, 0, 0, 0};
   STAMP(ts5);
 #endif
+  if (SPLIT && grp == 1) __builtin_amdgcn_s_barrier();         // the second group runs one barrier phase behind the first
   for (;;) {
     asm volatile("" : "+v"(tid));   // per-tile index math stays inside the loop (see wgfft)
     cx2 x[NPAIR];
@@ -655,7 +676,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     for (int h = 0; h < NPAIR; h++) {
       cf a, b;
       decode_pair<RAWW>(g, in, raw[h], a, b,
-                        RAWW == 2 ? ((P::G1 * tid + 2 * (h / P::R1)) & (T - 1)) : seq_cur);
+                        RAWW == 2 ? (cofs + ((P::G1 * tid + 2 * (h / P::R1)) & (Tw - 1))) : seq_cur);
       x[h] = make_cx2(a, b);
     }
 #if defined(FB_STAMPS) && FB_STAMPS == 1
@@ -677,21 +698,21 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
 #if !FB_TWIDDLE_IN_P2
-      const uint32_t nb = tile * T + col;
+      const uint32_t nb = tile * T + cofs + col;
       if (!(FB_DBG(g) & 8)) apply_pass_twiddle<R>(v, nb, p, pstride, logL, tw, g.tw_lo);
 #endif
-      // image index of element k: l0 + k*(pstride << logT) (pstride is a multiple of T2), so when that step is a
-      // multiple of 64 the swizzle and the padding of l0 carry over: one address per column, constant offsets
+      // image (of the group's columns) index of element k: l0 + k*(pstride << logTw) (pstride is a multiple of T2), so when
+      // that step is a multiple of 64 the swizzle and the padding of l0 carry over: one address per column, constant offsets
       auto img = [&](const uint32_t l) { return lds_pad(l ^ (((l >> 4) & swz) << 3)); };
-      const uint32_t l0 = ((((p >> logT2) << logT) + col) << logT2) | (p & (T2 - 1));
-      const uint32_t step = pstride << logT;
+      const uint32_t l0 = ((((p >> logT2) << logTw) + col) << logT2) | (p & (T2 - 1));
+      const uint32_t step = pstride << logTw;
       const bool aff = (step & 63) == 0 && (pstride & (T2 - 1)) == 0;
       const uint32_t b0 = img(l0), b1 = img(l0 + T2), sp = step + (step >> 4);
       if (aff) {                                       // uniform
 #pragma unroll
         for (int k = 0; k < R; k++) {
-          float* __restrict__ d0 = (float*)&lds[b0 + k * sp];
-          float* __restrict__ d1 = (float*)&lds[b1 + k * sp];
+          float* __restrict__ d0 = (float*)&lw[b0 + k * sp];
+          float* __restrict__ d1 = (float*)&lw[b1 + k * sp];
           d0[0] = v[k].x[0]; d0[1] = v[k].y[0];       // (re, im) of column col   (two dwords: no register shuffling)
           d1[0] = v[k].x[1]; d1[1] = v[k].y[1];       // column col + 1
         }
@@ -699,9 +720,9 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
 #pragma unroll
         for (int k = 0; k < R; k++) {
           const uint32_t ka = k * pstride + p;
-          const uint32_t l = ((((ka >> logT2) << logT) + col) << logT2) | (ka & (T2 - 1));
-          lds[img(l)] = cx2_lo(v[k]);
-          lds[img(l + T2)] = cx2_hi(v[k]);
+          const uint32_t l = ((((ka >> logT2) << logTw) + col) << logT2) | (ka & (T2 - 1));
+          lw[img(l)] = cx2_lo(v[k]);
+          lw[img(l + T2)] = cx2_hi(v[k]);
         }
       }
     };
@@ -723,25 +744,25 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     item = next;
     continue;
 #endif
-    if (FB_DBG(g) & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);
-    else wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
+    if (FB_DBG(g) & 4) wgfft_passthrough<LOGF>(tid, logTw, x, store);
+    else wgfft<LOGF, -1, true>(lw, ltw_w, tid, logTw, x, store);
     __syncthreads();
 #if defined(FB_STAMPS) && FB_STAMPS == 1
     STAMP(ts3);
 #endif
     if (!(FB_DBG(g) & 1)) {
-      const uint32_t nthr = blockDim.x;
+      const uint32_t nthr = nthr_w;
       if (co_fast) {
         // pair jj of a thread is pair 0 plus jj*2*nthr elements: a constant step in the padded image (co_lstep) and a
         // uniform step in A (co_gstep) -- one LDS address and one 32-bit global offset per THREAD, computed before the
         // tile loop; the per-pair part is an immediate / a scalar-register base (this loop issued 23 % of the pass's
         // vector instructions as per-pair address arithmetic, 64-bit shifts included)
-        const char* __restrict__ gb = (const char*)(Aseq + ((uint64_t)(tile * T) << logT2));
+        const char* __restrict__ gb = (const char*)(Aseq + ((uint64_t)(tile * T + cofs) << logT2));
 #pragma unroll
         for (int j4 = 0; j4 < PTS / 2; j4 += 4) {                  // four LDS reads in flight, then their stores
           float4 pr[4];
 #pragma unroll
-          for (int q = 0; q < 4; q++) pr[q] = *(const float4*)&lds[co_lds + (j4 + q) * co_lstep];
+          for (int q = 0; q < 4; q++) pr[q] = *(const float4*)&lw[co_lds + (j4 + q) * co_lstep];
           __builtin_amdgcn_sched_barrier(0);                         // (the min-register scheduler would pair every read with its store)
 #pragma unroll
           for (int q = 0; q < 4; q++) st_stream((float4*)(gb + (uint64_t)(j4 + q) * co_gstep * sizeof(cf) + co_goff), pr[q]);
@@ -750,10 +771,10 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
       } else {
 #pragma unroll 4
         for (int jj = 0; jj < PTS / 2; jj++) {
-          const uint32_t l = 2 * (tid + jj * nthr);                  // element index inside the staged tile
-          const uint32_t blkA = l >> (logT + logT2), within = l & ((1u << (logT + logT2)) - 1);
-          const float4 pr = *(const float4*)&lds[lds_pad(l ^ (((l >> 4) & swz) << 3))];
-          st_stream((float4*)&Aseq[((((uint64_t)blkA << g.logR) + tile * T) << logT2) + within], pr);
+          const uint32_t l = 2 * (tid + jj * nthr);                  // element index inside the staged image
+          const uint32_t blkA = l >> (logTw + logT2), within = l & ((1u << (logTw + logT2)) - 1);
+          const float4 pr = *(const float4*)&lw[lds_pad(l ^ (((l >> 4) & swz) << 3))];
+          st_stream((float4*)&Aseq[((((uint64_t)blkA << g.logR) + tile * T + cofs) << logT2) + within], pr);
         }
       }
     }
@@ -765,6 +786,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     if (!more) break;
     item = next;
   }
+  if (SPLIT && grp == 0) __builtin_amdgcn_s_barrier();         // the second group's last barrier
 #if defined(FB_STAMPS) && FB_STAMPS == 1
   if (threadIdx.x == 0 && blockIdx.x < 1024)
     for (int q = 0; q < 6; q++) atomicAdd(&g_stamps[blockIdx.x][q], acc_s[q]);
@@ -1168,7 +1190,6 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   cf kk[PTS / 2];                       // chirp of the current tile
   uint32_t kk_tile = ~0u;
   // FOLD: plan entry of this thread for the item about to be processed (tid < number of active bins of the part)
-  uint4 en_cur = make_uint4(0, 0, 0, 0);
   uint32_t fe0_cur = 0, fn_cur = 0;
   auto plan_fetch = [&](const Item it) {
     if constexpr (FOLD) {
@@ -1176,9 +1197,29 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       if (use_psl) { fe0_cur = psl[lp]; fn_cur = psl[lp + 1] - fe0_cur; }
       else { fe0_cur = out.pstart[part0 + lp]; fn_cur = out.pstart[part0 + lp + 1] - fe0_cur; }
       if (FB_DBG(g) & 16) fn_cur = 0;
-      if (fn_cur <= out.plan_cap && tid < fn_cur) en_cur = fent_all[fe0_cur + tid];      // plan_cap <= blockDim
     }
   };
+  // The active-bin entries of a part (16 bytes each, at most plan_cap <= blockDim of them) go from global memory STRAIGHT into
+  // their LDS buffer (global_load_lds_dwordx4: lane l of a wave lands at the wave's base + 16*l), asynchronously and
+  // without passing through registers.  Round 2 fetched them into a register at the top of the tile and stored them to
+  // LDS: the kernel sits at 256 registers, the value was spilled to scratch, and the ISA read `s_waitcnt vmcnt(0);
+  // global_load; s_waitcnt vmcnt(0); scratch_store; ...; scratch_load; s_waitcnt vmcnt(0); ds_write` -- two exposed memory
+  // round trips on the two waves everyone then waits for at the first barrier.  The entries of the NEXT item are now
+  // requested in the middle of the current tile's transform (behind a barrier that the previous readers of that buffer
+  // have passed) and are waited for, together with the prefetched tile, at the top of the next one.
+  // (needs a second stage: the request for the next item is issued from wgfft's `mid` hook behind the first exchange barrier;
+  //  single-stage transforms read their entries from global memory)
+  const bool plan_dma_ok = FOLD && FftPlan<LOGF>::NS >= 2 && use_psl;
+  auto plan_dma = [&](const Item it, const uint32_t buf) {
+    if constexpr (FOLD) {
+      const uint32_t fe0 = psl[it.lp], fn = (FB_DBG(g) & 16) ? 0u : psl[it.lp + 1] - fe0;
+      if (fn <= out.plan_cap && tid < fn)
+        __builtin_amdgcn_global_load_lds((const void*)(fent_all + fe0 + tid),
+                                         (__attribute__((address_space(3))) void*)((uint4*)&lds[plan_off] + buf * out.plan_cap + (tid & ~63u)),
+                                         16, 0, 0);
+    }
+  };
+  if (plan_dma_ok) plan_dma(item, 0);
 
 #if defined(FB_STAMPS) && FB_STAMPS == 3
   unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, acc_s[6] = {0, 0, 0, 0, 0, 0};
@@ -1203,7 +1244,9 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         // this part's active-bin entries travel with the chirp loads and are parked in LDS (double buffered: slower
         // waves may still be folding the previous tile from the other half); their offsets come from the LDS copy
         plan_fetch(item);
-        if (fn_cur <= out.plan_cap && tid < fn_cur) ((uint4*)&lds[plan_off] + (jt & 1) * out.plan_cap)[tid] = en_cur;
+        // the entries requested during the previous tile (or in front of the loop) have landed once every older load has
+        // -- they were issued half a tile ago, behind the prefetch of this tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       if constexpr (PAIR16) {
         if (pair16) {                       // hand the other channel's halves of the 16-byte pairs to the neighbour lane
@@ -1345,7 +1388,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       f_nact = fn_cur;
       ent = fent_all + f_e0;
       planl = (const uint4*)&lds[plan_off] + (jt & 1) * out.plan_cap;
-      in_lds = f_nact <= out.plan_cap;
+      in_lds = plan_dma_ok && f_nact <= out.plan_cap;
     }
     // accumulator of (work item w, phase bin b): one float4, or -- profile of npol 2 x ndim 2 -- a float2 in each of the
     // channel's two rows; the partial profiles of a segmented launch are packed in the same shape (rows of nbin bins)
@@ -1381,6 +1424,9 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
           en_pre = planl[tid >> logT3];
           acc_pre = acc_load(acc_row(tid), en_pre.x);
         }
+        // every wave is past this tile's first exchange barrier, i.e. has left the previous tile's fold: the other plan
+        // buffer is free for the entries of the next item
+        if (phase == 2 && plan_dma_ok && more) plan_dma(next, (jt + 1) & 1);
       }
     };
     if (FB_DBG(g) & 4) wgfft_passthrough<LOGF>(tid, logT, x, store);

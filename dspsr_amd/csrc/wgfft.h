@@ -38,7 +38,8 @@ inline uint32_t ltw_entries_host(int logF)
   for (int st = 0; st < ntw; st++) n += 4u << (logF - 4 * (st + 1));
   return n;
 }
-inline uint32_t lds_total_words_host(uint32_t points, int logF) { return lds_words_host(points) + ltw_entries_host(logF) + 8; }
+// (+ 16: a workgroup that works as two half-tile groups has two exchange buffers, each with its own 8 words of slack)
+inline uint32_t lds_total_words_host(uint32_t points, int logF) { return lds_words_host(points) + ltw_entries_host(logF) + 8 + 16; }
 
 
 constexpr int PTS = 32;      // points per thread
