@@ -28,7 +28,8 @@ mp, nkeep = line["config"]["max_parts"], line["config"]["nkeep"]
 sub = max(1, min(mp, (512 << 20) // (line["config"]["n_fft"] * 2 * 8)))       # parts per pass-2 / inverse sub-group
 ker = {}
 for k in mean["FETCH_SIZE"]:
-    parts = mp if ("raw_transpose" in k or "fwd_cols" in k) else sub
+    # passes 0 and 1 run once per launch group, pass 2 / inverse once per sub-group, the stand-alone fold once per BLOCK
+    parts = mp if ("raw_transpose" in k or "fwd_cols" in k) else line["config"]["parts_per_block"] if "fold_chunked" in k else sub
     ker[k] = {"fetch_KB": round(mean["FETCH_SIZE"][k], 1), "write_KB": round(mean["WRITE_SIZE"].get(k, 0.0), 1), "parts": parts,
               "MB_per_part": round((2 * mean["FETCH_SIZE"][k] + mean["WRITE_SIZE"].get(k, 0.0)) * 1024 / parts / 1e6, 2)}
 def per_part(pred):
