@@ -78,6 +78,10 @@ struct FbIn {
 struct FbOut {
   int kind;  // 0: none (benchmark), 1: complex filterbank rows, 2: detected, 3: detected and folded in the same
              //    kernel (base = device profile [chan][nbin] float4, ndim 4; plan per part, see fold_internal.h)
+             // 4: four-pass geometry, wide phase bins: k_inv_b reduces the detected samples of its tile to the sums of the
+             //    Tt-sample segments it holds (base = segment sums [chan][part][tile][t2][2] float4; pstart = the
+             //    time-ordered interval offsets of the block's bin plan, blk_first = their index per 1024 samples,
+             //    nparts_plan = parts of the block); fold_segment_combine adds them to the profile in time order
   float* base;
   uint64_t chan_stride, pol_stride, part_step;  // floats
   int state;                                    // detected: coherence / stokes
@@ -98,6 +102,8 @@ struct FbOut {
   uint32_t nparts_plan;
   uint32_t plan_cap;                            // kind 3: plan entries per LDS buffer (two buffers behind the twiddles)
   const Interval* piv;                          // kind 3: intervals (offset within the part, hits), time ordered per bin
+  const uint32_t* blk_first;                    // kind 4: interval that holds sample 1024*i of the block
+  const uint32_t* bin_start;                    // kind 4 (host side only): the intervals bucketed by phase bin (with piv)
 };
 
 #ifdef FB_STAMPS   // diagnostic build only (-DFB_STAMPS=1|2|3: pass to instrument): where a tile spends its cycles
@@ -1765,7 +1771,15 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
   }
 }
 
-template <int LOGF>
+// FOLDB (FbOut kind 4): the tile holds, for one channel, Mb runs of Tt consecutive output samples (run t2 = samples
+// t1 + Ma*t2, t1 in the tile's block): exactly the micro-blocks the long-run fold (fold.hip, FOLD_LONG_RUN) sums first.
+// The detected samples are staged in the exchange buffer ([t2][t1], XOR-swizzled so that both the stage's writes and the
+// per-run reads are conflict free); thread t2 adds its run in time order, cut at the one phase-bin boundary it may hold
+// (the host admits this path only for plans whose inner intervals are >= Tt samples), and writes the two piece sums --
+// 1/16 of the detected bytes instead of all of them.  fold_segment_combine (fold.hip) then adds, per (channel, bin), the
+// pieces of the bin's intervals in time order.  Deterministic; equal to the time-order sum to float rounding like the
+// long-run fold itself (other micro-block boundaries, so not bit-equal to it).
+template <int LOGF, bool FOLDB>
 __global__ __launch_bounds__(512) void k_inv_b(const FbGeom g, const cf* __restrict__ U, const FbOut out,
                                                const cf* __restrict__ tw, const uint64_t part0, const uint32_t nparts,
                                                const uint32_t run)
@@ -1817,6 +1831,18 @@ __global__ __launch_bounds__(512) void k_inv_b(const FbGeom g, const cf* __restr
     //  the unrolled loop; the keep window is the only per-element test)
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
+      if constexpr (FOLDB) {
+        // detected sample (run t2 = k*pstride + p, position j = col/2 in the run) -> float4 slot t2*Tt + (j ^ t2 % Tt)
+        const uint32_t j = col >> 1, Ttm = (1u << logTt) - 1;
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          const uint32_t t2 = k * pstride + p;
+          float q[4];
+          detect4(cx2_lo(v[k]), cx2_hi(v[k]), out.state, q);
+          *(float4*)&lds[2 * ((t2 << logTt) + (j ^ (t2 & Ttm)))] = make_float4(q[0], q[1], q[2], q[3]);
+        }
+        return;
+      }
       if (out.kind == 0) return;
       const uint32_t chan = out.chan0 + c;
       const uint32_t t1 = (tile << logTt) + (col >> 1);
@@ -1869,7 +1895,32 @@ __global__ __launch_bounds__(512) void k_inv_b(const FbGeom g, const cf* __restr
         });
       }
     };
-    wgfft<LOGF, +1>(lds, ltw_off, tid, logT, x, store);
+    wgfft<LOGF, +1, FOLDB>(lds, ltw_off, tid, logT, x, store);
+    if constexpr (FOLDB) {
+      __syncthreads();                                       // the tile's detected samples are staged
+      const uint32_t Tt = 1u << logTt, Ttm = Tt - 1;
+      for (uint32_t t2 = tid; t2 < (1u << LOGF); t2 += blockDim.x) {
+        // run t2: output positions pos0 .. pos0 + Tt - 1 of the backward transform; kept: [nfilt_pos, nfilt_pos + nkeep)
+        const uint32_t pos0 = (t2 << g.logMa) + (tile << logTt);
+        const uint32_t lo = g.nfilt_pos, hi = g.nfilt_pos + g.nkeep;
+        const uint32_t jlo = pos0 >= lo ? 0u : (lo - pos0 < Tt ? lo - pos0 : Tt), jhi = pos0 + Tt <= hi ? Tt : (hi > pos0 ? hi - pos0 : 0u);
+        float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+        if (jlo < jhi) {
+          const uint32_t i0 = (uint32_t)part * g.nkeep + (pos0 + jlo - g.nfilt_pos), i1 = i0 + (jhi - jlo);   // sample span in the block
+          uint32_t qi = out.blk_first[i0 >> 10];
+          while (out.pstart[qi + 1] <= i0) qi++;             // interval that holds sample i0 (inner intervals are >= Tt samples)
+          const uint32_t cut = out.pstart[qi + 1] < i1 ? out.pstart[qi + 1] : i1;
+          const uint32_t jc = jlo + (cut - i0);
+          const float4* __restrict__ src = (const float4*)&lds[2 * (t2 << logTt)];
+          for (uint32_t j = jlo; j < jc; j++) { const float4 q = src[j ^ (t2 & Ttm)]; sa.x += q.x; sa.y += q.y; sa.z += q.z; sa.w += q.w; }
+          for (uint32_t j = jc; j < jhi; j++) { const float4 q = src[j ^ (t2 & Ttm)]; sb.x += q.x; sb.y += q.y; sb.z += q.z; sb.w += q.w; }
+        }
+        float4* __restrict__ o = (float4*)out.base + ((((uint64_t)c * out.nparts_plan + part) * ntile + tile) << (LOGF + 1)) + 2 * t2;
+        o[0] = sa;
+        o[1] = sb;
+      }
+      // (the next tile's first exchange write sits behind a barrier: wgfft)
+    }
     if (!more) break;
     item = next;
   }
@@ -1898,7 +1949,7 @@ k2_t fb_pick2(int logf, bool full);
 k3_t fb_pick3(int logf, bool full);       // plain
 k3_t fb_pick3f(int logf, bool full);      // fused fold
 k3a_t fb_pick3a(int logf, bool blocked);
-k3b_t fb_pick3b(int logf);
+k3b_t fb_pick3b(int logf, bool foldb = false);
 void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, cf* Rt, uint64_t part0);
 
@@ -1925,7 +1976,7 @@ k3_t fb_pick3f(int logf, bool full) { return logf != 12 ? nullptr : (full ? k_in
 #endif
 #if FB_HAS(4)
 k3a_t fb_pick3a(int, bool) { return nullptr; }
-k3b_t fb_pick3b(int) { return nullptr; }
+k3b_t fb_pick3b(int, bool) { return nullptr; }
 #endif
 #else
 #if FB_HAS(1)
@@ -1973,9 +2024,14 @@ template <int... I> static k3a_t pick3a(int logf, bool blocked, iseq<I...>)
   static const k3a_t tb[] = {k_inv_a<I, true>...};
   return blocked ? tb[logf] : tn[logf];
 }
-template <int... I> static k3b_t pick3b(int logf, iseq<I...>) { static const k3b_t t[] = {k_inv_b<I>...}; return t[logf]; }
+template <int... I> static k3b_t pick3b(int logf, bool foldb, iseq<I...>)
+{
+  static const k3b_t t[] = {k_inv_b<I, false>...};
+  static const k3b_t f[] = {k_inv_b<I, true>...};
+  return foldb ? f[logf] : t[logf];
+}
 k3a_t fb_pick3a(int logf, bool blocked) { return pick3a(logf, blocked, seq_t()); }
-k3b_t fb_pick3b(int logf) { return pick3b(logf, seq_t()); }
+k3b_t fb_pick3b(int logf, bool foldb) { return pick3b(logf, foldb, seq_t()); }
 #endif
 #endif
 #if FB_HAS(1)
@@ -2023,6 +2079,9 @@ struct dspsr_amd_filterbank_impl {
   size_t fpart_floats = 0;
   uint32_t plan_cap = 0;     // fused fold: plan entries per LDS buffer behind the twiddle tables
   size_t lds3f = 0;          // dynamic LDS of the fused inverse pass
+  k3b_t k3bf = nullptr;      // four-pass fused fold: second inverse pass that leaves segment sums (FbOut kind 4)
+  float* msum = nullptr;     // ... [chan][part][tile][t2][2] float4 of one input channel's sub-band and one block
+  size_t msum_floats = 0;
 };
 
 }  // namespace dspsr_amd
@@ -2181,6 +2240,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     if (g.four_pass) {
       fb->k3a = fb_pick3a(g.logMa, g.xblocked != 0);
       fb->k3b = fb_pick3b(g.logMb);
+      fb->k3bf = fb_pick3b(g.logMb, true);
     } else {
       fb->k3 = fb_pick3(g.logM, full3);
       fb->k3f = fb_pick3f(g.logM, full3);
@@ -2204,6 +2264,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
       if (e == hipSuccess && fb->k3f) e = allow_lds(fb->k3f, fb->lds3f);
       if (e == hipSuccess && fb->k3a) e = allow_lds(fb->k3a, fb->lds3);
       if (e == hipSuccess && fb->k3b) e = allow_lds(fb->k3b, fb->lds4);
+      if (e == hipSuccess && fb->k3bf) e = allow_lds(fb->k3bf, fb->lds4);
     }
     if (!have || e != hipSuccess) {
       delete fb;
@@ -2264,6 +2325,7 @@ extern "C" void dspsr_amd_filterbank_destroy(dspsr_amd_filterbank* fb)
   if (fb->Rt) (void)hipFree(fb->Rt);
   if (fb->det) (void)hipFree(fb->det);
   if (fb->fpart) (void)hipFree(fb->fpart);
+  if (fb->msum) (void)hipFree(fb->msum);
   if (fb->tw_lo) (void)hipFree(fb->tw_lo);
   if (fb->tw_lo_m) (void)hipFree(fb->tw_lo_m);
   delete fb;
@@ -2406,7 +2468,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   k2_t k2 = fb->k2;
   k3_t k3 = out.kind == 3 ? fb->k3f : fb->k3;
   k3a_t k3a = fb->k3a;
-  k3b_t k3b = fb->k3b;
+  k3b_t k3b = out.kind == 4 ? fb->k3bf : fb->k3b;
   if (!k1 || !k2 || (g.four_pass ? (!k3a || !k3b) : !k3))
     return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: geometry not in this (experiment) build");
   hipError_t e;
@@ -2510,6 +2572,11 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         hipLaunchKernelGGL(k3b, dim3(grid_for(n3b, fb->ncu * fb->wg_per_cu)), dim3(fb->nt4), fb->lds4, ctx->stream, g, fb->A, co,
                            ctx->tw, part0, nb, 8u);
       }
+    }
+    if (out.kind == 4) {      // every part of this sub-band has left its segment sums: add them to the profile in time order
+      const int rc = fold_segment_combine(out.fold, fb->msum, co.chan0, g.C, (uint32_t)npart, g.nkeep, g.nfilt_pos, g.logTt, g.logMa,
+                                          g.logMb, out.bin_start, out.piv);
+      if (rc != DSPSR_AMD_OK) return rc;
     }
   }
   e = hipGetLastError();
@@ -2615,7 +2682,9 @@ extern "C" int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, con
 
 extern "C" int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb)
 {
-  if (!fb || fb->g.four_pass || fb->g.nkeep >= 65536) return 0;
+  if (!fb) return 0;
+  if (fb->g.four_pass) return fb->cfg.fused_fold != DSPSR_AMD_FUSED_NEVER && fb->k3bf && fb->g.logTt >= 3 ? 3 : 0;
+  if (fb->g.nkeep >= 65536) return 0;
   if (fb->cfg.fused_fold == DSPSR_AMD_FUSED_ALWAYS) return 1;
   if (fb->cfg.fused_fold == DSPSR_AMD_FUSED_NEVER) return 0;
   const uint64_t tiles = (uint64_t)(fb->g.C >> fb->g.logT3);
@@ -2671,7 +2740,37 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
   // (a bound profile whose rows are not float4 aligned also takes the separate launches: the fold kernel adds scalars)
   const bool prof_vec4 = planes2 ? (fold->span % 2 == 0 && ((uintptr_t)fold->profile % 16) == 0)
                                  : (fold->span % 4 == 0 && ((uintptr_t)fold->profile % 16) == 0);
-  if (!dspsr_amd_filterbank_fold_is_fused(fb) || !prof_vec4 || fold_plan_max_run(fold) >= (uint32_t)FB_ENV_INT("DSPSR_AMD_FUSED_MAX_RUN", (int)FOLD_FUSED_MAX_RUN)) {
+  if (dspsr_amd_filterbank_fold_is_fused(fb) == 3 && !planes2 && prof_vec4 && npart &&
+      fold_plan_max_run(fold) >= FOLD_LONG_RUN_HOST && npart * (uint64_t)fb->g.nkeep < (1ull << 32)) {
+    // Four-pass geometry (dsp::Convolution shapes, -F N:D with a long response) and wide phase bins: the second inverse pass
+    // reduces its tile to the sums of the Tt-sample segments it holds and a second kernel adds those in time order -- the
+    // detected time series (16 bytes per sample, written and read once) never reaches HBM.  Plans that do not qualify
+    // (gaps from zero weights, short inner intervals, a fold that does not cover the call) take Detection + Fold below.
+    bool ok = false;
+    const uint32_t* d_off = nullptr; const uint32_t* d_blk = nullptr; const uint32_t* d_bs = nullptr;
+    const Interval* d_siv = nullptr;
+    PlanSlot* sslot = nullptr;
+    int rc = fold_build_segment_plan(fold, npart * (uint64_t)fb->g.nkeep, 1u << fb->g.logTt, &ok, &d_off, &d_blk, &d_bs, &d_siv, &sslot);
+    if (rc != DSPSR_AMD_OK) return rc;
+    if (ok) {
+      const size_t need = ((size_t)fb->g.C * npart << (fb->g.logMf - fb->g.logTt)) * 8;       // segments x 2 pieces x float4
+      if (need > fb->msum_floats) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (fb->msum) (void)hipFree(fb->msum);
+        fb->msum = nullptr; fb->msum_floats = 0;
+        if (hipMalloc((void**)&fb->msum, need * sizeof(float)) != hipSuccess)
+          return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform_fold: hipMalloc of %zu segment-sum bytes failed", need * sizeof(float));
+        fb->msum_floats = need;
+      }
+      FbOut sout = {4, fb->msum, 0, 0, 0, state, 4, 0, fold->nbin, fold->span / 4, 1u, fold->span, nullptr, fold->nchan, 0, fold, d_off,
+                    (uint32_t)npart, 0, d_siv, d_blk, d_bs};
+      rc = fb_run(fb, in, sout, npart, in_chan_stride);
+      const int rc2 = fold_part_plan_submitted(fold, sslot);
+      return rc != DSPSR_AMD_OK ? rc : rc2;
+    }
+  }
+  const int fmode = dspsr_amd_filterbank_fold_is_fused(fb);
+  if ((fmode != 1 && fmode != 2) || !prof_vec4 || fold_plan_max_run(fold) >= (uint32_t)FB_ENV_INT("DSPSR_AMD_FUSED_MAX_RUN", (int)FOLD_FUSED_MAX_RUN)) {
     const uint64_t row = npart * fb->g.nkeep * 4;                       // floats per channel
     const size_t need = (size_t)row * nchan;
     if (!need) return DSPSR_AMD_OK;

@@ -266,6 +266,42 @@ __global__ __launch_bounds__(256) void k_fold_combine(float* __restrict__ prof, 
   }
 }
 
+// Four-pass fused fold, second half: thread (chan, bin) walks the bin's intervals in time order and adds the piece sums
+// k_inv_b<., true> left for every Tt-sample segment the interval covers: piece A of a segment entered at its first kept
+// sample, piece B of a segment entered behind its cut (fold_internal.h).  One dependent chain of float4 adds per
+// (chan, bin), 1/Tt of the samples long.
+__global__ __launch_bounds__(256) void k_fold_segsum(float* __restrict__ prof, const uint64_t prof_span, const uint32_t nbin,
+                                                     const float4* __restrict__ msum, const uint32_t npart, const uint32_t nkeep,
+                                                     const uint32_t nfilt_pos, const int logTt, const int logMa, const int logMb,
+                                                     const uint32_t* __restrict__ bin_start, const Interval* __restrict__ iv)
+{
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (b >= nbin) return;
+  const uint32_t i0 = bin_start[b], i1 = bin_start[b + 1];
+  if (i0 == i1) return;
+  const int logNt = logMa - logTt;                        // tiles (blocks of Tt values of t1) per channel
+  const uint32_t Tt = 1u << logTt, hi = nfilt_pos + nkeep;
+  float4* __restrict__ pp = (float4*)(prof + (uint64_t)c * prof_span) + b;
+  float4 acc = *pp;
+  const float4* __restrict__ mc = msum + (((uint64_t)c * npart) << (logNt + logMb + 1));
+  for (uint32_t i = i0; i < i1; i++) {
+    const Interval v = iv[i];
+    uint64_t idat = v.offset;
+    const uint64_t end = v.offset + v.hits;
+    while (idat < end) {
+      const uint32_t part = (uint32_t)(idat / nkeep), pos = (uint32_t)(idat - (uint64_t)part * nkeep) + nfilt_pos;
+      const uint32_t seg = pos >> logTt;                                        // position = seg*Tt + j = t1 + (t2 << logMa)
+      const uint32_t first = (seg << logTt) > nfilt_pos ? (seg << logTt) : nfilt_pos;       // the segment's first kept position
+      const uint32_t last = ((seg + 1) << logTt) < hi ? ((seg + 1) << logTt) : hi;         // one past its last kept position
+      const uint32_t t1blk = seg & ((1u << logNt) - 1), t2 = seg >> logNt;
+      const float4 q = mc[(((((uint64_t)part << logNt) + t1blk) << logMb) + t2) * 2 + (pos == first ? 0 : 1)];
+      acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+      idat += last - pos;                              // to the segment's end (an interval that ends inside took piece A, which ends there)
+    }
+  }
+  *pp = acc;
+}
+
 }  // namespace dspsr_amd
 
 using namespace dspsr_amd;
@@ -276,6 +312,8 @@ static void slot_free(PlanSlot& s)
   if (s.h_iv) (void)hipHostFree(s.h_iv);
   if (s.d_bin_start) (void)hipFree(s.d_bin_start);
   if (s.d_iv) (void)hipFree(s.d_iv);
+  if (s.h_aux) (void)hipHostFree(s.h_aux);
+  if (s.d_aux) (void)hipFree(s.d_aux);
   if (s.done) (void)hipEventDestroy(s.done);
   s = PlanSlot();
 }
@@ -768,5 +806,89 @@ int fold_part_plan_submitted(dspsr_amd_fold* f, PlanSlot* slot)
   hipError_t e = hipEventRecord(slot->done, f->ctx->stream);
   if (e != hipSuccess) return ctx_fail(f->ctx, DSPSR_AMD_EHIP, "fused fold: %s", hipGetErrorString(e));
   slot->pending = true;
+  return DSPSR_AMD_OK;
+}
+
+int fold_build_segment_plan(dspsr_amd_fold* f, uint64_t ndat, uint32_t seg, bool* ok, const uint32_t** d_run_off,
+                            const uint32_t** d_blk_first, const uint32_t** d_bin_start, const Interval** d_iv, PlanSlot** slot)
+{
+  dspsr_amd_ctx* ctx = f->ctx;
+  *ok = false;
+  if (f->binplan.empty() || ndat == 0 || ndat >= (1ull << 32)) return DSPSR_AMD_OK;
+  // (the open run's hits are final only once the plan is consumed: look at them without closing it)
+  const size_t nrun = f->binplan.size();
+  auto hits_of = [&](size_t i) { return i + 1 == nrun && f->current_hits ? f->current_hits : f->binplan[i].hits; };
+  uint64_t expect = 0;
+  for (size_t i = 0; i < nrun; i++) {
+    const RunBin& r = f->binplan[i];
+    const uint32_t h = hits_of(i);
+    if (r.offset != expect || h == 0) return DSPSR_AMD_OK;                 // a gap (dropped samples) or an offset start
+    if (i > 0 && i + 1 < nrun && h < seg) return DSPSR_AMD_OK;             // an inner interval shorter than a segment
+    expect += h;
+  }
+  if (expect != ndat) return DSPSR_AMD_OK;
+  if (f->current_hits) f->binplan.back().hits = f->current_hits;           // FoldCUDA.cu:163-164
+  f->current_hits = 0;
+  const uint32_t nbin = f->nbin;
+  PlanSlot& sl = f->slot[f->next_slot];
+  f->next_slot ^= 1;
+  if (sl.pending) {
+    const hipError_t e = hipEventSynchronize(sl.done);
+    if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "fused fold: %s", hipGetErrorString(e));
+    sl.pending = false;
+  }
+  const size_t nblk = (size_t)(ndat >> 10) + 1, naux = nrun + 1 + nblk;
+  if (!slot_reserve(sl, nbin + 1, nrun)) return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "fused fold: plan allocation failed");
+  if (naux > sl.aux_cap) {
+    if (sl.h_aux) (void)hipHostFree(sl.h_aux);
+    if (sl.d_aux) (void)hipFree(sl.d_aux);
+    sl.h_aux = nullptr; sl.d_aux = nullptr; sl.aux_cap = 0;
+    const size_t n = naux + naux / 2 + 16;
+    if (hipHostMalloc((void**)&sl.h_aux, n * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&sl.d_aux, n * sizeof(uint32_t)) != hipSuccess)
+      return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "fused fold: plan allocation failed");
+    sl.aux_cap = n;
+  }
+  uint32_t* off = sl.h_aux;
+  uint32_t* blk = sl.h_aux + nrun + 1;
+  for (size_t i = 0; i < nrun; i++) off[i] = (uint32_t)f->binplan[i].offset;
+  off[nrun] = (uint32_t)ndat;
+  size_t q = 0;
+  for (size_t i = 0; i < nblk; i++) {
+    const uint64_t s0 = (uint64_t)i << 10;
+    while (q + 1 < nrun && off[q + 1] <= s0) q++;
+    blk[i] = (uint32_t)q;
+  }
+  // the same intervals bucketed by phase bin, time order kept inside a bin (as dspsr_amd_fold_fold)
+  for (uint32_t b = 0; b <= nbin; b++) sl.h_bin_start[b] = 0;
+  for (const RunBin& r : f->binplan) sl.h_bin_start[r.ibin + 1]++;
+  for (uint32_t b = 0; b < nbin; b++) sl.h_bin_start[b + 1] += sl.h_bin_start[b];
+  f->cursor.assign(sl.h_bin_start, sl.h_bin_start + nbin);
+  for (const RunBin& r : f->binplan) {
+    Interval v; v.offset = r.offset; v.hits = r.hits; v.pad = 0;
+    sl.h_iv[f->cursor[r.ibin]++] = v;
+  }
+  hipError_t e = hipMemcpyAsync(sl.d_aux, sl.h_aux, naux * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(sl.d_bin_start, sl.h_bin_start, (nbin + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(sl.d_iv, sl.h_iv, nrun * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "fused fold: plan copy: %s", hipGetErrorString(e));
+  f->binplan.clear();
+  *d_run_off = sl.d_aux;
+  *d_blk_first = sl.d_aux + nrun + 1;
+  *d_bin_start = sl.d_bin_start;
+  *d_iv = sl.d_iv;
+  *slot = &sl;
+  *ok = true;
+  return DSPSR_AMD_OK;
+}
+
+int fold_segment_combine(dspsr_amd_fold* f, const float* msum, uint32_t chan0, uint32_t nchan, uint32_t npart, uint32_t nkeep,
+                         uint32_t nfilt_pos, int logTt, int logMa, int logMb, const uint32_t* d_bin_start, const Interval* d_iv)
+{
+  // (profile of npol 1 x ndim 4, rows 16-byte aligned: checked by the caller)
+  hipLaunchKernelGGL(k_fold_segsum, dim3((f->nbin + 255) / 256, nchan), dim3(256), 0, f->ctx->stream,
+                     f->profile + (uint64_t)chan0 * f->span, f->span, f->nbin, (const float4*)msum, npart, nkeep, nfilt_pos, logTt, logMa,
+                     logMb, d_bin_start, d_iv);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ctx_fail(f->ctx, DSPSR_AMD_EHIP, "fused fold: segment combine: %s", hipGetErrorString(e));
   return DSPSR_AMD_OK;
 }

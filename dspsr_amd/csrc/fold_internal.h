@@ -17,6 +17,9 @@ struct PlanSlot {
   uint32_t* d_bin_start = nullptr;
   dspsr_amd::Interval* d_iv = nullptr;
   size_t bin_cap = 0, iv_cap = 0;
+  uint32_t* h_aux = nullptr;         // pinned: time-ordered interval offsets + their index per 1024 samples (segment plan)
+  uint32_t* d_aux = nullptr;
+  size_t aux_cap = 0;
   hipEvent_t done = nullptr;
   bool pending = false;
 };
@@ -65,5 +68,20 @@ static inline uint32_t fold_plan_max_run(const dspsr_amd_fold* f)
 int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, const uint32_t** d_start,
                          const dspsr_amd::Interval** d_iv, PlanSlot** slot);
 int fold_part_plan_submitted(dspsr_amd_fold* f, PlanSlot* slot);
+
+// Four-pass fused fold (filterbank.hip k_inv_b<., true>): the pending plan must cover samples [0, ndat) without gaps and
+// every interval but the first and the last must hold at least `seg` samples (so that a `seg`-sample run of the last
+// inverse pass is cut by at most one phase-bin boundary).  *ok = false: the plan does not qualify and is left pending (the
+// caller takes Detection + Fold).  Otherwise the plan is consumed: on the device
+//   run_off[0 .. nrun]            start offsets of the time-ordered intervals, run_off[nrun] = ndat
+//   blk_first[0 .. ndat/1024]     index of the interval that holds sample 1024*i
+//   bin_start / iv                the same intervals bucketed by phase bin (time ordered inside a bin), as for k_fold_chunked
+int fold_build_segment_plan(dspsr_amd_fold* f, uint64_t ndat, uint32_t seg, bool* ok, const uint32_t** d_run_off,
+                            const uint32_t** d_blk_first, const uint32_t** d_bin_start, const dspsr_amd::Interval** d_iv, PlanSlot** slot);
+// profile[chan0 + c][bin] += the segment piece sums of the bin's intervals, in time order (c < nchan).
+//   msum: [c][part][tile][t2][2] float4 (ntile = 2^logNt tiles of 2^logTt samples, Mb = 2^logMb runs per tile, run t2 of tile
+//   `tile` = output positions tile*Tt + (t2 << logMa) ...); nkeep / nfilt_pos: the kept window of a part
+int fold_segment_combine(dspsr_amd_fold* f, const float* msum, uint32_t chan0, uint32_t nchan, uint32_t npart, uint32_t nkeep,
+                         uint32_t nfilt_pos, int logTt, int logMa, int logMb, const uint32_t* d_bin_start, const dspsr_amd::Interval* d_iv);
 // profile += sum of `nseg` partial profiles (packed [seg][chan][npol][nbin][ndim]) in order: segmented fused launches
 int fold_combine_partials(dspsr_amd_fold* f, const float* part, uint32_t nseg, uint32_t chan0, uint32_t nchan);

@@ -152,8 +152,13 @@ int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, const float* i
  *   2  inside the last pass with the parts of a launch cut into runs folded by different workgroups (8 .. ncu-1 tiles):
  *      run 0 continues the profile, the other runs go to partial profiles added in run order after the launch -- sums
  *      re-associated per run, equal to the time-order sums to float rounding, deterministic;
- *   0  Detection and Fold as separate launches on a block owned by the filterbank object (four-pass geometry, fewer than 8
- *      tiles, DSPSR_AMD_FUSED_NEVER).  Plans with runs of >= 64 samples per bin always take this path (fold.hip).
+ *   3  four-pass geometry (freq_res > 8192, dsp::Convolution shapes) and phase bins of >= 64 samples: the second inverse pass
+ *      reduces every run of 32 consecutive output samples it holds to (at most two) piece sums, a second kernel adds the
+ *      pieces of each (channel, bin) in time order -- re-associated like the long-run fold (fold.hip), deterministic; the
+ *      detected time series never reaches HBM.  Plans that do not qualify (narrow bins, zero weights, partial folds) take 0;
+ *   0  Detection and Fold as separate launches on a block owned by the filterbank object (fewer than 8 tiles,
+ *      DSPSR_AMD_FUSED_NEVER, or what the other modes turn down).  Three-pass plans with runs of >= 640 samples per bin
+ *      take this path too (fold.hip).
  * DSPSR_AMD_FUSED_ALWAYS forces mode 1 on any three-pass geometry. */
 int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb);
 int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const float* in_f32_dev, uint64_t in_chan_stride,

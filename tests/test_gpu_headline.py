@@ -209,7 +209,7 @@ def test_cfg1_pipeline_against_oracle(oracle, gpu):
     cfg = pipeline.Config(nchan=64, dispersion_measure=67.99, nbin=512, folding_period=0.0, freq_res=16384, ndim=4,
                           parts_per_block=6, max_parts=4)
     lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream, polyco=pipeline.Polyco(polyco_text))
-    assert not lt.fused_fold                                   # four-pass geometry: Detection + Fold as separate launches
+    assert lt.fused_mode == 3                                   # four-pass geometry, wide bins: segment sums in the last inverse pass
     nblocks, chans = 2, [0, 1, 31, 62, 63]
     step = cfg.parts_per_block * lt.nsamp_step
     raw = _noise_block(2 * (nblocks * step + lt.nsamp_overlap), seed=23)

@@ -275,9 +275,10 @@ def test_edge_cases_empty_and_ragged(oracle, gpu):
     eng.perform_fold(fold, 0, dspsr_amd.COHERENCE, raw=raw, scale=1.0)             # zero parts, empty plan
     assert float(np.abs(fold.synch()).max()) == 0.0
     eng.close()
-    # perform_fold on a four-pass geometry: not fused, the library runs Detection and Fold itself -- same sums
+    # perform_fold on a four-pass geometry with NARROW phase bins (4.9 samples each): mode 3 applies to wide bins only, so
+    # the library runs Detection and the exact Fold itself -- same sums
     big = dspsr_amd.FilterbankEngine(ctx).setup(2, 16384, 100, 100, 1, 2, True, None, max_parts=1)
-    assert not big.fold_is_fused()
+    assert big.fold_is_fused() == 3
     nk = 16384 - 200
     braw = torch.from_numpy(_raw(1 << 16, seed=9)).cuda()
     f2, f3 = dspsr_amd.FoldEngine(ctx), dspsr_amd.FoldEngine(ctx)
@@ -1071,6 +1072,67 @@ def test_fold_long_runs_reassociated(oracle, gpu, ndim, npol):
     want = np.zeros((nchan, npol, nbin, ndim), np.float64)
     np.add.at(want, (slice(None), slice(None), plan), det[:, :, idat_start:idat_start + ndat_fold, :].astype(np.float64))
     assert np.abs(res[0] - want).max() <= 2e-6 * np.abs(want).max()
+
+
+def test_four_pass_fused_fold_segment_sums(oracle, gpu):
+    """fold_is_fused() == 3: four-pass geometry (freq_res 16384 = 64 x 256, the dsp::Convolution shapes) with wide phase bins.
+    The second inverse pass leaves the sums of the 32-sample runs it holds (cut at phase-bin boundaries), a second kernel adds
+    them per (channel, bin) in time order.  Against perform_detect + the long-run Fold: hits identical, sums equal to float
+    rounding (both re-associate, with different micro-block grids); against a float64 fold of the detected samples <= 2e-6
+    of the profile maximum; two runs bit-identical; over several calls and launch groups (the profile is re-loaded);
+    plans that do not qualify -- a zero weight (gap), bins narrower than a run -- take the separate launches: same sums."""
+    dspsr_amd, ctx = gpu
+    o = oracle
+    C, M, nfilt, nbin = 4, 16384, (301, 212), 64
+    N, nkeep = C * M, M - sum(nfilt)
+    step, ovl = 2 * (N - sum(nfilt) * C), 2 * sum(nfilt) * C
+    npart, ncall = 5, 2
+    rng = np.random.default_rng(31)
+    kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, N)).astype(np.complex64)
+    eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, 2, True, kernel, max_parts=2)
+    assert eng.fold_is_fused() == 3
+    ndat = npart * nkeep
+    det = torch.zeros((C, 1, 4 * ndat), dtype=torch.float32, device="cuda")
+    for label, pps, weights in (("wide bins", 1.0 / (nbin * 700.3), None), ("a zero weight", 1.0 / (nbin * 700.3), "gap"),
+                                ("narrow bins", 1.0 / (nbin * 9.7), None)):
+        fused, sep, again = dspsr_amd.FoldEngine(ctx), dspsr_amd.FoldEngine(ctx), dspsr_amd.FoldEngine(ctx)
+        hits = [np.zeros(nbin, np.uint32) for _ in range(3)]
+        want = np.zeros((C, nbin, 4), np.float64)
+        for f in (fused, sep, again):
+            f.set_shape(C, 1, 4, nbin)
+        for call in range(ncall):
+            raw = torch.from_numpy(_raw(npart * step + ovl, seed=300 + call)).cuda()
+            phi = (0.21 + call * ndat * pps) % 1.0
+            w = None
+            if weights == "gap":
+                w = np.ones((ndat + 511) // 512, np.uint32)
+                w[3] = 0
+            for k, f in enumerate((fused, sep, again)):
+                f.set_nbin(nbin)
+                f.set_ndat(ndat, 0)
+                f.set_bins(phi, pps, ndat, 0, hits[k], weights=w, ndatperweight=512 if w is not None else 0)
+            eng.perform_detect(det, npart, dspsr_amd.COHERENCE, 4, raw=raw, scale=float(o.S8))
+            sep.fold(det)
+            eng.perform_fold(fused, npart, dspsr_amd.COHERENCE, raw=raw, scale=float(o.S8))
+            eng.perform_fold(again, npart, dspsr_amd.COHERENCE, raw=raw, scale=float(o.S8))
+            plan = o.fold_binplan(phi, pps, nbin, ndat) if w is None else o.fold_binplan_weighted(phi, pps, nbin, 0, ndat, w, 512, 0)
+            d = det.view(C, ndat, 4).cpu().numpy().astype(np.float64)
+            keep = plan < nbin
+            for c in range(C):
+                np.add.at(want[c], plan[keep], d[c][keep])
+        a, b, c2 = fused.synch().reshape(C, nbin, 4), sep.synch().reshape(C, nbin, 4), again.synch().reshape(C, nbin, 4)
+        assert np.array_equal(hits[0], hits[1]) and int(hits[0].sum()) == (ncall * ndat if w is None else ncall * (ndat - 512)), label
+        scale = np.abs(want).max()
+        assert scale > 0 and np.array_equal(a, c2), label                         # deterministic
+        # (narrow bins: the exact time-order float32 chain of ~2500 samples per bin, i.e. the CPU loop's own rounding)
+        tol = 5e-6 if label == "narrow bins" else 2e-6
+        assert np.abs(a - want).max() <= tol * scale, (label, np.abs(a - want).max() / scale)
+        assert np.abs(b - want).max() <= tol * scale, label
+        if label != "wide bins":
+            assert np.array_equal(a, b), label                                     # the fallback IS Detection + Fold
+        for f in (fused, sep, again):
+            f.close()
+    eng.close()
 
 
 @pytest.mark.parametrize("C,M,nfilt,nbin,real", [(512, 512, (27, 27), 1024, False),      # cfg4: 32 tiles of 16 channels
