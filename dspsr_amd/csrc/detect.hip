@@ -39,6 +39,36 @@ __global__ void k_polarimetry(const int state, const uint32_t ndim, const float*
   }
 }
 
+// ndim 2, two samples per thread: 16-byte loads of both polarisations, 16-byte stores of both planes (the layout the GPU
+// pipeline uses, in place, LoadToFold1.C:545-546,1105-1109).  Per-lane access width matters on this chip (8 B per lane streams
+// at 5.6 TB/s, 16 B at 7.1: tools/load_width_probe.hip).  Same expressions as k_polarimetry: identical results.
+__global__ __launch_bounds__(256) void k_polarimetry2x(const int state, const float* in, const uint64_t in_chan_stride,
+                                                       const uint64_t in_pol_stride, float* out, const uint64_t out_chan_stride,
+                                                       const uint64_t out_pol_stride, const uint64_t npair)
+{
+  const uint32_t chan = blockIdx.y;
+  const float4* p = (const float4*)(in + chan * in_chan_stride);
+  const float4* q = (const float4*)(in + chan * in_chan_stride + in_pol_stride);
+  float4* o0 = (float4*)(out + chan * out_chan_stride);
+  float4* o1 = (float4*)(out + chan * out_chan_stride + out_pol_stride);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npair; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float4 a = p[i], b = q[i];
+    float r[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const float ax = h ? a.z : a.x, ay = h ? a.w : a.y, bx = h ? b.z : b.x, by = h ? b.w : b.y;
+      const float pp = ax * ax + ay * ay;
+      const float qq = bx * bx + by * by;
+      const float re = ax * bx + ay * by;
+      const float im = ax * by - ay * bx;
+      r[h][0] = pp; r[h][1] = qq; r[h][2] = re; r[h][3] = im;
+      if (state == DSPSR_AMD_STOKES) { r[h][0] = pp + qq; r[h][1] = pp - qq; r[h][2] = 2.0f * re; r[h][3] = 2.0f * im; }
+    }
+    o0[i] = make_float4(r[0][0], r[0][1], r[1][0], r[1][1]);
+    o1[i] = make_float4(r[0][2], r[0][3], r[1][2], r[1][3]);
+  }
+}
+
 __global__ void k_square_law(const int intensity, const uint32_t npol, const float* __restrict__ in,
                              const uint64_t in_chan_stride, const uint64_t in_pol_stride, float* __restrict__ out,
                              const uint64_t out_chan_stride, const uint64_t out_pol_stride, const uint64_t ndat)
@@ -76,10 +106,19 @@ extern "C" int dspsr_amd_detect_polarimetry(dspsr_amd_ctx* ctx, int state, uint3
                     "dspsr_amd_detect_polarimetry: in-place only when ndim==2 (Detection.C:358-366)");
   if (ndat == 0 || nchan == 0) return DSPSR_AMD_OK;
   const uint32_t threads = 256;
-  uint64_t bx = (ndat + threads - 1) / threads;
-  if (bx > 4096) bx = 4096;
-  hipLaunchKernelGGL(k_polarimetry, dim3((uint32_t)bx, nchan), dim3(threads), 0, ctx->stream, state, ndim, in_dev,
-                     in_chan_stride, in_pol_stride, out_dev, out_chan_stride, out_pol_stride, ndat);
+  const bool vec = ndim == 2 && (ndat % 2) == 0 && ((uintptr_t)in_dev % 16) == 0 && ((uintptr_t)out_dev % 16) == 0 &&
+                   (in_chan_stride % 4) == 0 && (in_pol_stride % 4) == 0 && (out_chan_stride % 4) == 0 && (out_pol_stride % 4) == 0;
+  if (vec) {
+    uint64_t bx = (ndat / 2 + threads - 1) / threads;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(k_polarimetry2x, dim3((uint32_t)bx, nchan), dim3(threads), 0, ctx->stream, state, in_dev, in_chan_stride,
+                       in_pol_stride, out_dev, out_chan_stride, out_pol_stride, ndat / 2);
+  } else {
+    uint64_t bx = (ndat + threads - 1) / threads;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(k_polarimetry, dim3((uint32_t)bx, nchan), dim3(threads), 0, ctx->stream, state, ndim, in_dev,
+                       in_chan_stride, in_pol_stride, out_dev, out_chan_stride, out_pol_stride, ndat);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_detect_polarimetry: %s", hipGetErrorString(e));
   return DSPSR_AMD_OK;

@@ -327,6 +327,10 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
 // table (the remaining low bits of j), both correctly rounded -> about 1.2e-7 relative error.
 // NT twiddles exp(-2*pi*i*j[q]/2^logL) at once: all table loads are issued back to back (one memory round trip)
 // and only then combined -- evaluating them one by one costs a dependent L1/L2 round trip each
+#ifndef FB_FT_ROWS             // tile of k_float_transpose (rows x columns of 8-byte elements through LDS)
+#define FB_FT_ROWS 64
+#define FB_FT_COLS 64
+#endif
 #ifndef FB_SPLIT
 #define FB_SPLIT 0             // 1: pass 1 with two staggered four-wave groups per workgroup (see k_fwd_cols): correct (the whole
 #endif                         //    GPU suite passes with it) and exactly as fast -- profiles/r03_experiments.txt item 5; off
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(256) void k_raw_transpose(const FbGeom g, const FbI
 //   Rt[part][seq][tile][na][T1]   (lives in the X scratch, which is idle until pass 2 writes it)
 __global__ __launch_bounds__(256) void k_float_transpose(const FbGeom g, const FbIn in, cf* __restrict__ Rt, const uint64_t part0)
 {
-  constexpr uint32_t ROWS = 64, COLS = 64, PITCH = COLS + 1;
+  constexpr uint32_t ROWS = FB_FT_ROWS, COLS = FB_FT_COLS, PITCH = COLS + 1;
   __shared__ cf sm[ROWS * PITCH];
   const uint32_t tid = threadIdx.x;
   const uint32_t M = 1u << g.logM, Rr = 1u << g.logR;
@@ -2509,7 +2513,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         ci.kind = 3;
         ci.base = fb->Rt;
       } else if (pretf) {
-        fb_launch_float_transpose(dim3(Rr / 64, (M + 63) / 64, nb * fb->nseq), ctx->stream, g, ci, fb->X, part0);
+        fb_launch_float_transpose(dim3(Rr / FB_FT_COLS, (M + FB_FT_ROWS - 1) / FB_FT_ROWS, nb * fb->nseq), ctx->stream, g, ci, fb->X, part0);
         ci.kind = 5;
         ci.base = fb->X;
       }
