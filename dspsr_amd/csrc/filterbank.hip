@@ -327,7 +327,8 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
 // table (the remaining low bits of j), both correctly rounded -> about 1.2e-7 relative error.
 // NT twiddles exp(-2*pi*i*j[q]/2^logL) at once: all table loads are issued back to back (one memory round trip)
 // and only then combined -- evaluating them one by one costs a dependent L1/L2 round trip each
-#ifndef FB_FT_ROWS             // tile of k_float_transpose (rows x columns of 8-byte elements through LDS)
+#ifndef FB_FT_ROWS             // tile of k_float_transpose (rows x columns of 8-byte elements through LDS).  Only 64 x 64 is
+                               // validated: experiment builds with 32 x 128 and 16 x 256 faulted on the device (r03_experiments.txt)
 #define FB_FT_ROWS 64
 #define FB_FT_COLS 64
 #endif
