@@ -94,6 +94,7 @@ SYMBOLS = {
     "dspsr_amd_fold_set_bins": (_i, [_vp, _d, _d, _u64, _u64, _vp, C.POINTER(_u64)]),
     "dspsr_amd_fold_set_bins_weighted": (_i, [_vp, _d, _d, _u64, _u64, _vp, _u64, _u64, _u64, _vp, C.POINTER(_u64)]),
     "dspsr_amd_fold_fold": (_i, [_vp, _vp, _u64, _u64]),
+    "dspsr_amd_fold_fold_zeroed": (_i, [_vp, _vp, _u64, _u64, _vp]),
     "dspsr_amd_fold_profiles_dev": (_vp, [_vp]),
     "dspsr_amd_fold_get_ndat_folded": (_u64, [_vp]),
     "dspsr_amd_fold_zero": (_i, [_vp]),

@@ -266,6 +266,25 @@ __global__ __launch_bounds__(256) void k_fold_combine(float* __restrict__ prof, 
   }
 }
 
+// Zeroed samples (Fold.C:853-866, FoldCUDA.cu:415-470 fold1bin*hits): when the input carries zeroed (RFI-excised) samples
+// the number of samples a bin really received differs from channel to channel, so hits[] is kept per channel and counts,
+// for polarisation 0, the samples whose first float is not zero.  One thread per (channel, bin) walks the bin's intervals.
+__global__ __launch_bounds__(256) void k_fold_count_hits(const float* __restrict__ in, const uint64_t chan_stride, const uint32_t ndim,
+                                                         uint32_t* __restrict__ hits, const uint32_t nbin,
+                                                         const uint32_t* __restrict__ bin_start, const Interval* __restrict__ iv)
+{
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (b >= nbin) return;
+  const float* __restrict__ row = in + c * chan_stride;
+  uint32_t n = 0;
+  for (uint32_t i = bin_start[b]; i < bin_start[b + 1]; i++) {
+    const Interval v = iv[i];
+    const float* __restrict__ x = row + v.offset * ndim;
+    for (uint32_t h = 0; h < v.hits; h++) n += x[(uint64_t)h * ndim] != 0.0f;
+  }
+  hits[(uint64_t)c * nbin + b] += n;
+}
+
 // Four-pass fused fold, second half: thread (chan, bin) walks the bin's intervals in time order and adds the piece sums
 // k_inv_b<., true> left for every Tt-sample segment the interval covers: piece A of a segment entered at its first kept
 // sample, piece B of a segment entered behind its cut (fold_internal.h).  One dependent chain of float4 adds per
@@ -280,7 +299,7 @@ __global__ __launch_bounds__(256) void k_fold_segsum(float* __restrict__ prof, c
   const uint32_t i0 = bin_start[b], i1 = bin_start[b + 1];
   if (i0 == i1) return;
   const int logNt = logMa - logTt;                        // tiles (blocks of Tt values of t1) per channel
-  const uint32_t Tt = 1u << logTt, hi = nfilt_pos + nkeep;
+  const uint32_t hi = nfilt_pos + nkeep;
   float4* __restrict__ pp = (float4*)(prof + (uint64_t)c * prof_span) + b;
   float4 acc = *pp;
   const float4* __restrict__ mc = msum + (((uint64_t)c * npart) << (logNt + logMb + 1));
@@ -569,8 +588,24 @@ extern "C" int dspsr_amd_fold_zero(dspsr_amd_fold* f)
   return DSPSR_AMD_OK;
 }
 
+static int fold_fold_impl(dspsr_amd_fold* f, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
+                          uint32_t* hits_dev);
+
 extern "C" int dspsr_amd_fold_fold(dspsr_amd_fold* f, const float* in_dev, uint64_t in_chan_stride,
                                    uint64_t in_pol_stride)
+{
+  return fold_fold_impl(f, in_dev, in_chan_stride, in_pol_stride, nullptr);
+}
+
+extern "C" int dspsr_amd_fold_fold_zeroed(dspsr_amd_fold* f, const float* in_dev, uint64_t in_chan_stride,
+                                          uint64_t in_pol_stride, uint32_t* hits_dev)
+{
+  if (!hits_dev) return DSPSR_AMD_EINVAL;
+  return fold_fold_impl(f, in_dev, in_chan_stride, in_pol_stride, hits_dev);
+}
+
+static int fold_fold_impl(dspsr_amd_fold* f, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
+                          uint32_t* hits_dev)
 {
   if (!f || !in_dev) return DSPSR_AMD_EINVAL;
   dspsr_amd_ctx* ctx = f->ctx;
@@ -681,6 +716,9 @@ extern "C" int dspsr_amd_fold_fold(dspsr_amd_fold* f, const float* in_dev, uint6
       hipLaunchKernelGGL(k_fold_direct<1>, grid, dim3(threads), 0, ctx->stream, in_dev, in_chan_stride,
                          in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv);
   }
+  if (hits_dev)      // per-channel hits of a zeroed input: polarisation 0, first float of every planned sample
+    hipLaunchKernelGGL(k_fold_count_hits, dim3((nbin + 255) / 256, f->nchan), dim3(256), 0, ctx->stream, in_dev, in_chan_stride, f->ndim,
+                       hits_dev, nbin, sl.d_bin_start, sl.d_iv);
   e = hipGetLastError();
   if (e == hipSuccess) e = hipEventRecord(sl.done, ctx->stream);
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: %s", hipGetErrorString(e));

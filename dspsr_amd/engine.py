@@ -489,6 +489,14 @@ class FoldEngine:
         cs, ps = _strides3(inp)
         _check(self.ctx.handle, lib.dspsr_amd_fold_fold(self.handle, inp.data_ptr(), cs, ps), "dspsr_amd_fold_fold")
 
+    def fold_zeroed(self, inp, hits_dev):
+        """fold() of an input with zeroed samples: hits_dev (uint32 device tensor [nchan][nbin]) counts, per channel, the
+        planned samples of polarisation 0 whose first float is not zero (Fold.C:853-866)."""
+        cs, ps = _strides3(inp)
+        assert hits_dev.is_contiguous() and hits_dev.numel() == self.shape[0] * self.shape[2]
+        _check(self.ctx.handle, lib.dspsr_amd_fold_fold_zeroed(self.handle, inp.data_ptr(), cs, ps, hits_dev.data_ptr()),
+               "dspsr_amd_fold_fold_zeroed")
+
     def get_profiles_ptr(self):
         return lib.dspsr_amd_fold_profiles_dev(self.handle)
 

@@ -433,7 +433,8 @@ namespace HIP
   class FoldEngine : public dsp::Fold::Engine
   {
   public:
-    FoldEngine (dspsr_amd_ctx* _ctx, Chain* _chain = 0) : ctx (_ctx), fold_handle (0), chain (_chain), plan_ndat (0), plan_idat_start (0)
+    FoldEngine (dspsr_amd_ctx* _ctx, Chain* _chain = 0)
+      : ctx (_ctx), fold_handle (0), chain (_chain), plan_ndat (0), plan_idat_start (0), d_hits (0), d_hits_size (0)
     {
       use_set_bins = true;                       // plan built inside the library (Fold.C:730-740)
       check (ctx, dspsr_amd_fold_create (ctx, &fold_handle), "HIP::FoldEngine");
@@ -441,7 +442,7 @@ namespace HIP
       d_profiles->set_memory (new DeviceMemory (ctx));
       synchronized = true;                       // no data on either the host or the device (FoldCUDA.cu:52-53)
     }
-    ~FoldEngine () { dspsr_amd_fold_destroy (fold_handle); }
+    ~FoldEngine () { if (d_hits) dspsr_amd_free (ctx, d_hits); dspsr_amd_fold_destroy (fold_handle); }
 
     void set_nbin (unsigned nbin)
     { nbin_hits.assign (nbin, 0); check (ctx, dspsr_amd_fold_set_nbin (fold_handle, nbin), "HIP::FoldEngine::set_nbin"); }
@@ -493,6 +494,25 @@ namespace HIP
       }
       else if (chain)
         chain->flush ();
+      if (zeroed_samples && hits_nchan == nchan)
+      {
+        // the input carries zeroed (RFI-excised) samples: hits[] per channel, counted on the device from the data
+        // (Fold.C:853-866; CUDA twin fold1bin*hits, FoldCUDA.cu:415-576,622 with hits_on_gpu).  The counts live in a device
+        // buffer of this engine and are added to the host PhaseSeries' hits in synch()
+        const uint64_t nhits = uint64_t (nchan) * d_profiles->get_nbin ();
+        if (nhits != d_hits_size)
+        {
+          if (d_hits) check (ctx, dspsr_amd_free (ctx, d_hits), "HIP::FoldEngine::fold");
+          void* p = 0;
+          check (ctx, dspsr_amd_malloc (ctx, nhits * sizeof (uint32_t), &p), "HIP::FoldEngine::fold");
+          check (ctx, dspsr_amd_zero (ctx, p, nhits * sizeof (uint32_t)), "HIP::FoldEngine::fold");
+          d_hits = (uint32_t*) p; d_hits_size = nhits;
+        }
+        check (ctx, dspsr_amd_fold_fold_zeroed (fold_handle, input, uint64_t (npol) * input_span, input_span, d_hits),
+               "HIP::FoldEngine::fold");
+        synchronized = false;
+        return;
+      }
       // rows of the input are input_span floats apart, (ichan*npol + ipol)-th row, as fold1bin* index them
       check (ctx, dspsr_amd_fold_fold (fold_handle, input, uint64_t (npol) * input_span, input_span),
              "HIP::FoldEngine::fold");
@@ -508,11 +528,20 @@ namespace HIP
       out->copy_configuration (d_profiles);
       check (ctx, dspsr_amd_copy (ctx, out->internal_get_buffer (), d_profiles->internal_get_buffer (),
                                   d_profiles->internal_get_size (), DSPSR_AMD_D2H), "HIP::FoldEngine::synch");
+      if (d_hits && out->get_hits_nchan () * uint64_t (out->get_nbin ()) == d_hits_size)
+        // zeroed samples: the per-channel counts made on the device (TransferPhaseSeriesCUDA with transfer_hits)
+        check (ctx, dspsr_amd_copy (ctx, out->get_hits (0), d_hits, d_hits_size * sizeof (uint32_t), DSPSR_AMD_D2H),
+               "HIP::FoldEngine::synch");
       check (ctx, dspsr_amd_stream_sync (ctx), "HIP::FoldEngine::synch");
       synchronized = true;
     }
 
-    void zero () { get_profiles ()->zero (); }   // dsp/FoldCUDA.h:49: PhaseSeries::zero through its DeviceMemory
+    //! dsp/FoldCUDA.h:49: PhaseSeries::zero through its DeviceMemory (and the device hits of a zeroed input)
+    void zero ()
+    {
+      get_profiles ()->zero ();
+      if (d_hits) check (ctx, dspsr_amd_zero (ctx, d_hits, d_hits_size * sizeof (uint32_t)), "HIP::FoldEngine::zero");
+    }
 
   protected:
     dspsr_amd_ctx* ctx;
@@ -521,6 +550,8 @@ namespace HIP
     std::vector<unsigned> nbin_hits;
     Reference::To<Chain> chain;
     uint64_t plan_ndat, plan_idat_start;
+    uint32_t* d_hits;                            // zeroed samples: [nchan][nbin] counts on the device
+    uint64_t d_hits_size;
   };
 }
 

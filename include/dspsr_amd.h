@@ -219,6 +219,12 @@ int dspsr_amd_fold_set_bins_weighted(dspsr_amd_fold* fold, double phi, double ph
 /* fold(): accumulate in_dev rows (get_datptr(ichan,ipol) = in_dev + ichan*in_chan_stride + ipol*in_pol_stride)
  * into the device profile using the plan built since the last set_nbin (FoldCUDA.cu:586-697) */
 int dspsr_amd_fold_fold(dspsr_amd_fold* fold, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride);
+/* fold() of an input that carries zeroed (RFI-excised) samples -- Fold::Engine::zeroed_samples with hits_nchan == nchan
+ * (Fold.C:853-866, fold1bin*hits FoldCUDA.cu:415-576,622): as dspsr_amd_fold_fold, and hits_dev[ichan*nbin + ibin] (device,
+ * uint32) is incremented by the number of planned samples of polarisation 0 whose first float is not zero.  The hook the
+ * reference's spectral-kurtosis chain needs; the excision itself is not part of this path. */
+int dspsr_amd_fold_fold_zeroed(dspsr_amd_fold* fold, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
+                               uint32_t* hits_dev);
 float* dspsr_amd_fold_profiles_dev(dspsr_amd_fold* fold);   /* device [nchan][npol][nbin][ndim] (get_profiles) */
 uint64_t dspsr_amd_fold_get_ndat_folded(const dspsr_amd_fold* fold);
 int dspsr_amd_fold_zero(dspsr_amd_fold* fold);                                            /* Engine::zero */

@@ -281,6 +281,48 @@ int main ()
     fold.fold (0.5, pfold, 10, 100);  cpu_fold (0.5, 10, 100);
     if (check_result ("after reset")) return 1;
 
+    // ---------------------------------------------------------------- zeroed samples: per-channel hits counted on the device
+    {
+      // RFI-excised input (TimeSeries::get_zeroed_data, hits_nchan == nchan): Fold.C:853-866 counts, per channel, the samples
+      // of polarisation 0 whose first float is not zero; CUDA twin fold1bin*hits (FoldCUDA.cu:415-576)
+      dsp::TimeSeries z_h, z_d;
+      z_h.internal_match (&out_d); z_d.set_memory (dmem); z_d.internal_match (&out_d);
+      d2h (ctx, z_h, out_d);
+      for (unsigned c = 0; c < C; c++) for (uint64_t i = c; i < ndat; i += 3 + c)          // another pattern in every channel
+        for (unsigned p = 0; p < 2; p++) z_h.get_datptr (c, p)[2 * i] = z_h.get_datptr (c, p)[2 * i + 1] = 0.0f;
+      h2d (ctx, z_d, z_h);
+      z_d.set_zeroed_data (true);
+      dsp::Fold zfold;
+      HIP::FoldEngine* zeng = new HIP::FoldEngine (ctx);
+      zeng->get_profiles ()->set_hits_nchan (C);
+      zfold.set_input (&z_d); zfold.set_engine (zeng); zfold.set_nbin (nbin);
+      zfold.prepare_output ();
+      zfold.fold (0.37, pfold, 3, 70);
+      zfold.fold (0.81, pfold, 73, ndat - 73);
+      dsp::PhaseSeries* zres = zfold.get_result ();
+      REQUIRE (zres->get_hits_nchan () == C, "zeroed samples: result hits_nchan");
+      std::vector<unsigned> zh (size_t (C) * nbin, 0);
+      std::vector<float> zp (size_t (C) * 2 * nbin * 2, 0.0f);
+      auto zcpu = [&] (double phi, uint64_t i0, uint64_t n) {
+        for (uint64_t i = i0; i < i0 + n; i++) {
+          phi -= floor (phi);
+          const unsigned ibin = unsigned (phi * double (nbin));
+          phi += pps;
+          for (unsigned c = 0; c < C; c++) {
+            if (z_h.get_datptr (c, 0)[2 * i] != 0) zh[size_t (c) * nbin + ibin]++;
+            for (unsigned p = 0; p < 2; p++) for (unsigned d = 0; d < 2; d++)
+              zp[((size_t (c) * 2 + p) * nbin + ibin) * 2 + d] += z_h.get_datptr (c, p)[2 * i + d];
+          }
+        }
+      };
+      zcpu (0.37, 3, 70); zcpu (0.81, 73, ndat - 73);
+      for (unsigned c = 0; c < C; c++) for (unsigned b = 0; b < nbin; b++)
+        REQUIRE (zres->get_hits (c)[b] == zh[size_t (c) * nbin + b], "zeroed samples: hits[%u][%u] = %u != %u", c, b, zres->get_hits (c)[b], zh[size_t (c) * nbin + b]);
+      for (unsigned c = 0; c < C; c++) for (unsigned p = 0; p < 2; p++) for (unsigned k = 0; k < nbin * 2; k++)
+        REQUIRE (zres->get_datptr (c, p)[k] == zp[(size_t (c) * 2 + p) * nbin * 2 + k], "zeroed samples: profile[%u][%u][%u]", c, p, k);
+      printf ("zeroed samples: per-channel hits and sums == CPU loop\n");
+    }
+
     // ---------------------------------------------------------------- deferred mode + raw side channel
     if (deferred_section (ctx, dmem)) return 1;
 

@@ -62,7 +62,8 @@ namespace dsp {
     virtual void internal_match (const TimeSeries* other)                          // TimeSeries.h:88
     { Observation::copy_configuration (other); resize (other->get_ndat ()); }
     virtual void zero () { if (buffer) memory->do_zero (buffer, size); }           // TimeSeries::zero
-    bool get_zeroed_data () const { return false; }
+    bool get_zeroed_data () const { return zeroed_data; }                           // TimeSeries.h: set by the RFI excision
+    void set_zeroed_data (bool z) { zeroed_data = z; }
     int64_t get_input_sample () const { return input_sample; }                     // TimeSeries.h:122-125
     void set_input_sample (uint64_t sample) { input_sample = (int64_t) sample; }
     //! TimeSeries::reshape (used by an in-place Detection, Detection.C:190-200): same buffer, other (npol, ndim) split
@@ -72,6 +73,7 @@ namespace dsp {
     unsigned char* buffer;
     uint64_t size, span;
     int64_t input_sample = -1;
+    bool zeroed_data = false;
   };
   class BitSeries : public Observation {                    // Kernel/Classes/dsp/BitSeries.h:30-125: the packed block
   public:
@@ -105,18 +107,20 @@ namespace dsp {
   public:
     PhaseSeries () : integration_length (0), ndat_total (0) {}
     unsigned get_nbin () const { return (unsigned) ndat; }
-    void resize (uint64_t nbin) { TimeSeries::resize (nbin); hits.resize (nbin, 0); }          // PhaseSeries.C:83-110
-    unsigned* get_hits (unsigned = 0) { return hits.empty () ? 0 : &hits[0]; }
-    unsigned get_hits_nchan () const { return 1; }
+    void resize (uint64_t nbin) { TimeSeries::resize (nbin); hits.resize (nbin * hits_nchan, 0); }   // PhaseSeries.C:83-110
+    unsigned* get_hits (unsigned ichan = 0) { return hits.empty () ? 0 : &hits[0] + uint64_t (ichan) * ndat; }
+    unsigned get_hits_nchan () const { return hits_nchan; }
+    void set_hits_nchan (unsigned n) { hits_nchan = n; }                                        // PhaseSeries.h: per-channel hits
     void zero () { integration_length = 0; ndat_total = 0; hits.assign (hits.size (), 0); TimeSeries::zero (); }  // PhaseSeries.C:239-256
     void copy_configuration (const Observation* c)                                              // PhaseSeries.C:258-318
     {
       TimeSeries::copy_configuration (c);
       const PhaseSeries* like = dynamic_cast<const PhaseSeries*> (c);
-      if (like) { integration_length = like->integration_length; ndat_total = like->ndat_total; hits = like->hits; }
+      if (like) { integration_length = like->integration_length; ndat_total = like->ndat_total; hits_nchan = like->hits_nchan; hits = like->hits; }
     }
     double integration_length;
     uint64_t ndat_total;
+    unsigned hits_nchan = 1;
     std::vector<unsigned> hits;
   };
 }

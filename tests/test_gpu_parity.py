@@ -1074,6 +1074,38 @@ def test_fold_long_runs_reassociated(oracle, gpu, ndim, npol):
     assert np.abs(res[0] - want).max() <= 2e-6 * np.abs(want).max()
 
 
+def test_fold_zeroed_samples_per_channel_hits(oracle, gpu):
+    """dspsr_amd_fold_fold_zeroed: an input with zeroed (RFI-excised) samples keeps hits[] per channel -- the planned samples of
+    polarisation 0 whose first float is not zero (Fold.C:853-866, fold1bin*hits FoldCUDA.cu:415-576); the sums are those of
+    the plain fold."""
+    dspsr_amd, ctx = gpu
+    o = oracle
+    nchan, npol, ndim, nbin, ndat = 5, 2, 2, 48, 4000
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((nchan, npol, ndat, ndim)).astype(np.float32)
+    for c in range(nchan):
+        x[c, :, rng.random(ndat) < 0.1 * (c + 1)] = 0.0                 # a different excision pattern in every channel
+    det = torch.from_numpy(x.reshape(nchan, npol, ndat * ndim)).cuda()
+    hits_dev = torch.zeros((nchan, nbin), dtype=torch.int32, device="cuda")
+    f, g2 = dspsr_amd.FoldEngine(ctx), dspsr_amd.FoldEngine(ctx)
+    want = np.zeros((nchan, nbin), np.int64)
+    for phi, i0, n in ((0.3, 0, 1500), (0.77, 1500, 2500)):
+        for e in (f, g2):
+            e.set_shape(nchan, npol, ndim, nbin)
+            e.set_nbin(nbin)
+            e.set_ndat(n, i0)
+            e.set_bins(phi, 1.0 / 333.3, n, i0, np.zeros(nbin, np.uint32))
+        f.fold_zeroed(det, hits_dev)
+        g2.fold(det)
+        plan = o.fold_binplan(phi, 1.0 / 333.3, nbin, n)
+        for c in range(nchan):
+            np.add.at(want[c], plan, (x[c, 0, i0:i0 + n, 0] != 0).astype(np.int64))
+    assert np.array_equal(hits_dev.cpu().numpy().astype(np.int64), want) and want.sum() < nchan * ndat
+    assert np.array_equal(f.synch(), g2.synch())
+    f.close()
+    g2.close()
+
+
 def test_four_pass_fused_fold_segment_sums(oracle, gpu):
     """fold_is_fused() == 3: four-pass geometry (freq_res 16384 = 64 x 256, the dsp::Convolution shapes) with wide phase bins.
     The second inverse pass leaves the sums of the 32-sample runs it holds (cut at phase-bin boundaries), a second kernel adds
