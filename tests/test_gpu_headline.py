@@ -200,7 +200,8 @@ def test_headline_stokes_against_oracle(oracle, gpu):
 def test_cfg1_pipeline_against_oracle(oracle, gpu):
     """BASELINE configuration 1 as the pipeline really runs it: dspsr -F 64:D -x 16384 on the header.dada band, vela.par DM,
     512 phase bins, vela.polyco -- the FOUR-pass path (two-pass inverse, Convolution.C:338-461 geometry), Detection, and
-    the long-run fold (1090 samples per phase bin: re-associated micro-block sums, Fold.C:835-891 to rounding).
+    the long-run fold (1090 samples per phase bin: re-associated micro-block sums, Fold.C:835-891 to rounding); then the same
+    with the segment-sum fold forced (fold_is_fused() == 3, what cfg1 at its optimal response length takes).
     Against the float64 oracle on five channels: hits identical, folded profile <= 1e-5 of the profile maximum."""
     o = oracle
     from dspsr_amd import pipeline
@@ -209,7 +210,7 @@ def test_cfg1_pipeline_against_oracle(oracle, gpu):
     cfg = pipeline.Config(nchan=64, dispersion_measure=67.99, nbin=512, folding_period=0.0, freq_res=16384, ndim=4,
                           parts_per_block=6, max_parts=4)
     lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream, polyco=pipeline.Polyco(polyco_text))
-    assert lt.fused_mode == 3                                   # four-pass geometry, wide bins: segment sums in the last inverse pass
+    assert lt.fused_mode == 0     # four-pass geometry; only 1817 of 16384 samples are kept: Detection + the long-run Fold
     nblocks, chans = 2, [0, 1, 31, 62, 63]
     step = cfg.parts_per_block * lt.nsamp_step
     raw = _noise_block(2 * (nblocks * step + lt.nsamp_overlap), seed=23)
@@ -238,6 +239,18 @@ def test_cfg1_pipeline_against_oracle(oracle, gpu):
     err = np.abs(prof[chans] - ps.data[:, 0]).max() / np.abs(ps.data[..., :2]).max()
     assert err <= 1e-5, err
     lt.close()
+    ltf = pipeline.LoadToFold(pipeline.Config(**{**cfg.__dict__, "force_fused": True}), info, device=0,
+                              stream=torch.cuda.current_stream().cuda_stream, polyco=pipeline.Polyco(polyco_text))
+    assert ltf.fused_mode == 3
+    for b in range(nblocks):
+        ltf.process_block(raw[2 * b * step: 2 * (b * step + step + ltf.nsamp_overlap)])
+    ltf.finish_subint()
+    ltf.synchronize()
+    subf = ltf.subints[0]
+    assert np.array_equal(subf["hits"], ps.hits)
+    err = np.abs(subf["profile_dev"].cpu().numpy().reshape(64, 512, 4)[chans] - ps.data[:, 0]).max() / np.abs(ps.data[..., :2]).max()
+    assert err <= 1e-5, err
+    ltf.close()
 
 
 def _fb(oracle, gpu_mod, *a, **k):
