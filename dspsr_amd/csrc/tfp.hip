@@ -15,86 +15,99 @@
 namespace dspsr_amd {
 
 struct TfpParams {
-  const uint8_t* raw;      // generic 8-bit order, real, 2 pols, 1 channel: byte 2*t + p
+  const uint8_t* raw;      // generic 8-bit order, real, 2 pols, 1 channel: byte 2*t + p   (or the CASPSR 4+4 interleave)
   float* out;              // [nout][nchan][npol_out]
   uint64_t npart;          // parts available
   uint32_t sfactor;        // time scrunch factor (>= 1)
   uint32_t pscrunch;       // 1: sum the two polarisations (Intensity), 0: PPQQ
   float scale;
-  int logT;
+  int logT;                // columns of a workgroup tile = 2 polarisations x 2^(logT-1) consecutive parts
   int caspsr;
 };
 
-// (pol0, pol1) bytes of sample t: issued as independent loads and combined only when the tile is decoded, so that the
-// words of the NEXT tile stay in flight during the transform (combining here would wait for them at the prefetch)
-template <bool CASPSR> struct TfpRaw { uint32_t w[CASPSR ? 2 : 1]; };
-template <bool CASPSR> DEV TfpRaw<CASPSR> tfp_fetch(const TfpParams& p, const uint64_t t, const bool valid)
+// Round 3: the 2*nchan REAL samples of one polarisation and part are transformed as nchan COMPLEX points
+//   z[n] = x[2n] + i x[2n+1],  Z = FFT_nchan(z),  X[k] = A + w^k B,  A = (Z[k] + conj Z[nchan-k]) / 2,
+//   B = (Z[k] - conj Z[nchan-k]) / 2i,  w = exp(-i pi / nchan)          (k < nchan; the Nyquist bin is not kept)
+// instead of packing the two polarisations into one complex sequence of 2*nchan points and splitting the spectrum
+// (rounds 1-2).  Both polarisations of a part are now the two columns of a thread's butterfly pair: one 32-bit word of
+// the byte stream holds (p0[2n], p1[2n], p0[2n+1], p1[2n+1]) = (Re z0, Re z1, Im z0, Im z1), the transform is one radix-2
+// level shorter -- at nchan = 4096 exactly three radix-16 stages instead of three plus a radix-2 stage with its own LDS
+// exchange and barriers -- and the pair (Z[k], Z[nchan-k]) yields bins k AND nchan-k (X[nchan-k] = conj(A - w^k B)), so a
+// thread owns the bin pairs k <= nchan/2.  The pass is bound by its exchanged stages (0.8 TB/s of input), so the stage
+// it no longer runs is what it gains.
+
+// the (p0, p1) byte pairs of samples 2n and 2n+1 of one part: one aligned word in the generic order, two half words
+// (4 bytes apart) in the CASPSR order
+template <bool CASPSR> DEV uint32_t tfp_word(const uint8_t* img, const uint32_t t0 /* even sample index */)
 {
-  TfpRaw<CASPSR> r;
   if constexpr (CASPSR) {
-    const uint8_t* b = p.raw + (t >> 2) * 8 + (t & 3);
-    r.w[0] = valid ? b[0] : 0x80u;
-    r.w[1] = valid ? b[4] : 0x80u;
+    const uint8_t* a = img + (t0 >> 2) * 8 + (t0 & 3);
+    const uint32_t p0 = *(const uint16_t*)a, p1 = *(const uint16_t*)(a + 4);          // (p0[t0], p0[t0+1]), (p1[t0], p1[t0+1])
+    return (p0 & 0xffu) | ((p1 & 0xffu) << 8) | ((p0 >> 8) << 16) | ((p1 >> 8) << 24);
   } else {
-    r.w[0] = valid ? *(const uint16_t*)(p.raw + 2 * t) : 0x8080u;
+    return (uint32_t)*(const uint16_t*)(img + 2 * t0) | ((uint32_t)*(const uint16_t*)(img + 2 * t0 + 2) << 16);
   }
-  return r;
-}
-template <bool CASPSR> DEV uint32_t tfp_pair(const TfpRaw<CASPSR>& r)
-{
-  if constexpr (CASPSR) return (r.w[0] & 0xffu) | ((r.w[1] & 0xffu) << 8);
-  else return r.w[0] & 0xffffu;
 }
 
-// COAL: the T parts of a group are ONE contiguous range of T*L*2 bytes.  Loading it in first-stage order means 32 two-byte
-// loads per thread (128 bytes per wave instruction: 13.7 us per 16384-point group, the pass was bound by the issue of its
-// loads); instead every thread loads 16-byte pieces of the range (prefetched one group ahead, 4 registers per piece), the
-// bytes go through the -- at that moment idle -- exchange buffer, and the thread picks its 32 samples from LDS.
-// Needs a 16-byte aligned block (the host checks; otherwise the element-wise kernel runs).
-template <int LOGF, bool CASPSR, bool COAL>
+// COAL: the parts of a tile are ONE contiguous range of 2^15 bytes.  Every thread loads 16-byte pieces of the range
+// (prefetched one tile ahead, 4 registers per piece), the bytes go through the -- at that moment idle -- exchange buffer, and
+// the thread picks its 16 words from LDS.  Needs a 16-byte aligned block (the host checks; otherwise the words are loaded
+// from global memory as half words).
+template <int LOGC, bool CASPSR, bool COAL>
 __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __restrict__ tw)
 {
-  typedef FftPlan<LOGF> P;
+  typedef FftPlan<LOGC> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
   const uint32_t nt = blockDim.x;
-  const int logT = p.logT;
-  const uint32_t T = 1u << logT, L = 1u << LOGF, nchan = L >> 1;
+  const int logT = p.logT, logTp = logT - 1;                   // columns; parts per tile
+  const uint32_t Tp = 1u << logTp, C = 1u << LOGC;             // C = nchan complex points per polarisation and part
   const uint32_t npol_out = p.pscrunch ? 1 : 2;
-  // one item = the parts of one output sample, rounded up to whole column groups
   const uint64_t nout = p.npart / p.sfactor;
   const uint32_t ltw_off = lds_pad(PTS * nt) + 8;
-  ltw_fill<LOGF>(lds, ltw_off, tw, tid, nt);
-  constexpr int NB = (LOGF - 1 > 9) ? (1 << (LOGF - 1 - 9)) : 1;   // bins per thread at 512 threads
+  ltw_fill<LOGC>(lds, ltw_off, tw, tid, nt);
+  // bin pairs owned by a thread: k = tid + j*nt < C/2, paired with C-k; k = 0 is paired with C/2 (both are their own mirrors)
+  constexpr int NB = (1 << LOGC) / 2 > 512 ? (1 << LOGC) / 2 / 512 : 1;
+  float wc[NB], ws[NB];
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    // w^k = exp(-i pi k / C): argument of v_cos/v_sin in revolutions, k / 2C exact in float
+    const float x = (float)(threadIdx.x + j * nt) * __uint_as_float((uint32_t)(127 - (LOGC + 1)) << 23);
+    wc[j] = __builtin_amdgcn_cosf(x);
+    ws[j] = __builtin_amdgcn_sinf(x);
+  }
+  const float hs = 0.5f * p.scale;
 
-  // work items: groups of T consecutive parts, dealt in order so that a workgroup owns whole output samples
-  // when sfactor >= T, or several whole output samples when sfactor < T (host guarantees sfactor % T == 0
-  // or T % sfactor == 0)
-  const uint32_t groups_per_out = p.sfactor > T ? p.sfactor >> logT : 1;
-  const uint64_t nitem = p.sfactor > T ? nout : (nout * p.sfactor + T - 1) >> logT;
+  // work items: groups of Tp consecutive parts, dealt in order so that a workgroup owns whole output samples
+  // when sfactor >= Tp, or several whole output samples when sfactor < Tp (host guarantees sfactor % Tp == 0
+  // or Tp % sfactor == 0)
+  const uint32_t groups_per_out = p.sfactor > Tp ? p.sfactor >> logTp : 1;
+  const uint64_t nitem = p.sfactor > Tp ? nout : (nout * p.sfactor + Tp - 1) >> logTp;
+  const uint64_t raw_bytes = p.npart * (uint64_t)C * 4;         // 2C samples x 2 polarisations per part
 
-  auto fetch = [&](const uint64_t group, TfpRaw<CASPSR> (&ra)[NPAIR], TfpRaw<CASPSR> (&rb)[NPAIR]) {
-    const uint64_t part0 = group << logT;
+  // element i of a thread's first-stage butterfly pair: column pair (2*part_local, +1) = both polarisations, position n
+  auto elem = [&](const int g2, const int i, uint32_t& pl, uint32_t& n) {
+    const uint32_t e = first_stage_elem<LOGC>(tid, logT, g2, i);
+    pl = (e & ((1u << logT) - 1)) >> 1;
+    n = e >> logT;
+  };
+  uint32_t rw[NPAIR];                                           // non-COAL: the words of the next tile
+  auto fetch = [&](const uint64_t group) {
+    const uint64_t part0 = group << logTp;
 #pragma unroll
     for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
       for (int i = 0; i < P::R1; i++) {
-        const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
-        const uint32_t col = e & (T - 1), n = e >> logT;
-        const uint64_t pa = part0 + col, pb = pa + 1;
-        ra[(g2 / 2) * P::R1 + i] = tfp_fetch<CASPSR>(p, pa * L + n, pa < p.npart);
-        rb[(g2 / 2) * P::R1 + i] = tfp_fetch<CASPSR>(p, pb * L + n, pb < p.npart);
+        uint32_t pl, n;
+        elem(g2, i, pl, n);
+        const uint64_t part = part0 + pl;
+        rw[(g2 / 2) * P::R1 + i] = part < p.npart ? tfp_word<CASPSR>(p.raw + part * (uint64_t)C * 4, 2 * n) : 0x80808080u;
       }
   };
-
-  // the 8-bit samples of the next group are requested while the current one is transformed (register prefetch,
-  // as in the filterbank passes); past the end the loads are skipped by the part bound inside fetch()
-  TfpRaw<CASPSR> ra[NPAIR], rb[NPAIR];
-  constexpr uint32_t NCH = (PTS * 2) / 16;                 // 16-byte pieces per thread: 32 points x 2 bytes
+  constexpr uint32_t NCH = (PTS * 2) / 16;                      // 16-byte pieces per thread: 2^15 bytes per tile
   uint4 piece[NCH];
-  const uint64_t raw_bytes = p.npart * (uint64_t)L * 2;
   auto fetch_pieces = [&](const uint64_t group) {
-    const uint64_t base = (group << logT) * (uint64_t)L * 2;
+    const uint64_t base = (group << logTp) * (uint64_t)C * 4;
 #pragma unroll
     for (uint32_t r = 0; r < NCH; r++) {
       const uint64_t off = base + 16ull * (tid + r * nt);
@@ -103,18 +116,18 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
   };
   if (blockIdx.x < nitem) {
     if constexpr (COAL) fetch_pieces((uint64_t)blockIdx.x * groups_per_out);
-    else fetch((uint64_t)blockIdx.x * groups_per_out, ra, rb);
+    else fetch((uint64_t)blockIdx.x * groups_per_out);
   }
   for (uint64_t item = blockIdx.x; item < nitem; item += gridDim.x) {
-    float acc[NB][2];
+    float acc[NB][2][2];                                        // [bin pair][k / C-k][pol]
 #pragma unroll
-    for (int j = 0; j < NB; j++) acc[j][0] = acc[j][1] = 0.f;
+    for (int j = 0; j < NB; j++) acc[j][0][0] = acc[j][0][1] = acc[j][1][0] = acc[j][1][1] = 0.f;
     for (uint32_t gi = 0; gi < groups_per_out; gi++) {
       const uint64_t group = item * groups_per_out + gi;
       asm volatile("" : "+v"(tid));
       cx2 x[NPAIR];
       if constexpr (COAL) {
-        // the group's bytes, in file order, into the exchange buffer (the previous group's read-back ended with a barrier)
+        // the tile's bytes, in file order, into the exchange buffer (the previous tile's read-back ended with a barrier)
         uint8_t* img = (uint8_t*)lds;
 #pragma unroll
         for (uint32_t r = 0; r < NCH; r++) *(uint4*)(img + 16u * (tid + r * nt)) = piece[r];
@@ -123,124 +136,124 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
         for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
           for (int i = 0; i < P::R1; i++) {
-            const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
-            const uint32_t col = e & (T - 1), n = e >> logT;
-            const uint32_t sa = col * L + n, sb = sa + L;           // columns col and col + 1 (T >= 2)
-            uint32_t wa, wb;
-            if constexpr (CASPSR) {
-              const uint8_t* a = img + (sa >> 2) * 8 + (sa & 3);
-              const uint8_t* b = img + (sb >> 2) * 8 + (sb & 3);
-              wa = (uint32_t)a[0] | ((uint32_t)a[4] << 8);
-              wb = (uint32_t)b[0] | ((uint32_t)b[4] << 8);
-            } else {
-              wa = *(const uint16_t*)(img + 2 * sa);
-              wb = *(const uint16_t*)(img + 2 * sb);
-            }
-            ra[(g2 / 2) * P::R1 + i].w[0] = wa & 0xffu;
-            rb[(g2 / 2) * P::R1 + i].w[0] = wb & 0xffu;
-            if constexpr (CASPSR) {
-              ra[(g2 / 2) * P::R1 + i].w[1] = wa >> 8;
-              rb[(g2 / 2) * P::R1 + i].w[1] = wb >> 8;
-            } else {
-              ra[(g2 / 2) * P::R1 + i].w[0] = wa;
-              rb[(g2 / 2) * P::R1 + i].w[0] = wb;
-            }
+            uint32_t pl, n;
+            elem(g2, i, pl, n);
+            rw[(g2 / 2) * P::R1 + i] = tfp_word<CASPSR>(img + (pl << (LOGC + 2)), 2 * n);
           }
       }
 #pragma unroll
       for (int h = 0; h < NPAIR; h++) {
-        const uint32_t w = tfp_pair<CASPSR>(ra[h]) | (tfp_pair<CASPSR>(rb[h]) << 16);
-        x[h] = make_cx2(make_float2(((float)(int8_t)(w & 0xff) + 0.5f) * p.scale, ((float)(int8_t)((w >> 8) & 0xff) + 0.5f) * p.scale),
-                        make_float2(((float)(int8_t)((w >> 16) & 0xff) + 0.5f) * p.scale, ((float)(int8_t)(w >> 24) + 0.5f) * p.scale));
+        const uint32_t w = rw[h];                               // (p0[2n], p1[2n], p0[2n+1], p1[2n+1])
+        x[h].x = (v2f){__builtin_fmaf((float)(int8_t)(w & 0xff), p.scale, hs), __builtin_fmaf((float)(int8_t)((w >> 8) & 0xff), p.scale, hs)};
+        x[h].y = (v2f){__builtin_fmaf((float)(int8_t)((w >> 16) & 0xff), p.scale, hs), __builtin_fmaf((float)(int8_t)(w >> 24), p.scale, hs)};
       }
       {
         const uint64_t next = gi + 1 < groups_per_out ? group + 1 : (item + gridDim.x) * groups_per_out;
         if (gi + 1 < groups_per_out || item + gridDim.x < nitem) {
           if constexpr (COAL) fetch_pieces(next);
-          else fetch(next, ra, rb);
+          else fetch(next);
         }
       }
-      if constexpr (COAL) __syncthreads();      // every thread has taken its samples: the exchanges may overwrite the image
+      if constexpr (COAL) __syncthreads();      // every thread has taken its words: the exchanges may overwrite the image
       auto store = [&](const uint32_t col, const uint32_t pp, const uint32_t pstride, auto& v) {
         constexpr int R = sizeof(v) / sizeof(v[0]);
 #pragma unroll
         for (int k = 0; k < R; k++) {
           const uint32_t pos = k * pstride + pp;
-          *(float4*)&lds[lds_pad((pos << logT) | col)] = make_float4(v[k].x[0], v[k].y[0], v[k].x[1], v[k].y[1]);
+          // (Re p0, Re p1, Im p0, Im p1): the register order of the pair, and what the read-back wants for packed arithmetic
+          *(float4*)&lds[lds_pad((pos << logT) | col)] = make_float4(v[k].x[0], v[k].x[1], v[k].y[0], v[k].y[1]);
         }
       };
-      wgfft<LOGF, -1, true>(lds, ltw_off, tid, logT, x, store);
+      wgfft<LOGC, -1, true>(lds, ltw_off, tid, logT, x, store);
       __syncthreads();
-      // Hermitian split, power, time scrunch (columns = consecutive parts, added in time order)
-      const uint64_t part_first = group << logT, part_end = nout * p.sfactor;
+      // real-transform post-processing, power, time scrunch (parts added in time order)
+      const uint64_t part_first = group << logTp, part_end = nout * p.sfactor;
       const uint32_t phase_first = (uint32_t)(part_first % p.sfactor);       // wave-uniform: no division per bin
       const uint64_t out_first = part_first / p.sfactor;
-      // Whole group inside one output sample (tscrunch >= T, all parts present): no per-column bookkeeping, the columns of
-      // a bin are read two at a time (16 bytes).  0 + p0 == p0, so starting an output sample from zero gives the sums of
-      // TScrunch.C:193-200 bit for bit.
-      const bool whole = p.sfactor >= T && T >= 2 && part_first + T <= part_end;
-      if (whole) {
-        const bool emit = phase_first + T == p.sfactor;
-#pragma unroll
-        for (int j = 0; j < NB; j++) {
-          const uint32_t k = tid + j * nt;
-          if (k < nchan) {
-            const uint32_t km = (L - k) & (L - 1);
-            float s0 = phase_first == 0 ? 0.f : acc[j][0], s1 = phase_first == 0 ? 0.f : acc[j][1];
-            const uint32_t ia = lds_pad(k << logT), ib = lds_pad(km << logT);
-            for (uint32_t c = 0; c < T; c += 2) {
-              const uint32_t ca = c + ((c >> 6) << 2);          // lds_pad(e0 + c) for e0 a multiple of 64 (T >= 64) or c < 64
-              const float4 a2 = *(const float4*)&lds[T >= 64 ? ia + ca : ia + c];
-              const float4 b2 = *(const float4*)&lds[T >= 64 ? ib + ca : ib + c];
-#pragma unroll
-              for (int h = 0; h < 2; h++) {
-                const float ax = h ? a2.z : a2.x, ay = h ? a2.w : a2.y, bx = h ? b2.z : b2.x, by = h ? b2.w : b2.y;
-                const float x0r = 0.5f * (ax + bx), x0i = 0.5f * (ay - by);
-                const float x1r = 0.5f * (ay + by), x1i = 0.5f * (bx - ax);
-                float p0 = x0r * x0r; p0 += x0i * x0i;            // TFPFilterbank.C:56-59
-                float p1 = x1r * x1r; p1 += x1i * x1i;
-                if (p.pscrunch) { p0 += p1; p1 = 0.f; }
-                s0 += p0; s1 += p1;
-              }
-            }
-            acc[j][0] = s0; acc[j][1] = s1;
-            if (emit) {
-              float* o = p.out + (out_first * nchan + k) * npol_out;
-              o[0] = s0;
-              if (!p.pscrunch) o[1] = s1;
-            }
-          }
+      // powers of bins k and C-k of both polarisations (packed: .x = p0, .y = p1) from (Z[k], Z[C-k]) of one part;
+      // staged float4 = (Re p0, Re p1, Im p0, Im p1)
+      auto powers1 = [&](const float4 zk, const float4 zm, const float c, const float sn, v2f& pk, v2f& pm) {
+        const v2f zr = {zk.x, zk.y}, zi = {zk.z, zk.w}, mr = {zm.x, zm.y}, mi = {zm.z, zm.w};
+        const v2f ar = 0.5f * (zr + mr), ai = 0.5f * (zi - mi);            // A = (Z[k] + conj Z[C-k]) / 2
+        const v2f br = 0.5f * (zi + mi), bi = 0.5f * (mr - zr);            // B = (Z[k] - conj Z[C-k]) / 2i
+        const v2f wr = c * br + sn * bi, wi = c * bi - sn * br;            // w^k B,  w^k = (c, -sn)
+        const v2f xr = ar + wr, xi = ai + wi, yr = ar - wr, yi = ai - wi;  // X[k] = A + w^k B,  X[C-k] = conj(A - w^k B)
+        pk = xr * xr; pk += xi * xi;                                        // TFPFilterbank.C:56-59: Re^2 then += Im^2
+        pm = yr * yr; pm += yi * yi;
+      };
+      auto powers = [&](const uint32_t k, const uint32_t c2, const float c, const float sn, float (&pw)[2][2]) {
+        v2f pk, pm;
+        if (k == 0) {               // bins 0 and C/2 are their own mirrors: X[0] from Z[0] (w = 1), X[C/2] from Z[C/2] (w = -i)
+          const float4 z0 = *(const float4*)&lds[lds_pad(2 * c2)], zh = *(const float4*)&lds[lds_pad(((C / 2) << logT) | (2 * c2))];
+          v2f unused;
+          powers1(z0, z0, 1.0f, 0.0f, pk, unused);
+          powers1(zh, zh, 0.0f, 1.0f, pm, unused);
+        } else {
+          powers1(*(const float4*)&lds[lds_pad((k << logT) | (2 * c2))], *(const float4*)&lds[lds_pad(((C - k) << logT) | (2 * c2))], c, sn, pk, pm);
         }
-      } else
+        if (p.pscrunch) { pk[0] += pk[1]; pm[0] += pm[1]; pk[1] = pm[1] = 0.f; }   // :79-80 pol sum BEFORE the time sum
+        pw[0][0] = pk[0]; pw[0][1] = pk[1]; pw[1][0] = pm[0]; pw[1][1] = pm[1];
+      };
+      // Whole group inside one output sample (tscrunch >= Tp, all parts present): no per-part bookkeeping.
+      // 0 + p0 == p0, so starting an output sample from zero gives the sums of TScrunch.C:193-200 bit for bit.
+      const bool whole = p.sfactor >= Tp && part_first + Tp <= part_end;
 #pragma unroll
       for (int j = 0; j < NB; j++) {
         const uint32_t k = tid + j * nt;
-        if (k < nchan) {
-          const uint32_t km = (L - k) & (L - 1);
+        if (k >= C / 2 && C > 1) continue;
+        const uint32_t km = k ? C - k : C / 2;                               // the second bin of the pair
+        const bool two = km != k;                                            // (C = 1: bin 0 alone)
+        if (whole) {
+          const bool emit = phase_first + Tp == p.sfactor;
+          float s[2][2];
+#pragma unroll
+          for (int b = 0; b < 2; b++) { s[b][0] = phase_first == 0 ? 0.f : acc[j][b][0]; s[b][1] = phase_first == 0 ? 0.f : acc[j][b][1]; }
+          for (uint32_t c2 = 0; c2 < Tp; c2++) {
+            float pw[2][2];
+            powers(k, c2, wc[j], ws[j], pw);
+#pragma unroll
+            for (int b = 0; b < 2; b++) { s[b][0] += pw[b][0]; s[b][1] += pw[b][1]; }
+          }
+#pragma unroll
+          for (int b = 0; b < 2; b++) { acc[j][b][0] = s[b][0]; acc[j][b][1] = s[b][1]; }
+          if (emit) {
+            float* o = p.out + (out_first * C + k) * npol_out;
+            o[0] = s[0][0];
+            if (!p.pscrunch) o[1] = s[0][1];
+            if (two) {
+              float* om = p.out + (out_first * C + km) * npol_out;
+              om[0] = s[1][0];
+              if (!p.pscrunch) om[1] = s[1][1];
+            }
+          }
+        } else {
           uint32_t phase = phase_first;
           uint64_t oidx = out_first;
-          for (uint32_t c = 0; c < T; c++) {
-            const uint64_t part = part_first + c;
-            if (part >= part_end) break;
-            const cf a = lds[lds_pad((k << logT) | c)], b = lds[lds_pad((km << logT) | c)];
-            const float x0r = 0.5f * (a.x + b.x), x0i = 0.5f * (a.y - b.y);
-            const float x1r = 0.5f * (a.y + b.y), x1i = 0.5f * (b.x - a.x);
-            float p0 = x0r * x0r; p0 += x0i * x0i;            // TFPFilterbank.C:56-59
-            float p1 = x1r * x1r; p1 += x1i * x1i;
-            if (p.pscrunch) { p0 += p1; p1 = 0.f; }                 // TFPFilterbank.C:79-80: pol sum BEFORE the time sum
-            if (phase == 0) { acc[j][0] = p0; acc[j][1] = p1; }     // TScrunch.C:193-194
-            else { acc[j][0] += p0; acc[j][1] += p1; }               // TScrunch.C:199-200
+          for (uint32_t c2 = 0; c2 < Tp; c2++) {
+            if (part_first + c2 >= part_end) break;
+            float pw[2][2];
+            powers(k, c2, wc[j], ws[j], pw);
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+              if (phase == 0) { acc[j][b][0] = pw[b][0]; acc[j][b][1] = pw[b][1]; }       // TScrunch.C:193-194
+              else { acc[j][b][0] += pw[b][0]; acc[j][b][1] += pw[b][1]; }                 // TScrunch.C:199-200
+            }
             if (++phase == p.sfactor) {
-              float* o = p.out + (oidx * nchan + k) * npol_out;
-              o[0] = acc[j][0];
-              if (!p.pscrunch) o[1] = acc[j][1];
+              float* o = p.out + (oidx * C + k) * npol_out;
+              o[0] = acc[j][0][0];
+              if (!p.pscrunch) o[1] = acc[j][0][1];
+              if (two) {
+                float* om = p.out + (oidx * C + km) * npol_out;
+                om[0] = acc[j][1][0];
+                if (!p.pscrunch) om[1] = acc[j][1][1];
+              }
               phase = 0;
               oidx++;
             }
           }
         }
       }
-      __syncthreads();    // LDS is overwritten by the next group's exchanges
+      __syncthreads();    // LDS is overwritten by the next tile's exchanges
     }
   }
 }
@@ -272,10 +285,10 @@ extern "C" int dspsr_amd_tfp_filterbank(dspsr_amd_ctx* ctx, const dspsr_amd_tfp_
   if (cfg->npol != 2)
     return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_tfp_filterbank: only real dual-polarisation 8-bit input is built (npol=%u)", cfg->npol);
   const uint32_t sf = cfg->tscrunch ? cfg->tscrunch : 1;
-  int logF = 0;
-  while ((1u << logF) < 2 * nchan) logF++;
-  const int logT = 14 - logF;
-  const uint32_t T = 1u << logT;
+  int logC = 0;                                       // nchan complex points per polarisation and part (see k_tfp)
+  while ((1u << logC) < nchan) logC++;
+  const int logT = 14 - logC;                         // columns per workgroup tile = 2 polarisations x T parts
+  const uint32_t T = 1u << (logT - 1);
   if (!((sf % T) == 0 || (T % sf) == 0))
     return ctx_fail(ctx, DSPSR_AMD_EINVAL,
                     "dspsr_amd_tfp_filterbank: tscrunch=%u must divide or be a multiple of %u parts per workgroup", sf, T);
@@ -289,12 +302,12 @@ extern "C" int dspsr_amd_tfp_filterbank(dspsr_amd_ctx* ctx, const dspsr_amd_tfp_
   p.raw = (const uint8_t*)raw_dev; p.out = out_dev; p.npart = npart; p.sfactor = sf; p.pscrunch = cfg->pscrunch ? 1 : 0;
   p.scale = scale; p.logT = logT; p.caspsr = raw_layout == DSPSR_AMD_RAW_CASPSR;
   // whole-range 16-byte loads need an aligned block, at least two columns per group (T >= 2) and full-size workgroups
-  const bool coal = ((uintptr_t)raw_dev & 15) == 0 && logT >= 1;
-  ktfp_t k = pick_tfp(logF, p.caspsr != 0, coal, mkseq_t<14>::type());
-  const size_t lds = lds_total_words_host(16384, logF) * sizeof(cf);
+  const bool coal = ((uintptr_t)raw_dev & 15) == 0;
+  ktfp_t k = pick_tfp(logC, p.caspsr != 0, coal, mkseq_t<14>::type());
+  const size_t lds = lds_total_words_host(16384, logC) * sizeof(cf);
   hipError_t e = dspsr_amd_allow_lds((const void*)k, lds);      // raised once per kernel, not per call
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_tfp_filterbank: %s", hipGetErrorString(e));
-  const uint64_t nitem = sf > T ? nout : (nout * sf + T - 1) >> logT;
+  const uint64_t nitem = sf > T ? nout : (nout * sf + T - 1) >> (logT - 1);
   const uint32_t ncu = ctx->ncu;
   const uint32_t grid = (uint32_t)(nitem < ncu ? nitem : ncu);
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, ctx->stream, p, ctx->tw);
