@@ -332,6 +332,10 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
 #define FB_FT_ROWS 64
 #define FB_FT_COLS 64
 #endif
+#ifndef FB_DEFER_CO
+#define FB_DEFER_CO 0          // 1: pass 1 copies a staged tile out at the top of the NEXT tile, in front of its register-only
+                               //    first stage (measured: 540 -> 598 us per 32 parts, profiles/r03_experiments.txt item 8; off)
+#endif
 #ifndef FB_SPLIT
 #define FB_SPLIT 0             // 1: pass 1 with two staggered four-wave groups per workgroup (see k_fwd_cols): correct (the whole
 #endif                         //    GPU suite passes with it) and exactly as fast -- profiles/r03_experiments.txt item 5; off
@@ -665,6 +669,41 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
   const uint32_t co_lds = lds_pad(co_l0 ^ (((co_l0 >> 4) & co_swz) << 3)), co_lstep = co_n2 + ((co_n2 >> 6) << 2);
   const uint32_t co_goff = (uint32_t)(((((uint64_t)(co_l0 >> co_sh) << g.logR) << logT2) + (co_l0 & ((1u << co_sh) - 1))) * sizeof(cf));
   const uint64_t co_gstep = ((uint64_t)(co_n2 >> co_sh) << g.logR) << logT2;       // elements of A per pair step
+  // copy-out of a staged tile (all of the group's threads; `tid` is the thread of the group)
+  auto copy_out = [&](const uint32_t tile, cf* __restrict__ Aseq) {
+    const uint32_t swz = co_swz;
+    if (!(FB_DBG(g) & 1)) {
+    const uint32_t nthr = nthr_w;
+    if (co_fast) {
+      // pair jj of a thread is pair 0 plus jj*2*nthr elements: a constant step in the padded image (co_lstep) and a
+      // uniform step in A (co_gstep) -- one LDS address and one 32-bit global offset per THREAD, computed before the
+      // tile loop; the per-pair part is an immediate / a scalar-register base (this loop issued 23 % of the pass's
+      // vector instructions as per-pair address arithmetic, 64-bit shifts included)
+      const char* __restrict__ gb = (const char*)(Aseq + ((uint64_t)(tile * T + cofs) << logT2));
+#pragma unroll
+      for (int j4 = 0; j4 < PTS / 2; j4 += 4) {                  // four LDS reads in flight, then their stores
+        float4 pr[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) pr[q] = *(const float4*)&lw[co_lds + (j4 + q) * co_lstep];
+        __builtin_amdgcn_sched_barrier(0);                         // (the min-register scheduler would pair every read with its store)
+#pragma unroll
+        for (int q = 0; q < 4; q++) st_stream((float4*)(gb + (uint64_t)(j4 + q) * co_gstep * sizeof(cf) + co_goff), pr[q]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll 4
+      for (int jj = 0; jj < PTS / 2; jj++) {
+        const uint32_t l = 2 * (tid + jj * nthr);                  // element index inside the staged image
+        const uint32_t blkA = l >> (logTw + logT2), within = l & ((1u << (logTw + logT2)) - 1);
+        const float4 pr = *(const float4*)&lw[lds_pad(l ^ (((l >> 4) & swz) << 3))];
+        st_stream((float4*)&Aseq[((((uint64_t)blkA << g.logR) + tile * T + cofs) << logT2) + within], pr);
+      }
+    }
+  }
+  };
+  [[maybe_unused]] uint32_t co_tile = 0;
+  [[maybe_unused]] cf* co_Aseq = nullptr;
+  [[maybe_unused]] bool co_pending = false;
   uint32_t item, next;
   uint32_t j = 0;
   if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
@@ -695,6 +734,12 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
 #endif
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
     if (more) fetch(next, raw);
+#if FB_DEFER_CO
+    // The PREVIOUS tile is copied out here, in front of this tile's first butterfly stage -- which works in registers
+    // until its exchange barrier -- so that the 128 KB of stores drain while the vector unit computes, instead of in a phase
+    // of their own at the end of the tile with the vector unit idle (the staged image is not touched before that barrier)
+    if (co_pending) copy_out(co_tile, co_Aseq);
+#endif
 #if defined(FB_STAMPS) && FB_STAMPS == 1
     STAMP(ts2);
 #endif
@@ -761,34 +806,11 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
 #if defined(FB_STAMPS) && FB_STAMPS == 1
     STAMP(ts3);
 #endif
-    if (!(FB_DBG(g) & 1)) {
-      const uint32_t nthr = nthr_w;
-      if (co_fast) {
-        // pair jj of a thread is pair 0 plus jj*2*nthr elements: a constant step in the padded image (co_lstep) and a
-        // uniform step in A (co_gstep) -- one LDS address and one 32-bit global offset per THREAD, computed before the
-        // tile loop; the per-pair part is an immediate / a scalar-register base (this loop issued 23 % of the pass's
-        // vector instructions as per-pair address arithmetic, 64-bit shifts included)
-        const char* __restrict__ gb = (const char*)(Aseq + ((uint64_t)(tile * T + cofs) << logT2));
-#pragma unroll
-        for (int j4 = 0; j4 < PTS / 2; j4 += 4) {                  // four LDS reads in flight, then their stores
-          float4 pr[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) pr[q] = *(const float4*)&lw[co_lds + (j4 + q) * co_lstep];
-          __builtin_amdgcn_sched_barrier(0);                         // (the min-register scheduler would pair every read with its store)
-#pragma unroll
-          for (int q = 0; q < 4; q++) st_stream((float4*)(gb + (uint64_t)(j4 + q) * co_gstep * sizeof(cf) + co_goff), pr[q]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-#pragma unroll 4
-        for (int jj = 0; jj < PTS / 2; jj++) {
-          const uint32_t l = 2 * (tid + jj * nthr);                  // element index inside the staged image
-          const uint32_t blkA = l >> (logTw + logT2), within = l & ((1u << (logTw + logT2)) - 1);
-          const float4 pr = *(const float4*)&lw[lds_pad(l ^ (((l >> 4) & swz) << 3))];
-          st_stream((float4*)&Aseq[((((uint64_t)blkA << g.logR) + tile * T + cofs) << logT2) + within], pr);
-        }
-      }
-    }
+#if FB_DEFER_CO
+    co_tile = tile; co_Aseq = Aseq; co_pending = true;          // copied out at the top of the next tile (or behind the loop)
+#else
+    copy_out(tile, Aseq);
+#endif
 #if defined(FB_STAMPS) && FB_STAMPS == 1
     STAMP(ts4);
     acc_s[0] += ts0 - ts5; acc_s[1] += ts1 - ts0; acc_s[2] += ts2 - ts1; acc_s[3] += ts3 - ts2; acc_s[4] += ts4 - ts3; acc_s[5] += 1;
@@ -797,13 +819,15 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     if (!more) break;
     item = next;
   }
+#if FB_DEFER_CO
+  if (co_pending) copy_out(co_tile, co_Aseq);
+#endif
   if (SPLIT && grp == 0) __builtin_amdgcn_s_barrier();         // the second group's last barrier
 #if defined(FB_STAMPS) && FB_STAMPS == 1
   if (threadIdx.x == 0 && blockIdx.x < 1024)
     for (int q = 0; q < 6; q++) atomicAdd(&g_stamps[blockIdx.x][q], acc_s[q]);
 #endif
 }
-
 #endif  // FB_HAS(1)
 
 #if FB_HAS(2)
