@@ -572,6 +572,7 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
         dist.broadcast_object_list(ids, src=0)
         rccl = dspsr_amd.Communicator(lt.ctx, world, rank, ids[0])
         lt.set_rccl_communicator(rccl)
+        lt.copy_subints = False          # no archive writer here: each merged sub-integration is left in the pinned buffer it arrived in
     elif world > 1 and sharded:
         gather = torch.zeros(world * lt.nchan_out * lt.npol_out * cfg.nbin * cfg.ndim, dtype=torch.float32, device="cuda")
     comm = dist if world > 1 else None

@@ -106,6 +106,7 @@ SYMBOLS = {
     "dspsr_amd_comm_rank": (_i, [_vp]),
     "dspsr_amd_comm_size": (_i, [_vp]),
     "dspsr_amd_reduce_profiles_start": (_i, [_vp, _i, _i, _vp, _u64, _u64, _u64, _vp, _u32, _d, _u64, _i]),
+    "dspsr_amd_reduce_profiles_result": (_vp, [_vp, C.POINTER(_u64)]),
     "dspsr_amd_reduce_profiles_finish": (_i, [_vp, _vp, _vp, C.POINTER(_d), C.POINTER(_u64), C.POINTER(_i)]),
     "dspsr_amd_dedispersion_prepare": (_i, [C.POINTER(DedispersionConfig), C.POINTER(DedispersionInfo), C.c_char_p,
                                             _sz]),

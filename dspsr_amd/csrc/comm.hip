@@ -89,6 +89,13 @@ __global__ void k_pack_rows(const float* __restrict__ prof, const uint64_t span,
   }
 }
 
+// SUM mode, root: the reduced doubles back to float (rounded once), so that half the bytes cross to the host and no host loop
+// touches the profile
+__global__ void k_unpack_sum(const double* __restrict__ in, float* __restrict__ out, const uint64_t n)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+
 }  // namespace
 
 struct dspsr_amd_comm {
@@ -112,6 +119,7 @@ struct dspsr_amd_comm {
   double length = 0.0;
   uint64_t ndat_total = 0;
   size_t tail_off = 0;                            // check_hits: where the MIN / MAX of hits[] arrive in `host`
+  size_t meta_off = 0;                            // SUM, root: where the reduced counters (doubles) arrive in `host`
 };
 
 static int comm_fail(dspsr_amd_comm* c, int code, const char* what, ncclResult_t r)
@@ -204,7 +212,12 @@ extern "C" int dspsr_amd_reduce_profiles_start(dspsr_amd_comm* c, int mode, int 
   const size_t nmeta = (size_t)nbin + 2;                                   // SUM: hits, ndat_total, integration_length as doubles
   const size_t send_bytes = sum ? (n + nmeta) * sizeof(double) : n * sizeof(float);
   const size_t recv_bytes = !is_root ? 0 : (sum ? send_bytes : (size_t)c->nranks * n * sizeof(float));
-  const size_t host_bytes = (recv_bytes > nmeta * sizeof(double) ? recv_bytes : nmeta * sizeof(double)) + 2 * (size_t)nbin * sizeof(uint32_t);
+  // pinned host buffer: [merged profile, floats (root)] [merged counters, doubles (root, SUM)] [this rank's counters going out
+  // (SUM)] [MIN / MAX of hits[] (check_hits)]
+  const size_t prof_bytes = !is_root ? 0 : (((sum ? n : (size_t)c->nranks * n) * sizeof(float) + 7) & ~(size_t)7);
+  const size_t meta_off = prof_bytes, stage_off = meta_off + (is_root && sum ? nmeta * sizeof(double) : 0);
+  const size_t tail_off = stage_off + (sum ? nmeta * sizeof(double) : 0);
+  const size_t host_bytes = tail_off + 2 * (size_t)nbin * sizeof(uint32_t);
   if (!reserve_dev(&c->send, &c->send_cap, send_bytes) || (recv_bytes && !reserve_dev(&c->recv, &c->recv_cap, recv_bytes)) ||
       (check_hits && !reserve_dev((void**)&c->hmm, &c->hmm_cap, 2 * (size_t)nbin * sizeof(uint32_t))))
     return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_reduce_profiles_start: staging allocation failed");
@@ -222,7 +235,7 @@ extern "C" int dspsr_amd_reduce_profiles_start(dspsr_amd_comm* c, int mode, int 
   hipError_t e = hipSuccess;
   if (sum) {
     hipLaunchKernelGGL(k_pack_rows<double>, dim3(gx), dim3(256), 0, ctx->stream, profile_dev, span_floats, row_floats, n, (double*)c->send);
-    double* m = (double*)c->host;
+    double* m = (double*)((char*)c->host + stage_off);
     for (uint32_t b = 0; b < nbin; b++) m[b] = (double)hits_host[b];
     m[nbin] = (double)ndat_total;
     m[nbin + 1] = integration_length;
@@ -233,7 +246,7 @@ extern "C" int dspsr_amd_reduce_profiles_start(dspsr_amd_comm* c, int mode, int 
   if (e == hipSuccess && check_hits) {
     // hits[] of this rank, twice (the all-reduces work in place: MIN in the first copy, MAX in the second); staged in the
     // tail of the pinned buffer, which the result does not reach
-    uint32_t* hh = (uint32_t*)((char*)c->host + host_bytes - 2 * (size_t)nbin * sizeof(uint32_t));
+    uint32_t* hh = (uint32_t*)((char*)c->host + tail_off);
     memcpy(hh, hits_host, nbin * sizeof(uint32_t));
     memcpy(hh + nbin, hits_host, nbin * sizeof(uint32_t));
     e = hipMemcpyAsync(c->hmm, hh, 2 * (size_t)nbin * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
@@ -253,15 +266,23 @@ extern "C" int dspsr_amd_reduce_profiles_start(dspsr_amd_comm* c, int mode, int 
   const ncclResult_t r2 = L->GroupEnd();
   if (r == ncclSuccess) r = r2;
   if (r != ncclSuccess) return comm_fail(c, DSPSR_AMD_EHIP, "dspsr_amd_reduce_profiles_start: RCCL", r);
-  if (is_root) e = hipMemcpyAsync(c->host, c->recv, recv_bytes, hipMemcpyDeviceToHost, c->stream);
+  if (is_root && sum) {
+    // the staging buffer is free once the reduce has read it: the floats of the merged profile go there, then to the host
+    hipLaunchKernelGGL(k_unpack_sum, dim3(gx), dim3(256), 0, c->stream, (const double*)c->recv, (float*)c->send, n);
+    e = hipMemcpyAsync(c->host, c->send, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync((char*)c->host + meta_off, (const double*)c->recv + n, nmeta * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  } else if (is_root) {
+    e = hipMemcpyAsync(c->host, c->recv, recv_bytes, hipMemcpyDeviceToHost, c->stream);
+  }
   if (e == hipSuccess && check_hits)
-    e = hipMemcpyAsync((char*)c->host + host_bytes - 2 * (size_t)nbin * sizeof(uint32_t), c->hmm, 2 * (size_t)nbin * sizeof(uint32_t),
-                       hipMemcpyDeviceToHost, c->stream);
+    e = hipMemcpyAsync((char*)c->host + tail_off, c->hmm, 2 * (size_t)nbin * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipEventRecord(c->done, c->stream);
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_reduce_profiles_start: %s", hipGetErrorString(e));
   c->pending = true;
   c->mode = mode; c->root = root; c->check = check_hits; c->n = n; c->nbin = nbin;
-  c->tail_off = host_bytes - 2 * (size_t)nbin * sizeof(uint32_t);
+  c->tail_off = tail_off;
+  c->meta_off = meta_off;
   c->hits.assign(hits_host, hits_host + nbin);
   c->length = integration_length;
   c->ndat_total = ndat_total;
@@ -288,11 +309,11 @@ extern "C" int dspsr_amd_reduce_profiles_finish(dspsr_amd_comm* c, float* profil
   }
   if (c->rank != c->root) return DSPSR_AMD_OK;
   if (c->mode == DSPSR_AMD_REDUCE_SUM) {
-    const double* d = (const double*)c->host;
-    if (profile_host) for (uint64_t i = 0; i < n; i++) profile_host[i] = (float)d[i];
-    if (hits_host) for (uint32_t b = 0; b < nbin; b++) hits_host[b] = (uint32_t)d[n + b];
-    if (ndat_total) *ndat_total = (uint64_t)d[n + nbin];
-    if (integration_length) *integration_length = d[n + nbin + 1];
+    const double* d = (const double*)((const char*)c->host + c->meta_off);
+    if (profile_host) memcpy(profile_host, c->host, n * sizeof(float));
+    if (hits_host) for (uint32_t b = 0; b < nbin; b++) hits_host[b] = (uint32_t)d[b];
+    if (ndat_total) *ndat_total = (uint64_t)d[nbin];
+    if (integration_length) *integration_length = d[nbin + 1];
   } else {
     if (profile_host) memcpy(profile_host, c->host, (size_t)c->nranks * n * sizeof(float));
     if (hits_host) memcpy(hits_host, c->hits.data(), nbin * sizeof(uint32_t));
@@ -300,4 +321,11 @@ extern "C" int dspsr_amd_reduce_profiles_finish(dspsr_amd_comm* c, float* profil
     if (integration_length) *integration_length = c->length;
   }
   return DSPSR_AMD_OK;
+}
+
+extern "C" const float* dspsr_amd_reduce_profiles_result(const dspsr_amd_comm* c, uint64_t* nfloat)
+{
+  if (!c || c->pending || c->rank != c->root) { if (nfloat) *nfloat = 0; return nullptr; }
+  if (nfloat) *nfloat = c->mode == DSPSR_AMD_REDUCE_SUM ? c->n : (uint64_t)c->nranks * c->n;
+  return (const float*)c->host;
 }

@@ -566,22 +566,26 @@ class Communicator:
                                                    int(ndat_total), 1 if check_hits else 0), "dspsr_amd_reduce_profiles_start")
         self._shape = (mode, root, nrow * row_floats, hits.size)
 
-    def finish(self):
+    def finish(self, copy=True):
         """Waits.  Returns (profile, hits, integration_length, ndat_total, hits_identical): numpy arrays on the root
-        (profile flat: the SUM, or the nranks slices in rank order), None for the first four elsewhere."""
+        (profile flat: the SUM, or the nranks slices in rank order), None for the first four elsewhere.
+        copy=False: `profile` is a view of the communicator's pinned host buffer (valid until the next start) -- what a writer
+        that consumes the sub-integration at once wants."""
         mode, root, n, nbin = self._shape
         same = C.c_int(1)
         if self.rank != root:
             _check(self.ctx.handle, lib.dspsr_amd_reduce_profiles_finish(self.handle, None, None, None, None, C.byref(same)),
                    "dspsr_amd_reduce_profiles_finish")
             return None, None, None, None, bool(same.value)
-        prof = np.empty(n * (self.nranks if mode == self.GATHER else 1), np.float32)
         hits = np.empty(nbin, np.uint32)
         length, ndat = C.c_double(), C.c_uint64()
         _check(self.ctx.handle,
-               lib.dspsr_amd_reduce_profiles_finish(self.handle, prof.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p),
+               lib.dspsr_amd_reduce_profiles_finish(self.handle, None, hits.ctypes.data_as(C.c_void_p),
                                                     C.byref(length), C.byref(ndat), C.byref(same)), "dspsr_amd_reduce_profiles_finish")
-        return prof, hits, length.value, ndat.value, bool(same.value)
+        nf = C.c_uint64()
+        ptr = lib.dspsr_amd_reduce_profiles_result(self.handle, C.byref(nf))
+        prof = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(nf.value,))
+        return (prof.copy() if copy else prof), hits, length.value, ndat.value, bool(same.value)
 
     def close(self):
         if self.handle and self.ctx.handle:

@@ -797,6 +797,7 @@ class LoadToFold:
 
     comm = None                 # dspsr_amd.Communicator (RCCL behind the C-ABI): the product's exchange
     _comm_pending = None
+    copy_subints = True          # False: `subints` profiles stay views of the communicator's pinned buffer (see collect_subint)
 
     def set_rccl_communicator(self, comm):
         """The exchange of a multi-GPU run: a dspsr_amd.Communicator (dspsr_amd_comm_*, csrc/comm.hip -- the same C entry
@@ -804,13 +805,17 @@ class LoadToFold:
         exist for the gloo CPU tests and for rehearsing several ranks on one device (RCCL needs one GPU per rank)."""
         self.comm = comm
 
-    def collect_subint(self):
-        """Wait for the exchange finish_subint(wait=False) started and append its result to `subints` (root only)."""
+    def collect_subint(self, copy=None):
+        """Wait for the exchange finish_subint(wait=False) started and append its result to `subints` (root only).
+        copy=False (default: self.copy_subints, True): the entry's profile is a VIEW of the communicator's pinned buffer, valid
+        until the next dump starts -- for a writer that consumes each sub-integration as it arrives."""
         if self._comm_pending is None:
             return
+        if copy is None:
+            copy = self.copy_subints
         check = self._comm_pending
         self._comm_pending = None
-        prof, hits, length, ndat_total, same = self.comm.finish()
+        prof, hits, length, ndat_total, same = self.comm.finish(copy=copy)
         if check and not same:
             raise DspsrAmdError("sub-band ranks disagree on hits[]: the shards are not sample aligned "
                                 "(different nfilt_pos/neg, start time or rate)")
@@ -826,7 +831,7 @@ class LoadToFold:
         snapshot on the compute stream, the collective on the communicator's stream -- the next block's kernels overlap
         it; wait=False leaves it in flight until collect_subint() or the next dump."""
         if self.comm is not None:
-            self.collect_subint()                                       # one exchange in flight per communicator
+            self.collect_subint(copy=self.copy_subints)                 # one exchange in flight per communicator
             n = self.npol_out * self.cfg.nbin * self.cfg.ndim           # floats per channel: rows are packed
             self.comm.start(self.comm.SUM if replicas else self.comm.GATHER, self.fold.get_profiles_ptr(), n, self.nchan_out, n,
                             self.hits, self.integration_length, self.ndat_total, root=0,

@@ -266,6 +266,9 @@ int dspsr_amd_reduce_profiles_start(dspsr_amd_comm* comm, int mode, int root, co
                                     double integration_length, uint64_t ndat_total, int check_hits);
 int dspsr_amd_reduce_profiles_finish(dspsr_amd_comm* comm, float* profile_host, uint32_t* hits_host, double* integration_length,
                                      uint64_t* ndat_total, int* hits_identical);
+/* root, after finish: the merged profile where the exchange left it -- the communicator's pinned host buffer (*nfloat floats,
+ * valid until the next start) -- for a writer that wants to read it in place (pass profile_host = NULL to finish) */
+const float* dspsr_amd_reduce_profiles_result(const dspsr_amd_comm* comm, uint64_t* nfloat);
 
 /* ---- integer-sample inter-channel delay (-K): dsp::SampleDelay (Signal/General/SampleDelay.C:52-195) --------------
  * create    : SampleDelay::build (:52-102) from the delay of each row, delays_host[ichan*npol+ipol] (the values

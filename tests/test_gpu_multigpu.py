@@ -166,6 +166,9 @@ def test_rccl_communicator_world1(gpu):
         p.zero_()                                                    # stream ordered behind the snapshot
         got, h, length, ndat, same = comm.finish()
         assert same and np.array_equal(got, want) and np.array_equal(h, hits) and length == 12.625 and ndat == (1 << 40) + 7
+    comm.start(comm.SUM, prof.data_ptr(), span, nrow, row, hits, 1.0, 5, check_hits=False)
+    view = comm.finish(copy=False)[0]                                # in place: the communicator's pinned buffer
+    assert not view.flags.owndata and np.array_equal(view, want)
     with pytest.raises(dspsr_amd.DspsrAmdError):
         comm.finish()                                                # nothing in flight
     # ---- pipeline level
