@@ -524,6 +524,43 @@ def engine_boundary(torch):
     return rec
 
 
+def open_rccl_exchange(ctx, torch, dist, rank, world):
+    """The C-ABI communicator (dspsr_amd_comm_*) for this rank's pipeline context plus one tiny trial exchange.  If any rank
+    cannot (no librccl to dlopen, init refused), ALL ranks agree to run the exchange through the launcher's process group
+    instead -- which is RCCL too -- and the bench line says so.  Returns (communicator or None, reason or None)."""
+    import dspsr_amd
+    ok, note, rccl = 1, None, None
+    try:
+        ids = [dspsr_amd.Communicator.unique_id() if rank == 0 else None]
+    except Exception as e:                                                # noqa: BLE001 -- reported in the line
+        ids, ok, note = [None], 0, "%s" % e
+    dist.broadcast_object_list(ids, src=0)
+    if ids[0] is not None:
+        try:
+            rccl = dspsr_amd.Communicator(ctx, world, rank, ids[0])
+            trial = torch.full((4, 8), float(rank + 1), dtype=torch.float32, device="cuda")
+            rccl.start(rccl.SUM, trial.data_ptr(), 8, 4, 8, np.ones(4, np.uint32), 1.0, 4, check_hits=True)
+            got = rccl.finish()
+            if rank == 0 and (float(got[0][0]) != world * (world + 1) / 2 or int(got[1][0]) != world or not got[4]):
+                raise RuntimeError("trial exchange returned %r" % (got[0][:2],))
+        except Exception as e:                                            # noqa: BLE001
+            ok, note = 0, "%s" % e
+    else:
+        ok = 0
+    t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t.item()) == 1:
+        return rccl, None
+    notes = [None] * world
+    dist.all_gather_object(notes, note)
+    note = "; ".join(sorted({n_ for n_ in notes if n_})) or "unknown"
+    if rank == 0:
+        print("bench: C-ABI RCCL communicator unavailable (%s): exchange through torch.distributed" % note, file=sys.stderr)
+    if rccl is not None:
+        rccl.close()
+    return None, note
+
+
 def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, steps, warmup, full=True):
     """One filterbank + detect + fold workload on this process group: the timed region (barrier, `steps` steps with a
     sub-integration dump every args.dump_steps, barrier), then -- outside it -- the unfused roofline blocks and the
@@ -567,12 +604,14 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
     # the exchange: RCCL behind the C-ABI (dspsr_amd_comm_*), one communicator per pipeline context; the unique id travels
     # over the launcher's process group.  One-device rehearsals (gloo) keep the torch.distributed form of the same exchange.
     gather, rccl = None, None
+    rccl_note = None
     if world > 1 and not single:
-        ids = [dspsr_amd.Communicator.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        rccl = dspsr_amd.Communicator(lt.ctx, world, rank, ids[0])
-        lt.set_rccl_communicator(rccl)
-        lt.copy_subints = False          # no archive writer here: each merged sub-integration is left in the pinned buffer it arrived in
+        rccl, rccl_note = open_rccl_exchange(lt.ctx, torch, dist, rank, world)
+        if rccl is not None:
+            lt.set_rccl_communicator(rccl)
+            lt.copy_subints = False      # no archive writer here: each merged sub-integration is left in the pinned buffer it arrived in
+        elif sharded:
+            gather = torch.zeros(world * lt.nchan_out * lt.npol_out * cfg.nbin * cfg.ndim, dtype=torch.float32, device="cuda")
     elif world > 1 and sharded:
         gather = torch.zeros(world * lt.nchan_out * lt.npol_out * cfg.nbin * cfg.ndim, dtype=torch.float32, device="cuda")
     comm = dist if world > 1 else None
@@ -672,7 +711,9 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
         achieved = b_alg * cfg.parts_per_block * lt.in_nchan / (fb_ms * 1e-3) / 1e9
         exch = ("dspsr_amd_reduce_profiles_* (RCCL behind the C-ABI, csrc/comm.hip), snapshot on the compute stream, collective "
                 "on its own stream" if rccl is not None else
-                "torch.distributed (gloo rehearsal on one device)" if world > 1 else "one rank: no exchange")
+                "torch.distributed (gloo rehearsal on one device)" if world > 1 and single else
+                "torch.distributed over RCCL -- the C-ABI communicator was unavailable: %s" % rccl_note if world > 1 else
+                "one rank: no exchange")
         par = ("sub-band per GPU x%d (input channel g of %d, slice g of the full-band kernel; per dump ONE ncclGather of the "
                "ranks' slices; %s)" % (world, info.nchan, exch)) if sharded else \
               ("time-slice replicas x%d (blocks dealt round robin; per dump ONE packed ncclReduce(SUM) of profile + hits + "

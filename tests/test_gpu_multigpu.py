@@ -204,6 +204,30 @@ def test_rccl_communicator_world1(gpu):
     ctx.close()
 
 
+def test_bench_rccl_setup_and_agreed_fallback(gpu, monkeypatch):
+    """bench.open_rccl_exchange: communicator + trial exchange over a (one-rank) process group; when the communicator cannot
+    be made every rank falls back together and the reason is kept for the bench line."""
+    import torch.distributed as dist
+    import dspsr_amd
+    sys.path.insert(0, ROOT)
+    import bench
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1)
+    try:
+        ctx = dspsr_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+        comm, note = bench.open_rccl_exchange(ctx, torch, dist, 0, 1)
+        assert comm is not None and note is None
+        comm.close()
+
+        def refuse(*a, **k):
+            raise dspsr_amd.DspsrAmdError("no librccl here")
+        monkeypatch.setattr(dspsr_amd.Communicator, "unique_id", staticmethod(refuse))
+        comm, note = bench.open_rccl_exchange(ctx, torch, dist, 0, 1)
+        assert comm is None and "no librccl here" in note
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("workload,extra", [("cfg4", ["--parts-per-block", "16"]),
                                             ("target", ["--parts-per-block", "4", "--max-parts", "2"]),
                                             (None, [])])
