@@ -385,6 +385,58 @@ def cpu_baseline_c(wl, geom, ncore, parts_per_worker=4):
                       "%.1f s wall, %.1f core-seconds" % (ncore, parts_per_worker, samples / 1e6, wall, sum(r[1] for r in res))}
 
 
+def oracle_check(wl, cfg, info, torch, nparts=2):
+    """Part of the cpu_baseline leg (N = 1, after the timed region): the product path against the float64 oracle on the SAME
+    bytes, beside the number -- `nparts` overlap-save parts of a dispersed, pulse-modulated 8-bit signal (dspsr_amd.synth, the
+    band's own DM) through the workload's launch path (same kernels as the timed region, a block of `nparts`
+    parts) and through oracle/dspsr_oracle.py: unpack -> filterbank x chirp -> coherency products -> fold.  Every channel.
+    hits[] must be identical and the profile within 1e-5 of its maximum (the tolerance of tests/test_gpu_parity.py); a
+    failure ends the run like the parity gate."""
+    import dataclasses
+    import oracle.dspsr_oracle as o
+    from dspsr_amd import pipeline, synth
+    small = dataclasses.replace(cfg, parts_per_block=nparts, max_parts=nparts)
+    lt = pipeline.LoadToFold(small, info, device=torch.cuda.current_device(), stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        ndat = nparts * lt.nsamp_step + lt.nsamp_overlap
+        period = 0.25 * ndat * wl["tsamp_us"] * 1e-6                 # four pulses in the sample
+        rawh = synth.voltages(ndat, wl["freq"], wl["bw"], wl["tsamp_us"], wl["dm"], period, npol=2, ndim=wl["ndim"],
+                              nchan=wl["in_nchan"], layout="caspsr" if wl["machine"] == "CASPSR" else "generic")
+        lt.process_block(torch.from_numpy(rawh).cuda())
+        lt.finish_subint()
+        lt.synchronize()
+        sub = lt.subints[-1]
+        prof = sub["profile_dev"].cpu().numpy().reshape(lt.nchan_out, small.nbin, 4).astype(np.float64)
+        t0 = time.perf_counter()
+        obs = o.Observation(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=wl["in_nchan"], npol=2, ndim=wl["ndim"],
+                            tsamp_us=wl["tsamp_us"], machine=wl["machine"], dispersion_measure=wl["dm"])
+        resp = o.Dedispersion()
+        resp.set_frequency_resolution(wl["freq_res"])
+        resp.match(obs, wl["nchan"])
+        plan = o.filterbank_plan(obs, wl["nchan"], resp)
+        # (the chirp the device multiplies by -- host C++ build, compared with the oracle's own below -- so that the figure is
+        #  about the transforms, detection and fold, not about the last bit of a sincos)
+        fb = o.filterbank(o.unpack_8bit(rawh, obs).astype(np.float64), plan, np.asarray(lt.response.kernel).astype(np.complex128),
+                          dtype=np.float64)
+        det = o.detect_layout(o.detect_products(fb, "Coherence"), 4)                 # [chan][1][ndat][4]
+        fobs = o.filterbank_output_observation(obs, plan)
+        ps = o.PhaseSeries(det.shape[0], 1, 4, small.nbin, data=np.zeros((det.shape[0], 1, small.nbin, 4), np.float64))
+        o.fold(det, fobs, o.FoldConfig(nbin=small.nbin, folding_period=small.folding_period), ps)
+        same_hits = bool(np.array_equal(sub["hits"], ps.hits)) and int(ps.hits.sum()) == nparts * lt.nkeep
+        err = float(np.abs(prof - ps.data[:, 0]).max() / np.abs(ps.data[..., :2]).max())
+        kerr = float(np.abs(lt.response.kernel - resp.buffer).max())
+        rec = {"status": "ok" if same_hits and err <= 1e-5 else "FAILED", "profile_max_err_rel": err, "tolerance": 1e-5,
+               "hits_identical": same_hits, "chirp_max_abs_diff": kerr, "channels": int(det.shape[0]), "parts": nparts,
+               "input": "dispersed pulse-modulated noise (dspsr_amd.synth.voltages: DM %g, four pulses in %d samples/pol), 8-bit"
+                        % (wl["dm"], ndat),
+               "oracle": "oracle/dspsr_oracle.py in float64, %.1f s" % (time.perf_counter() - t0)}
+    finally:
+        lt.close()
+    if rec["status"] != "ok":
+        raise ParityGateError("bench.py oracle check FAILED: %r" % (rec,))
+    return rec
+
+
 def cpu_baseline(wl, geom, parts_per_worker=8):
     """Times the CPU port on ALL host cores of this process's affinity mask with the reference's own parallelisation
     model -- one worker per time block (dspsr -t <ncores>, MultiThread.C:65-82) -- on a bounded sample of the workload.
@@ -592,7 +644,8 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
                              subband=rank if sharded else None)
 
     # synthetic block resident in HBM: seeded Gaussian noise, sigma = 24 LSB (content does not change the work; the
-    # oracle comparisons on a dispersed pulsed signal are the -m gpu tests, tests/test_gpu_headline.py)
+    # comparison with the oracle on a dispersed pulsed signal is oracle_check() below, beside the number, and the -m gpu
+    # tests, tests/test_gpu_headline.py)
     nbytes = lt.block_bytes()
     gen = torch.Generator(device="cuda").manual_seed(20100413 + rank)
     raw = torch.empty(nbytes, dtype=torch.int8, device="cuda")
@@ -783,6 +836,8 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
             except Exception as e:  # the oracle is only a reported baseline
                 out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 1, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+            if not sharded and args.ndim == 4:
+                out["parity_gate"]["oracle_check"] = oracle_check(wl, cfg, info, torch)    # raises on a mismatch
     if rccl is not None:
         rccl.close()
     lt.close()
