@@ -828,6 +828,152 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
     for (int q = 0; q < 6; q++) atomicAdd(&g_stamps[blockIdx.x][q], acc_s[q]);
 #endif
 }
+
+// ------------------------------------------------------------------------------------ P1, paired tiles (round 3)
+// Long transforms (L = Fa*Fb >= 2^25: -F 64:D at the optimal response length, dsp::Convolution shapes) leave pass 1 tiles of
+// T1 = 2 columns and pass 2 tiles of T2 = 4 rows, so a pass-1 tile meets a pass-2 tile in T1*T2 = 8 elements: 64-byte runs
+// of A, half a cache line per store run -- pass 1 then moves its bytes at 2.7 TB/s where the same bytes in 256-byte runs
+// (headline geometry) go at 5.0 (tools/run_length_probe.hip: stores in 64-byte runs 3.2-3.4 TB/s at any stride, 128-byte runs
+// 4.6-4.8).  Here a work item is a PAIR of adjacent tiles (columns 4j .. 4j+3): the two are transformed one after the other,
+// the outputs of the first wait in registers (64) while the second runs through the one exchange buffer, and the four
+// columns are then staged and copied out together, half the rows at a time (the buffer holds 2^14 elements: 4 columns x
+// Fa/2 rows) -- runs of 2*T1*T2 elements, whole 128-byte lines.  The layout of A and everything behind it are unchanged.
+// Full-size tiles of two columns only (Fa = 2^13 at 2^14 points per workgroup): the last stage is the radix-2 one, so the two
+// outputs of a butterfly are row ka (lower half) and ka + Fa/2 (upper half).
+struct KeepOut {
+  cx2* o;
+  uint32_t p0;
+  int h;
+  template <int R> DEV void operator()(const uint32_t, const uint32_t p, const uint32_t, cx2 (&v)[R])
+  {
+    static_assert(R == 2, "k_fwd_cols_dual: radix-2 last stage");
+    if (h == 0) p0 = p;
+    o[2 * h] = v[0];
+    o[2 * h + 1] = v[1];
+  }
+};
+template <int RAWW>
+__global__ __launch_bounds__(512) void k_fwd_cols_dual(const FbGeom g, const FbIn in, cf* __restrict__ A,
+                                                       const cf* __restrict__ tw, const uint64_t part0,
+                                                       const uint32_t nparts, const uint32_t nseq, const uint32_t run)
+{
+  constexpr int LOGF = 13, LOGT = 1;
+  typedef FftPlan<LOGF> P;
+  static_assert(FB_TWIDDLE_IN_P2, "k_fwd_cols_dual: the inter-pass twiddle belongs to pass 2");
+  static_assert(P::REM == 1 && PTS / 2 / 2 == 8, "k_fwd_cols_dual: 2^13-point columns, radix-2 last stage");
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  uint32_t tid = threadIdx.x;
+  const int logT2 = g.logT2;
+  const uint32_t T = 2, T2 = 1u << logT2;
+  const int logL = LOGF + g.logR;
+  const uint64_t L = 1ull << logL;
+  const int logNp = g.logR - LOGT - 1;                  // pairs of tiles per sequence
+  const uint32_t npair = 1u << logNp, ntile = npair << 1;
+  const uint32_t total = npair * nseq * nparts;
+  auto seq_of = [&](const uint32_t rest) { return nseq == 2 ? (rest & 1u) : 0u; };
+  auto part_of = [&](const uint32_t rest) { return nseq == 2 ? (rest >> 1) : rest; };
+  auto fetch = [&](const uint32_t item, const uint32_t sub, RawW<RAWW> (&raw)[PTS / 2]) {
+    const uint32_t tile = ((item & (npair - 1)) << 1) | sub;
+    const uint32_t rest = item >> logNp;
+    const uint32_t seq = seq_of(rest);
+    const bool pret = in.kind == 3 || in.kind == 5;   // pre-transposed: [part][tile][na][T] pairs, contiguous per tile
+    const uint64_t t0 = pret ? ((uint64_t)rest * ntile + tile) * ((uint64_t)T << LOGF) : (part0 + part_of(rest)) * in.part_step + tile * T;
+    constexpr uint32_t MS = 1u << (LOGF - P::LOGR1);
+    const uint64_t step = pret ? ((uint64_t)MS << LOGT) : ((uint64_t)MS << g.logR);
+#pragma unroll
+    for (int g2 = 0; g2 < P::G1; g2 += 2) {
+      const uint32_t eb = P::G1 * tid + g2;               // row eb >> 1, column eb & 1 (= 0)
+      const uint64_t tb = t0 + (eb & (T - 1)) + (pret ? (uint64_t)((eb >> LOGT) << LOGT) : (((uint64_t)(eb >> LOGT)) << g.logR));
+#pragma unroll
+      for (int i = 0; i < P::R1; i++) raw[(g2 / 2) * P::R1 + i] = fetch_pair<RAWW>(g, in, seq, tb + i * step);
+    }
+  };
+  const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;
+  ltw_fill<LOGF>(lds, ltw_off, tw, threadIdx.x, blockDim.x);
+  // staged image of one half: A-layout order l = ((ka_local / T2) * 4 + column) * T2 + ka % T2, padded by two elements
+  // per 32 (a thread stages 32 consecutive elements: with the exchange buffer's padding of 4 per 64 the lanes of a wave would
+  // meet in 8 banks); same size as the exchange buffer
+  auto img = [](const uint32_t l) { return l + ((l >> 5) << 1); };
+  // copy-out: 16-byte unit u = tid + 512*jj -> image element 2u, A element ((l >> sh) << logR << logT2) + (l & mask)
+  const int sh = 2 + logT2;
+  const uint32_t co_l0 = 2 * threadIdx.x;
+  const uint32_t co_lds = img(co_l0), co_lstep = img(1024);                                   // 1024 is a multiple of 32
+  const uint64_t co_goff = (((uint64_t)(co_l0 >> sh) << g.logR) << logT2) + (co_l0 & ((1u << sh) - 1));
+  const uint64_t co_gstep = ((uint64_t)(1024u >> sh) << g.logR) << logT2;
+  uint32_t item, next;
+  uint32_t j = 0;
+  if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
+  RawW<RAWW> raw0[PTS / 2], raw1[PTS / 2];
+  fetch(item, 0, raw0);
+  fetch(item, 1, raw1);
+  for (;;) {
+    asm volatile("" : "+v"(tid));
+    const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
+    const uint32_t seq_cur = seq_of(item >> logNp);
+    cx2 o0[PTS / 2], o1[PTS / 2];
+    uint32_t p0;
+    {
+      cx2 x[NPAIR];
+#pragma unroll
+      for (int h = 0; h < NPAIR; h++) {
+        cf a, b;
+        decode_pair<RAWW>(g, in, raw0[h], a, b, seq_cur);
+        x[h] = make_cx2(a, b);
+      }
+      if (more) fetch(next, 0, raw0);
+      KeepOut keep{o0, 0u, 0};
+      wgfft<LOGF, -1, false>(lds, ltw_off, tid, LOGT, x, keep);
+      p0 = keep.p0;
+    }
+    {
+      cx2 x[NPAIR];
+#pragma unroll
+      for (int h = 0; h < NPAIR; h++) {
+        cf a, b;
+        decode_pair<RAWW>(g, in, raw1[h], a, b, seq_cur);
+        x[h] = make_cx2(a, b);
+      }
+      if (more) fetch(next, 1, raw1);
+      KeepOut keep{o1, 0u, 0};
+      wgfft<LOGF, -1, false>(lds, ltw_off, tid, LOGT, x, keep);
+    }
+    const uint32_t pair = item & (npair - 1);
+    cf* __restrict__ Aseq = A + (uint64_t)(item >> logNp) * L + ((uint64_t)(pair * 4) << logT2);
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+      __syncthreads();                 // the exchange buffer (second transform's last stage / the other half's copy-out) has been read
+#pragma unroll
+      for (int h = 0; h < PTS / 4; h++) {
+        const uint32_t p = p0 + h;                                             // row of the half
+        const uint32_t l = (((p >> logT2) << 2) << logT2) | (p & (T2 - 1));     // column 0 of the four
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          const cx2 v = s2 ? o1[2 * h + hh] : o0[2 * h + hh];
+          float* __restrict__ d0 = (float*)&lds[img(l + ((2 * s2) << logT2))];
+          float* __restrict__ d1 = (float*)&lds[img(l + ((2 * s2 + 1) << logT2))];
+          d0[0] = v.x[0]; d0[1] = v.y[0];
+          d1[0] = v.x[1]; d1[1] = v.y[1];
+        }
+      }
+      __syncthreads();
+      if (!(FB_DBG(g) & 1)) {
+        const char* __restrict__ gb = (const char*)(Aseq + (uint64_t)hh * (L >> 1) + co_goff);
+#pragma unroll
+        for (int j4 = 0; j4 < PTS / 2; j4 += 4) {
+          float4 pr[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) pr[q] = *(const float4*)&lds[co_lds + (j4 + q) * co_lstep];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 4; q++) st_stream((float4*)(gb + (uint64_t)(j4 + q) * co_gstep * sizeof(cf)), pr[q]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (!more) break;
+    item = next;
+  }
+}
 #endif  // FB_HAS(1)
 
 #if FB_HAS(2)
@@ -1974,6 +2120,7 @@ constexpr int MAX_LOGF = 13;    // every pass keeps >= 2 columns per workgroup
 typedef mkseq<MAX_LOGF + 1>::type seq_t;
 // kernel tables live in the translation unit that instantiates the kernels
 k1_t fb_pick1(int logf, int raww, bool full);
+k1_t fb_pick1_dual(int raww);      // pass 1 on pairs of two-column tiles (2^13-point columns), or null
 k2_t fb_pick2(int logf, bool full);
 k3_t fb_pick3(int logf, bool full);       // plain
 k3_t fb_pick3f(int logf, bool full);      // fused fold
@@ -1984,6 +2131,7 @@ void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, c
 
 #ifdef FB_ONLY_HEADLINE   // experiment builds: only the kernels of the headline geometry (M = 4096, Rr = 2048, 8-bit)
 #if FB_HAS(1)
+k1_t fb_pick1_dual(int) { return nullptr; }
 k1_t fb_pick1(int logf, int raww, bool full)
 {
   if (logf == 12 && raww == 2 && full) return k_fwd_cols<12, 2, 2>;
@@ -2018,6 +2166,8 @@ template <int... I> static k1_t pick1(int logf, int raww, bool full, iseq<I...>)
   return full ? (raww == 1 ? f1[logf] : f4[logf]) : (raww == 1 ? t1[logf] : t4[logf]);
 }
 k1_t fb_pick1(int logf, int raww, bool full) { return pick1(logf, raww, full, seq_t()); }
+// (8-bit input only: with float32 input the two tiles' prefetch alone is 128 registers)
+k1_t fb_pick1_dual(int raww) { return raww == 1 ? k_fwd_cols_dual<1> : nullptr; }
 #endif
 #if FB_HAS(2)
 template <int... I> static k2_t pick2(int logf, bool full, iseq<I...>)
@@ -2095,6 +2245,7 @@ struct dspsr_amd_filterbank_impl {
   cf* tw_lo = nullptr;
   cf* tw_lo_m = nullptr;
   uint16_t* Rt = nullptr;   // pre-transposed 8-bit pairs of the parts of one launch group
+  k1_t k1d_w1 = nullptr, k1d_w4 = nullptr;   // pass 1 on pairs of tiles (64-byte A runs otherwise), see k_fwd_cols_dual
   float* det = nullptr;     // detected block of perform_fold when the fused kernel would not fill the chip
   size_t det_floats = 0;
   bool kernel_set = false;
@@ -2265,6 +2416,11 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
 #if defined(FB_ONLY_HEADLINE) && defined(DSPSR_AMD_EXPERIMENT)
     fb->k1_w2 = fb_pick1(g.logM, 2, full1);
 #endif
+    // two-column tiles of 2^13 rows whose A runs would be half cache lines: transformed in pairs (k_fwd_cols_dual)
+    if (full1 && g.logM == 13 && g.logT1 == 1 && g.logT1 + g.logT2 < 4 && g.logR >= 2 && !FB_ENV_SET("DSPSR_AMD_NO_DUAL")) {
+      fb->k1d_w1 = fb_pick1_dual(1);
+      fb->k1d_w4 = fb_pick1_dual(4);
+    }
     fb->k2 = fb_pick2(g.logR, full2);
     if (g.four_pass) {
       fb->k3a = fb_pick3a(g.logMa, g.xblocked != 0);
@@ -2288,6 +2444,8 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
       if (fb->k1_w1) e = allow_lds(fb->k1_w1, fb->lds1);
       if (e == hipSuccess && fb->k1_w4) e = allow_lds(fb->k1_w4, fb->lds1);
       if (e == hipSuccess && fb->k1_w2) e = allow_lds(fb->k1_w2, fb->lds1);
+      if (e == hipSuccess && fb->k1d_w1) e = allow_lds(fb->k1d_w1, fb->lds1);
+      if (e == hipSuccess && fb->k1d_w4) e = allow_lds(fb->k1d_w4, fb->lds1);
       if (e == hipSuccess) e = allow_lds(fb->k2, fb->lds2);
       if (e == hipSuccess && fb->k3) e = allow_lds(fb->k3, fb->lds3);
       if (e == hipSuccess && fb->k3f) e = allow_lds(fb->k3f, fb->lds3f);
@@ -2494,6 +2652,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   }
 #endif
   k1_t k1 = raww == 1 ? fb->k1_w1 : raww == 2 ? fb->k1_w2 : fb->k1_w4;
+  const k1_t k1d = raww == 1 ? fb->k1d_w1 : raww == 4 ? fb->k1d_w4 : nullptr;
   k2_t k2 = fb->k2;
   k3_t k3 = out.kind == 3 ? fb->k3f : fb->k3;
   k3a_t k3a = fb->k3a;
@@ -2542,8 +2701,12 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         ci.kind = 5;
         ci.base = fb->X;
       }
-      hipLaunchKernelGGL(k1, dim3(grid_for(n1, fb->ncu * fb->wg1)), dim3(fb->nt1), fb->lds1, ctx->stream, g, ci, fb->A, ctx->tw,
-                         part0, nb, fb->nseq, run1);
+      if (k1d)
+        hipLaunchKernelGGL(k1d, dim3(grid_for(n1 / 2, fb->ncu * fb->wg1)), dim3(fb->nt1), fb->lds1, ctx->stream, g, ci, fb->A, ctx->tw,
+                           part0, nb, fb->nseq, run1 / 2);
+      else
+        hipLaunchKernelGGL(k1, dim3(grid_for(n1, fb->ncu * fb->wg1)), dim3(fb->nt1), fb->lds1, ctx->stream, g, ci, fb->A, ctx->tw,
+                           part0, nb, fb->nseq, run1);
       ci = in; ci.ichan = ichan; ci.nchan = fb->cfg.input_nchan;
       if (in.kind == 0) ci.base = in_f32 + ichan * in_chan_stride_bytes_or_floats;
       // Pass 2 and the inverse pass run in sub-groups of a few parts, so that

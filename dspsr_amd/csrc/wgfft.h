@@ -245,6 +245,10 @@ template <int LOGF> DEV uint32_t first_stage_elem(uint32_t tid, int logT, int g,
 // Out: void operator()(uint32_t col, uint32_t p, uint32_t pstride, cx2 (&v)[R])
 //      v[k] holds output position k*pstride + p of columns col (even, .x[0]/.y[0]) and col + 1
 struct NoMid { DEV void operator()(int) const {} };
+// an Out that keeps the last-stage outputs in registers is told which of the thread's butterfly pairs a call is (`h`, a
+// compile-time constant after unrolling), so that its register array is indexed statically
+template <class O> DEV auto out_set_h(O& o, const int h, int) -> decltype((void)(o.h = h)) { o.h = h; }
+template <class O> DEV void out_set_h(O&, const int, long) {}
 
 // Mid: called once per stage between the butterflies and the exchange (`mid(stage + 1)`; the driver calls
 // `mid(0)` before the first stage).  The passes use it to issue the global loads of their NEXT tile in
@@ -308,6 +312,7 @@ DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const 
     const uint32_t p = rest & ((1u << logP) - 1);
     const uint32_t s = rest >> logP;
     if constexpr (LAST) {
+      out_set_h(out, h, 0);
       out(col, p, 1u << logP, v[h]);     // Q == 1, s == 0
     } else {
       const uint32_t e0 = ((((s << (logP + LOGR)) + p) << logT) | col), step = 1u << (logP + logT);

@@ -272,6 +272,13 @@ def test_filterbank_cfg1_optimal_size(oracle, gpu):
     _fb(oracle, gpu, 64, 262144, (7226, 7341), 1, layout="caspsr")
 
 
+def test_filterbank_cfg1_optimal_size_paired_pass1_tiles(oracle, gpu):
+    # the same geometry over three parts in launch groups of two and one: L = 2^25 -> pass 1 on PAIRS of two-column tiles
+    # (k_fwd_cols_dual: the outputs of the first tile wait in registers, four columns are copied out together in whole cache
+    # lines); every (pair, part) item against the float64 oracle
+    _fb(oracle, gpu, 64, 262144, (7226, 7341), 3, layout="caspsr", max_parts=2, seed=11)
+
+
 def test_cfg3_pipeline_geometry(gpu):
     """cfg3 through the driver: the host preparation yields the Appendix-B numbers and the fused fold conserves power."""
     dspsr_amd = gpu
