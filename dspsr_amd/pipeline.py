@@ -124,6 +124,127 @@ class Polyco:
         return sec
 
 
+class ChebyPredictor:
+    """TEMPO2 predictor (`dspsr -P file` with a `ChebyModelSet`; PSRCHIVE `Pulsar::T2Predictor` over tempo2's
+    `T2Predictor` library -- both external to the reference tree, `Fold.C:229-262` only asks the generator for one): per
+    segment a two-dimensional Chebyshev series in time and observing frequency,
+        phase(t, f) = sum'_i sum'_j c[i][j] T_i(x) T_j(y) + DISPERSION_CONSTANT / f^2,
+        x = -1 + 2 (t - t0) / (t1 - t0) over TIME_RANGE (MJD),  y = -1 + 2 (f - f0) / (f1 - f0) over FREQ_RANGE (MHz),
+    primed sums (first term halved), spin frequency = d phase / dt.  Same duck-typed interface as `Polyco` (phase_frac,
+    frequency, phase, iphase), so `LoadToFold(polyco=ChebyPredictor(text))` folds with it.  The constant term (1e9 ... 1e11
+    turns) is split into integer and fractional turns from its decimal text, so that the fractional phase keeps double
+    precision.  Parity: unpinned (tempo2 is not in the image; the series convention is the one its published
+    construction -- coefficients 4/(nx ny) times the cosine sums -- implies)."""
+
+    def __init__(self, text: str, observing_frequency: float | None = None):
+        from decimal import Decimal
+        self.segments = []
+        seg = None
+        for line in text.splitlines():
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == "ChebyModel" and tok[1] == "BEGIN":
+                seg = {"coef": []}
+            elif tok[0] == "ChebyModel" and tok[1] == "END":
+                nx, ny = seg["nx"], seg["ny"]
+                flat = seg.pop("coef")
+                if len(flat) != nx * ny:
+                    raise DspsrAmdError("ChebyPredictor: %d coefficients, NCOEFF_TIME x NCOEFF_FREQ = %d" % (len(flat), nx * ny))
+                # c[i][j]: one COEFFS record per time index i, NCOEFF_FREQ values each; the constant is kept as text
+                c00 = Decimal(flat[0]) / 4
+                seg["c00_int"] = int(c00 // 1)
+                seg["c00_frac"] = float(c00 - (c00 // 1))
+                seg["c"] = [[float(flat[i * ny + j]) for j in range(ny)] for i in range(nx)]
+                seg["c"][0][0] = 0.0
+                self.segments.append(seg)
+                seg = None
+            elif seg is not None:
+                if tok[0] == "TIME_RANGE":
+                    seg["t0"], seg["t1"] = self._mjd(tok[1]), self._mjd(tok[2])
+                elif tok[0] == "FREQ_RANGE":
+                    seg["f0"], seg["f1"] = float(tok[1]), float(tok[2])
+                elif tok[0] == "DISPERSION_CONSTANT":
+                    seg["dc"] = float(tok[1])
+                elif tok[0] == "NCOEFF_TIME":
+                    seg["nx"] = int(tok[1])
+                elif tok[0] == "NCOEFF_FREQ":
+                    seg["ny"] = int(tok[1])
+                elif tok[0] == "COEFFS":
+                    seg["coef"].extend(tok[1:])
+                elif tok[0][0] in "+-.0123456789":       # continuation line of a COEFFS record
+                    seg["coef"].extend(tok)
+        if not self.segments:
+            raise DspsrAmdError("ChebyPredictor: no ChebyModel in the predictor text")
+        s0 = self.segments[0]
+        self.observing_frequency = observing_frequency if observing_frequency is not None else 0.5 * (s0["f0"] + s0["f1"])
+
+    @staticmethod
+    def _mjd(tok):
+        day, _, frac = tok.partition(".")
+        return int(day), float("0." + (frac or "0"))
+
+    def _segment(self, day, sec):
+        t = sec / 86400.0
+        for s in self.segments:
+            a = (day - s["t0"][0]) + (t - s["t0"][1])
+            b = (s["t1"][0] - day) + (s["t1"][1] - t)
+            if a >= 0.0 and b >= 0.0:
+                return s, a, a + b
+        raise DspsrAmdError("ChebyPredictor: MJD %d + %.3f s is outside every TIME_RANGE" % (day, sec))
+
+    def _time_series(self, s):
+        """The series in x alone at the observing frequency: a[i] = sum'_j c[i][j] T_j(y); plus the constant parts."""
+        key = ("a", self.observing_frequency)
+        if s.get("key") != key:
+            y = -1.0 + 2.0 * (self.observing_frequency - s["f0"]) / (s["f1"] - s["f0"])
+            ty = [1.0, y]
+            for j in range(2, s["ny"]):
+                ty.append(2.0 * y * ty[-1] - ty[-2])
+            s["a"] = [sum((0.5 if j == 0 else 1.0) * s["c"][i][j] * ty[j] for j in range(s["ny"])) for i in range(s["nx"])]
+            s["disp"] = s.get("dc", 0.0) / (self.observing_frequency * self.observing_frequency)
+            s["key"] = key
+        return s["a"]
+
+    def _eval(self, day, sec):
+        s, a, span = self._segment(day, sec)
+        x = -1.0 + 2.0 * a / span
+        co = self._time_series(s)
+        tprev, tcur = 1.0, x
+        val = 0.5 * co[0] + (co[1] * x if len(co) > 1 else 0.0)
+        # derivative with respect to x: T_n' = n U_{n-1};  U_0 = 1, U_1 = 2x, U_n = 2x U_{n-1} - U_{n-2}
+        uprev, ucur = 1.0, 2.0 * x
+        der = co[1] if len(co) > 1 else 0.0
+        for n in range(2, len(co)):
+            tprev, tcur = tcur, 2.0 * x * tcur - tprev
+            val += co[n] * tcur
+            der += co[n] * n * ucur
+            uprev, ucur = ucur, 2.0 * x * ucur - uprev
+        return s, val + s["disp"], der * 2.0 / (span * 86400.0)
+
+    def phase(self, day, sec):
+        s, val, _ = self._eval(day, sec)
+        fr = s["c00_frac"] + val
+        fi = math.floor(fr)
+        return int(s["c00_int"] + fi), fr - fi
+
+    def phase_frac(self, day, sec):
+        return self.phase(day, sec)[1]
+
+    def frequency(self, day, sec):
+        return self._eval(day, sec)[2]
+
+    def iphase(self, phase, day, sec_guess):
+        sec = sec_guess
+        for _ in range(20):
+            pi, pf = self.phase(day, sec)
+            step = ((pi - phase[0]) + (pf - phase[1])) / self.frequency(day, sec)
+            sec -= step
+            if abs(step) < 1e-12:
+                break
+        return sec
+
+
 def choose_nbin(folding_period, rate, requested_nbin=0, maximum_nbin=1024, minimum_bin_width=1.2,
                 power_of_two=True, force_sensible_nbin=False):
     """dsp::Fold::choose_nbin (Fold.C:291-382): largest power of two <= period / (1.2 * tsamp), capped at

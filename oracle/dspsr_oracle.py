@@ -868,6 +868,80 @@ class Polyco:
         return self.f0 + d / 60.0
 
 
+class ChebyPredictor:
+    """TEMPO2 predictor text (ChebyModelSet), restated from the published definition of tempo2's T2Predictor -- ext, absent
+    from /root/reference (Fold.C:229-262 only asks Pulsar::Generator for a predictor): phase(t, f) = primed double Chebyshev
+    sum over TIME_RANGE x FREQ_RANGE + DISPERSION_CONSTANT / f^2, frequency = d phase / dt.  Written independently of the
+    product's pipeline.ChebyPredictor (numpy's chebval2d / chebder here, explicit recurrences there).  "parity unpinned"."""
+
+    def __init__(self, text: str, observing_frequency: float | None = None):
+        from fractions import Fraction
+        self.seg = []
+        cur = None
+        for line in text.splitlines():
+            t = line.split()
+            if not t:
+                continue
+            if t[:2] == ["ChebyModel", "BEGIN"]:
+                cur = {"v": []}
+            elif t[:2] == ["ChebyModel", "END"]:
+                nx, ny = cur["nx"], cur["ny"]
+                c = np.array([float(v) for v in cur["v"]], np.float64).reshape(nx, ny)
+                const = Fraction(cur["v"][0]) / 4
+                cur["ci"] = const.numerator // const.denominator
+                cur["cf"] = float(const - cur["ci"])
+                c[0, :] *= 0.5
+                c[:, 0] *= 0.5
+                c[0, 0] = 0.0
+                cur["c"] = c
+                self.seg.append(cur)
+                cur = None
+            elif cur is not None:
+                if t[0] == "TIME_RANGE":
+                    cur["t"] = [(int(v.partition(".")[0]), float("0." + (v.partition(".")[2] or "0"))) for v in t[1:3]]
+                elif t[0] == "FREQ_RANGE":
+                    cur["f"] = (float(t[1]), float(t[2]))
+                elif t[0] == "DISPERSION_CONSTANT":
+                    cur["dc"] = float(t[1])
+                elif t[0] == "NCOEFF_TIME":
+                    cur["nx"] = int(t[1])
+                elif t[0] == "NCOEFF_FREQ":
+                    cur["ny"] = int(t[1])
+                elif t[0] == "COEFFS":
+                    cur["v"] += t[1:]
+                else:
+                    try:
+                        float(t[0])
+                        cur["v"] += t
+                    except ValueError:
+                        pass
+        self.observing_frequency = observing_frequency if observing_frequency is not None else 0.5 * sum(self.seg[0]["f"])
+
+    def _xy(self, day, sec):
+        for s in self.seg:
+            a = (day - s["t"][0][0]) + (sec / 86400.0 - s["t"][0][1])
+            b = (s["t"][1][0] - day) + (s["t"][1][1] - sec / 86400.0)
+            if a >= 0 and b >= 0:
+                y = -1.0 + 2.0 * (self.observing_frequency - s["f"][0]) / (s["f"][1] - s["f"][0])
+                return s, -1.0 + 2.0 * a / (a + b), y, a + b
+        raise ValueError("ChebyPredictor: epoch outside every TIME_RANGE")
+
+    def phase(self, day, sec):
+        s, x, y, _ = self._xy(day, sec)
+        v = float(np.polynomial.chebyshev.chebval2d(x, y, s["c"])) + s.get("dc", 0.0) / self.observing_frequency ** 2
+        fr = s["cf"] + v
+        fi = math.floor(fr)
+        return int(s["ci"] + fi), fr - fi
+
+    def phase_frac(self, day, sec):
+        return self.phase(day, sec)[1]
+
+    def frequency(self, day, sec):
+        s, x, y, span = self._xy(day, sec)
+        d = np.polynomial.chebyshev.chebder(s["c"], axis=0)
+        return float(np.polynomial.chebyshev.chebval2d(x, y, d)) * 2.0 / (span * 86400.0)
+
+
 def utc_to_mjd(utc: str) -> tuple[int, float]:
     """YYYY-MM-DD-hh:mm:ss -> (integer MJD, seconds of day).  (MJD class is ext.)"""
     y, mo, d, hms = utc.split("-")
@@ -1085,6 +1159,8 @@ def predictor_phase(cfg: "FoldConfig", obs: Observation, t_seconds: float) -> tu
     day, sec = utc_to_mjd(obs.utc_start)
     sec += t_seconds
     pc = cfg.polyco
+    if isinstance(pc, ChebyPredictor):
+        return pc.phase(day, sec)
     dt = pc._dt_min(day, sec)
     poly = 0.0
     for c in pc.coef[::-1]:

@@ -327,6 +327,41 @@ def test_edge_cases_empty_and_ragged(oracle, gpu):
     lt.close()
 
 
+def test_pipeline_folds_with_tempo2_predictor(oracle, gpu):
+    """dspsr -P <ChebyModelSet>: phase and period from a TEMPO2 predictor at each block's first sample (Fold.C:943-958 through
+    the duck-typed predictor interface) -- the pipeline with pipeline.ChebyPredictor against the oracle's fold with the
+    oracle's own evaluator: hits identical, profile within 1e-5."""
+    import cheby_fixture as cf
+    from dspsr_amd import pipeline, synth
+    o = oracle
+    text = cf.cheby_text()
+    freq, bw, tsamp, dm, nchan, nbin = 1382.0, -16.0, 1.0 / 32.0, 30.0, 16, 64
+    cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=0.0, ndim=4, parts_per_block=2, max_parts=2)
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine="DADA")
+    lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream, polyco=pipeline.ChebyPredictor(text, freq))
+    step = 2 * lt.nsamp_step
+    rawh = synth.voltages(2 * step + lt.nsamp_overlap, freq, bw, tsamp, dm, 0.004)
+    d_raw = torch.from_numpy(rawh).cuda()
+    for b in range(2):
+        lt.process_block(d_raw[2 * b * step: 2 * (b * step + step + lt.nsamp_overlap)])
+    lt.finish_subint()
+    lt.synchronize()
+    got = lt.subints[0]["profile_dev"].cpu().numpy().reshape(nchan, 1, nbin, 4)
+    obs = o.Observation(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, dispersion_measure=dm)
+    resp = o.Dedispersion().match(obs, nchan)
+    plan = o.filterbank_plan(obs, nchan, resp)
+    fb = o.filterbank(o.unpack_8bit(rawh, obs), plan, lt.response.kernel, dtype=np.float64)
+    det = o.detect_layout(o.detect_products(fb, "Coherence"), 4)
+    fobs = o.filterbank_output_observation(obs, plan)
+    ps = o.PhaseSeries(nchan, 1, 4, nbin, data=np.zeros((nchan, 1, nbin, 4), np.float64))
+    fcfg = o.FoldConfig(nbin=nbin, polyco=o.ChebyPredictor(text, freq))
+    for b in range(2):
+        o.fold(det, fobs, fcfg, ps, idat_start=2 * b * plan.nkeep, ndat_fold=2 * plan.nkeep)
+    assert np.array_equal(lt.subints[0]["hits"], ps.hits) and int(ps.hits.sum()) == 4 * plan.nkeep
+    assert np.abs(got - ps.data).max() <= 1e-5 * np.abs(ps.data).max()
+    lt.close()
+
+
 def test_filterbank_errors(gpu):
     dspsr_amd, ctx = gpu
     with pytest.raises(dspsr_amd.DspsrAmdError):

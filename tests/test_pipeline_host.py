@@ -260,3 +260,34 @@ def test_phase_resolved_divisions(oracle, use_polyco, turns, ref):
             seen += cnt
         pos += blk
     assert seen == pos - div.bounds(0)[0]
+
+
+def test_cheby_predictor_closed_form_and_oracle(oracle):
+    """TEMPO2 predictor (ChebyModelSet): the product's evaluator and the oracle's independent one against the closed form of
+    the phase law the synthetic predictor text was fitted to (tests/cheby_fixture.py; tempo2 itself is absent: parity
+    unpinned) -- integer and fractional turns apart at 1.2e10 turns, spin frequency, two segments, iphase round trip."""
+    import cheby_fixture as cf
+    from dspsr_amd import pipeline
+    text = cf.cheby_text()
+    for f in (None, 1400.0, 1200.5):
+        a, b = pipeline.ChebyPredictor(text, f), oracle.ChebyPredictor(text, f)
+        fobs = f if f is not None else 1382.0                                  # default: the middle of FREQ_RANGE
+        assert a.observing_frequency == b.observing_frequency == fobs
+        for sec in (0.05 * 86400 + 0.5, 7545.0, 7545.0 + 3.3, 0.15 * 86400 - 1.0, 0.15 * 86400 + 1.0, 0.2 * 86400 + 17.0):
+            ph, fr = cf.closed_form(sec, fobs)
+            wi, wf = int(ph // 1), float(ph - ph // 1)
+            for pr in (a, b):
+                gi, gf = pr.phase(55299, sec)
+                assert abs((gi - wi) + (gf - wf)) <= 1e-9, (sec, gi, gf, wi, wf)
+                assert abs(pr.frequency(55299, sec) - fr) <= 1e-11 * fr
+                assert pr.phase_frac(55299, sec) == gf
+            ai, af = a.phase(55299, sec)
+            bi, bf = b.phase(55299, sec)
+            assert abs((ai - bi) + (af - bf)) <= 1e-10
+        t = a.iphase((a.phase(55299, 7545.0)[0] + 3, 0.25), 55299, 7545.0)
+        gi, gf = a.phase(55299, t)
+        assert gi == a.phase(55299, 7545.0)[0] + 3 and abs(gf - 0.25) <= 1e-9
+    with pytest.raises(pipeline.DspsrAmdError):
+        pipeline.ChebyPredictor(text).phase(55299, 0.3 * 86400)                    # outside every TIME_RANGE
+    with pytest.raises(pipeline.DspsrAmdError):
+        pipeline.ChebyPredictor("ChebyModelSet 0 segments\n")
