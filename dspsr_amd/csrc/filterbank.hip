@@ -2245,6 +2245,7 @@ struct dspsr_amd_filterbank_impl {
   cf* tw_lo = nullptr;
   cf* tw_lo_m = nullptr;
   uint16_t* Rt = nullptr;   // pre-transposed 8-bit pairs of the parts of one launch group
+  PlanSlot* plan_wait = nullptr;             // fold plan on its way to the device: the first kernel that reads it waits (fold_plan_wait)
   k1_t k1d_w1 = nullptr, k1d_w4 = nullptr;   // pass 1 on pairs of tiles (64-byte A runs otherwise), see k_fwd_cols_dual
   float* det = nullptr;     // detected block of perform_fold when the fused kernel would not fill the chip
   size_t det_floats = 0;
@@ -2595,6 +2596,11 @@ static int fb_launch_fused(dspsr_amd_filterbank* fb, k3_t k3, const cf* X, const
     if (nseg > 16) nseg = 16;
     if (nseg < 1) nseg = 1;
   }
+  if (fb->plan_wait) {
+    const int rc = fold_plan_wait(co.fold, fb->plan_wait);
+    fb->plan_wait = nullptr;
+    if (rc != DSPSR_AMD_OK) return rc;
+  }
   co.plan_cap = fb->plan_cap;
   co.nseg = nseg;
   co.part = nullptr;
@@ -2761,6 +2767,11 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         const uint64_t n3a = ((uint64_t)g.C << (g.logMb - g.logTm)) * nb, n3b = ((uint64_t)g.C << (g.logMa - g.logTt)) * nb;
         hipLaunchKernelGGL(k3a, dim3(grid_for(n3a, fb->ncu * fb->wg_per_cu)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern,
                            fb->A, ctx->tw, nb, 8u);
+        if (out.kind == 4 && fb->plan_wait) {      // the fused second pass reads the segment plan
+          const int rc = fold_plan_wait(out.fold, fb->plan_wait);
+          fb->plan_wait = nullptr;
+          if (rc != DSPSR_AMD_OK) return rc;
+        }
         hipLaunchKernelGGL(k3b, dim3(grid_for(n3b, fb->ncu * fb->wg_per_cu)), dim3(fb->nt4), fb->lds4, ctx->stream, g, fb->A, co,
                            ctx->tw, part0, nb, 8u);
       }
@@ -2960,7 +2971,9 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
       }
       FbOut sout = {4, fb->msum, 0, 0, 0, state, 4, 0, fold->nbin, fold->span / 4, 1u, fold->span, nullptr, fold->nchan, 0, fold, d_off,
                     (uint32_t)npart, 0, d_siv, d_blk, d_bs};
+      fb->plan_wait = sslot;
       rc = fb_run(fb, in, sout, npart, in_chan_stride);
+      if (fb->plan_wait) { (void)fold_plan_wait(fold, sslot); fb->plan_wait = nullptr; }       // (no consumer was launched)
       const int rc2 = fold_part_plan_submitted(fold, sslot);
       return rc != DSPSR_AMD_OK ? rc : rc2;
     }
@@ -2993,7 +3006,9 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
   // (float4 from one channel to the next: span/4, or both rows of the channel, 2*span/4)
   FbOut out = {3, fold->profile, 0, 0, 0, state, 4, 0, fold->nbin, planes2 ? fold->span / 2 : fold->span / 4, planes2 ? 2u : 1u,
                fold->span, nullptr, fold->nchan, 0, fold, d_start, (uint32_t)npart, 0, d_iv};
+  fb->plan_wait = slot;
   rc = fb_run(fb, in, out, npart, in_chan_stride);
+  if (fb->plan_wait) { (void)fold_plan_wait(fold, slot); fb->plan_wait = nullptr; }            // (no consumer was launched)
   const int rc2 = fold_part_plan_submitted(fold, slot);
   return rc != DSPSR_AMD_OK ? rc : rc2;
 }

@@ -334,12 +334,14 @@ static void slot_free(PlanSlot& s)
   if (s.h_aux) (void)hipHostFree(s.h_aux);
   if (s.d_aux) (void)hipFree(s.d_aux);
   if (s.done) (void)hipEventDestroy(s.done);
+  if (s.ready) (void)hipEventDestroy(s.ready);
   s = PlanSlot();
 }
 
 static bool slot_reserve(PlanSlot& s, size_t nbin1, size_t niv)
 {
   if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return false;
+  if (!s.ready && hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess) return false;
   if (nbin1 > s.bin_cap) {
     if (s.h_bin_start) (void)hipHostFree(s.h_bin_start);
     if (s.d_bin_start) (void)hipFree(s.d_bin_start);
@@ -360,6 +362,28 @@ static bool slot_reserve(PlanSlot& s, size_t nbin1, size_t niv)
   return true;
 }
 
+// Plans go to the device on the fold's own stream, not in the compute stream: there a pair of small host-to-device copies
+// stood between the last kernel of one block and the first of the next (about 45 us of idle device per block in the kernel
+// trace, 3.5 % of a cfg4 block), although the kernel that reads the plan is launched several passes later.  The pinned
+// source and the device copy of a slot are only rewritten after its `done` event (recorded on the compute stream behind the
+// consumer) has been waited for on the host.
+struct PlanCopy { void* dst; const void* src; size_t bytes; };
+static hipError_t plan_upload(dspsr_amd_fold* f, PlanSlot& sl, const PlanCopy* c, const int n)
+{
+  hipError_t e = hipSuccess;
+  if (!f->upload) e = hipStreamCreateWithFlags(&f->upload, hipStreamNonBlocking);
+  for (int i = 0; i < n && e == hipSuccess; i++)
+    if (c[i].bytes) e = hipMemcpyAsync(c[i].dst, c[i].src, c[i].bytes, hipMemcpyHostToDevice, f->upload);
+  if (e == hipSuccess) e = hipEventRecord(sl.ready, f->upload);
+  return e;
+}
+int fold_plan_wait(dspsr_amd_fold* f, PlanSlot* slot)
+{
+  const hipError_t e = hipStreamWaitEvent(f->ctx->stream, slot->ready, 0);
+  if (e != hipSuccess) return ctx_fail(f->ctx, DSPSR_AMD_EHIP, "fold: plan wait: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}
+
 extern "C" int dspsr_amd_fold_create(dspsr_amd_ctx* ctx, dspsr_amd_fold** out)
 {
   if (!ctx || !out) return DSPSR_AMD_EINVAL;
@@ -375,6 +399,7 @@ extern "C" void dspsr_amd_fold_destroy(dspsr_amd_fold* f)
   (void)hipStreamSynchronize(f->ctx->stream);
   if (f->profile && !f->bound) (void)hipFree(f->profile);
   if (f->part) (void)hipFree(f->part);
+  if (f->upload) { (void)hipStreamSynchronize(f->upload); (void)hipStreamDestroy(f->upload); }
   slot_free(f->slot[0]);
   slot_free(f->slot[1]);
   delete f;
@@ -638,11 +663,12 @@ static int fold_fold_impl(dspsr_amd_fold* f, const float* in_dev, uint64_t in_ch
     Interval v; v.offset = r.offset; v.hits = r.hits; v.pad = 0;
     sl.h_iv[f->cursor[r.ibin]++] = v;
   }
-  e = hipMemcpyAsync(sl.d_bin_start, sl.h_bin_start, (nbin + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
-                     ctx->stream);
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(sl.d_iv, sl.h_iv, niv * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);
+  {
+    const PlanCopy pc[2] = {{sl.d_bin_start, sl.h_bin_start, (nbin + 1) * sizeof(uint32_t)}, {sl.d_iv, sl.h_iv, niv * sizeof(Interval)}};
+    e = plan_upload(f, sl, pc, 2);
+  }
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: plan copy: %s", hipGetErrorString(e));
+  if (fold_plan_wait(f, &sl) != DSPSR_AMD_OK) return DSPSR_AMD_EHIP;
 
   // sample span covered by the plan (intervals are time ordered)
   uint64_t first = f->binplan.front().offset, last = f->binplan.back().offset + f->binplan.back().hits;
@@ -813,9 +839,8 @@ int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, cons
     }
   }
   st[npart] = (uint32_t)e;
-  hipError_t er = hipMemcpyAsync(sl.d_bin_start, sl.h_bin_start, nwords * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-  if (er == hipSuccess && npiece)
-    er = hipMemcpyAsync(sl.d_iv, sl.h_iv, npiece * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);
+  const PlanCopy pc[2] = {{sl.d_bin_start, sl.h_bin_start, nwords * sizeof(uint32_t)}, {sl.d_iv, sl.h_iv, npiece * sizeof(Interval)}};
+  const hipError_t er = plan_upload(f, sl, pc, 2);      // the caller waits (fold_plan_wait) in front of the kernel that reads it
   if (er != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "fused fold: plan copy: %s", hipGetErrorString(er));
   f->binplan.clear();
   *d_start = sl.d_bin_start;
@@ -905,9 +930,9 @@ int fold_build_segment_plan(dspsr_amd_fold* f, uint64_t ndat, uint32_t seg, bool
     Interval v; v.offset = r.offset; v.hits = r.hits; v.pad = 0;
     sl.h_iv[f->cursor[r.ibin]++] = v;
   }
-  hipError_t e = hipMemcpyAsync(sl.d_aux, sl.h_aux, naux * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(sl.d_bin_start, sl.h_bin_start, (nbin + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(sl.d_iv, sl.h_iv, nrun * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream);
+  const PlanCopy pc[3] = {{sl.d_aux, sl.h_aux, naux * sizeof(uint32_t)}, {sl.d_bin_start, sl.h_bin_start, (nbin + 1) * sizeof(uint32_t)},
+                          {sl.d_iv, sl.h_iv, nrun * sizeof(Interval)}};
+  hipError_t e = plan_upload(f, sl, pc, 3);             // the caller waits (fold_plan_wait) in front of the kernel that reads it
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "fused fold: plan copy: %s", hipGetErrorString(e));
   f->binplan.clear();
   *d_run_off = sl.d_aux;

@@ -22,6 +22,7 @@ struct PlanSlot {
   size_t aux_cap = 0;
   hipEvent_t done = nullptr;
   bool pending = false;
+  hipEvent_t ready = nullptr;        // the plan's copies (issued on the fold's upload stream) have landed
 };
 
 struct dspsr_amd_fold {
@@ -34,6 +35,7 @@ struct dspsr_amd_fold {
   size_t part_floats = 0;
   bool bound = false;           // profile points into the engine-owned device PhaseSeries (dspsr_amd_fold_bind_profile)
   // run-length plan, as CUDA::FoldEngine (FoldCUDA.cu:64-113)
+  hipStream_t upload = nullptr;  // plans travel host -> device beside the compute stream (see plan_upload in fold.hip)
   std::vector<dspsr_amd::RunBin> binplan;
   uint32_t current_bin = 0, current_hits = 0, folding_nbin = 0;
   uint64_t ndat_fold = 0;
@@ -67,6 +69,8 @@ static inline uint32_t fold_plan_max_run(const dspsr_amd_fold* f)
 // fold_part_plan_submitted() must be called after the kernels that read the plan have been enqueued.
 int fold_build_part_plan(dspsr_amd_fold* f, uint32_t nkeep, uint32_t npart, const uint32_t** d_start,
                          const dspsr_amd::Interval** d_iv, PlanSlot** slot);
+// the compute stream waits until the plan in `slot` has landed (call right in front of the first kernel that reads it)
+int fold_plan_wait(dspsr_amd_fold* f, PlanSlot* slot);
 int fold_part_plan_submitted(dspsr_amd_fold* f, PlanSlot* slot);
 
 // Four-pass fused fold (filterbank.hip k_inv_b<., true>): the pending plan must cover samples [0, ndat) without gaps and

@@ -1,5 +1,5 @@
 """Host time per LoadToFold.process_block call (enqueue only) against the GPU time of the block.
-usage: python tools/host_overhead.py [parts_per_block] [max_parts]"""
+usage: python tools/host_overhead.py [parts_per_block] [max_parts] [workload]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,10 +7,12 @@ from dspsr_amd import pipeline
 import bench
 ppb = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 mp = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-wl = bench.WORKLOADS["target"]
-info = pipeline.InputInfo(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=1, npol=2, ndim=1, tsamp_us=wl["tsamp_us"], machine="CASPSR")
-cfg = pipeline.Config(nchan=1024, dispersion_measure=1000.0, nbin=1024, folding_period=0.0893, freq_res=4096, parts_per_block=ppb, max_parts=mp)
-lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+wl = bench.WORKLOADS[sys.argv[3] if len(sys.argv) > 3 else "target"]
+info = pipeline.InputInfo(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=wl["in_nchan"], npol=2, ndim=wl["ndim"], tsamp_us=wl["tsamp_us"],
+                          machine=wl["machine"])
+cfg = pipeline.Config(nchan=wl["nchan"], dispersion_measure=wl["dm"], nbin=wl["nbin"], folding_period=0.0893, freq_res=wl["freq_res"],
+                      parts_per_block=ppb, max_parts=mp)
+lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream, subband=0 if wl["in_nchan"] > 1 else None)
 raw = (torch.randn(lt.block_bytes(), device="cuda") * 24).round().clamp(-128, 127).to(torch.int8)
 for _ in range(3):
     lt.process_block(raw)
