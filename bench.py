@@ -929,7 +929,8 @@ def main():
         short = argparse.Namespace(**vars(args))
         ssteps, swarm = max(5, min(args.steps, 10)), 3
         if world <= WORKLOADS["cfg4"]["in_nchan"]:
-            shard = run_fold_workload("cfg4", short, *ctx, steps=max(ssteps, 2 * args.dump_steps), warmup=swarm, full=False)
+            # (blocks of 1.4 ms: enough of them that the first block's host preparation and the last dump do not weigh)
+            shard = run_fold_workload("cfg4", short, *ctx, steps=max(4 * ssteps, 8 * args.dump_steps), warmup=swarm, full=False)
             if rank == 0:
                 out["subband_shard"] = brief(shard)
                 out["subband_shard"]["note"] = ("the north-star scaling curve: rank g = sub-band g of the NCHAN-8 band (weak scaling, "
@@ -938,11 +939,11 @@ def main():
         if world == 1:
             others = []
             for w in ("cfg1", "cfg1opt", "cfg2", "cfg3"):
-                others.append(brief(run_fold_workload(w, short, *ctx, steps=5, warmup=2, full=False)))
+                others.append(brief(run_fold_workload(w, short, *ctx, steps=2 * ssteps, warmup=swarm, full=False)))
             sm = argparse.Namespace(**vars(args))
-            sm.steps, sm.warmup, sm.no_cpu_baseline = 5, 2, True
+            sm.steps, sm.warmup, sm.no_cpu_baseline = 2 * ssteps, swarm, True
             rec5 = bench_search_mode(sm, WORKLOADS["cfg5"], torch)
-            others.append({"workload": "cfg5", "value": rec5["value"], "unit": rec5["unit"], "ms_per_step": rec5["ms_per_step"], "steps": 5,
+            others.append({"workload": "cfg5", "value": rec5["value"], "unit": rec5["unit"], "ms_per_step": rec5["ms_per_step"], "steps": rec5["steps"],
                            "roofline_frac": rec5["roofline"]["frac"], "roofline_kernel": rec5["roofline"]["kernel"],
                            "command": rec5["config"]["command"]})
             out["other_workloads"] = others
