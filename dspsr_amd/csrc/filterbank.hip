@@ -2726,7 +2726,10 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
       if (p23auto < 1) p23auto = 1;
       // (the fused kernel gains less, +1.4 % Msamples/s measured in three alternating runs, but consistently)
       const bool sub_fused = FB_ENV_INT("DSPSR_AMD_P23_SUB_FUSED", 1) != 0;
-      const uint32_t p23sub = (g.four_pass || (co.kind == 3 && !sub_fused) || p23sub_env == 0) ? nb
+      // (segmented fused fold -- geometries with fewer channel tiles than compute units: every launch of the fused kernel
+      //  brings a memset and a combine pass over the partial profiles, so whole launches win: 50 MHz sub-band geometry
+      //  43.5k -> 46.0k Msamples/s, -F 256:D 60.3k -> 60.6-61.3k, tools/exp_p23.sh)
+      const uint32_t p23sub = (g.four_pass || (co.kind == 3 && (!sub_fused || fused_segmented)) || p23sub_env == 0) ? nb
                               : (p23sub_env > 0 ? (uint32_t)p23sub_env : (uint32_t)(p23auto < nb ? p23auto : nb));
       if (p23sub < nb) {
         const size_t lds3s = co.kind == 3 ? fb->lds3f : fb->lds3;
