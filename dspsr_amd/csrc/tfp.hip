@@ -48,6 +48,12 @@ template <bool CASPSR> DEV uint32_t tfp_word(const uint8_t* img, const uint32_t 
     return (uint32_t)*(const uint16_t*)(img + 2 * t0) | ((uint32_t)*(const uint16_t*)(img + 2 * t0 + 2) << 16);
   }
 }
+// the same from a 4-byte aligned image (the LDS copy of a 16-byte aligned block): generic order = one aligned word
+template <bool CASPSR> DEV uint32_t tfp_word_aligned(const uint8_t* img, const uint32_t t0)
+{
+  if constexpr (CASPSR) return tfp_word<true>(img, t0);
+  else return *(const uint32_t*)(img + 2 * t0);
+}
 
 // COAL: the parts of a tile are ONE contiguous range of 2^15 bytes.  Every thread loads 16-byte pieces of the range
 // (prefetched one tile ahead, 4 registers per piece), the bytes go through the -- at that moment idle -- exchange buffer, and
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
           for (int i = 0; i < P::R1; i++) {
             uint32_t pl, n;
             elem(g2, i, pl, n);
-            rw[(g2 / 2) * P::R1 + i] = tfp_word<CASPSR>(img + (pl << (LOGC + 2)), 2 * n);
+            rw[(g2 / 2) * P::R1 + i] = tfp_word_aligned<CASPSR>(img + (pl << (LOGC + 2)), 2 * n);
           }
       }
 #pragma unroll
@@ -155,14 +161,17 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
         }
       }
       if constexpr (COAL) __syncthreads();      // every thread has taken its words: the exchanges may overwrite the image
+      // staged transform: one plane of C float4 per part (column pair), (Re p0, Re p1, Im p0, Im p1) -- the register order of
+      // the pair and what the read-back wants for packed arithmetic; the planes are 8 float4 apart modulo the bank period, so the
+      // lanes of a store (two parts, consecutive positions) and of a read-back (consecutive bins of one part) fall on
+      // different banks (position-major staging read back with a 2-way conflict)
+      float4* const stg = (float4*)lds;
+      const uint32_t plane = C + (Tp <= 64 ? 8u : 0u);       // (the buffer's slack holds 512 float4 of padding)
       auto store = [&](const uint32_t col, const uint32_t pp, const uint32_t pstride, auto& v) {
         constexpr int R = sizeof(v) / sizeof(v[0]);
+        float4* const d = stg + (col >> 1) * plane + pp;
 #pragma unroll
-        for (int k = 0; k < R; k++) {
-          const uint32_t pos = k * pstride + pp;
-          // (Re p0, Re p1, Im p0, Im p1): the register order of the pair, and what the read-back wants for packed arithmetic
-          *(float4*)&lds[lds_pad((pos << logT) | col)] = make_float4(v[k].x[0], v[k].x[1], v[k].y[0], v[k].y[1]);
-        }
+        for (int k = 0; k < R; k++) d[k * pstride] = make_float4(v[k].x[0], v[k].x[1], v[k].y[0], v[k].y[1]);
       };
       wgfft<LOGC, -1, true>(lds, ltw_off, tid, logT, x, store);
       __syncthreads();
@@ -184,12 +193,12 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
       auto powers = [&](const uint32_t k, const uint32_t c2, const float c, const float sn, float (&pw)[2][2]) {
         v2f pk, pm;
         if (k == 0) {               // bins 0 and C/2 are their own mirrors: X[0] from Z[0] (w = 1), X[C/2] from Z[C/2] (w = -i)
-          const float4 z0 = *(const float4*)&lds[lds_pad(2 * c2)], zh = *(const float4*)&lds[lds_pad(((C / 2) << logT) | (2 * c2))];
+          const float4 z0 = stg[c2 * plane], zh = stg[c2 * plane + C / 2];
           v2f unused;
           powers1(z0, z0, 1.0f, 0.0f, pk, unused);
           powers1(zh, zh, 0.0f, 1.0f, pm, unused);
         } else {
-          powers1(*(const float4*)&lds[lds_pad((k << logT) | (2 * c2))], *(const float4*)&lds[lds_pad(((C - k) << logT) | (2 * c2))], c, sn, pk, pm);
+          powers1(stg[c2 * plane + k], stg[c2 * plane + (C - k)], c, sn, pk, pm);
         }
         if (p.pscrunch) { pk[0] += pk[1]; pm[0] += pm[1]; pk[1] = pm[1] = 0.f; }   // :79-80 pol sum BEFORE the time sum
         pw[0][0] = pk[0]; pw[0][1] = pk[1]; pw[1][0] = pm[0]; pw[1][1] = pm[1];
