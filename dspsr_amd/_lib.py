@@ -80,6 +80,7 @@ SYMBOLS = {
     "dspsr_amd_rescale_destroy": (None, [_vp]),
     "dspsr_amd_rescale_transform": (_i, [_vp, _vp, _vp, _u64]),
     "dspsr_amd_rescale_get": (_i, [_vp, _vp, _vp]),
+    "dspsr_amd_rescale_pscrunch_digitize": (_i, [_vp, _vp, _u64, _i, _f, _i, _i, _vp]),
     "dspsr_amd_sigproc_digitize": (_i, [_vp, _vp, _u64, _u32, _u32, _i, _i, _d, _f, _i, _i, _vp]),
     "dspsr_amd_detect_polarimetry": (_i, [_vp, _i, _u32, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u64]),
     "dspsr_amd_detect_square_law": (_i, [_vp, _i, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u32, _u64]),

@@ -208,10 +208,11 @@ extern "C" void dspsr_amd_rescale_destroy(dspsr_amd_rescale* r)
   delete r;
 }
 
-extern "C" int dspsr_amd_rescale_transform(dspsr_amd_rescale* r, const float* in_tfp_dev, float* out_tfp_dev, uint64_t ndat)
+// Rescale::transformation over one block: statistics per interval segment, then `apply(start, n)` for the segment's samples
+// with the offset / scale in force for it (the plain apply pass, or the fused apply + PScrunch + digitiser)
+template <class Apply>
+static int rescale_block(dspsr_amd_rescale* r, const float* in_tfp_dev, uint64_t ndat, const char* who, Apply&& apply)
 {
-  if (!r || (!in_tfp_dev && ndat) || (!out_tfp_dev && ndat)) return DSPSR_AMD_EINVAL;
-  if (!ndat) return DSPSR_AMD_OK;
   dspsr_amd_ctx* ctx = r->ctx;
   if (!r->nsample) r->nsample = ndat;                       // Rescale::init: nsample = input->get_ndat()
   const uint32_t ncol = r->ncol;
@@ -233,7 +234,7 @@ extern "C" int dspsr_amd_rescale_transform(dspsr_amd_rescale* r, const float* in
       r->part_cap = 0;
       const size_t bytes = (size_t)nslice * ncol * sizeof(double);
       if (hipMalloc((void**)&r->part_sum, bytes) != hipSuccess || hipMalloc((void**)&r->part_sq, bytes) != hipSuccess)
-        return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_rescale_transform: hipMalloc of the partial sums failed");
+        return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "%s: hipMalloc of the partial sums failed", who);
       r->part_cap = nslice;
     }
     const float* seg = in_tfp_dev + start * ncol;
@@ -248,16 +249,26 @@ extern "C" int dspsr_amd_rescale_transform(dspsr_amd_rescale* r, const float* in
       r->isample = 0;
       r->first_call = false;
     }
-    const uint64_t nel = n * ncol;
-    uint64_t gb = (nel + 255) / 256;
-    if (gb > 4096) gb = 4096;
-    hipLaunchKernelGGL(k_rescale_apply, dim3((uint32_t)gb), dim3(256), 0, ctx->stream, seg, out_tfp_dev + start * ncol, nel,
-                       ncol, r->offset, r->scale);
+    apply(start, n);
     start = end;
   } while (start < ndat);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_rescale_transform: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "%s: %s", who, hipGetErrorString(e));
   return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_rescale_transform(dspsr_amd_rescale* r, const float* in_tfp_dev, float* out_tfp_dev, uint64_t ndat)
+{
+  if (!r || (!in_tfp_dev && ndat) || (!out_tfp_dev && ndat)) return DSPSR_AMD_EINVAL;
+  if (!ndat) return DSPSR_AMD_OK;
+  const uint32_t ncol = r->ncol;
+  return rescale_block(r, in_tfp_dev, ndat, "dspsr_amd_rescale_transform", [&](const uint64_t start, const uint64_t n) {
+    const uint64_t nel = n * ncol;
+    uint64_t gb = (nel + 255) / 256;
+    if (gb > 4096) gb = 4096;
+    hipLaunchKernelGGL(k_rescale_apply, dim3((uint32_t)gb), dim3(256), 0, r->ctx->stream, in_tfp_dev + start * ncol,
+                       out_tfp_dev + start * ncol, nel, ncol, r->offset, r->scale);
+  });
 }
 
 extern "C" int dspsr_amd_rescale_get(dspsr_amd_rescale* r, float* offset_host, float* scale_host)
@@ -270,6 +281,101 @@ extern "C" int dspsr_amd_rescale_get(dspsr_amd_rescale* r, float* offset_host, f
   if (e == hipSuccess) e = hipStreamSynchronize(r->ctx->stream);
   if (e != hipSuccess) return ctx_fail(r->ctx, DSPSR_AMD_EHIP, "dspsr_amd_rescale_get: %s", hipGetErrorString(e));
   return DSPSR_AMD_OK;
+}
+
+// digitiser constants, SigProcDigitizer.C:112-158
+struct DigiParams { float mean, scale, xpol_offset; int max; };
+static DigiParams digi_params(int nbit, int use_digi_scales, double input_scale, float scale_fac)
+{
+  DigiParams d = {0.f, 0.f, 0.f, 0};
+  const float digi_sigma = 6.f;
+  switch (nbit) {                                            // :112-143
+    case 1: d.mean = 0.5f; d.scale = 1.f; d.max = 1; break;
+    case 2: d.mean = 1.5f; d.scale = 1.f; d.max = 3; break;
+    case 4: d.mean = 7.5f; d.scale = d.mean / digi_sigma; d.max = 15; break;
+    case 8: d.mean = 127.5f; d.scale = d.mean / digi_sigma; d.max = 255; break;
+    case 16: d.mean = 32768.0f; d.scale = d.mean / digi_sigma; d.max = 65535; break;
+  }
+  if (!use_digi_scales) { d.xpol_offset = d.mean; d.mean = 0.f; d.scale = 1.f; }          // :148-154
+  d.scale = (float)((double)d.scale / (input_scale * (double)scale_fac));                // :158 (get_scale() is a double)
+  return d;
+}
+
+// digifil's output stage behind the TFP filterbank in ONE pass over the detected block (LoadToFil.C:318-362): Rescale's
+// (x + offset) * scale per polarisation (Rescale.C:352), PScrunch's (p0 + p1) * float(1/sqrt 2) (PScrunch.C:52,72-90) and the
+// digitiser (SigProcDigitizer.C:160-236), the same float operations in the same order as the three kernels above -- the
+// rescaled block and the intensity block are not written (200 of the 343 MB the separate passes move per 67 MB block).
+// One thread per output byte (sub-byte: 8/nbit consecutive output channels; 16-bit: per sample); blockIdx.y walks the rows.
+template <int SPB>       // samples per output byte (1 for 8 and 16 bits)
+__global__ __launch_bounds__(256) void k_rescale_pscrunch_digitize(const float* __restrict__ in, uint8_t* __restrict__ out,
+                                                                   const uint32_t ndat, const uint32_t nchan, const int nbit,
+                                                                   const float* __restrict__ offset, const float* __restrict__ scale,
+                                                                   const float pscale, const float digi_scale, const float digi_mean,
+                                                                   const int digi_max, const int flip_band, const int swap_band)
+{
+  constexpr uint32_t spb = SPB;
+  const uint32_t units = nchan / spb;                            // bytes (16-bit: samples) per time sample
+  const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= units) return;
+  // the thread's channels and their offset / scale are the same for every row
+  uint32_t ic[SPB];
+  float o0[SPB], o1[SPB], s0[SPB], s1[SPB];
+#pragma unroll
+  for (uint32_t j = 0; j < spb; j++) {
+    uint32_t c = w * spb + j;                                    // ChannelSort, SigProcDigitizer.C:52-65
+    if (swap_band) c = (c + nchan / 2) % nchan;
+    if (flip_band) c = nchan - c - 1;
+    ic[j] = c;
+    o0[j] = offset[2 * c]; o1[j] = offset[2 * c + 1];
+    s0[j] = scale[2 * c]; s1[j] = scale[2 * c + 1];
+  }
+  for (uint32_t idat = blockIdx.y; idat < ndat; idat += gridDim.y) {
+    const float2* __restrict__ row = (const float2*)(in + (uint64_t)idat * nchan * 2);
+    uint32_t byte = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < spb; j++) {
+      const float2 p = row[ic[j]];
+      const float a = __fmul_rn(__fadd_rn(p.x, o0[j]), s0[j]), b = __fmul_rn(__fadd_rn(p.y, o1[j]), s1[j]);     // Rescale.C:352
+      const float x = __fmul_rn(__fadd_rn(a, b), pscale);                                                       // PScrunch.C:84
+      const double d = (double)__fadd_rn(__fmul_rn(x, digi_scale), digi_mean) + 0.5;                            // :198
+      int r = (d >= 2147483648.0 || d <= -2147483649.0 || d != d) ? (int)0x80000000 : (int)d;
+      r = r < 0 ? 0 : r;
+      r = r > digi_max ? digi_max : r;
+      byte |= (uint32_t)r << (j * (nbit >= 8 ? 0 : nbit));
+    }
+    if (nbit == 16) ((uint16_t*)out)[(uint64_t)idat * units + w] = (uint16_t)byte;
+    else out[(uint64_t)idat * units + w] = (uint8_t)byte;
+  }
+}
+
+extern "C" int dspsr_amd_rescale_pscrunch_digitize(dspsr_amd_rescale* r, const float* in_tfp_dev, uint64_t ndat, int nbit,
+                                                   float scale_fac, int flip_band, int swap_band, void* out_dev)
+{
+  if (!r || ((!in_tfp_dev || !out_dev) && ndat)) return DSPSR_AMD_EINVAL;
+  dspsr_amd_ctx* ctx = r->ctx;
+  if (r->npol != 2)
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_rescale_pscrunch_digitize: two polarisations in (PPQQ), npol=%u", r->npol);
+  if (nbit != 1 && nbit != 2 && nbit != 4 && nbit != 8 && nbit != 16)
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dsp::SigProcDigitizer::set_nbit nbit=%i not understood", nbit);
+  if (nbit < 8 && r->nchan % (8 / nbit))
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_rescale_pscrunch_digitize: nchan=%u not a multiple of %d samples per byte",
+                    r->nchan, 8 / nbit);
+  if (!ndat) return DSPSR_AMD_OK;
+  const DigiParams d = digi_params(nbit, 1, 1.0, scale_fac);        // behind Rescale the input scale is 1 (Rescale.C:204)
+  const uint32_t nchan = r->nchan, spb = nbit >= 8 ? 1 : 8 / nbit, units = nchan / spb;
+  const float pscale = (float)(1.0 / sqrt(2.0));                     // PScrunch.C:52
+  const size_t out_row = (size_t)units * (nbit == 16 ? 2 : 1);
+  return rescale_block(r, in_tfp_dev, ndat, "dspsr_amd_rescale_pscrunch_digitize", [&](const uint64_t start, const uint64_t n) {
+    for (uint64_t s0 = 0; s0 < n; s0 += 1u << 30) {                 // (32-bit row counter in the kernel)
+      const uint32_t rows = (uint32_t)(n - s0 < (1u << 30) ? n - s0 : (1u << 30));
+      const uint32_t gy = rows < 8192 ? rows : 8192;
+      auto k = spb == 1 ? k_rescale_pscrunch_digitize<1> : spb == 2 ? k_rescale_pscrunch_digitize<2>
+               : spb == 4 ? k_rescale_pscrunch_digitize<4> : k_rescale_pscrunch_digitize<8>;
+      hipLaunchKernelGGL(k, dim3((units + 255) / 256, gy), dim3(256), 0, ctx->stream,
+                         in_tfp_dev + (start + s0) * (uint64_t)nchan * 2, (uint8_t*)out_dev + (start + s0) * out_row, rows, nchan, nbit,
+                         r->offset, r->scale, pscale, d.scale, d.mean, d.max, flip_band, swap_band);
+    }
+  });
 }
 
 extern "C" int dspsr_amd_sigproc_digitize(dspsr_amd_ctx* ctx, const float* in_tfp_dev, uint64_t ndat, uint32_t nchan,
@@ -291,19 +397,9 @@ extern "C" int dspsr_amd_sigproc_digitize(dspsr_amd_ctx* ctx, const float* in_tf
   }
   if (nbit < 8 && nchan % (8 / nbit))
     return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_sigproc_digitize: nchan=%u not a multiple of %d samples per byte", nchan, 8 / nbit);
-  float digi_mean = 0.f, digi_scale = 0.f;
-  const float digi_sigma = 6.f;
-  int digi_max = 0;
-  switch (nbit) {                                            // SigProcDigitizer.C:112-143
-    case 1: digi_mean = 0.5f; digi_scale = 1.f; digi_max = 1; break;
-    case 2: digi_mean = 1.5f; digi_scale = 1.f; digi_max = 3; break;
-    case 4: digi_mean = 7.5f; digi_scale = digi_mean / digi_sigma; digi_max = 15; break;
-    case 8: digi_mean = 127.5f; digi_scale = digi_mean / digi_sigma; digi_max = 255; break;
-    case 16: digi_mean = 32768.0f; digi_scale = digi_mean / digi_sigma; digi_max = 65535; break;
-  }
-  float xpol_offset = 0.f;
-  if (!use_digi_scales) { xpol_offset = digi_mean; digi_mean = 0.f; digi_scale = 1.f; }   // :148-154
-  digi_scale = (float)((double)digi_scale / (input_scale * (double)scale_fac));           // :158 (get_scale() is a double)
+  const DigiParams dp = digi_params(nbit, use_digi_scales, input_scale, scale_fac);
+  const float digi_mean = dp.mean, digi_scale = dp.scale, xpol_offset = dp.xpol_offset;
+  const int digi_max = dp.max;
   const uint32_t spb = nbit >= 8 ? 1 : 8 / nbit;
   const uint64_t units = ndat * npol * (nchan / spb);
   uint64_t gb = (units + 255) / 256;

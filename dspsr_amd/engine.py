@@ -371,6 +371,18 @@ class Rescale:
                "dspsr_amd_rescale_transform")
         return out
 
+    def pscrunch_digitize(self, inp, out, nbit=8, scale_fac=1.0, flip_band=False, swap_band=False):
+        """Rescale -> PScrunch -> SigProcDigitizer of a PPQQ block [ndat][nchan][2] in one pass (the bytes of transform() +
+        pscrunch_tfp() + sigproc_digitize(), without the two intermediate blocks)."""
+        ndat = inp.numel() // (self.nchan * self.npol)
+        need = ndat * self.nchan * nbit // 8
+        if out.numel() * out.element_size() < need:
+            raise DspsrAmdError("dspsr_amd.Rescale.pscrunch_digitize: out holds %d bytes, %d needed" % (out.numel() * out.element_size(), need))
+        _check(self.ctx.handle,
+               lib.dspsr_amd_rescale_pscrunch_digitize(self.handle, inp.data_ptr(), ndat, nbit, scale_fac, int(flip_band), int(swap_band),
+                                                       out.data_ptr()), "dspsr_amd_rescale_pscrunch_digitize")
+        return out
+
     def get(self):
         off = np.empty(self.nchan * self.npol, np.float32)
         sc = np.empty(self.nchan * self.npol, np.float32)

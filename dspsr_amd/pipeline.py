@@ -1124,6 +1124,8 @@ class LoadToFil:
     (LoadToFil.C:196-362): TFPFilterbank (PPQQ) + TScrunch [one kernel] -> Rescale (per pol and channel, in place)
     -> PScrunch -> SigProcDigitizer.  process_block returns the packed block (device uint8, [time][chan] n-bit)."""
 
+    fused_output = True          # Rescale + PScrunch + digitiser as one pass (False: the three operations one after the other)
+
     def __init__(self, cfg: SearchConfig, info: InputInfo, device: int = 0, stream: int | None = None):
         import torch
         self.torch = torch
@@ -1167,11 +1169,16 @@ class LoadToFil:
         nout = npart // cfg.tscrunch
         det = self.detected[:nout]
         tfp_filterbank(self.ctx, raw, cfg.nchan, npart, det, False, cfg.tscrunch, self.layout, self.scale8)
+        packed = self.packed[:nout * self.bytes_per_sample]
+        if self.rescale is not None and self.fused_output and cfg.nbit in (1, 2, 4, 8, 16):
+            # Rescale -> PScrunch -> digitiser in one pass over the PPQQ block (identical bytes, LoadToFil.C:318-362)
+            self.rescale.pscrunch_digitize(det, packed, cfg.nbit, cfg.scale_fac, flip_band=self.info.bandwidth > 0, swap_band=False)
+            self.ndat_out += nout
+            return packed
         if self.rescale is not None:
             self.rescale.transform(det)                                            # in place, LoadToFil.C:325-326
         inten = self.intensity[:nout]
         pscrunch_tfp(self.ctx, det, inten, cfg.nchan, 2)                            # LoadToFil.C:333-343
-        packed = self.packed[:nout * self.bytes_per_sample]
         # after Rescale the input scale is 1 (Rescale.C:204); without it the TFP filterbank leaves scale 1 as well
         sigproc_digitize(self.ctx, inten, packed, cfg.nchan, 1, cfg.nbit, use_digi_scales=self.rescale is not None,
                          input_scale=1.0, scale_fac=cfg.scale_fac, flip_band=self.info.bandwidth > 0, swap_band=False)

@@ -305,6 +305,13 @@ int dspsr_amd_rescale_create(dspsr_amd_ctx* ctx, uint32_t nchan, uint32_t npol, 
 void dspsr_amd_rescale_destroy(dspsr_amd_rescale* r);
 int dspsr_amd_rescale_transform(dspsr_amd_rescale* r, const float* in_tfp_dev, float* out_tfp_dev, uint64_t ndat);
 int dspsr_amd_rescale_get(dspsr_amd_rescale* r, float* offset_host, float* scale_host);   /* [npol*nchan]: index ichan*npol+ipol */
+/* digifil's whole output stage behind the TFP filterbank (LoadToFil.C:318-362) in one pass over a PPQQ block [ndat][nchan][2]:
+ * dsp::Rescale (statistics and intervals exactly as dspsr_amd_rescale_transform, Rescale.C:217-388) -> dsp::PScrunch
+ * (PScrunch.C:52,72-90) -> dsp::SigProcDigitizer::pack (SigProcDigitizer.C:112-236; nbit 1/2/4/8/16, input scale 1 behind Rescale),
+ * the same float operations in the same order as the three separate calls -- identical bytes -- without writing the rescaled
+ * and the summed block.  out_dev: [ndat][nchan * nbit / 8] bytes. */
+int dspsr_amd_rescale_pscrunch_digitize(dspsr_amd_rescale* r, const float* in_tfp_dev, uint64_t ndat, int nbit, float scale_fac,
+                                        int flip_band, int swap_band, void* out_dev);
 int dspsr_amd_sigproc_digitize(dspsr_amd_ctx* ctx, const float* in_tfp_dev, uint64_t ndat, uint32_t nchan, uint32_t npol,
                                int nbit, int use_digi_scales, double input_scale, float scale_fac, int flip_band,
                                int swap_band, void* out_dev);

@@ -784,6 +784,37 @@ def test_rescale_matches_oracle(oracle, gpu, nchan, npol, ndat, interval, consta
     r.close()
 
 
+@pytest.mark.parametrize("nbit", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("nchan,ndat,interval,flip,swap", [(1024, 700, 0, True, False), (64, 513, 200, False, True), (256, 97, 1000, True, True)])
+def test_fused_output_stage_identical_bytes(gpu, nbit, nchan, ndat, interval, flip, swap):
+    """dspsr_amd_rescale_pscrunch_digitize == dspsr_amd_rescale_transform -> dspsr_amd_pscrunch_tfp -> dspsr_amd_sigproc_digitize
+    (LoadToFil.C:318-362) byte for byte over several blocks, with Rescale intervals that end inside a block and band flips /
+    swaps -- and the same Rescale state afterwards."""
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(31)
+    ra, rb = dspsr_amd.Rescale(ctx, nchan, 2, interval, False), dspsr_amd.Rescale(ctx, nchan, 2, interval, False)
+    nbytes = ndat * nchan * nbit // 8
+    for b in range(3):
+        gain = rng.uniform(0.5, 20.0, (1, nchan, 2)).astype(np.float32) * (1 + b)
+        x = (rng.standard_normal((ndat, nchan, 2)).astype(np.float32) ** 2 * gain + gain).astype(np.float32)
+        x[3, 5, 0], x[4, 6, 1], x[5, 7, 0] = np.inf, np.nan, 1e30
+        d = torch.from_numpy(x).cuda()
+        sep = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        resc = ra.transform(d, torch.empty_like(d))
+        inten = torch.empty((ndat, nchan), dtype=torch.float32, device="cuda")
+        dspsr_amd.pscrunch_tfp(ctx, resc, inten, nchan, 2)
+        dspsr_amd.sigproc_digitize(ctx, inten, sep, nchan, 1, nbit, True, 1.0, 0.75, flip, swap)
+        fused = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        rb.pscrunch_digitize(d, fused, nbit, 0.75, flip, swap)
+        assert torch.equal(sep, fused) and int(fused.max()) > 0
+        (oa, sa), (ob, sb) = ra.get(), rb.get()
+        assert np.array_equal(oa, ob, equal_nan=True) and np.array_equal(sa, sb, equal_nan=True)
+    with pytest.raises(dspsr_amd.DspsrAmdError):
+        rb.pscrunch_digitize(d, torch.zeros(nbytes - 1, dtype=torch.uint8, device="cuda"), nbit)
+    ra.close()
+    rb.close()
+
+
 @pytest.mark.parametrize("nbit", [1, 2, 4, 8, 16, -32])
 @pytest.mark.parametrize("nchan,npol,flip,swap,rescale", [(1024, 1, True, False, True), (64, 4, False, True, False),
                                                          (256, 2, True, True, True)])
