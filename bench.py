@@ -217,10 +217,11 @@ def bench_search_mode(args, wl, torch):
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "cfg5", "command": wl["cmd"], "nchan": nchan, "tscrunch": sf,
                       "parts_per_block": npart, "input": "8-bit dual-pol, resident in HBM",
-                      "chain": "TFPFilterbank+detect+TScrunch -> Rescale(10 s) -> PScrunch -> SigProcDigitizer(8 bit)",
+                      "chain": "TFPFilterbank+detect+TScrunch [k_tfp] -> Rescale statistics -> Rescale apply + PScrunch + SigProcDigitizer(8 bit) "
+                               "[one pass, dspsr_amd_rescale_pscrunch_digitize]",
                       "note": "search mode: detected, scrunched and digitised, NOT folded"},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_tfp<13>",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_tfp<12> (TFP filterbank + detection + tscrunch)",
                         "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(k_ms, 4)}}
     if not args.no_cpu_baseline:
         import oracle.dspsr_oracle as o
