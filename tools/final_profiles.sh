@@ -1,0 +1,17 @@
+#!/bin/bash
+# tools/final_profiles.sh TAG : on the GPU box -- the committed evidence of a round from ONE box: rocprofv3 kernel stats + bench
+# line of the default workload and of every other BASELINE workload (gpurun_out/TAG/<wl>_kernel_stats.txt, <wl>_bench.json)
+T=$1
+R=${GRAFT_REPO_ROOT:-$PWD}
+mkdir -p $R/gpurun_out/$T
+cd /tmp && export TMPDIR=/tmp && cd $R
+for w in target cfg1 cfg1opt cfg2 cfg3 cfg4 cfg5; do
+  a="--workload $w"; [ $w = target ] && a="--no-companions"
+  rm -rf gpurun_out/$T/prof_$w
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/prof_$w -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline $a > gpurun_out/$T/${w}_bench.json 2> gpurun_out/$T/${w}.err || { echo "$w failed"; tail -3 gpurun_out/$T/${w}.err; exit 1; }
+  python tools/kstats.py gpurun_out/$T/prof_$w > gpurun_out/$T/${w}_kernel_stats.txt
+  cp $(ls gpurun_out/$T/prof_$w/*/*_kernel_stats.csv | head -1) gpurun_out/$T/${w}_kernel_stats.csv
+  rm -rf gpurun_out/$T/prof_$w
+  echo "== $w: $(grep -o '"value": [0-9.]*' gpurun_out/$T/${w}_bench.json | head -1) $(grep -o '"frac": [0-9.]*' gpurun_out/$T/${w}_bench.json | head -1)"
+  head -6 gpurun_out/$T/${w}_kernel_stats.txt
+done
