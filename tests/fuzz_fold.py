@@ -101,7 +101,9 @@ for i in range(max(4, ncases // 3)):
         freq, bw, dm, nchan, freq_res, nbin, period, ppb, mp, sub, len(res[0]), mode)
     good = len(res[0]) == len(res[1])
     for a, b in zip(res[0], res[1]):
-        scale = max(np.abs(b[1]).max(), 1e-30)
+        # (float32 sums of N samples per bin, associated differently by the two paths: the same sqrt(N) allowance as above --
+        #  186 000 hits per bin gave 3.8e-6, identical for every launch shape)
+        scale = max(np.abs(b[1]).max(), 1e-30) * max(1.0, (float(b[0].max()) / 100.0) ** 0.5)
         good = good and np.array_equal(a[0], b[0]) and a[2] == b[2] and np.abs(a[1] - b[1]).max() <= 2e-6 * scale
     if good:
         print("ok   ", desc, flush=True)
