@@ -1222,7 +1222,9 @@ def subint_turns_sample_bounds(cfg: "FoldConfig", obs: Observation, division_tur
     def at(turns):
         tot = pf + turns
         ti = math.floor(tot)
-        return predictor_iphase(cfg, obs, (pi + int(ti), tot - ti), t0 + turns * (cfg.folding_period or 1.0 / cfg.polyco.f0))
+        guess = cfg.folding_period or (1.0 / cfg.polyco.f0 if hasattr(cfg.polyco, "f0") else
+                                       1.0 / cfg.polyco.frequency(*[a + b for a, b in zip(utc_to_mjd(obs.utc_start), (0, t0))]))
+        return predictor_iphase(cfg, obs, (pi + int(ti), tot - ti), t0 + turns * guess)
     mjd1, mjd2 = at(division * division_turns), at((division + 1) * division_turns)
     samples = int(round((mjd1 - obs.start_seconds) * rate))
     lower = obs.start_seconds + samples / rate

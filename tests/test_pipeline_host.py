@@ -56,7 +56,7 @@ def test_subint_pieces_cover_block_and_match_oracle_boundaries(oracle):
                 assert abs(v - (hi - lo)) <= 1
 
 
-@pytest.mark.parametrize("use_polyco", [False, True])
+@pytest.mark.parametrize("use_polyco", [False, True, "tempo2"])
 @pytest.mark.parametrize("turns,fractional", [(1.0, False), (3.0, False), (2.5, True)])
 def test_turns_mode_divisions_match_oracle(oracle, use_polyco, turns, fractional):
     """dspsr -s / -turns N (TimeDivide.C:360-436,461-500): division boundaries from the pulse phase -- constant period and
@@ -68,7 +68,12 @@ def test_turns_mode_divisions_match_oracle(oracle, use_polyco, turns, fractional
     obs = oracle.Observation(tsamp_us=1e6 / rate)
     obs.start_seconds = t_start
     if use_polyco:
-        pc, opc = pipeline.Polyco(text), oracle.Polyco.parse(text)
+        if use_polyco == "tempo2":                                          # ChebyModelSet predictor, same interface
+            import cheby_fixture as cf
+            ctext = cf.cheby_text()
+            pc, opc = pipeline.ChebyPredictor(ctext, 1400.0), oracle.ChebyPredictor(ctext, 1400.0)
+        else:
+            pc, opc = pipeline.Polyco(text), oracle.Polyco.parse(text)
         ocfg = oracle.FoldConfig(nbin=64, polyco=opc)
         assert pc.phase(55299, 7545.0 + 3.3) == oracle.predictor_phase(ocfg, obs, 3.3)
         phase = lambda t: pc.phase(55299, 7545.0 + t)
