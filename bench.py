@@ -947,6 +947,12 @@ def main():
             others.append({"workload": "cfg5", "value": rec5["value"], "unit": rec5["unit"], "ms_per_step": rec5["ms_per_step"], "steps": rec5["steps"],
                            "roofline_frac": rec5["roofline"]["frac"], "roofline_kernel": rec5["roofline"]["kernel"],
                            "command": rec5["config"]["command"]})
+            fo = argparse.Namespace(**vars(args))
+            fo.steps, fo.warmup, fo.no_cpu_baseline = 2 * ssteps, swarm, True
+            recf = bench_fold_only(fo, WORKLOADS["fold"], torch)                 # BASELINE.md benchmark B (Benchmark/fold.csh): dsp::Fold alone
+            others.append({"workload": "fold", "value": recf["value"], "unit": recf["unit"], "ms_per_step": recf["ms_per_step"],
+                           "steps": recf["steps"], "roofline_frac": recf["roofline"]["frac"], "roofline_kernel": recf["roofline"]["kernel"],
+                           "command": recf["config"]["command"]})
             out["other_workloads"] = others
             out["config"]["engine_boundary"] = engine_boundary(torch)
     finish(out)
