@@ -279,6 +279,12 @@ def test_filterbank_cfg1_optimal_size_paired_pass1_tiles(oracle, gpu):
     _fb(oracle, gpu, 64, 262144, (7226, 7341), 3, layout="caspsr", max_parts=2, seed=11)
 
 
+def test_paired_pass1_tiles_complex_input(oracle, gpu):
+    # complex dual-polarisation input of N = 2^25 points per polarisation: two sequences per part (nseq = 2) through the paired
+    # pass-1 tiles (k_fwd_cols_dual walks (pair, sequence, part) items), two channels of 2^24 bins each
+    _fb(oracle, gpu, 2, 1 << 24, (600000, 500000), 1, real=False, seed=12)
+
+
 def test_cfg3_pipeline_geometry(gpu):
     """cfg3 through the driver: the host preparation yields the Appendix-B numbers and the fused fold conserves power."""
     dspsr_amd = gpu
