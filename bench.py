@@ -147,8 +147,11 @@ def bench_fold_only(args, wl, torch):
                       "note": "time samples per second; every sample carries nchan*npol = %d floats" % (nchan * npol)},
            "parity_gate": {"status": "ok", "checks": ["hits.sum() == ndat", "profile == float64 index_add (rel %.1e)" % rel]},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_fold_chunked<1,.>",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic("fold", None, "hbm_bytes_per_launch"),
+                        "traffic_source": measured_traffic.source, "kernel": "k_fold_chunked<1,.>",
                         "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(k_ms, 4)}}
+    if res["roofline"]["traffic"]:
+        res["roofline"]["traffic_ratio"] = round(res["roofline"]["traffic"] / b_alg, 3)
     if not args.no_cpu_baseline:
         import oracle.dspsr_oracle as o
         nc = nchan                                              # one whole block (about 1.5 s on one core)
@@ -221,8 +224,11 @@ def bench_search_mode(args, wl, torch):
                                "[one pass, dspsr_amd_rescale_pscrunch_digitize]",
                       "note": "search mode: detected, scrunched and digitised, NOT folded"},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_tfp<12> (TFP filterbank + detection + tscrunch)",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic("cfg5", None, "hbm_bytes_per_launch"),
+                        "traffic_source": measured_traffic.source, "kernel": "k_tfp<12> (TFP filterbank + detection + tscrunch)",
                         "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(k_ms, 4)}}
+    if res["roofline"]["traffic"]:
+        res["roofline"]["traffic_ratio"] = round(res["roofline"]["traffic"] / b_alg, 3)
     if not args.no_cpu_baseline:
         import oracle.dspsr_oracle as o
         n = 512
@@ -243,14 +249,16 @@ def algorithmic_bytes_per_part(npol, nsamp_fft, nbit, N, nchan_subband, nkeep):
 
 
 def measured_traffic(workload, max_parts, key="hbm_bytes_per_launch_group"):
-    """HBM bytes per launch group from the committed PMC profile (rocprofv3 cannot run inside the bench);
-    None when the profile was taken for another workload / grouping."""
+    """HBM bytes per launch group (or, cfg5 / fold: per launch of the roofline kernel) from the committed PMC profile
+    (tools/pmc_traffic.sh; rocprofv3 cannot run inside the bench); None when the newest profile of the workload was taken
+    for another grouping."""
     import glob
+    measured_traffic.source = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):   # newest round first
         try:
             d = json.load(open(path))
-            if d["workload"] == workload and d["parts_per_launch_group"] == max_parts and key in d:
-                measured_traffic.source = os.path.relpath(path, ROOT)
+            if d["workload"] == workload and (max_parts is None or d["parts_per_launch_group"] == max_parts) and key in d:
+                measured_traffic.source = "%s (commit %s)" % (os.path.relpath(path, ROOT), d.get("commit"))
                 return d[key]
         except Exception:
             pass
@@ -407,7 +415,7 @@ def oracle_check(wl, cfg, info, torch, nparts=2):
         lt.finish_subint()
         lt.synchronize()
         sub = lt.subints[-1]
-        prof = sub["profile_dev"].cpu().numpy().reshape(lt.nchan_out, small.nbin, 4).astype(np.float64)
+        prof = pipeline.subint_profile(sub).reshape(lt.nchan_out, small.nbin, 4).astype(np.float64)
         t0 = time.perf_counter()
         obs = o.Observation(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=wl["in_nchan"], npol=2, ndim=wl["ndim"],
                             tsamp_us=wl["tsamp_us"], machine=wl["machine"], dispersion_measure=wl["dm"])
@@ -577,47 +585,98 @@ def engine_boundary(torch):
     return rec
 
 
-def open_rccl_exchange(ctx, torch, dist, rank, world):
-    """The C-ABI communicator (dspsr_amd_comm_*) for this rank's pipeline context plus one tiny trial exchange.  If any rank
-    cannot (no librccl to dlopen, init refused), ALL ranks agree to run the exchange through the launcher's process group
-    instead -- which is RCCL too -- and the bench line says so.  Returns (communicator or None, reason or None)."""
-    import dspsr_amd
-    ok, note, rccl = 1, None, None
-    try:
-        ids = [dspsr_amd.Communicator.unique_id() if rank == 0 else None]
-    except Exception as e:                                                # noqa: BLE001 -- reported in the line
-        ids, ok, note = [None], 0, "%s" % e
-    dist.broadcast_object_list(ids, src=0)
-    if ids[0] is not None:
+RCCL_SETUP_TIMEOUT_S = 120.0
+
+
+def _bounded(what, fn, rank, timeout=None):
+    """Runs fn() on a helper thread and waits at most RCCL_SETUP_TIMEOUT_S for it.  ncclCommInitRank and the trial exchange
+    are collectives: a rank whose peers never arrive would block for ever (ctypes releases the GIL, so this thread can watch).
+    A rank that is stuck EXITS non-zero with a message -- the launcher then tears the job down -- instead of hanging the run.
+    Returns (result, exception)."""
+    import threading
+    box = {}
+
+    def run():
         try:
-            rccl = dspsr_amd.Communicator(ctx, world, rank, ids[0])
-            trial = torch.full((4, 8), float(rank + 1), dtype=torch.float32, device="cuda")
-            rccl.start(rccl.SUM, trial.data_ptr(), 8, 4, 8, np.ones(4, np.uint32), 1.0, 4, check_hits=True)
-            got = rccl.finish()
-            if rank == 0 and (float(got[0][0]) != world * (world + 1) / 2 or int(got[1][0]) != world or not got[4]):
-                raise RuntimeError("trial exchange returned %r" % (got[0][:2],))
-        except Exception as e:                                            # noqa: BLE001
-            ok, note = 0, "%s" % e
-    else:
-        ok = 0
-    t = torch.tensor([ok], dtype=torch.int32, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    if int(t.item()) == 1:
-        return rccl, None
-    notes = [None] * world
-    dist.all_gather_object(notes, note)
-    note = "; ".join(sorted({n_ for n_ in notes if n_})) or "unknown"
-    if rank == 0:
-        print("bench: C-ABI RCCL communicator unavailable (%s): exchange through torch.distributed" % note, file=sys.stderr)
-    if rccl is not None:
-        rccl.close()
-    return None, note
+            box["r"] = fn()
+        except BaseException as e:                                        # noqa: BLE001 -- handed to the caller
+            box["e"] = e
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(RCCL_SETUP_TIMEOUT_S if timeout is None else timeout)
+    if th.is_alive():
+        print("bench: rank %d: %s did not return within %.0f s (a peer failed or never entered it): giving up"
+              % (rank, what, RCCL_SETUP_TIMEOUT_S if timeout is None else timeout), file=sys.stderr, flush=True)
+        os._exit(3)
+    return box.get("r"), box.get("e")
 
 
-def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, steps, warmup, full=True):
-    """One filterbank + detect + fold workload on this process group: the timed region (barrier, `steps` steps with a
-    sub-integration dump every args.dump_steps, barrier), then -- outside it -- the unfused roofline blocks and the
-    parity gate.  Returns the result record on rank 0 (None elsewhere).  full: cpu_baseline / --h2d companions too."""
+def open_rccl_exchange(ctx, torch, dist, rank, world):
+    """The C-ABI communicator (dspsr_amd_comm_*) for this rank's pipeline context plus one tiny trial exchange.
+    Every collective step (ncclCommInitRank inside comm_create, the trial's start / finish) is entered only after ALL ranks
+    have agreed, over the launcher's process group, that the step before it succeeded everywhere -- a rank that failed
+    early (no librccl to dlopen, comm_create refused) can therefore not leave the others blocked inside a collective -- and
+    each such step runs under a bounded wait (_bounded).  If any rank cannot, ALL ranks run the exchange through the
+    launcher's process group instead -- which is RCCL too -- and the bench line says so at top level (`exchange`).
+    Returns (communicator or None, reason or None)."""
+    import dspsr_amd
+    state = {"ok": 1, "note": None}
+
+    def agree(stage):
+        t = torch.tensor([state["ok"]], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 1:
+            return True
+        notes = [None] * world
+        dist.all_gather_object(notes, state["note"])
+        state["note"] = "%s: %s" % (stage, "; ".join(sorted({n_ for n_ in notes if n_})) or "unknown")
+        return False
+
+    def give_up(rccl):
+        if rank == 0:
+            print("bench: C-ABI RCCL communicator unavailable (%s): exchange through torch.distributed" % state["note"], file=sys.stderr)
+        if rccl is not None:
+            try:
+                rccl.close()
+            except Exception:                                             # noqa: BLE001
+                pass
+        return None, state["note"]
+
+    # 1. librccl loads and answers on EVERY rank (each asks for an id of its own; rank 0's is the one that is used)
+    uid = None
+    try:
+        uid = dspsr_amd.Communicator.unique_id()
+    except Exception as e:                                                # noqa: BLE001 -- reported in the line
+        state["ok"], state["note"] = 0, "%s" % e
+    if not agree("dlopen / ncclGetUniqueId"):
+        return give_up(None)
+    ids = [uid if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    # 2. ncclCommInitRank: collective, all ranks enter it (they all passed step 1)
+    rccl, err = _bounded("dspsr_amd_comm_create (ncclCommInitRank)", lambda: dspsr_amd.Communicator(ctx, world, rank, ids[0]), rank)
+    if err is not None:
+        state["ok"], state["note"] = 0, "%s" % err
+    if not agree("comm_create"):
+        return give_up(rccl)
+    # 3. one tiny exchange: collective again, entered by all (they all hold a communicator)
+    def trial():
+        t = torch.full((4, 8), float(rank + 1), dtype=torch.float32, device="cuda")
+        rccl.start(rccl.SUM, t.data_ptr(), 8, 4, 8, np.ones(4, np.uint32), 1.0, 4, check_hits=True)
+        got = rccl.finish()
+        if rank == 0 and (float(got[0][0]) != world * (world + 1) / 2 or int(got[1][0]) != world or not got[4]):
+            raise RuntimeError("trial exchange returned %r" % (got[0][:2],))
+    _, err = _bounded("the trial exchange", trial, rank)
+    if err is not None:
+        state["ok"], state["note"] = 0, "%s" % err
+    if not agree("trial exchange"):
+        return give_up(rccl)
+    return rccl, None
+
+
+def make_fold_pipeline(name, args, torch, rank, world, local_rank):
+    """The pipeline object and the synthetic 8-bit block (resident in HBM) of one filterbank + detect + fold workload, in
+    the launch shape the bench times (parts per block / per launch group).  Shared by run_fold_workload and
+    tools/pmc_workload.py, so the PMC counters are collected on exactly the timed launches."""
     import dspsr_amd
     from dspsr_amd import pipeline
     wl = WORKLOADS[name]
@@ -655,6 +714,17 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
         e = min(nbytes, s + chunk)
         raw[s:e] = torch.randn(e - s, generator=gen, device="cuda").mul_(24.0).round_().clamp_(-128, 127).to(torch.int8)
 
+    return lt, raw, cfg, info, wl, sharded
+
+
+def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, steps, warmup, full=True):
+    """One filterbank + detect + fold workload on this process group: the timed region (barrier, `steps` steps with a
+    sub-integration dump every args.dump_steps, barrier), then -- outside it -- the unfused roofline blocks and the
+    parity gate.  Returns the result record on rank 0 (None elsewhere).  full: cpu_baseline / --h2d companions too."""
+    import dspsr_amd
+    from dspsr_amd import pipeline
+    lt, raw, cfg, info, wl, sharded = make_fold_pipeline(name, args, torch, rank, world, local_rank)
+    nbytes = raw.numel()
     # the exchange: RCCL behind the C-ABI (dspsr_amd_comm_*), one communicator per pipeline context; the unique id travels
     # over the launcher's process group.  One-device rehearsals (gloo) keep the torch.distributed form of the same exchange.
     gather, rccl = None, None
@@ -768,6 +838,9 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
                 "torch.distributed (gloo rehearsal on one device)" if world > 1 and single else
                 "torch.distributed over RCCL -- the C-ABI communicator was unavailable: %s" % rccl_note if world > 1 else
                 "one rank: no exchange")
+        # which transport carried the dumps, at a glance (a SCALE record must not mistake the fallback for the C-ABI path)
+        exchange = ("rccl-c-abi" if rccl is not None else "gloo-rehearsal" if world > 1 and single else
+                    "fallback" if world > 1 else "none")
         par = ("sub-band per GPU x%d (input channel g of %d, slice g of the full-band kernel; per dump ONE ncclGather of the "
                "ranks' slices; %s)" % (world, info.nchan, exch)) if sharded else \
               ("time-slice replicas x%d (blocks dealt round robin; per dump ONE packed ncclReduce(SUM) of profile + hits + "
@@ -776,7 +849,7 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
             "metric": "Msamples/s dedispersed+folded", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "exchange": exchange,
             "config": {"workload": name, "command": wl["cmd"], "nchan": cfg.nchan, "freq_res": r.ndat,
                        "n_fft": N, "nfilt_pos": r.impulse_pos, "nfilt_neg": r.impulse_neg, "nkeep": lt.nkeep,
                        "nsamp_step": lt.nsamp_step, "dm": cfg.dispersion_measure, "nbin": cfg.nbin,
@@ -788,6 +861,7 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic(name, cfg.max_parts),
+                         "traffic_source": measured_traffic.source,
                          "traffic_unit": "HBM bytes per launch group of %d parts (PMC counters of a separate rocprofv3 run on the "
                                          "commit named in %s -- not measured in this run); "
                                          "algorithmic bytes for the same group: %d"
@@ -796,12 +870,18 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
                          "kernel": "filterbank launch group k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,false> "
                                    "(FFT+chirp+detect, detected output written)",
                          "algorithmic_bytes_per_part": b_alg, "group_ms_per_block": round(fb_ms, 4),
+                         "traffic_ratio": None,
                          "region": ("%d extra blocks right after the timed region with Detection and Fold as "
                                     "separate operations (HIP events on the launch stream)" % extra) if fused
                                    else "the timed region (HIP events on the launch stream)"},
         }
+        if out["roofline"]["traffic"]:
+            out["roofline"]["traffic_ratio"] = round(out["roofline"]["traffic"] / (b_alg * cfg.max_parts), 3)
+        out["config"]["exchange"] = exchange
+        if exchange == "fallback":
+            out["config"]["exchange_fallback_reason"] = rccl_note
+        out["config"]["reduce_ms_per_dump"] = round(reduce_ms, 4) if world > 1 else None      # one rank: no exchange
         if world > 1:
-            out["config"]["reduce_ms_per_dump"] = round(reduce_ms, 4)
             out["config"]["identical_hits"] = hits_ok
         if fused:
             b_fused = b_alg - 2 * nchan_subband * lt.nkeep * 8         # no detected output: input once + chirp once
@@ -815,20 +895,25 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
                 "algorithmic_bytes_per_part": b_fused, "group_ms_per_block": round(timed_ms, 4),
                 "note": "the fused group also does the fold; its algorithmic bytes have no output term "
                         "(SURVEY 8(d)), so this fraction is not comparable with roofline.frac"}
-        if full and args.h2d:
-            # host-buffer hand-over through the product's own feeder (pipeline.LoadToFold.process_host_blocks): block i+1
-            # is copied H2D on a second stream while block i is processed
+        if full and (args.h2d or (world == 1 and not args.no_h2d)):
+            # The PCIe-inclusive companion of `value` (the reference's path always starts in host memory,
+            # TransferCUDA.C:24-85 / TransferBitSeriesCUDA.C:23-70): host-buffer hand-over through the product's own feeder
+            # (pipeline.LoadToFold.process_host_blocks): block i+1 is copied H2D on a second stream while block i is
+            # processed.  By default a short leg (5 blocks) beside the headline; --h2d times `steps` blocks.
+            hsteps = steps if args.h2d else min(steps, 5)
             host = raw.cpu().pin_memory()
-            lt.process_host_blocks(host for _ in range(3))
+            lt.process_host_blocks(host for _ in range(2))
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            lt.process_host_blocks(host for _ in range(steps))
+            lt.process_host_blocks(host for _ in range(hsteps))
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             out["config"]["pcie_inclusive"] = {
-                "value": round(cfg.parts_per_block * lt.nsamp_step * steps / dt / 1e6, 1), "unit": "Msamples/s",
-                "note": "blocks copied from pinned host memory (%.1f MB each) on a second stream, double buffered"
-                        % (raw.numel() / 1e6)}
+                "value": round(cfg.parts_per_block * lt.nsamp_step * hsteps / dt / 1e6, 1), "unit": "Msamples/s", "steps": hsteps,
+                "effective_GBps": round(raw.numel() * hsteps / dt / 1e9, 1),
+                "note": "the same blocks copied from pinned host memory (%.1f MB each) on a second stream, double buffered, "
+                        "overlapped with the kernels; `value` above is for blocks already resident in HBM" % (raw.numel() / 1e6)}
+            del host
         if full and world == 1 and not args.no_cpu_baseline:
             geom = {"freq_res": r.ndat, "nkeep": lt.nkeep, "nsamp_step": lt.nsamp_step, "nsamp_overlap": lt.nsamp_overlap,
                     "nfilt_pos": r.impulse_pos, "kernel": r.kernel, "scale8": lt.scale8, "out_rate": lt.out_rate}
@@ -852,9 +937,12 @@ def brief(rec):
     b = {"workload": rec["config"]["workload"], "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"],
          "steps": rec["steps"], "roofline_frac": rec["roofline"]["frac"], "roofline_kernel": rec["roofline"]["kernel"].split(" (")[0],
          "command": rec["config"]["command"]}
-    for k in ("parts_per_block", "max_parts", "fused_fold", "parallelism", "reduce_ms_per_dump", "identical_hits"):
+    for k in ("parts_per_block", "max_parts", "fused_fold", "parallelism", "exchange", "exchange_fallback_reason",
+              "reduce_ms_per_dump", "identical_hits"):
         if k in rec["config"]:
             b[k] = rec["config"][k]
+    b["roofline_traffic_ratio"] = rec["roofline"].get("traffic_ratio")
+    b["roofline_traffic_source"] = rec["roofline"].get("traffic_source")
     if "parity_gate" in rec:
         b["parity_gate"] = rec["parity_gate"]["status"]
     return b
@@ -880,6 +968,7 @@ def main():
     ap.add_argument("--h2d", action="store_true",
                     help="also measure the PCIe-inclusive rate: every block copied from pinned host memory on a second "
                          "stream, double buffered, overlapped with the kernels (reported as config.pcie_inclusive)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the short PCIe-inclusive leg of the default single-GPU run")
     ap.add_argument("--no-fused-fold", action="store_true",
                     help="Detection and Fold as separate operations (detected time series through HBM)")
     args = ap.parse_args()
@@ -946,12 +1035,14 @@ def main():
             rec5 = bench_search_mode(sm, WORKLOADS["cfg5"], torch)
             others.append({"workload": "cfg5", "value": rec5["value"], "unit": rec5["unit"], "ms_per_step": rec5["ms_per_step"], "steps": rec5["steps"],
                            "roofline_frac": rec5["roofline"]["frac"], "roofline_kernel": rec5["roofline"]["kernel"],
+                           "roofline_traffic_ratio": rec5["roofline"].get("traffic_ratio"), "roofline_traffic_source": rec5["roofline"].get("traffic_source"),
                            "command": rec5["config"]["command"]})
             fo = argparse.Namespace(**vars(args))
             fo.steps, fo.warmup, fo.no_cpu_baseline = 2 * ssteps, swarm, True
             recf = bench_fold_only(fo, WORKLOADS["fold"], torch)                 # BASELINE.md benchmark B (Benchmark/fold.csh): dsp::Fold alone
             others.append({"workload": "fold", "value": recf["value"], "unit": recf["unit"], "ms_per_step": recf["ms_per_step"],
                            "steps": recf["steps"], "roofline_frac": recf["roofline"]["frac"], "roofline_kernel": recf["roofline"]["kernel"],
+                           "roofline_traffic_ratio": recf["roofline"].get("traffic_ratio"), "roofline_traffic_source": recf["roofline"].get("traffic_source"),
                            "command": recf["config"]["command"]})
             out["other_workloads"] = others
             out["config"]["engine_boundary"] = engine_boundary(torch)

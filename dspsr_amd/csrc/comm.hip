@@ -23,8 +23,21 @@
 // RCCL is opened with dlopen at the first communicator (no link-time dependency: the library loads, and every other
 // entry point works, where no RCCL is installed; a process that already holds an RCCL -- PyTorch's -- shares it).
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <string.h>
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+// Built where the RCCL headers are not installed: the few types and enumerators the dlopen'ed entry points take, as rccl.h
+// declares them (NCCL's stable ABI).  The library then still builds, and comm_* report at run time whether a librccl loads.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6,
+               ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+}
+#endif
 
 #include "engine_internal.h"
 

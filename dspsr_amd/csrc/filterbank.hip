@@ -2709,7 +2709,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
       }
       if (k1d)
         hipLaunchKernelGGL(k1d, dim3(grid_for(n1 / 2, fb->ncu * fb->wg1)), dim3(fb->nt1), fb->lds1, ctx->stream, g, ci, fb->A, ctx->tw,
-                           part0, nb, fb->nseq, run1 / 2);
+                           part0, nb, fb->nseq, run1 / 2 ? run1 / 2 : 1u);     // (run is a divisor in persistent_item: never 0)
       else
         hipLaunchKernelGGL(k1, dim3(grid_for(n1, fb->ncu * fb->wg1)), dim3(fb->nt1), fb->lds1, ctx->stream, g, ci, fb->A, ctx->tw,
                            part0, nb, fb->nseq, run1);

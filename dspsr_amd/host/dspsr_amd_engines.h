@@ -22,9 +22,19 @@
 //   * Fold folds only a piece of the block (a sub-integration boundary inside it, Subint.h:234-309), a Fold input that is
 //     not the Detection output, a detected shape other than (npol 2, ndim 2) / (npol 1, ndim 4), square-law detection;
 //   * TimeSeriesEngine::copy_data_fpt reads the pending output (a second consumer that goes through an engine).
+//   * more than one FoldEngine is registered on the chain (dspsr folds N pulsars from ONE detected series: every
+//     fold[ifold]->set_input (to_fold), LoadToFold1.C:917-924,948-955,1206): the first fold() of a block executes the recorded
+//     calls, every Fold then reads the detected series that really exists -- never fused;
+//   * the Fold input carries zeroed (RFI-excised) samples with per-channel hits (Fold.C:853-866): eager, the engine counts
+//     the hits from the data.
+// What a fused block leaves behind is a detected TimeSeries that was NEVER WRITTEN.  Any later engine call that reads it
+// before the next perform() -- a FoldEngine that was not registered on the chain, a second Detection, copy_data_fpt --
+// throws Error (InvalidState) instead of returning stale data.  A recorded block that reaches the next perform() without
+// having been folded (Fold skipped it) cannot be executed any more -- DSPSR has refilled its input -- and is an
+// Error (InvalidState) too unless the caller has accepted that with set_drop_unfolded (true) (counted in get_dropped_blocks).
 // A consumer of the intermediate TimeSeries that bypasses the engines (dsp::Dump, a TransferCUDA to the host) cannot be
-// seen from here: deferred mode is for pipelines in which Detection is the only reader of the Filterbank output and Fold
-// the only reader of the Detection output (dspsr's default fold pipeline); it is opt-in for that reason.
+// seen from here: deferred mode is for pipelines in which Detection is the only reader of the Filterbank output and the
+// Folds on the chain the only readers of the Detection output (dspsr's default fold pipeline); it is opt-in for that reason.
 //
 // RAW INPUT (FilterbankEngine::set_raw_input).  The reference unpacks 8-bit data to float32 in front of the Filterbank (4x
 // the bytes).  The twin of dsp::TransferBitSeriesCUDA (Signal/General/TransferBitSeriesCUDA.C:23-70) hands the packed
@@ -56,11 +66,32 @@ namespace HIP
   class Chain : public Reference::Able
   {
   public:
-    Chain (dspsr_amd_ctx* _ctx) : ctx (_ctx), deferred (false), fused_blocks (0), eager_blocks (0), dropped_blocks (0)
+    Chain (dspsr_amd_ctx* _ctx) : ctx (_ctx), deferred (false), fused_blocks (0), eager_blocks (0), dropped_blocks (0),
+                                  nfold (0), drop_unfolded (false), consumed_fb (0), consumed_det (0)
     { fbk.pending = false; det.pending = false; fbk.raw = 0; }
 
     void set_deferred (bool flag) { if (!flag) flush (); deferred = flag; }
     bool get_deferred () const { return deferred; }
+
+    //! FoldEngines of this pipeline thread (they register themselves); with more than one, fold() never fuses
+    void register_fold () { nfold ++; }
+    void unregister_fold () { if (nfold) nfold --; }
+    unsigned get_nfold () const { return nfold; }
+
+    //! accept that a recorded block which no Fold asked for is discarded at the next perform() (default: Error)
+    void set_drop_unfolded (bool flag) { drop_unfolded = flag; }
+    bool get_drop_unfolded () const { return drop_unfolded; }
+
+    //! the fused launch group has consumed the recorded block: its intermediate TimeSeries were never written
+    void mark_consumed () { consumed_fb = fbk.out; consumed_det = det.out; }
+    void clear_consumed () { consumed_fb = 0; consumed_det = 0; }
+    //! throws if `series` is such a never-written intermediate (a reader the fusion could not see)
+    void require_written (const dsp::TimeSeries* series, const char* method) const
+    {
+      if (series && (series == consumed_fb || series == consumed_det))
+        throw Error (InvalidState, method, "this TimeSeries is an intermediate of a block that the deferred HIP::Chain ran as one "
+                     "fused launch group: it was never written (register every FoldEngine on the chain, or do not defer)");
+    }
 
     //! blocks that went through the fused launch group / through the separate launches / recorded and never consumed
     uint64_t get_fused_blocks () const { return fused_blocks; }
@@ -85,6 +116,16 @@ namespace HIP
     //! the same if `series` is the output of a recorded call (a second reader)
     void flush_if (const dsp::TimeSeries* series)
     { if ((fbk.pending && series == fbk.out) || (det.pending && (series == det.out || series == det.in))) flush (); }
+    //! a recorded block is still pending when the next one arrives: DSPSR has refilled its input, it cannot run any more
+    void unfolded_block ()
+    {
+      fbk.pending = false; det.pending = false;
+      if (!drop_unfolded)
+        throw Error (InvalidState, "HIP::FilterbankEngine::perform", "the block recorded by the deferred HIP::Chain was never "
+                     "folded and cannot be executed any more (its input has been refilled): another reader of the Filterbank / "
+                     "Detection output would see stale data.  Chain::set_drop_unfolded (true) accepts the loss");
+      dropped_blocks ++;
+    }
 
     // ---- arguments recorded by FilterbankEngine::perform
     struct FilterbankCall
@@ -128,6 +169,10 @@ namespace HIP
     dspsr_amd_ctx* ctx;
     bool deferred;
     uint64_t fused_blocks, eager_blocks, dropped_blocks;
+    unsigned nfold;
+    bool drop_unfolded;
+    const dsp::TimeSeries* consumed_fb;           // intermediates of the last fused block (never written), until the next perform()
+    const dsp::TimeSeries* consumed_det;
   };
 
   //! dsp::Memory on the MI355X: allocation bound to one context/stream (SingleThread.C:237-244)
@@ -160,7 +205,11 @@ namespace HIP
     //! `from`, starting at idat_start, to the start of the rows of the parent
     void copy_data_fpt (const dsp::TimeSeries* from, uint64_t idat_start = 0, uint64_t ndat = 0)
     {
-      if (chain) { chain->flush_if (from); chain->flush_if (to); }   // a reader of a recorded block: execute it first
+      if (chain)
+      {
+        chain->flush_if (from); chain->flush_if (to);                // a reader of a recorded block: execute it first
+        chain->require_written (from, "HIP::TimeSeriesEngine::copy_data_fpt");
+      }
       const unsigned nchan = to->get_nchan (), npol = to->get_npol (), ndim = to->get_ndim ();
       float* obase = to->get_datptr (0, 0);
       const float* ibase = from->get_datptr (0, 0);
@@ -248,7 +297,8 @@ namespace HIP
       if (chain && out)
       {
         Chain::FilterbankCall& c = chain->fbk;
-        if (c.pending) { c.pending = false; chain->det.pending = false; chain->dropped_blocks ++; }   // never asked for
+        chain->clear_consumed ();                                    // `out` is about to be written (or recorded) anew
+        if (c.pending) chain->unfolded_block ();                     // never folded: Error, or dropped if the caller opted in
         c.fb = fb; c.in = in; c.out = out;
         c.ibase = ibase; c.ics = ics; c.ips = ips; c.obase = obase; c.ocs = ocs; c.ops = ops;
         c.npart = npart; c.in_step = in_step; c.out_step = out_step;
@@ -386,6 +436,7 @@ namespace HIP
       {
         Chain::DetectionCall& c = chain->det;
         if (c.pending) chain->flush ();
+        chain->require_written (in, "HIP::DetectionEngine::polarimetry");
         c.ndim = ndim; c.state = state; c.in = in; c.out = out;
         c.ibase = ibase; c.ics = in->get_nchan () > 1 ? in->get_datptr (1, 0) - ibase : 0; c.ips = in->get_datptr (0, 1) - ibase;
         c.obase = obase; c.ocs = out->get_nchan () > 1 ? out->get_datptr (1, 0) - obase : 0;
@@ -407,7 +458,7 @@ namespace HIP
 
     void square_law (const dsp::TimeSeries* in, dsp::TimeSeries* out)
     {
-      if (chain) chain->flush ();
+      if (chain) { chain->flush (); chain->require_written (in, "HIP::DetectionEngine::square_law"); }
       const float* ibase = in->get_datptr (0, 0);
       float* obase = out->get_datptr (0, 0);
       check (ctx, dspsr_amd_detect_square_law (ctx, out->get_state () == Signal::Intensity, ibase,
@@ -441,8 +492,14 @@ namespace HIP
       d_profiles = new dsp::PhaseSeries;
       d_profiles->set_memory (new DeviceMemory (ctx));
       synchronized = true;                       // no data on either the host or the device (FoldCUDA.cu:52-53)
+      if (chain) chain->register_fold ();
     }
-    ~FoldEngine () { if (d_hits) dspsr_amd_free (ctx, d_hits); dspsr_amd_fold_destroy (fold_handle); }
+    ~FoldEngine ()
+    {
+      if (chain) chain->unregister_fold ();
+      if (d_hits) dspsr_amd_free (ctx, d_hits);
+      dspsr_amd_fold_destroy (fold_handle);
+    }
 
     void set_nbin (unsigned nbin)
     { nbin_hits.assign (nbin, 0); check (ctx, dspsr_amd_fold_set_nbin (fold_handle, nbin), "HIP::FoldEngine::set_nbin"); }
@@ -479,10 +536,15 @@ namespace HIP
         const Chain::FilterbankCall& f = chain->fbk;
         const Chain::DetectionCall& d = chain->det;
         const dsp::TimeSeries* in = parent->get_input ();
+        // (one Fold per chain only: a second Fold of the same detected series -- dspsr folding several pulsars,
+        //  LoadToFold1.C:917-955,1206 -- needs the series itself; zeroed samples with per-channel hits are counted from the
+        //  data by the eager kernel, Fold.C:853-866)
         const bool whole = d.pending && in == d.out && plan_idat_start == 0 && plan_ndat == in->get_ndat ()
-                           && in->get_ndat () == d.ndat && ((npol == 2 && ndim == 2 && d.ndim == 2) || (npol == 1 && ndim == 4 && d.ndim == 4));
+                           && in->get_ndat () == d.ndat && ((npol == 2 && ndim == 2 && d.ndim == 2) || (npol == 1 && ndim == 4 && d.ndim == 4))
+                           && chain->get_nfold () <= 1 && !(zeroed_samples && hits_nchan == nchan);
         if (whole)
         {
+          chain->mark_consumed ();
           chain->fbk.pending = false; chain->det.pending = false;
           check (ctx, dspsr_amd_filterbank_perform_fold (f.fb, f.raw ? 0 : f.ibase, f.ics, f.ips, f.in_step, f.raw, f.raw_layout,
                                                         f.raw_scale, d.state, fold_handle, f.npart), "HIP::FoldEngine::fold");
@@ -494,6 +556,7 @@ namespace HIP
       }
       else if (chain)
         chain->flush ();
+      if (chain) chain->require_written (parent->get_input (), "HIP::FoldEngine::fold");
       if (zeroed_samples && hits_nchan == nchan)
       {
         // the input carries zeroed (RFI-excised) samples: hits[] per channel, counted on the device from the data

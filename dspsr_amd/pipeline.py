@@ -373,6 +373,16 @@ def normalise_profile(profile, hits, scale):
 # (Archiver.C:430-893): the Observation keys in the DADA ASCII convention (ASCIIObservation.C:82-415), then
 # hits[nbin] (uint32, little endian) and the profile sums [nchan][npol][nbin][ndim] (float32, little endian,
 # un-normalised: Archiver divides by scale*hits, :773-893).  INTEGRATION.md shows the reader a maintainer adds.
+def subint_profile(sub):
+    """The profile of one entry of LoadToFold.subints as a host float32 array, whichever path delivered it: `profile` (host
+    memory: the RCCL exchange of dspsr_amd_reduce_profiles_finish, or merge_subints) or `profile_dev` (a device tensor: one
+    rank, or the torch.distributed forms)."""
+    prof = sub.get("profile")
+    if prof is None:
+        prof = sub["profile_dev"].cpu().numpy()
+    return np.asarray(prof, dtype=np.float32)
+
+
 PHASE_SERIES_MAGIC = "DSPSR_AMD_PHASESERIES"
 PHASE_SERIES_HDR_SIZE = 4096
 
@@ -444,10 +454,15 @@ class PhaseSeries:
 
     @classmethod
     def from_subint(cls, ctx, sub, obs, start_time=0.0, end_time=0.0):
-        """Wrap a dict of LoadToFold.subints (the device copy `profile_dev`, hits, integration_length, ndat_total)."""
+        """Wrap a dict of LoadToFold.subints (hits, integration_length, ndat_total and the device copy `profile_dev`, or the
+        host array `profile` an RCCL exchange delivered -- uploaded here)."""
         ps = cls(ctx, obs)
         ps.nbin = len(sub["hits"])
-        ps.profile = sub["profile_dev"].view(obs["nchan"], obs["npol"], ps.nbin * obs["ndim"])
+        dev = sub.get("profile_dev")
+        if dev is None:
+            import torch
+            dev = torch.from_numpy(np.ascontiguousarray(subint_profile(sub)).reshape(-1)).to("cuda:%d" % ctx.device)
+        ps.profile = dev.view(obs["nchan"], obs["npol"], ps.nbin * obs["ndim"])
         ps.hits = np.array(sub["hits"], dtype=np.uint32)
         ps.integration_length, ps.ndat_total = float(sub["integration_length"]), int(sub["ndat_total"])
         ps.start_time, ps.end_time = start_time, end_time
@@ -950,9 +965,14 @@ class LoadToFold:
         (replicas=True) SUM profiles, hits, integration_length and ndat_total.
         With an RCCL communicator (set_rccl_communicator) the exchange is dspsr_amd_reduce_profiles_start/finish: a
         snapshot on the compute stream, the collective on the communicator's stream -- the next block's kernels overlap
-        it; wait=False leaves it in flight until collect_subint() or the next dump."""
+        it; wait=False leaves it in flight until collect_subint() or the next dump.
+        check_hits (default True) adds a MIN/MAX all-reduce of hits[] to the sub-band exchange (two small collectives in the
+        same group; nothing for replicas): pass False inside a timed loop that has checked once."""
         if self.comm is not None:
-            self.collect_subint(copy=self.copy_subints)                 # one exchange in flight per communicator
+            # (one exchange in flight per communicator.  The result of the previous one is COPIED here even with
+            #  copy_subints False: start() below may grow the pinned buffer a view would point into -- a view is only handed
+            #  out when the caller collects the sub-integration itself)
+            self.collect_subint(copy=True)
             n = self.npol_out * self.cfg.nbin * self.cfg.ndim           # floats per channel: rows are packed
             self.comm.start(self.comm.SUM if replicas else self.comm.GATHER, self.fold.get_profiles_ptr(), n, self.nchan_out, n,
                             self.hits, self.integration_length, self.ndat_total, root=0,

@@ -31,7 +31,10 @@ static void d2h (dspsr_amd_ctx* ctx, dsp::TimeSeries& host, const dsp::TimeSerie
 // (Filterbank.C:547-553), Detection::Engine::polarimetry in place (Detection.C:325-334, LoadToFold1.C:545-546), then
 // Fold::fold's set_nbin / set_ndat / set_bins / Engine::fold (Fold.C:724-741,817-829) -- through eager adaptors, deferred
 // adaptors on float32 rows and deferred adaptors on the packed 8-bit block must give the same PhaseSeries bit for bit.
-struct Variant { const char* name; bool chain, deferred, raw; int fused_mode; bool pieces, finish_each; };
+// nfold 2: TWO dsp::Fold (different periods and phases, as dspsr folds several pulsars) read the ONE detected series
+// (LoadToFold1.C:917-924,948-955,1206) -- the second profile is appended to `profile` / `hits`.  zeroed: the detected series
+// carries zeroed samples and the PhaseSeries per-channel hits (Fold.C:853-866): hits then holds C*nbin counts.
+struct Variant { const char* name; bool chain, deferred, raw; int fused_mode; bool pieces, finish_each; int nfold; bool zeroed; };
 
 static int run_variant (dspsr_amd_ctx* ctx, dsp::Memory* dmem, const Variant& v, const std::vector<signed char>& raw_h, float scale,
                         unsigned C, unsigned M, unsigned pos, unsigned neg, unsigned npart, unsigned nblock, const dsp::Response& resp,
@@ -56,10 +59,12 @@ static int run_variant (dspsr_amd_ctx* ctx, dsp::Memory* dmem, const Variant& v,
   HIP::DetectionEngine dete (ctx, chain);
   out_d.set_nchan (C); out_d.set_npol (2); out_d.set_ndim (2); out_d.set_rate (1e6 / (2 * C));
   out_d.set_memory (dmem); out_d.resize (ndat);
-  dsp::Fold fold;
+  dsp::Fold fold, fold2;
   HIP::FoldEngine* eng = new HIP::FoldEngine (ctx, chain);
   fold.set_input (&out_d); fold.set_engine (eng); fold.set_nbin (nbin);
-  const double pfold = 37.7 / out_d.get_rate ();
+  if (v.zeroed) { out_d.set_zeroed_data (true); eng->get_profiles ()->set_hits_nchan (C); }
+  if (v.nfold == 2) { fold2.set_input (&out_d); fold2.set_engine (new HIP::FoldEngine (ctx, chain)); fold2.set_nbin (nbin); }
+  const double pfold = 37.7 / out_d.get_rate (), pfold2 = 23.3 / out_d.get_rate ();
   for (unsigned b = 0; b < nblock; b++)
   {
     // block b of the stream: packed bytes ((t*nchan + c)*npol + p)*ndim + d = 2*t + p, and their unpacked image
@@ -90,14 +95,20 @@ static int run_variant (dspsr_amd_ctx* ctx, dsp::Memory* dmem, const Variant& v,
       fold.fold (phi + 0.5, pfold, 700, ndat - 700);
     } else
       fold.fold (phi, pfold, 0, ndat);
+    if (v.nfold == 2) { fold2.prepare_output (); fold2.fold (0.73 - 0.21 * b, pfold2, 0, ndat); }   // fold[1] of the same block
   }
-  dsp::PhaseSeries* res = fold.get_result ();
-  REQUIRE (res->get_nbin () == nbin && res->get_nchan () == C && res->get_npol () == 2 && res->get_ndim () == 2, "%s: result shape", v.name);
-  profile.resize (size_t (C) * 2 * nbin * 2);
-  for (unsigned c = 0; c < C; c++) for (unsigned p = 0; p < 2; p++)
-    memcpy (&profile[(size_t (c) * 2 + p) * nbin * 2], res->get_datptr (c, p), nbin * 2 * sizeof (float));
-  hits.assign (res->get_hits (), res->get_hits () + nbin);
-  length = res->integration_length;
+  profile.clear (); hits.clear ();
+  for (int f = 0; f < v.nfold; f++)
+  {
+    dsp::PhaseSeries* res = (f ? fold2 : fold).get_result ();
+    REQUIRE (res->get_nbin () == nbin && res->get_nchan () == C && res->get_npol () == 2 && res->get_ndim () == 2, "%s: result shape", v.name);
+    const size_t at = profile.size ();
+    profile.resize (at + size_t (C) * 2 * nbin * 2);
+    for (unsigned c = 0; c < C; c++) for (unsigned p = 0; p < 2; p++)
+      memcpy (&profile[at + (size_t (c) * 2 + p) * nbin * 2], res->get_datptr (c, p), nbin * 2 * sizeof (float));
+    hits.insert (hits.end (), res->get_hits (), res->get_hits () + nbin * res->get_hits_nchan ());
+    if (f == 0) length = res->integration_length;
+  }
   counters[0] = chain ? chain->get_fused_blocks () : 0;
   counters[1] = chain ? chain->get_eager_blocks () : 0;
   counters[2] = chain ? chain->get_dropped_blocks () : 0;
@@ -117,13 +128,13 @@ static int deferred_section (dspsr_amd_ctx* ctx, dsp::Memory* dmem)
   const float scale = 0.0123f;
   const Variant variants[] = {
     // name                                                           chain  deferred raw    fused mode               pieces finish
-    {"eager adaptors, no chain",                                       false, false,   false, DSPSR_AMD_FUSED_AUTO,   false, false},
-    {"chain, not deferred",                                            true,  false,   false, DSPSR_AMD_FUSED_AUTO,   false, false},
-    {"deferred, float32 rows, fused kernel (one workgroup per tile)",  true,  true,    false, DSPSR_AMD_FUSED_ALWAYS, false, false},
-    {"deferred, packed 8-bit block, fused kernel",                     true,  true,    true,  DSPSR_AMD_FUSED_ALWAYS, false, false},
-    {"deferred, packed 8-bit block, library's choice of launches",     true,  true,    true,  DSPSR_AMD_FUSED_AUTO,   false, false},
-    {"eager, packed 8-bit block (perform_raw inside perform)",         true,  false,   true,  DSPSR_AMD_FUSED_AUTO,   false, false},
-    {"deferred + finish() after every perform (record_time)",          true,  true,    true,  DSPSR_AMD_FUSED_ALWAYS, false, true},
+    {"eager adaptors, no chain",                                       false, false,   false, DSPSR_AMD_FUSED_AUTO,   false, false, 1, false},
+    {"chain, not deferred",                                            true,  false,   false, DSPSR_AMD_FUSED_AUTO,   false, false, 1, false},
+    {"deferred, float32 rows, fused kernel (one workgroup per tile)",  true,  true,    false, DSPSR_AMD_FUSED_ALWAYS, false, false, 1, false},
+    {"deferred, packed 8-bit block, fused kernel",                     true,  true,    true,  DSPSR_AMD_FUSED_ALWAYS, false, false, 1, false},
+    {"deferred, packed 8-bit block, library's choice of launches",     true,  true,    true,  DSPSR_AMD_FUSED_AUTO,   false, false, 1, false},
+    {"eager, packed 8-bit block (perform_raw inside perform)",         true,  false,   true,  DSPSR_AMD_FUSED_AUTO,   false, false, 1, false},
+    {"deferred + finish() after every perform (record_time)",          true,  true,    true,  DSPSR_AMD_FUSED_ALWAYS, false, true,  1, false},
   };
   std::vector<float> want, got;
   std::vector<unsigned> whits, ghits;
@@ -149,14 +160,93 @@ static int deferred_section (dspsr_amd_ctx* ctx, dsp::Memory* dmem)
     printf ("deferred section: %-66s == eager  (%llu fused, %llu eager)\n", v.name, (unsigned long long) cnt[0], (unsigned long long) cnt[1]);
   }
   // a sub-integration boundary inside a block: that block falls back to the separate launches, the others stay fused
-  const Variant pe = {"eager, block 1 folded in two pieces", false, false, false, DSPSR_AMD_FUSED_AUTO, true, false};
-  const Variant pd = {"deferred, block 1 folded in two pieces", true, true, true, DSPSR_AMD_FUSED_ALWAYS, true, false};
+  const Variant pe = {"eager, block 1 folded in two pieces", false, false, false, DSPSR_AMD_FUSED_AUTO, true, false, 1, false};
+  const Variant pd = {"deferred, block 1 folded in two pieces", true, true, true, DSPSR_AMD_FUSED_ALWAYS, true, false, 1, false};
   if (run_variant (ctx, dmem, pe, raw_h, scale, C, M, pos, neg, npart, nblock, resp, nbin, want, whits, wlen, cnt)) return 1;
   if (run_variant (ctx, dmem, pd, raw_h, scale, C, M, pos, neg, npart, nblock, resp, nbin, got, ghits, glen, cnt)) return 1;
   REQUIRE (ghits == whits && glen == wlen, "pieces: hits / integration_length differ");
   for (size_t k = 0; k < want.size (); k++) REQUIRE (got[k] == want[k], "pieces: profile[%zu] = %.9g != %.9g", k, got[k], want[k]);
   REQUIRE (cnt[0] == nblock - 1 && cnt[1] == 1 && cnt[2] == 0, "pieces: %llu fused / %llu eager blocks", (unsigned long long) cnt[0], (unsigned long long) cnt[1]);
   printf ("deferred section: block with a sub-integration boundary falls back to eager, result identical\n");
+
+  // TWO Folds on one deferred chain (dspsr folding several pulsars from one detected series, LoadToFold1.C:917-955,1206):
+  // the chain must never fuse -- the second Fold reads the detected TimeSeries, which a fused block never writes
+  {
+    const Variant te = {"eager, two Folds of one detected series", false, false, false, DSPSR_AMD_FUSED_AUTO, false, false, 2, false};
+    const Variant td = {"deferred chain, two Folds of one detected series", true, true, true, DSPSR_AMD_FUSED_ALWAYS, false, false, 2, false};
+    if (run_variant (ctx, dmem, te, raw_h, scale, C, M, pos, neg, npart, nblock, resp, nbin, want, whits, wlen, cnt)) return 1;
+    if (run_variant (ctx, dmem, td, raw_h, scale, C, M, pos, neg, npart, nblock, resp, nbin, got, ghits, glen, cnt)) return 1;
+    REQUIRE (want.size () == 2 * size_t (C) * 2 * nbin * 2 && got.size () == want.size (), "two folds: profile sizes");
+    REQUIRE (ghits == whits && glen == wlen, "two folds: hits / integration_length differ");
+    double p2 = 0;
+    for (size_t k = want.size () / 2; k < want.size (); k++) p2 += double (want[k]) * want[k];
+    REQUIRE (p2 > 0, "two folds: the second eager profile is all zero");
+    for (size_t k = 0; k < want.size (); k++) REQUIRE (got[k] == want[k], "two folds: profile[%zu] = %.9g != %.9g (fold %zu)", k, got[k], want[k], k / (want.size () / 2));
+    REQUIRE (cnt[0] == 0 && cnt[1] == nblock && cnt[2] == 0, "two folds: %llu fused / %llu eager blocks (must never fuse)", (unsigned long long) cnt[0], (unsigned long long) cnt[1]);
+    printf ("deferred section: two Folds on one deferred chain: never fused, both profiles == eager\n");
+  }
+  // zeroed (RFI-excised) input with per-channel hits in deferred mode: the eager fold counts the hits from the data
+  {
+    const Variant ze = {"eager, zeroed samples", false, false, false, DSPSR_AMD_FUSED_AUTO, false, false, 1, true};
+    const Variant zd = {"deferred chain, zeroed samples", true, true, true, DSPSR_AMD_FUSED_ALWAYS, false, false, 1, true};
+    if (run_variant (ctx, dmem, ze, raw_h, scale, C, M, pos, neg, npart, nblock, resp, nbin, want, whits, wlen, cnt)) return 1;
+    if (run_variant (ctx, dmem, zd, raw_h, scale, C, M, pos, neg, npart, nblock, resp, nbin, got, ghits, glen, cnt)) return 1;
+    REQUIRE (whits.size () == size_t (C) * nbin && ghits == whits, "zeroed deferred: per-channel hits differ");
+    uint64_t hsum = 0;
+    for (size_t k = 0; k < whits.size (); k++) hsum += whits[k];
+    REQUIRE (hsum > 0, "zeroed deferred: no hits counted");
+    for (size_t k = 0; k < want.size (); k++) REQUIRE (got[k] == want[k], "zeroed deferred: profile[%zu]", k);
+    REQUIRE (cnt[0] == 0 && cnt[1] == nblock, "zeroed deferred: %llu fused blocks (must be eager)", (unsigned long long) cnt[0]);
+    printf ("deferred section: zeroed samples on a deferred chain take the eager fold, per-channel hits == eager\n");
+  }
+  // what the chain must refuse: (a) a recorded block that no Fold asked for, (b) a reader of a fused block's intermediates
+  {
+    const uint64_t ndat = uint64_t (npart) * (M - pos - neg);
+    HIP::Chain* chain = new HIP::Chain (ctx);
+    Reference::To<HIP::Chain> keep = chain;
+    chain->set_deferred (true);
+    dsp::TimeSeries in_d, out_d, copy_d;
+    in_d.set_nchan (1); in_d.set_npol (2); in_d.set_ndim (1); in_d.set_state (Signal::Nyquist); in_d.set_rate (1e6);
+    in_d.set_memory (dmem); in_d.resize (ndat_in); in_d.zero ();
+    dsp::Filterbank fbk;
+    fbk.nchan_subband = C; fbk.freq_res = M; fbk.input = &in_d; fbk.response = &resp;
+    HIP::FilterbankEngine fbe (ctx, chain);
+    fbe.set_fused_fold (DSPSR_AMD_FUSED_ALWAYS);
+    fbe.setup (&fbk);
+    HIP::DetectionEngine dete (ctx, chain);
+    out_d.set_nchan (C); out_d.set_npol (2); out_d.set_ndim (2); out_d.set_rate (1e6 / (2 * C));
+    out_d.set_memory (dmem); out_d.resize (ndat);
+    copy_d.set_memory (dmem); copy_d.internal_match (&out_d);
+    dsp::Fold fold;
+    fold.set_input (&out_d); fold.set_engine (new HIP::FoldEngine (ctx, chain)); fold.set_nbin (nbin);
+    auto block = [&] (bool do_fold) {
+      out_d.set_state (Signal::Analytic);
+      fbe.perform (&in_d, &out_d, npart, step, 2 * (M - pos - neg));
+      dete.polarimetry (2, &out_d, &out_d);
+      out_d.set_state (Signal::Coherence);
+      if (do_fold) { fold.prepare_output (); fold.fold (0.3, 37.7 / out_d.get_rate (), 0, ndat); }
+    };
+    block (false);                                         // recorded, never folded
+    bool threw = false;
+    try { block (true); } catch (Error& e) { threw = true; }
+    REQUIRE (threw, "an unfolded recorded block must be an Error at the next perform()");
+    chain->set_drop_unfolded (true);
+    block (false);
+    block (true);
+    REQUIRE (chain->get_dropped_blocks () == 1 && chain->get_fused_blocks () == 1, "drop_unfolded: %llu dropped / %llu fused",
+             (unsigned long long) chain->get_dropped_blocks (), (unsigned long long) chain->get_fused_blocks ());
+    // the last block was fused: out_d was never written; a reader that goes through an engine of the chain is refused
+    HIP::TimeSeriesEngine tse (ctx, chain);
+    tse.prepare (&copy_d);
+    threw = false;
+    try { tse.copy_data_fpt (&out_d, 0, 16); } catch (Error& e) { threw = true; }
+    REQUIRE (threw, "copy_data_fpt from the never-written intermediate of a fused block must be an Error");
+    threw = false;
+    try { dete.polarimetry (2, &out_d, &copy_d); } catch (Error& e) { threw = true; }
+    REQUIRE (threw, "a second Detection of a fused block's intermediate must be an Error");
+    block (true);                                          // the next block clears the mark
+    printf ("deferred section: unfolded block / reader of a fused block's intermediates are refused loudly\n");
+  }
   return 0;
 }
 

@@ -107,6 +107,7 @@ def test_bench_gpus_n_is_one_command_and_fails_loudly():
     parent returns non-zero instead of hanging or printing a number."""
     import subprocess
     import sys
+    import sys
     if torch.cuda.is_available():
         pytest.skip("a GPU is present (the GPU suite runs the real thing)")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -121,3 +122,22 @@ def test_reduce_single_rank_is_identity():
     from dspsr_amd.pipeline import reduce_subbands
     p = torch.arange(10, dtype=torch.float32)
     assert reduce_subbands(p) is p
+
+
+def test_bench_bounded_wait_exits_instead_of_hanging():
+    import subprocess
+    import sys
+    """bench._bounded: a collective set-up step whose peers never arrive (ncclCommInitRank with a rank missing) must end the
+    rank with a non-zero exit code and a message, not hang the 8-GPU run; a step that returns in time hands back its result
+    or its exception."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "r, e = bench._bounded('fast step', lambda: 7, 0, timeout=5.0); assert r == 7 and e is None\n"
+            "r, e = bench._bounded('failing step', lambda: 1 / 0, 0, timeout=5.0); assert r is None and isinstance(e, ZeroDivisionError)\n"
+            "print('before', flush=True)\n"
+            "bench._bounded('stuck step', lambda: time.sleep(60), 3, timeout=0.3)\n"
+            "print('not reached', flush=True)\n" % root)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3, (p.returncode, p.stderr[-500:])
+    assert "before" in p.stdout and "not reached" not in p.stdout
+    assert "rank 3: stuck step did not return" in p.stderr

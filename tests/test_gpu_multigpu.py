@@ -222,7 +222,23 @@ def test_bench_rccl_setup_and_agreed_fallback(gpu, monkeypatch):
             raise dspsr_amd.DspsrAmdError("no librccl here")
         monkeypatch.setattr(dspsr_amd.Communicator, "unique_id", staticmethod(refuse))
         comm, note = bench.open_rccl_exchange(ctx, torch, dist, 0, 1)
-        assert comm is None and "no librccl here" in note
+        assert comm is None and "no librccl here" in note and note.startswith("dlopen")
+        monkeypatch.undo()
+        # a rank that fails in comm_create: the ranks agree on that BEFORE anyone enters the trial collective
+        real_init = dspsr_amd.Communicator.__init__
+
+        def refuse_init(self, *a, **k):
+            raise dspsr_amd.DspsrAmdError("ncclCommInitRank refused")
+        monkeypatch.setattr(dspsr_amd.Communicator, "__init__", refuse_init)
+        comm, note = bench.open_rccl_exchange(ctx, torch, dist, 0, 1)
+        assert comm is None and note.startswith("comm_create") and "refused" in note
+        monkeypatch.setattr(dspsr_amd.Communicator, "__init__", real_init)
+        # ... and one whose trial exchange fails
+        def bad_finish(self, *a, **k):
+            raise dspsr_amd.DspsrAmdError("collective failed")
+        monkeypatch.setattr(dspsr_amd.Communicator, "finish", bad_finish)
+        comm, note = bench.open_rccl_exchange(ctx, torch, dist, 0, 1)
+        assert comm is None and note.startswith("trial exchange") and "collective failed" in note
         ctx.close()
     finally:
         dist.destroy_process_group()
@@ -249,7 +265,10 @@ def test_bench_two_ranks_one_command(gpu, workload, extra):
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["parity_gate"]["status"] == "ok"
     assert ("sub-band" if workload == "cfg4" else "replicas") in res["config"]["parallelism"]
     assert res["config"]["reduce_ms_per_dump"] > 0
+    # which transport carried the dumps is a top-level field (here: the one-device gloo rehearsal, never "rccl-c-abi")
+    assert res["exchange"] == "gloo-rehearsal" and res["config"]["exchange"] == "gloo-rehearsal"
     if workload is None:
+        assert res["subband_shard"]["exchange"] == "gloo-rehearsal"
         assert res["config"]["workload"] == "target"
         sh = res["subband_shard"]
         assert sh["workload"] == "cfg4" and sh["value"] > 0 and sh["ms_per_step"] > 0 and sh["reduce_ms_per_dump"] > 0
