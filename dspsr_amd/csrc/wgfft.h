@@ -334,7 +334,11 @@ DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const 
 // May be called repeatedly (persistent workgroup): the barrier in front of the first LDS write
 // also separates it from the previous tile's last-stage LDS reads.
 // STAGED: `out` writes into the exchange buffer (the caller copies it out after a barrier).
-template <int LOGF, int SIGN, bool STAGED = false, class Out, class Mid>
+// FROM_LDS: the caller has already written the tile into the exchange buffer -- element (pos, col) at word
+// lds_pad(pos*T + col), column pairs in split form as the stages write them -- and passed a barrier; the first stage then
+// reads its inputs there like every later stage (x is not used).  This is how a pass chains two transforms over different
+// axes of one tile without leaving the workgroup (k_rows_inv: FFT over the rows in registers, inverse FFT over the bins here).
+template <int LOGF, int SIGN, bool STAGED = false, bool FROM_LDS = false, class Out, class Mid>
 DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx2 (&x)[NPAIR], Out& out, Mid& mid)
 {
   typedef FftPlan<LOGF> P;
@@ -343,9 +347,9 @@ DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx
   asm volatile("" : "+v"(tid));
   mid(0);
   if constexpr (P::NS <= 1) {
-    wgfft_stage<P::LOGR1, SIGN, true, true, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out, mid, 1);
+    wgfft_stage<P::LOGR1, SIGN, !FROM_LDS, true, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out, mid, 1);
   } else {
-    wgfft_stage<4, SIGN, true, false, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out, mid, 1);
+    wgfft_stage<4, SIGN, !FROM_LDS, false, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out, mid, 1);
     int logP = 4;
     uint32_t toff = ltw_off + (4u << (LOGF - 4));
 #pragma unroll
@@ -358,11 +362,11 @@ DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx
     else wgfft_stage<4, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out, mid, P::NS);
   }
 }
-template <int LOGF, int SIGN, bool STAGED = false, class Out>
+template <int LOGF, int SIGN, bool STAGED = false, bool FROM_LDS = false, class Out>
 DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx2 (&x)[NPAIR], Out& out)
 {
   NoMid mid;
-  wgfft<LOGF, SIGN, STAGED>(lds, ltw_off, tid, logT, x, out, mid);
+  wgfft<LOGF, SIGN, STAGED, FROM_LDS>(lds, ltw_off, tid, logT, x, out, mid);
 }
 
 // Ablation only (DSPSR_AMD_DEBUG bit 4): hands the first-stage registers straight to `out` in the shape

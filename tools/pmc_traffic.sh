@@ -22,13 +22,18 @@ done
 python3 - "$T" "$W" "$K" "$MODES" <<'PY'
 import collections, csv, glob, json, subprocess, sys
 tag, wl, K, modes = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4].split()
-skip = ("at::", "at_cuda", "elementwise", "distribution", "philox", "Cijk")          # torch kernels that only make the synthetic block
+# torch kernels that only make the synthetic block (its chunks are assembled with device-to-device copies; the pipeline itself
+# issues none for a resident block: fold plans travel by hipMemcpyAsync from pinned memory, which is not a kernel)
+skip = ("at::", "at_cuda", "elementwise", "distribution", "philox", "Cijk", "copyBuffer")
 out = {"workload": wl, "blocks": K,
        "source": "tools/pmc_traffic.sh (tools/pmc_workload.py: K identical blocks in bench.py's launch shape): rocprofv3 --pmc FETCH_SIZE / "
                  "--pmc WRITE_SIZE in separate passes with --kernel-trace only; reads = 2 x FETCH_SIZE (gfx950 correction, "
-                 "MI355X_MICROARCH.md HBM section); KB = 1024 B; every kernel of the run except torch's generators, memsets included"}
+                 "MI355X_MICROARCH.md HBM section); KB = 1024 B; every kernel of the run except torch's generators and copies, memsets "
+                 "included; the unfused group is the filterbank launch group bench.py's `roofline` prices (FFT + chirp + detect, "
+                 "detected output written): the stand-alone Fold kernels that follow it are listed under `kernels` and summed in "
+                 "`fold_MB_per_part`, not in the group"}
 for m in modes:
-    tot = {}
+    tot, foldb = {}, 0.0
     ker = collections.defaultdict(lambda: {"calls_per_block": 0.0, "fetch_KB_per_block": 0.0, "write_KB_per_block": 0.0})
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f = glob.glob("gpurun_out/%s/pmc_%s_%s_%s/**/*counter_collection.csv" % (tag, wl, m, c), recursive=True)[0]
@@ -39,7 +44,10 @@ for m in modes:
                 continue
             k = n.split("(")[0].replace("void dspsr_amd::", "").replace("dspsr_amd::", "").strip()
             v = float(r["Counter_Value"])
-            s += v
+            if m == "unfused" and "k_fold_" in k and wl not in ("fold",):
+                foldb += v * (2 if c == "FETCH_SIZE" else 1) * 1024 / K          # stand-alone Fold behind the priced group
+            else:
+                s += v
             e = ker[k]
             if c == "FETCH_SIZE":
                 e["calls_per_block"] += 1.0 / K
@@ -63,6 +71,8 @@ for m in modes:
     out["algorithmic_bytes_per_block" + sfx] = line["algorithmic_bytes_per_block"]
     out["algorithmic_MB_per_part" + sfx] = round(line["algorithmic_bytes_per_block"] / (ppb * nch) / 1e6, 2)
     out["traffic_ratio" + sfx] = round(hbm / line["algorithmic_bytes_per_block"], 3)
+    if foldb:
+        out["fold_MB_per_part"] = round(foldb / (ppb * nch) / 1e6, 2)
     out["kernels" + sfx] = dict(ker)
     if "roofline_kernel" in line:                       # cfg5 / fold: the dominant kernel on its own, per launch
         k = [n for n in ker if line["roofline_kernel"] in n]
