@@ -699,7 +699,7 @@ def make_fold_pipeline(name, args, torch, rank, world, local_rank):
     cfg = pipeline.Config(nchan=wl["nchan"], dispersion_measure=wl["dm"], nbin=wl["nbin"],
                           folding_period=0.0893, freq_res=wl["freq_res"], ndim=args.ndim,
                           parts_per_block=parts_per_block, max_parts=max_parts,
-                          fused_fold=not args.no_fused_fold)
+                          fused_fold=not args.no_fused_fold, two_pass=not getattr(args, "no_two_pass", False))
     lt = pipeline.LoadToFold(cfg, info, device=local_rank, stream=torch.cuda.current_stream().cuda_stream,
                              subband=rank if sharded else None)
 
@@ -833,6 +833,10 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
         nsamp_fft = 2 * N if info.ndim == 1 else N
         b_alg = algorithmic_bytes_per_part(2, nsamp_fft * info.ndim, 8, N, nchan_subband, lt.nkeep)
         achieved = b_alg * cfg.parts_per_block * lt.in_nchan / (fb_ms * 1e-3) / 1e9
+        npass = lt.fb.npass(True)
+        group = {2: ("k_raw_cols+k_fwd_col1+k_rows_inv<.,.,false>", "k_raw_cols+k_fwd_col1+k_rows_inv<.,.,true>"),
+                 3: ("k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,false>", "k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,true>"),
+                 4: ("k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b", "k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b<.,true>+k_fold_segsum")}[npass]
         exch = ("dspsr_amd_reduce_profiles_* (RCCL behind the C-ABI, csrc/comm.hip), snapshot on the compute stream, collective "
                 "on its own stream" if rccl is not None else
                 "torch.distributed (gloo rehearsal on one device)" if world > 1 and single else
@@ -855,7 +859,7 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
                        "nsamp_step": lt.nsamp_step, "dm": cfg.dispersion_measure, "nbin": cfg.nbin,
                        "parts_per_block": cfg.parts_per_block, "max_parts": cfg.max_parts,
                        "input": "8-bit dual-pol, resident in HBM",
-                       "detected_ndim": cfg.ndim, "fused_fold": bool(fused), "parallelism": par,
+                       "detected_ndim": cfg.ndim, "fused_fold": bool(fused), "transform_passes": npass, "parallelism": par,
                        "realtime_factor": round(value / world / (info.rate / 1e6), 3)},
             "parity_gate": gate,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -867,8 +871,7 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
                                          "algorithmic bytes for the same group: %d"
                                          % (cfg.max_parts, measured_traffic.source or "profiles/r*_traffic.json: none for this shape",
                                             b_alg * cfg.max_parts),
-                         "kernel": "filterbank launch group k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,false> "
-                                   "(FFT+chirp+detect, detected output written)",
+                         "kernel": "filterbank launch group %s (FFT+chirp+detect, detected output written)" % group[0],
                          "algorithmic_bytes_per_part": b_alg, "group_ms_per_block": round(fb_ms, 4),
                          "traffic_ratio": None,
                          "region": ("%d extra blocks right after the timed region with Detection and Fold as "
@@ -890,8 +893,7 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
                 "bound": "hbm", "achieved": round(ach_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach_f / HBM_PEAK_GBS, 4),
                 "traffic": measured_traffic(name, cfg.max_parts, "hbm_bytes_per_launch_group_fused"),
-                "kernel": "k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,true> (FFT+chirp+detect+fold in one "
-                          "launch group, the timed region)",
+                "kernel": "%s (FFT+chirp+detect+fold in one launch group, the timed region)" % group[1],
                 "algorithmic_bytes_per_part": b_fused, "group_ms_per_block": round(timed_ms, 4),
                 "note": "the fused group also does the fold; its algorithmic bytes have no output term "
                         "(SURVEY 8(d)), so this fraction is not comparable with roofline.frac"}
@@ -969,6 +971,8 @@ def main():
                     help="also measure the PCIe-inclusive rate: every block copied from pinned host memory on a second "
                          "stream, double buffered, overlapped with the kernels (reported as config.pcie_inclusive)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the short PCIe-inclusive leg of the default single-GPU run")
+    ap.add_argument("--no-two-pass", action="store_true",
+                    help="short-response geometries (cfg4) through the three-pass kernels instead of the two-pass path (A/B runs)")
     ap.add_argument("--no-fused-fold", action="store_true",
                     help="Detection and Fold as separate operations (detected time series through HBM)")
     args = ap.parse_args()

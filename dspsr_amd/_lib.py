@@ -68,6 +68,7 @@ SYMBOLS = {
     "dspsr_amd_filterbank_perform_detect": (_i, [_vp, _vp, _u64, _u64, _u64, _vp, _i, _f, _i, _u32, _vp, _u64, _u64,
                                                  _u64]),
     "dspsr_amd_filterbank_fold_is_fused": (_i, [_vp]),
+    "dspsr_amd_filterbank_npass": (_i, [_vp, _i]),
     "dspsr_amd_filterbank_perform_fold": (_i, [_vp, _vp, _u64, _u64, _u64, _vp, _i, _f, _i, _vp, _u64]),
     "dspsr_amd_sample_delay_create": (_i, [_vp, _u32, _u32, _vp, _i, _pp]),
     "dspsr_amd_sample_delay_destroy": (None, [_vp]),

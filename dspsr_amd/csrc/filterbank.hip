@@ -1705,17 +1705,27 @@ __global__ __launch_bounds__(256) void k_raw_cols(const FbGeom g, const FbIn in,
   const uint64_t part = blockIdx.y;
   const uint32_t na0 = blockIdx.x * R;
   const uint64_t t0 = (part0 + part) * in.part_step + ((uint64_t)na0 << logFb);
-  const uint4* __restrict__ src = (const uint4*)((const uint8_t*)in.base + 4 * t0);
+  if (in.nchan == 1) {
+    const uint4* __restrict__ src = (const uint4*)((const uint8_t*)in.base + 4 * t0);
 #pragma unroll 4
-  for (uint32_t q = 0; q < NS / 4 / 256; q++) {
-    const uint32_t v = tid + 256 * q;
-    const uint4 w = src[v];
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    for (uint32_t q = 0; q < NS / 4 / 256; q++) {
+      const uint32_t v = tid + 256 * q;
+      const uint4 w = src[v];
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint32_t sidx = 4 * v + k, nb = sidx & (Fb - 1), r = sidx >> logFb;
-      sm[nb * RP + r] = (uint16_t)(ww[k] & 0xffffu);
-      sm[(Fb + nb) * RP + r] = (uint16_t)(ww[k] >> 16);
+      for (int k = 0; k < 4; k++) {
+        const uint32_t sidx = 4 * v + k, nb = sidx & (Fb - 1), r = sidx >> logFb;
+        sm[nb * RP + r] = (uint16_t)(ww[k] & 0xffffu);
+        sm[(Fb + nb) * RP + r] = (uint16_t)(ww[k] >> 16);
+      }
+    }
+  } else {
+    // several input channels in the block (byte ((t*nchan + c)*npol + p)*2 + d): this channel's word of every sample
+    const uint32_t* __restrict__ src = (const uint32_t*)in.base;
+    for (uint32_t sidx = tid; sidx < NS; sidx += 256) {
+      const uint32_t w = src[(t0 + sidx) * in.nchan + in.ichan], nb = sidx & (Fb - 1), r = sidx >> logFb;
+      sm[nb * RP + r] = (uint16_t)(w & 0xffffu);
+      sm[(Fb + nb) * RP + r] = (uint16_t)(w >> 16);
     }
   }
   __syncthreads();
@@ -1833,11 +1843,10 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
                                                   const uint32_t nparts, const uint32_t run)
 {
   static_assert(LOGM + LOGFB == 13 && LOGFB >= 1 && LOGFB <= 4, "k_rows_inv: Fb channels x 2 pols x M bins = 2^14 points");
-  typedef FftPlan<LOGM> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
   constexpr int logT3 = LOGFB, logT = LOGFB + 1;
-  constexpr uint32_t Fb = 1u << LOGFB, T3 = Fb, M = 1u << LOGM, NJ = 16 / Fb;
+  constexpr uint32_t Fb = 1u << LOGFB, T3 = Fb, NJ = 16 / Fb;
   constexpr int logCa = 14 - LOGM;                                  // Fa / M: channel stride between the rows kb of a tile
   const uint64_t L = 1ull << (14 + LOGFB);
   const uint32_t ntile = 1u << logCa;
@@ -2596,6 +2605,11 @@ k3_t fb_pick3(int logf, bool full);       // plain
 k3_t fb_pick3f(int logf, bool full);      // fused fold
 k3a_t fb_pick3a(int logf, bool blocked);
 k3b_t fb_pick3b(int logf, bool foldb = false);
+// two-pass path (FB_HAS(6)): pass 1 on whole columns, rows + inverse pass (M = 2^logm, Fb = 2^(13 - logm)), the 8-bit regroup
+typedef void (*k1c_t)(FbGeom, FbIn, cf*, const cf*, uint32_t, uint32_t, uint32_t);
+k1c_t fb_pick_col1();
+k3_t fb_pick_rinv(int logm, bool fold);
+void fb_launch_raw_cols(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, cf* Rt, uint64_t part0);
 
@@ -2624,6 +2638,11 @@ k3_t fb_pick3f(int logf, bool full) { return logf != 12 ? nullptr : (full ? k_in
 #if FB_HAS(4)
 k3a_t fb_pick3a(int, bool) { return nullptr; }
 k3b_t fb_pick3b(int, bool) { return nullptr; }
+#endif
+#if FB_HAS(6)
+k1c_t fb_pick_col1() { return nullptr; }
+k3_t fb_pick_rinv(int, bool) { return nullptr; }
+void fb_launch_raw_cols(dim3, hipStream_t, const FbGeom&, const FbIn&, uint16_t*, uint64_t) {}
 #endif
 #else
 #if FB_HAS(1)
@@ -2682,6 +2701,23 @@ template <int... I> static k3b_t pick3b(int logf, bool foldb, iseq<I...>)
 k3a_t fb_pick3a(int logf, bool blocked) { return pick3a(logf, blocked, seq_t()); }
 k3b_t fb_pick3b(int logf, bool foldb) { return pick3b(logf, foldb, seq_t()); }
 #endif
+#if FB_HAS(6)
+k1c_t fb_pick_col1() { return k_fwd_col1<1>; }
+k3_t fb_pick_rinv(int logm, bool fold)
+{
+  switch (logm) {
+    case 9: return fold ? k_rows_inv<9, 4, true> : k_rows_inv<9, 4, false>;
+    case 10: return fold ? k_rows_inv<10, 3, true> : k_rows_inv<10, 3, false>;
+    case 11: return fold ? k_rows_inv<11, 2, true> : k_rows_inv<11, 2, false>;
+    case 12: return fold ? k_rows_inv<12, 1, true> : k_rows_inv<12, 1, false>;
+    default: return nullptr;
+  }
+}
+void fb_launch_raw_cols(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0)
+{
+  hipLaunchKernelGGL(k_raw_cols, grid, dim3(256), 0, stream, g, in, Rt, part0);
+}
+#endif
 #endif
 #if FB_HAS(1)
 void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0)
@@ -2730,6 +2766,12 @@ struct dspsr_amd_filterbank_impl {
   size_t fpart_floats = 0;
   uint32_t plan_cap = 0;     // fused fold: plan entries per LDS buffer behind the twiddle tables
   size_t lds3f = 0;          // dynamic LDS of the fused inverse pass
+  // two-pass path of short responses (complex dual-pol 8-bit input, nchan_subband * freq_res^2 == 2^27): see FB_HAS(6)
+  bool two_pass = false;
+  k1c_t k1c = nullptr;
+  k3_t k2r = nullptr, k2rf = nullptr;
+  size_t lds1c = 0, lds2r = 0, lds2rf = 0;
+  uint32_t plan_cap2 = 0;
   k3b_t k3bf = nullptr;      // four-pass fused fold: second inverse pass that leaves segment sums (FbOut kind 4)
   float* msum = nullptr;     // ... [chan][part][tile][t2][2] float4 of one input channel's sub-band and one block
   size_t msum_floats = 0;
@@ -2788,6 +2830,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   g.xblock = g.kblock = 0;
   g.xstride = fb->L;
   g.logMa = g.logMb = g.logTm = g.logTt = 0;
+  g.logFb2 = 0;
   g.tw_lo = g.tw_lo_m = nullptr;
   g.real_input = cfg->real_input ? 1 : 0;
   g.npol = cfg->npol;
@@ -2823,7 +2866,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   }
   // ... otherwise four: L = Fa*Fb forward (whole spectrum, blocked by pass-2 tile), freq_res = Ma*Mb inverse in two passes.
   // This also covers nchan_subband = 1 (dsp::Convolution) and freq_res up to 2^26.
-  if (cfg->force_four_pass || !three_ok) {
+  if (cfg->force_four_pass == 1 || !three_ok) {
     int la = (logL + 1) / 2;
     if (la > MAX_LOGF) la = MAX_LOGF;
     const int lb = logL - la;
@@ -2928,6 +2971,32 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
       delete fb;
       return have ? fb_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_filterbank_create: hipFuncSetAttribute: %s", hipGetErrorString(e))
                   : fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: geometry not in this (experiment) build");
+    }
+  }
+  // Two-pass path: forward and inverse levels together fit two workgroup tiles (FB_HAS(6)).  Complex dual-pol input with
+  // nchan_subband * freq_res^2 == 2^27 and 512 <= freq_res <= 4096 (the 50 MHz sub-band geometry -F 512:D -x 512); taken per call
+  // when the input is the generic 8-bit block (fb_run), the three-pass kernels above serve every other input form.
+  // force_four_pass == 2 switches it off (comparison runs and tests).
+  if (!g.four_pass && !cfg->real_input && cfg->npol == 2 && cfg->force_four_pass != 2 && logMf >= 9 && logMf <= 12 &&
+      logC + 2 * logMf == 27 && ctx->ncu > 0 && FB_ENV_INT("DSPSR_AMD_NO_TWO_PASS", 0) == 0) {
+    fb->k1c = fb_pick_col1();
+    fb->k2r = fb_pick_rinv(logMf, false);
+    fb->k2rf = fb_pick_rinv(logMf, true);
+    if (fb->k1c && fb->k2r && fb->k2rf) {
+      g.logFb2 = 13 - logMf;
+      fb->lds1c = lds_total_words_host(1u << 14, 13) * sizeof(cf);
+      fb->lds2r = lds_total_words_host(1u << 14, logMf) * sizeof(cf);
+      const size_t psl_bytes = FB_PSL_MAX * sizeof(uint32_t);
+      const size_t spare = 160 * 1024 - 64 - fb->lds2r - 16 - psl_bytes;
+      uint32_t cap = fb->lds2r + 64 + 16 + psl_bytes < 160 * 1024 ? (uint32_t)(spare / 32) : 0;
+      if (cap > 512) cap = 512;
+      if (cap < 16) cap = 0;
+      fb->plan_cap2 = cap;
+      fb->lds2rf = fb->lds2r + 16 + (size_t)cap * 32 + psl_bytes;
+      hipError_t e2 = allow_lds(fb->k1c, fb->lds1c);
+      if (e2 == hipSuccess) e2 = allow_lds(fb->k2r, fb->lds2r);
+      if (e2 == hipSuccess) e2 = allow_lds(fb->k2rf, fb->lds2rf);
+      fb->two_pass = e2 == hipSuccess;
     }
   }
   fb->max_parts = cfg->max_parts ? cfg->max_parts : 1;
@@ -3054,11 +3123,12 @@ static uint32_t grid_for(uint64_t items, uint32_t ncu)
 // are cut into runs folded by different workgroups (k_inv_chan, "Segmented"): partial profiles zeroed before, added to the
 // profile in run order after the launch.  segmented == false: one workgroup owns a tile for all parts (exact time order).
 static int fb_launch_fused(dspsr_amd_filterbank* fb, k3_t k3, const cf* X, const cf* kern, FbOut co, uint64_t part0, uint32_t ns,
-                           bool segmented)
+                           bool segmented, bool two_pass = false)
 {
   dspsr_amd_ctx* ctx = fb->ctx;
   const FbGeom& g = fb->g;
-  const uint32_t tiles = g.C >> g.logT3, wgs = fb->ncu * fb->wg3;
+  // (two-pass path: the tile is Fb = 2^logFb2 channels, one 512-thread workgroup per compute unit)
+  const uint32_t tiles = two_pass ? g.C >> g.logFb2 : g.C >> g.logT3, wgs = two_pass ? fb->ncu : fb->ncu * fb->wg3;
   uint32_t nseg = 1;
   if (segmented && tiles < wgs) {
     nseg = wgs / tiles;
@@ -3071,7 +3141,7 @@ static int fb_launch_fused(dspsr_amd_filterbank* fb, k3_t k3, const cf* X, const
     fb->plan_wait = nullptr;
     if (rc != DSPSR_AMD_OK) return rc;
   }
-  co.plan_cap = fb->plan_cap;
+  co.plan_cap = two_pass ? fb->plan_cap2 : fb->plan_cap;
   co.nseg = nseg;
   co.part = nullptr;
   if (nseg > 1) {
@@ -3090,7 +3160,8 @@ static int fb_launch_fused(dspsr_amd_filterbank* fb, k3_t k3, const cf* X, const
     co.part = fb->fpart;
   }
   const uint32_t grid = nseg > 1 ? tiles * nseg : grid_for(tiles, wgs);
-  hipLaunchKernelGGL(k3, dim3(grid), dim3(fb->nt3), fb->lds3f, ctx->stream, g, X, kern, co, ctx->tw, part0, ns, ns);
+  hipLaunchKernelGGL(k3, dim3(grid), dim3(two_pass ? 512u : fb->nt3), two_pass ? fb->lds2rf : fb->lds3f, ctx->stream, g, X, kern, co,
+                     ctx->tw, part0, ns, ns);
   if (nseg > 1) return fold_combine_partials(co.fold, fb->fpart, nseg - 1, co.chan0, g.C);
   return DSPSR_AMD_OK;
 }
@@ -3110,7 +3181,11 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   // like the (pol0, pol1) pairs of real input, one aligned word per two columns
   const bool fastc = in.kind == 1 && !g.real_input && g.npol == 2 && fb->cfg.input_nchan == 1 &&
                      ((uintptr_t)in.base % 16) == 0 && (in.part_step % 4) == 0 && g.logR >= 3;
-  bool pret = (fast8 || fastc) && g.logR >= 2 && g.logT1 <= 5 && !FB_ENV_SET("DSPSR_AMD_NO_PRETRANSPOSE");   // rows of >= 128 B need no regrouping
+  // the two-pass path of short responses takes exactly this input form (and out.kind 0..3; the four-pass segment sums never
+  // apply: freq_res <= 4096)
+  const bool two = fb->two_pass && in.kind == 1 && !g.real_input && g.npol == 2 && out.kind != 4 &&
+                   ((uintptr_t)in.base % (fb->cfg.input_nchan == 1 ? 16 : 4)) == 0 && (in.part_step % 4) == 0;
+  bool pret = two || ((fast8 || fastc) && g.logR >= 2 && g.logT1 <= 5 && !FB_ENV_SET("DSPSR_AMD_NO_PRETRANSPOSE"));   // rows of >= 128 B need no regrouping
   if (pret && in.kind == 2 && (in.part_step % 4) != 0) pret = false;
   if (pret && !fb->Rt) {
     if (hipMalloc((void**)&fb->Rt, (size_t)fb->max_parts * fb->nseq * fb->L * sizeof(uint16_t)) != hipSuccess)
@@ -3160,6 +3235,26 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         if (i3b > per_part_items) per_part_items = i3b;
         while (nb > 1 && per_part_items * nb >= (1ull << 31)) nb /= 2;
         nb_step = nb;
+      }
+      if (two) {
+        // Two passes (FB_HAS(6)): regroup per column, whole-column forward pass, rows + inverse pass -- the spectrum never
+        // leaves the chip.  Launches are whole groups (the segmented fused fold pays a memset and a combine pass per launch).
+        const uint32_t Fb = 1u << g.logFb2;
+        fb_launch_raw_cols(dim3((uint32_t)(fb->L / 8192), nb), ctx->stream, g, ci, fb->Rt, part0);
+        FbIn cr = ci;
+        cr.kind = 3;
+        cr.base = fb->Rt;
+        const uint64_t n1c = (uint64_t)Fb * 2 * nb;
+        hipLaunchKernelGGL(fb->k1c, dim3(grid_for(n1c, fb->ncu)), dim3(512), fb->lds1c, ctx->stream, g, cr, fb->A, ctx->tw, nb, 2u, 32u);
+        const uint32_t tiles = g.C >> g.logFb2;
+        if (co.kind == 3) {
+          const int rc = fb_launch_fused(fb, fb->k2rf, fb->A, kern, co, part0, nb, fused_segmented, true);
+          if (rc != DSPSR_AMD_OK) return rc;
+        } else {
+          hipLaunchKernelGGL(fb->k2r, dim3(grid_for((uint64_t)tiles * nb, fb->ncu)), dim3(512), fb->lds2r, ctx->stream, g, fb->A, kern, co,
+                             ctx->tw, part0, nb, nb);
+        }
+        continue;
       }
       // persistent grids: one workgroup per CU (LDS-limited), a multiple of 8 so the XCD-aware item order applies
       const uint64_t n1 = (uint64_t)(Rr >> g.logT1) * fb->nseq * nb, n2 = (uint64_t)(M >> g.logT2) * fb->nseq * nb,
@@ -3354,6 +3449,13 @@ extern "C" int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, con
   }
   FbOut out = {2, det_dev, det_chan_stride, det_pol_stride, 0, state, ndim, 0};
   return fb_run(fb, in, out, npart, in_chan_stride);
+}
+
+extern "C" int dspsr_amd_filterbank_npass(const dspsr_amd_filterbank* fb, int raw_input)
+{
+  if (!fb) return 0;
+  if (fb->g.four_pass) return 4;
+  return fb->two_pass && raw_input ? 2 : 3;
 }
 
 extern "C" int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb)

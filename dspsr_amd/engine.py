@@ -142,11 +142,13 @@ class FilterbankEngine:
         self.handle = None
 
     def setup(self, nchan_subband, freq_res, nfilt_pos, nfilt_neg, input_nchan=1, npol=2, real_input=True,
-              kernel: np.ndarray | None = None, max_parts: int = 1, force_four_pass: bool = False,
+              kernel: np.ndarray | None = None, max_parts: int = 1, force_four_pass: bool | int = False,
               fused_fold: int = _lib.FUSED_AUTO):
+        """force_four_pass: False / 0 = passes chosen from the geometry, True / 1 = two-pass inverse everywhere, 2 = never the
+        two-pass path of short responses (dspsr_amd_filterbank_config::force_four_pass)."""
         self.close()
         cfg = _lib.FilterbankConfig(nchan_subband, freq_res, nfilt_pos, nfilt_neg, input_nchan, npol,
-                                    1 if real_input else 0, max_parts, 1 if force_four_pass else 0, fused_fold)
+                                    1 if real_input else 0, max_parts, int(force_four_pass), fused_fold)
         h = C.c_void_p()
         _check(self.ctx.handle, lib.dspsr_amd_filterbank_create(self.ctx.handle, C.byref(cfg), C.byref(h)),
                "dspsr_amd_filterbank_create")
@@ -230,6 +232,10 @@ class FilterbankEngine:
                                                        raw.data_ptr() if raw is not None else None, layout, scale,
                                                        state, ndim, det.data_ptr(), dcs, dps, npart),
                "dspsr_amd_filterbank_perform_detect")
+
+    def npass(self, raw_input: bool = True) -> int:
+        """Transform passes of a call: 2 (short responses on the 8-bit block), 3, or 4 (two-pass inverse)."""
+        return int(lib.dspsr_amd_filterbank_npass(self.handle, 1 if raw_input else 0))
 
     def fold_is_fused(self) -> int:
         """0: perform_fold runs Detection + Fold launches; 1: it folds inside the last filterbank pass with exact time-order

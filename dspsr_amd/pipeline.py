@@ -40,6 +40,8 @@ class Config:
     fused_fold: bool = True           # fold inside the last filterbank pass when possible (identical sums, no
                                       # detected time series in HBM); False = Detection and Fold as separate ops
     force_fused: bool = False         # fuse also where the channel tiles do not fill the chip (slower there, same sums)
+    two_pass: bool = True             # short responses (complex dual-pol input, nchan_subband * freq_res^2 == 2^27): forward and
+                                      # inverse transforms in two workgroup tiles; False = the three-pass kernels (A/B runs)
     interchan_dedispersion: bool = False   # -K: remove the inter-channel dispersion delay (LoadToFold1.C:605-624)
     record_time: bool = False              # -r: time every operation (Operation.C:90-113); each one then ends with a stream
                                            # synchronisation so that the wall times are honest (FilterbankCUDA.cu:302-303)
@@ -647,7 +649,7 @@ class LoadToFold:
         self.nchan_out = nsub * self.in_nchan                              # output channels this instance produces
         self.fb = FilterbankEngine(self.ctx).setup(nsub, r.ndat, r.impulse_pos, r.impulse_neg,
                                                    self.in_nchan, info.npol, info.ndim == 1, kernel,
-                                                   max_parts=cfg.max_parts,
+                                                   max_parts=cfg.max_parts, force_four_pass=0 if cfg.two_pass else 2,
                                                    fused_fold=(_lib.FUSED_NEVER if not cfg.fused_fold else
                                                                _lib.FUSED_ALWAYS if cfg.force_fused else _lib.FUSED_AUTO))
         self.nkeep, self.nsamp_step, self.nsamp_overlap = self.fb.nkeep, self.fb.nsamp_step, self.fb.nsamp_overlap

@@ -84,8 +84,10 @@ typedef struct {
   uint32_t npol;            /* 1 or 2 */
   uint32_t real_input;      /* 1: Signal::Nyquist (ndim 1), 0: Signal::Analytic (ndim 2) */
   uint32_t max_parts;       /* parts processed per launch group (scratch is sized for this); 0 => default */
-  uint32_t force_four_pass; /* 1: two-pass inverse (the path of freq_res > 8192 and of dsp::Convolution) also where the
-                               single-pass inverse would do; same results to rounding.  0 => chosen from the geometry */
+  uint32_t force_four_pass; /* 0 => passes chosen from the geometry; 1: two-pass inverse (the path of freq_res > 8192 and of
+                               dsp::Convolution) also where the single-pass inverse would do; 2: never the two-pass path of
+                               short responses (complex dual-pol input, nchan_subband * freq_res^2 == 2^27: forward and
+                               inverse transforms in two tiles); same results to rounding in every case */
   uint32_t fused_fold;      /* dspsr_amd_filterbank_perform_fold: DSPSR_AMD_FUSED_AUTO (fold inside the last filterbank
                                pass when the channel tiles fill the chip), _ALWAYS, _NEVER -- same sums bit for bit */
 } dspsr_amd_filterbank_config;
@@ -161,6 +163,14 @@ int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, const float* i
  *      take this path too (fold.hip).
  * DSPSR_AMD_FUSED_ALWAYS forces mode 1 on any three-pass geometry. */
 int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb);
+/* How many transform passes (trips of the part through HBM scratch + 1) a call makes -- the role of the plan choice inside
+ * CUDA::FilterbankEngine::setup (FilterbankCUDA.cu:92-116: one forward and one batched backward cuFFT plan).  raw_input != 0:
+ * the answer for dspsr_amd_filterbank_perform_raw / _detect / _fold on a generic 8-bit block, else for float32 rows.
+ *   2  short responses: complex dual-pol 8-bit input with nchan_subband * freq_res^2 == 2^27 (one 50 MHz sub-band, -F 512:D
+ *      -x 512): whole-column forward pass, then rows + chirp + inverse transforms in ONE tile -- the spectrum stays on chip;
+ *   3  forward columns, forward rows, inverse per channel (freq_res <= 8192);
+ *   4  two-pass inverse (freq_res > 8192, dsp::Convolution shapes, force_four_pass = 1). */
+int dspsr_amd_filterbank_npass(const dspsr_amd_filterbank* fb, int raw_input);
 int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const float* in_f32_dev, uint64_t in_chan_stride,
                                       uint64_t in_pol_stride, uint64_t in_step, const int8_t* raw_dev, int raw_layout,
                                       float scale, int state, dspsr_amd_fold* fold, uint64_t npart);

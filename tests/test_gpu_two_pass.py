@@ -1,0 +1,145 @@
+"""The two-pass path of short responses (csrc/filterbank.hip, FB_HAS(6): k_raw_cols -> k_fwd_col1 -> k_rows_inv).
+
+Complex dual-pol 8-bit input with nchan_subband * freq_res^2 == 2^27 (BASELINE cfg 4: one 50 MHz sub-band, -F 512:D -x 512):
+the forward transform (2^14-point columns) and rows + chirp + inverse transforms in TWO workgroup tiles instead of three.
+Reference arithmetic: Filterbank.C:561-662 (forward FFT, Response::operate, nchan_subband backward FFTs, keep window),
+Detection (cross_detect.ic:23-43), Fold.C:835-891 -- the same oracle and tolerances as tests/test_gpu_parity.py:
+  * filterbank output vs the float64 oracle: rms(err)/rms(out) <= 2e-6 * sqrt(log2 2N), max <= 8x that
+  * two-pass vs three-pass (force_four_pass = 2) of the SAME library: both within that bound of the oracle, and within 4e-6 of
+    each other relative to the rms (different association of the same transform)
+  * fused fold with one workgroup per tile == perform_detect + fold, bit for bit (exact time order in both)
+"""
+import math
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import _fb_case, _raw, gpu  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+# (nchan_subband, freq_res, (nfilt_pos, nfilt_neg)): C * M^2 == 2^27, Fb = 2^13 / M rows per inverse tile
+GEOMETRIES = [(512, 512, (27, 27)), (128, 1024, (100, 61)), (32, 2048, (200, 301)), (8, 4096, (422, 400))]
+
+
+@pytest.mark.parametrize("C,M,nfilt", GEOMETRIES)
+def test_two_pass_filterbank_against_oracle(oracle, gpu, C, M, nfilt):
+    """Every geometry of the family, three parts in launch groups of two (a full and a ragged group), against the float64
+    oracle; then the same input through the three-pass kernels of the same library."""
+    got2, ref = _fb_case(oracle, gpu, C, M, nfilt, 3, npol=2, real=False, max_parts=2, seed=11)
+    got3, _ = _fb_case(oracle, gpu, C, M, nfilt, 3, npol=2, real=False, max_parts=2, seed=11, four_pass=2)
+    rms = math.sqrt(np.mean(np.abs(ref) ** 2))
+    d = np.abs(got2 - got3)
+    assert d.max() > 0, "force_four_pass = 2 must take other kernels than the default (identical bits: the two-pass path did not run)"
+    assert math.sqrt(np.mean(d ** 2)) <= 4e-6 * rms and d.max() <= 4e-5 * rms
+
+
+def test_two_pass_multichannel_input(oracle, gpu):
+    """Several input channels in the block (the NCHAN-8 full-band form of cfg 4, here 3 channels): the regroup pass picks one
+    channel's words; every input channel against the oracle with its own slice of the kernel."""
+    _fb_case(oracle, gpu, 512, 512, (27, 27), 2, npol=2, real=False, input_nchan=3, max_parts=2, seed=5)
+
+
+def test_two_pass_float_input_takes_three_passes(oracle, gpu):
+    """float32 rows (Filterbank::Engine::perform) are not regrouped per column: the object serves them with its three-pass
+    kernels -- same object family, same oracle bound."""
+    _fb_case(oracle, gpu, 128, 1024, (100, 61), 2, npol=2, real=False, max_parts=2, use_raw=False)
+
+
+@pytest.mark.parametrize("ndim", [4, 2, 1])
+@pytest.mark.parametrize("state", ["Coherence", "Stokes"])
+def test_two_pass_detected_output(oracle, gpu, ndim, state):
+    """perform_detect through the two-pass path: coherency / Stokes products (cross_detect.ic:23-43, stokes_detect.ic:21-44) of
+    the filterbank output, against the float64 oracle's filterbank output detected in float64."""
+    dspsr_amd, ctx = gpu
+    o = oracle
+    C, M, nfilt, npart = 128, 1024, (100, 61), 3
+    N, nkeep = C * M, M - sum(nfilt)
+    rng = np.random.default_rng(3)
+    kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, N)).astype(np.complex64)
+    step, ovl = N - sum(nfilt) * C, sum(nfilt) * C
+    raw = _raw(npart * step + ovl, 2, 2, 1, seed=8)
+    obs = o.Observation(nchan=1, npol=2, ndim=2, machine="DADA")
+    plan = o.FilterbankPlan(C, 1, C, M, N, nfilt[0], nfilt[1], sum(nfilt), N, ovl, step, nkeep, float(N) * M, False)
+    ref = o.filterbank(o.unpack_8bit(raw, obs), plan, kernel, npart=npart, dtype=np.float64)       # [chan][pol][t] complex
+    p, q = ref[:, 0], ref[:, 1]
+    pp, qq, cr = np.abs(p) ** 2, np.abs(q) ** 2, p * np.conj(q)
+    want = np.stack([pp + qq, pp - qq, 2 * cr.real, -2 * cr.imag] if state == "Stokes" else [pp, qq, cr.real, -cr.imag], axis=-1)
+    eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, 2, False, kernel, max_parts=2)
+    det = torch.zeros((C, 4 // ndim, ndim * npart * nkeep), dtype=torch.float32, device="cuda")
+    st = dspsr_amd.STOKES if state == "Stokes" else dspsr_amd.COHERENCE
+    eng.perform_detect(det, npart, st, ndim, raw=torch.from_numpy(raw).cuda(), scale=float(o.S8))
+    eng.finish()
+    got = det.cpu().numpy().reshape(C, 4 // ndim, npart * nkeep, ndim).transpose(0, 2, 1, 3).reshape(C, npart * nkeep, 4)
+    eng.close()
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("C,M,nfilt,nbin,period_samples", [(512, 512, (27, 27), 64, 71.3), (128, 1024, (100, 61), 128, 300.7),
+                                                           (8, 4096, (422, 400), 32, 97.1)])
+def test_two_pass_fused_fold_bit_identical(oracle, gpu, C, M, nfilt, nbin, period_samples):
+    """perform_fold through k_rows_inv<., ., true> with one workgroup per tile for all parts of a launch (FUSED_ALWAYS: exact
+    time order) == perform_detect + FoldEngine.fold (Fold.C:835-891), bit for bit, over several calls and launch groups."""
+    dspsr_amd, ctx = gpu
+    o = oracle
+    N, nkeep = C * M, M - sum(nfilt)
+    step, ovl = N - sum(nfilt) * C, sum(nfilt) * C
+    npart, ncall = 5, 3
+    rng = np.random.default_rng(23)
+    kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, N)).astype(np.complex64)
+    eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, 2, False, kernel, max_parts=2, fused_fold=dspsr_amd.FUSED_ALWAYS)
+    assert eng.fold_is_fused() == 1
+    folds = [dspsr_amd.FoldEngine(ctx), dspsr_amd.FoldEngine(ctx)]
+    hits = [np.zeros(nbin, np.uint32), np.zeros(nbin, np.uint32)]
+    for f in folds:
+        f.set_shape(C, 1, 4, nbin)
+    det = torch.zeros((C, 1, 4 * npart * nkeep), dtype=torch.float32, device="cuda")
+    pps = 1.0 / period_samples
+    for call in range(ncall):
+        raw = torch.from_numpy(_raw(npart * step + ovl, 2, 2, 1, seed=100 + call)).cuda()
+        ndat = npart * nkeep
+        phi = (0.37 + call * ndat * pps) % 1.0
+        for k, f in enumerate(folds):
+            f.set_nbin(nbin)
+            f.set_ndat(ndat, 0)
+            f.set_bins(phi, pps, ndat, 0, hits[k])
+        eng.perform_detect(det, npart, dspsr_amd.COHERENCE, 4, raw=raw, scale=float(o.S8))
+        folds[0].fold(det)
+        eng.perform_fold(folds[1], npart, dspsr_amd.COHERENCE, raw=raw, scale=float(o.S8))
+    a, b = folds[0].synch(), folds[1].synch()
+    assert np.array_equal(hits[0], hits[1]) and int(hits[0].sum()) == ncall * npart * nkeep
+    assert np.abs(a).max() > 0 and np.array_equal(a, b)
+    eng.close()
+    for f in folds:
+        f.close()
+
+
+def test_two_pass_segmented_fused_fold_and_pipeline(oracle, gpu):
+    """The cfg 4 shard as the bench runs it (pipeline.LoadToFold on sub-band g of an NCHAN-8 band, segmented fused fold: the
+    32 tiles do not fill the chip) against (a) the same pipeline with Detection and Fold as separate launches (<= 2e-6 of the
+    profile maximum: the part runs of the segmented fold are re-associated) and (b) the three-pass pipeline (two_pass=False),
+    identical hits in every case."""
+    dspsr_amd, _ = gpu
+    from dspsr_amd import pipeline
+    info = pipeline.InputInfo(centre_frequency=1382.0, bandwidth=-400.0, nchan=8, npol=2, ndim=2, tsamp_us=0.02, machine="DADA")
+    res = {}
+    for key, kw in (("two_fused", {}), ("two_unfused", {"fused_fold": False}), ("three_fused", {"two_pass": False})):
+        cfg = pipeline.Config(nchan=4096, dispersion_measure=1000.0, nbin=1024, folding_period=0.0893, freq_res=512, ndim=4,
+                              parts_per_block=24, max_parts=24, **kw)
+        lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream, subband=5)
+        raw = torch.from_numpy(_raw(lt.block_bytes() // 4, 2, 2, 1, seed=77)).cuda()
+        for _ in range(2):
+            lt.process_block(raw)
+        lt.finish_subint()
+        lt.synchronize()
+        s = lt.subints[0]
+        res[key] = (s["hits"].copy(), pipeline.subint_profile(s).reshape(-1), lt.fused_fold)
+        lt.close()
+    assert res["two_fused"][2] and not res["two_unfused"][2]
+    h, p, _ = res["two_fused"]
+    assert int(h.sum()) == 2 * 24 * 458 and np.abs(p).max() > 0
+    for key in ("two_unfused", "three_fused"):
+        assert np.array_equal(res[key][0], h), key
+        assert np.abs(res[key][1] - p).max() <= 2e-6 * np.abs(p).max(), (key, np.abs(res[key][1] - p).max() / np.abs(p).max())

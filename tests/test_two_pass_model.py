@@ -1,0 +1,41 @@
+"""Index model of the two-pass path (csrc/filterbank.hip FB_HAS(6)) in numpy: the decomposition the kernels implement --
+   n = nb + Fb*na, Fa = 2^14 as even/odd 2^13-point transforms + one radix-2 step (k_fwd_col1), A[a][nb][j] with ka = a*M + j,
+   twiddle W_L^{nb*ka}, Fb-point transforms over nb -> kb, channel c = a + (Fa/M)*kb, chirp, inverse M-point transforms
+   (k_rows_inv) -- equals the direct formulation of Filterbank.C:561-662 (forward FFT of L points, Response::operate, backward
+   FFTs of M contiguous bins per channel).  Small sizes (Fa = 2^6): the index algebra does not depend on them."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("logFa,logM,logFb", [(6, 3, 2), (6, 4, 1), (8, 4, 3)])
+def test_two_pass_decomposition_equals_direct(logFa, logM, logFb):
+    Fa, M, Fb = 1 << logFa, 1 << logM, 1 << logFb
+    L = Fa * Fb
+    C = L // M
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(L) + 1j * rng.standard_normal(L)
+    H = np.exp(1j * rng.uniform(-np.pi, np.pi, L))
+    # direct: forward FFT, x response, backward (unnormalised) FFT of each channel's M bins
+    X = np.fft.fft(x) * H
+    want = np.stack([np.fft.ifft(X[c * M:(c + 1) * M]) * M for c in range(C)])
+    # pass 1: column nb = samples nb + Fb*na; even / odd halves + radix-2 combine with W = exp(-2 pi i / Fa)
+    A = np.zeros((Fa // M, Fb, M), complex)
+    for nb in range(Fb):
+        y = x[nb::Fb]
+        E, O = np.fft.fft(y[0::2]), np.fft.fft(y[1::2])
+        k = np.arange(Fa // 2)
+        w = np.exp(-2j * np.pi * k / Fa)
+        Y = np.concatenate([E + w * O, E - w * O])
+        assert np.allclose(Y, np.fft.fft(y))
+        A[:, nb, :] = Y.reshape(Fa // M, M)                  # A[a][nb][j], ka = a*M + j
+    # pass 2: tile a: twiddle, Fb-point transform over nb, chirp, inverse over j
+    got = np.zeros((C, M), complex)
+    for a in range(Fa // M):
+        ka = a * M + np.arange(M)
+        v = A[a] * np.exp(-2j * np.pi * np.outer(np.arange(Fb), ka) / L)      # [nb][j]
+        S = np.fft.fft(v, axis=0)                                                # [kb][j]: bin k = ka + Fa*kb
+        for kb in range(Fb):
+            c = a + (Fa // M) * kb
+            assert np.allclose(S[kb], np.fft.fft(x)[c * M:(c + 1) * M])
+            got[c] = np.fft.ifft(S[kb] * H[c * M:(c + 1) * M]) * M
+    assert np.allclose(got, want)
