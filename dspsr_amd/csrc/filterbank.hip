@@ -121,6 +121,15 @@ extern "C" int dspsr_amd_debug_stamps(unsigned long long* out_host, int zero)   
 
 // Experiment (-DFB_STAGGER=n): the persistent workgroups of a launch start n*8128 cycles apart in four phases, so that
 // the compute units are not all in their load / store phases at the same time
+// Experiment (-DFB_SETPRIO=1): static priority for the second-dispatched half of an 8-wave workgroup (waves 4-7 lose the
+// VALU arbitration against their older SIMD partners, MI355X_MICROARCH.md "Two waves per SIMD" item 4)
+DEV void fb_setprio()
+{
+#ifdef FB_SETPRIO
+  if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(FB_SETPRIO);
+#endif
+}
+
 DEV void fb_stagger()
 {
 #ifdef FB_STAGGER
@@ -662,6 +671,7 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
   cf* const lw = lds + grp * ldsH;                               // this group's exchange buffer
   const uint32_t ltw_w = ltw_off - grp * ldsH;                   // the shared tables, relative to it
   fb_stagger();
+  fb_setprio();
   // copy-out of the staged tile (see the end of the tile loop): thread part of the addresses, once per kernel
   const uint32_t co_swz = (PTS * blockDim.x) >= 256 ? 1u : 0u;
   const uint32_t co_l0 = 2 * (SPLIT ? (threadIdx.x & 255u) : threadIdx.x);
@@ -1024,6 +1034,7 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
   fb_stagger();
+  fb_setprio();
   // copy-out of the staged tile (end of the tile loop): thread part of the addresses, once per kernel
   const uint32_t co_swz = (PTS * blockDim.x) >= 256 ? 3u : 0u;
   const uint32_t co_l0 = 2 * threadIdx.x, co_n2 = LOGT >= 0 ? (2u << (LOGF + LOGT - LOG_PTS)) : 2 * blockDim.x;   // full tiles: a constant
@@ -1299,6 +1310,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;      // behind the exchange buffer (16-byte aligned)
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
   fb_stagger();
+  fb_setprio();
   // FOLD: two buffers of out.plan_cap plan entries behind the twiddle tables (cf index, 16-byte aligned), followed by
   // a copy of the launch's nparts + 1 part offsets into the plan (PSL_MAX words): a part's entries are then found
   // without a dependent pair of global loads, and are fetched one item ahead (registers) like the tile itself
