@@ -108,15 +108,19 @@ struct FbOut {
   const uint32_t* bin_start;                    // kind 4 (host side only): the intervals bucketed by phase bin (with piv)
 };
 
-#ifdef FB_STAMPS   // diagnostic build only (-DFB_STAMPS=1|2|3: pass to instrument): where a tile spends its cycles
-                   // (s_memtime per phase, lane 0 of wave 0 of every workgroup)
-__device__ unsigned long long g_stamps[1024][8];
+#ifdef FB_STAMPS   // diagnostic build only (-DFB_STAMPS=1|2|3|6|7: pass to instrument -- 6 = k_fwd_col1, 7 = k_rows_inv): where a
+                   // tile spends its cycles (s_memtime per phase, lane 0 of wave 0 of every workgroup).  The counters live in
+                   // the translation unit of the instrumented kernel (single-TU builds, or the FB_PART that holds it)
 #define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-extern "C" int dspsr_amd_debug_stamps(unsigned long long* out_host, int zero)   // single-TU experiment builds only
+#define FB_STAMPS_PART (FB_STAMPS == 1 ? 1 : FB_STAMPS == 2 ? 2 : FB_STAMPS == 3 ? 5 : 6)
+#if !defined(FB_PART) || FB_PART == FB_STAMPS_PART
+__device__ unsigned long long g_stamps[1024][8];
+extern "C" int dspsr_amd_debug_stamps(unsigned long long* out_host, int zero)
 {
   if (zero) { static unsigned long long z[1024][8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
   return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
 }
+#endif
 #endif
 
 // Experiment (-DFB_STAGGER=n): the persistent workgroups of a launch start n*8128 cycles apart in four phases, so that
@@ -1808,22 +1812,39 @@ __global__ __launch_bounds__(512) void k_fwd_col1(const FbGeom g, const FbIn in,
   if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
   RawW<RAWW> raw[PTS / 2];
   fetch(item, raw);
+#if defined(FB_STAMPS) && FB_STAMPS == 6
+  unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, acc_s[6] = {0, 0, 0, 0, 0, 0};
+  STAMP(ts5);
+#endif
   for (;;) {
     asm volatile("" : "+v"(tid));
     cx2 x[NPAIR];
+#if defined(FB_STAMPS) && FB_STAMPS == 6
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(ts0);
+#endif
 #pragma unroll
     for (int h = 0; h < NPAIR; h++) {
       cf a, b;
       decode_pair<RAWW>(g, in, raw[h], a, b, 0);
       x[h] = make_cx2(a, b);                                           // (even sample, odd sample) of position tid + 512*h
     }
+#if defined(FB_STAMPS) && FB_STAMPS == 6
+    STAMP(ts1);
+#endif
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
     if (more) fetch(next, raw);
+#if defined(FB_STAMPS) && FB_STAMPS == 6
+    STAMP(ts2);
+#endif
     Col1Out out;
     out.img = lds;
     out.h = 0;
     wgfft<LOGF, -1, true>(lds, ltw_off, tid, LOGT, x, out);
     __syncthreads();
+#if defined(FB_STAMPS) && FB_STAMPS == 6
+    STAMP(ts3);
+#endif
     // copy-out: the staged column (natural order of ka) as 16-byte pairs, runs of M elements: A[seq][ka / M][nb][ka % M]
     const uint32_t nb = item & ((1u << logFb) - 1);
     cf* __restrict__ Aseq = A + ((uint64_t)(item >> logFb) << (14 + logFb));
@@ -1840,9 +1861,18 @@ __global__ __launch_bounds__(512) void k_fwd_col1(const FbGeom g, const FbIn in,
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#if defined(FB_STAMPS) && FB_STAMPS == 6
+    STAMP(ts4);
+    acc_s[0] += ts0 - ts5; acc_s[1] += ts1 - ts0; acc_s[2] += ts2 - ts1; acc_s[3] += ts3 - ts2; acc_s[4] += ts4 - ts3; acc_s[5] += 1;
+    ts5 = ts4;
+#endif
     if (!more) break;
     item = next;
   }
+#if defined(FB_STAMPS) && FB_STAMPS == 6
+  if (threadIdx.x == 0 && blockIdx.x < 1024)
+    for (int q = 0; q < 6; q++) atomicAdd(&g_stamps[blockIdx.x][q], acc_s[q]);
+#endif
 }
 
 // P2': see the head of this section.  LOGM + LOGFB == 13: a tile is Fb channels x 2 polarisations x M bins = 2^14 points;
@@ -1865,17 +1895,26 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
   struct Abk { cf a, b; };
   struct Item { uint32_t tile, lp; };
   auto chan_of = [&](const uint32_t tile, const uint32_t kb) { return tile + (kb << logCa); };
+  // Loads: the lane pair (2q, 2q + 1) needs bins j = 2q, 2q + 1 of both polarisations.  The even lane loads the two bins of
+  // polarisation 0, the odd lane those of polarisation 1 -- one aligned 16-byte load each instead of two 8-byte ones (half the
+  // load instructions: 8-byte-per-lane streams run at 5.6 TB/s, 16-byte ones at 7.1, tools/load_width_probe.hip; the wave
+  // time of the prefetch is the ISSUE of its loads) -- and the halves are swapped between the two lanes when the tile is consumed.
   auto fetch = [&](const Item item, Abk (&raw)[PTS / 2]) {
-    const cf* __restrict__ A0 = A + (uint64_t)item.lp * 2 * L + (((uint64_t)item.tile << LOGFB) << LOGM) + tid;
+    const cf* __restrict__ A0 = A + (uint64_t)item.lp * 2 * L + ((tid & 1u) ? L : 0) + (((uint64_t)item.tile << LOGFB) << LOGM) + (tid & ~1u);
 #pragma unroll
     for (uint32_t jq = 0; jq < NJ; jq++)
 #pragma unroll
       for (uint32_t nb = 0; nb < Fb; nb++) {
+        const float4 v = ld_stream((const float4*)(A0 + (nb << LOGM) + 512u * jq));
         Abk r;
-        r.a = ld_stream(A0 + (nb << LOGM) + 512u * jq);
-        r.b = ld_stream(A0 + L + (nb << LOGM) + 512u * jq);
+        r.a = make_float2(v.x, v.y);             // even lane: pol 0 of bin j     | odd lane: pol 1 of bin j - 1
+        r.b = make_float2(v.z, v.w);             //            pol 0 of bin j + 1 |           pol 1 of bin j
         raw[jq * Fb + nb] = r;
       }
+  };
+  auto swap1 = [](const cf v) {                  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
+    return make_float2(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0xB1, 0xf, 0xf, false)),
+                       __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0xB1, 0xf, 0xf, false)));
   };
   auto load_chirp = [&](const Item item, cf (&kk)[PTS / 2]) {
     if (kernel) {
@@ -1965,10 +2004,18 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
     }
   };
   if (plan_dma_ok) plan_dma(item, 0);
+#if defined(FB_STAMPS) && FB_STAMPS == 7
+  unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, ts6, acc_s[7] = {0, 0, 0, 0, 0, 0, 0};
+  STAMP(ts5);
+#endif
 
   for (;;) {
     asm volatile("" : "+v"(tid));
     cx2 x[NPAIR];
+#if defined(FB_STAMPS) && FB_STAMPS == 7
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(ts0);
+#endif
     {
       if (item.tile != kk_tile) {
         load_chirp(item, kk);
@@ -1984,7 +2031,12 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
       for (uint32_t jq = 0; jq < NJ; jq++) {
         cx2 v[Fb];
 #pragma unroll
-        for (uint32_t nb = 0; nb < Fb; nb++) v[nb] = make_cx2(raw[jq * Fb + nb].a, raw[jq * Fb + nb].b);
+        for (uint32_t nb = 0; nb < Fb; nb++) {
+          const Abk r = raw[jq * Fb + nb];
+          const bool odd = tid & 1u;
+          const cf recv = swap1(odd ? r.a : r.b);       // the even lane hands over bin j + 1 of pol 0, the odd one bin j - 1 of pol 1
+          v[nb] = make_cx2(odd ? recv : r.a, odd ? r.b : recv);
+        }
         const uint32_t ka = (item.tile << LOGM) + tid + 512u * jq;
         uint32_t jw[4];
         cf t[4];
@@ -1997,8 +2049,14 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
         for (uint32_t kb = 0; kb < Fb; kb++) x[jq * Fb + kb] = cmuls(v[kb], kk[jq * Fb + kb]);
       }
     }
+#if defined(FB_STAMPS) && FB_STAMPS == 7
+    STAMP(ts1);
+#endif
     const bool more = next_item(++j, next);
     if (more) fetch(next, raw);
+#if defined(FB_STAMPS) && FB_STAMPS == 7
+    STAMP(ts2);
+#endif
     // rows -> bins: element (bin j, column 2*kb + pol) of the inverse transform's tile, as the stages exchange them
     __syncthreads();                     // every wave has finished with the previous tile's image (last stage / fold phase)
 #pragma unroll
@@ -2011,6 +2069,9 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
       }
     }
     __syncthreads();
+#if defined(FB_STAMPS) && FB_STAMPS == 7
+    STAMP(ts6);
+#endif
 
     const uint32_t tile = item.tile;
     const uint64_t part = part0 + item.lp;
@@ -2077,9 +2138,10 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
     const uint4* __restrict__ ent = nullptr;
     const uint4* planl = nullptr;
     bool in_lds = false;
-    uint4 en_pre = make_uint4(0, 0, 0, 0);
-    float4 acc_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint4 en_pre = make_uint4(0, 0, 0, 0), en_pre2 = make_uint4(0, 0, 0, 0);
+    float4 acc_pre = make_float4(0.f, 0.f, 0.f, 0.f), acc_pre2 = acc_pre;
     constexpr bool PRE = FOLD && FftPlan<LOGM>::NS >= 2;
+    constexpr bool PRE2 = PRE && LOGFB >= 3;              // >= 8 channels per tile: a thread may fold a second item
     if constexpr (FOLD) {
       f_e0 = fe0_cur;
       f_nact = fn_cur;
@@ -2115,10 +2177,21 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
           en_pre = planl[tid >> logT3];
           acc_pre = acc_load(acc_row(tid), en_pre.x);
         }
+        // (many channels per tile: a part's active bins x Fb channels exceed the workgroup, so a thread folds a second
+        //  item -- its accumulator is requested here as well instead of costing a memory round trip in the fold phase)
+        if constexpr (PRE2) {
+          if (phase == 2 && in_lds && tid + 512u < (f_nact << logT3)) {
+            en_pre2 = planl[(tid + 512u) >> logT3];
+            acc_pre2 = acc_load(acc_row(tid + 512u), en_pre2.x);
+          }
+        }
         if (phase == 2 && plan_dma_ok && more) plan_dma(next, (jt + 1) & 1);
       }
     };
     wgfft<LOGM, +1, FOLD, true>(lds, ltw_off, tid, logT, x, store, mid);
+#if defined(FB_STAMPS) && FB_STAMPS == 7
+    STAMP(ts3);
+#endif
     if constexpr (FOLD) {
       __syncthreads();
       const bool pre = PRE && in_lds;
@@ -2129,6 +2202,9 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
         if (pre && w == tid) {
           en = en_pre;
           acc = acc_pre;
+        } else if (PRE2 && pre && w == tid + 512u) {
+          en = en_pre2;
+          acc = acc_pre2;
         } else {
           en = in_lds ? planl[w >> logT3] : ent[w >> logT3];
           acc = acc_load(acc_row(w), en.x);
@@ -2157,10 +2233,19 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
         acc_store(pp, en.x, acc);
       }
     }
+#if defined(FB_STAMPS) && FB_STAMPS == 7
+    STAMP(ts4);
+    acc_s[0] += ts0 - ts5; acc_s[1] += ts1 - ts0; acc_s[2] += ts2 - ts1; acc_s[3] += ts6 - ts2; acc_s[4] += ts3 - ts6; acc_s[6] += ts4 - ts3; acc_s[5] += 1;
+    ts5 = ts4;
+#endif
     if (!more) break;
     item = next;
     jt++;
   }
+#if defined(FB_STAMPS) && FB_STAMPS == 7
+  if (threadIdx.x == 0 && blockIdx.x < 1024)
+    for (int q = 0; q < 7; q++) atomicAdd(&g_stamps[blockIdx.x][q], acc_s[q]);
+#endif
 }
 #endif  // FB_HAS(6)
 
