@@ -9,6 +9,7 @@
 // CPU loop Fold.C:844-852 -- results are deterministic and bit-identical to the CPU fold of
 // the same detected samples.
 #include <algorithm>
+#include <string.h>
 #include <math.h>
 #include <vector>
 
@@ -251,6 +252,107 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
 #pragma unroll
         for (int d = 0; d < NDIM; d++) out[r * out_rs + b * NDIM + d] = acc[j][r][d];
   }
+}
+
+
+// Dense variant (round 4).  The walk above takes its intervals from global memory; the loads are small, but the per-wave
+// vector-memory counter is in order, so every `s_waitcnt` in front of an interval's use also waits for the NEXT chunk's
+// prefetch, issued just before -- a workgroup has bytes in flight for part of its time only (0.50 of the HBM peak on the
+// reference's fold benchmark).  When no phase bin receives more than ONE run of samples per chunk (always, once the folding
+// period exceeds FOLD_CHUNK samples: Benchmark/fold.csh 2794, the headline's detected series 34816) the plan is a dense table
+//   tab[chunk][bin] = first sample of the run inside the chunk | samples << 11      (0: none; runs are cut at chunk ends)
+// built on the host from the same run-length plan.  A thread's entries for chunk c + 1 travel with the prefetch of chunk c + 1
+// and are waited for together with it at the top of the next iteration: the add phase issues no vector-memory instruction and
+// no wait, so the prefetch stays in flight across it.  Same bins per thread, same chunk grid, one run per (chunk, bin) in
+// chunk order: every (chan, pol, bin, dim) sum has exactly the association of k_fold_chunked<., false, .> and of Fold.C:844-852.
+template <int NDIM, int NROW>
+__global__ __launch_bounds__(1024) void k_fold_dense(const float* __restrict__ in, const uint64_t chan_stride,
+                                                     const uint64_t pol_stride, float* __restrict__ prof,
+                                                     const uint64_t prof_span, const uint32_t nbin,
+                                                     const uint32_t* __restrict__ tab, const uint64_t first, const uint64_t last)
+{
+  extern __shared__ __attribute__((aligned(16))) float fold_lds[];   // NROW x FOLD_CHUNK * NDIM floats
+  const uint32_t ipol = blockIdx.x * NROW, npol = gridDim.x * NROW, ichan = blockIdx.y;
+  constexpr uint32_t RS = FOLD_CHUNK * NDIM;
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const float* __restrict__ row = in + ichan * chan_stride + ipol * pol_stride;
+  float* __restrict__ out = prof + ((uint64_t)ichan * npol + ipol) * prof_span;
+  const uint32_t bz = blockIdx.z, nz = gridDim.z;
+  constexpr uint32_t NF4 = FOLD_CHUNK * NDIM / 4;
+  constexpr uint32_t MAXR = NF4 / 256;
+  uint32_t bin[FOLD_BPT];
+  float acc[FOLD_BPT][NROW][NDIM];
+#pragma unroll
+  for (int j = 0; j < FOLD_BPT; j++) {
+    bin[j] = bz + nz * (tid + j * nt);
+#pragma unroll
+    for (int r = 0; r < NROW; r++)
+#pragma unroll
+      for (int d = 0; d < NDIM; d++) acc[j][r][d] = bin[j] < nbin ? out[r * prof_span + bin[j] * NDIM + d] : 0.f;
+  }
+  const float* __restrict__ src0 = row + first * NDIM;
+  const uint64_t nfl_total = (last - first) * NDIM;
+  const uint32_t nchunk = (uint32_t)((last - first + FOLD_CHUNK - 1) / FOLD_CHUNK);
+  float4 pre[NROW][MAXR];
+  uint32_t tabn[FOLD_BPT];
+  auto fetch = [&](const uint32_t c) {
+#pragma unroll
+    for (int rw = 0; rw < NROW; rw++) {
+      const float4* __restrict__ src = (const float4*)(src0 + rw * pol_stride);
+#pragma unroll
+      for (uint32_t r = 0; r < MAXR; r++) {
+        const uint32_t q = tid + r * nt;
+        const uint64_t k = (uint64_t)c * NF4 + q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < NF4) {
+          if (4 * k + 4 <= nfl_total) {
+            v = src[k];
+          } else if (4 * k < nfl_total) {                  // ragged end of the span: never read past it
+            const float* t = (const float*)(src + k);
+            const uint32_t n = (uint32_t)(nfl_total - 4 * k);
+            v.x = t[0];
+            if (n > 1) v.y = t[1];
+            if (n > 2) v.z = t[2];
+          }
+        }
+        pre[rw][r] = v;
+      }
+    }
+    const uint32_t* __restrict__ tc = tab + (uint64_t)c * nbin;
+#pragma unroll
+    for (int j = 0; j < FOLD_BPT; j++) tabn[j] = bin[j] < nbin ? tc[bin[j]] : 0u;
+  };
+  if (nchunk) fetch(0);
+  for (uint32_t c = 0; c < nchunk; c++) {
+    __syncthreads();                                    // previous chunk fully consumed
+#pragma unroll
+    for (int rw = 0; rw < NROW; rw++)
+#pragma unroll
+      for (uint32_t r = 0; r < MAXR; r++)
+        if (tid + r * nt < NF4) ((float4*)(fold_lds + rw * RS))[tid + r * nt] = pre[rw][r];
+    uint32_t tabc[FOLD_BPT];
+#pragma unroll
+    for (int j = 0; j < FOLD_BPT; j++) tabc[j] = tabn[j];
+    if (c + 1 < nchunk) fetch(c + 1);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FOLD_BPT; j++) {
+      const uint32_t n = tabc[j] >> 11, x0 = (tabc[j] & 2047u) * NDIM;
+#pragma unroll 4
+      for (uint32_t h = 0; h < n; h++)
+#pragma unroll
+        for (int r = 0; r < NROW; r++)
+#pragma unroll
+          for (int d = 0; d < NDIM; d++) acc[j][r][d] += fold_lds[r * RS + x0 + h * NDIM + d];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < FOLD_BPT; j++)
+    if (bin[j] < nbin)
+#pragma unroll
+      for (int r = 0; r < NROW; r++)
+#pragma unroll
+        for (int d = 0; d < NDIM; d++) out[r * prof_span + bin[j] * NDIM + d] = acc[j][r][d];
 }
 
 // LONG: profile[row][bin][dim] += partial sums of the time segments, in time order
@@ -686,13 +788,6 @@ static int fold_fold_impl(dspsr_amd_fold* f, const float* in_dev, uint64_t in_ch
     Interval v; v.offset = r.offset; v.hits = r.hits; v.pad = 0;
     sl.h_iv[f->cursor[r.ibin]++] = v;
   }
-  {
-    const PlanCopy pc[2] = {{sl.d_bin_start, sl.h_bin_start, (nbin + 1) * sizeof(uint32_t)}, {sl.d_iv, sl.h_iv, niv * sizeof(Interval)}};
-    e = plan_upload(f, sl, pc, 2);
-  }
-  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: plan copy: %s", hipGetErrorString(e));
-  if (fold_plan_wait(f, &sl) != DSPSR_AMD_OK) return DSPSR_AMD_EHIP;
-
   // sample span covered by the plan (intervals are time ordered)
   uint64_t first = f->binplan.front().offset, last = f->binplan.back().offset + f->binplan.back().hits;
   first -= first % 4;                                  // keeps 16-byte alignment of the chunk loads for any ndim
@@ -700,6 +795,50 @@ static int fold_fold_impl(dspsr_amd_fold* f, const float* in_dev, uint64_t in_ch
   uint32_t max_run = 0;
   for (const RunBin& r : f->binplan) if (r.hits > max_run) max_run = r.hits;
   const bool lng = aligned && nbin <= (uint32_t)FOLD_BPT * 1024 && max_run >= FOLD_LONG_RUN;   // re-associated sums (see FOLD_LONG_RUN)
+  // Dense per-chunk table (k_fold_dense): at most one run per (chunk, phase bin), runs cut at the chunk ends
+  bool dense = false;
+  size_t ntab = 0;
+  if (aligned && !lng && nbin <= (uint32_t)FOLD_BPT * 1024) {
+    const uint64_t nchunk = (last - first + FOLD_CHUNK - 1) / FOLD_CHUNK;
+    ntab = (size_t)nchunk * nbin;
+    if (ntab <= ((size_t)1 << 24)) {
+      if (ntab > sl.aux_cap) {
+        if (sl.h_aux) (void)hipHostFree(sl.h_aux);
+        if (sl.d_aux) (void)hipFree(sl.d_aux);
+        sl.h_aux = nullptr; sl.d_aux = nullptr; sl.aux_cap = 0;
+        const size_t n = ntab + ntab / 4 + 1024;
+        if (hipHostMalloc((void**)&sl.h_aux, n * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&sl.d_aux, n * sizeof(uint32_t)) != hipSuccess)
+          return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_fold_fold: plan allocation failed");
+        sl.aux_cap = n;
+      }
+      ::memset((void*)sl.h_aux, 0, ntab * sizeof(uint32_t));
+      dense = true;
+      for (const RunBin& r : f->binplan) {
+        uint64_t off = r.offset - first;
+        uint32_t left = r.hits;
+        while (left) {
+          const uint64_t c = off / FOLD_CHUNK;
+          const uint32_t s0 = (uint32_t)(off % FOLD_CHUNK), n = left < FOLD_CHUNK - s0 ? left : FOLD_CHUNK - s0;
+          uint32_t& t = sl.h_aux[c * nbin + r.ibin];
+          if (t) { dense = false; break; }               // a second run of this bin in the chunk: the interval walk handles it
+          t = s0 | (n << 11);
+          off += n;
+          left -= n;
+        }
+        if (!dense) break;
+      }
+    }
+  }
+  {
+    // (the interval lists are still needed by the walk kernels and by the per-channel hit count of a zeroed input)
+    const bool need_iv = !dense || hits_dev;
+    const PlanCopy pc[3] = {{sl.d_bin_start, sl.h_bin_start, need_iv ? (nbin + 1) * sizeof(uint32_t) : 0},
+                            {sl.d_iv, sl.h_iv, need_iv ? niv * sizeof(Interval) : 0},
+                            {sl.d_aux, sl.h_aux, dense ? ntab * sizeof(uint32_t) : 0}};
+    e = plan_upload(f, sl, pc, 3);
+  }
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fold_fold: plan copy: %s", hipGetErrorString(e));
+  if (fold_plan_wait(f, &sl) != DSPSR_AMD_OK) return DSPSR_AMD_EHIP;
   const uint32_t nrow = f->npol * f->nchan;
   // exact mode: rows x bin groups, at least two workgroups per CU when the band has few channels
   uint32_t nsplit = 1;
@@ -738,15 +877,25 @@ static int fold_fold_impl(dspsr_amd_fold* f, const float* in_dev, uint64_t in_ch
                              ? f->npol : 1u;
     dim3 grid(f->npol / nrw, f->nchan, lng ? nseg : nsplit);
     const size_t lds = ((size_t)FOLD_CHUNK + (lng ? FOLD_CHUNK / FOLD_MB : 0)) * f->ndim * nrw * sizeof(float);
+#define FOLD_DENSE(ND, NR) hipLaunchKernelGGL((k_fold_dense<ND, NR>), grid, dim3(threads), lds, ctx->stream, in_dev, in_chan_stride, \
+                                             in_pol_stride, f->profile, f->span, nbin, sl.d_aux, first, last)
 #define FOLD_LAUNCH(ND, LG, NR) hipLaunchKernelGGL((k_fold_chunked<ND, LG, NR>), grid, dim3(threads), lds, ctx->stream, in_dev, \
                                                in_chan_stride, in_pol_stride, f->profile, f->span, nbin, sl.d_bin_start, sl.d_iv, first, last, \
                                                f->part, cps)
+    if (dense) {
+      if (f->ndim == 4) FOLD_DENSE(4, 1);
+      else if (f->ndim == 2 && nrw == 2) FOLD_DENSE(2, 2);
+      else if (f->ndim == 2) FOLD_DENSE(2, 1);
+      else if (nrw == 4) FOLD_DENSE(1, 4);
+      else FOLD_DENSE(1, 1);
+    } else
     if (f->ndim == 4) { if (lng) FOLD_LAUNCH(4, true, 1); else FOLD_LAUNCH(4, false, 1); }
     else if (f->ndim == 2 && nrw == 2) { if (lng) FOLD_LAUNCH(2, true, 2); else FOLD_LAUNCH(2, false, 2); }
     else if (f->ndim == 2) { if (lng) FOLD_LAUNCH(2, true, 1); else FOLD_LAUNCH(2, false, 1); }
     else if (nrw == 4) { if (lng) FOLD_LAUNCH(1, true, 4); else FOLD_LAUNCH(1, false, 4); }
     else { if (lng) FOLD_LAUNCH(1, true, 1); else FOLD_LAUNCH(1, false, 1); }
 #undef FOLD_LAUNCH
+#undef FOLD_DENSE
     if (lng) {
       const uint64_t n = (uint64_t)nrow * nbin * f->ndim;
       uint32_t gx = (uint32_t)((n + 255) / 256);
