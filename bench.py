@@ -78,7 +78,7 @@ def bench_fold_only(args, wl, torch):
     """Benchmark/fold.csh: one step = one block of `ndat` detected samples (1024 channels x 4 products, FPT floats resident
     in HBM -- the reference's Dummy unpacker does not touch the data either) folded with the vela.polyco predictor:
     phase and period from the polynomial at the block's first sample, the double-precision bin plan on the host
-    (Fold.C:718-787), k_fold_chunked on the device (Fold.C:835-891).  nbin as dsp::Fold::choose_nbin picks it."""
+    (Fold.C:718-787), k_fold_dense / k_fold_chunked on the device (Fold.C:835-891).  nbin as dsp::Fold::choose_nbin picks it."""
     import dspsr_amd
     from dspsr_amd import pipeline
     nchan, npol, ndat = wl["nchan"], wl["npol"], wl["ndat"]
@@ -148,7 +148,7 @@ def bench_fold_only(args, wl, torch):
            "parity_gate": {"status": "ok", "checks": ["hits.sum() == ndat", "profile == float64 index_add (rel %.1e)" % rel]},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic("fold", None, "hbm_bytes_per_launch"),
-                        "traffic_source": measured_traffic.source, "kernel": "k_fold_chunked<1,.>",
+                        "traffic_source": measured_traffic.source, "kernel": "k_fold_dense<1,4> (dense per-chunk run table; k_fold_chunked for plans with two runs of a bin per chunk)",
                         "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(k_ms, 4)}}
     if res["roofline"]["traffic"]:
         res["roofline"]["traffic_ratio"] = round(res["roofline"]["traffic"] / b_alg, 3)

@@ -59,7 +59,8 @@ struct FbGeom {
   uint64_t xstride;                      // elements from one spectrum (sequence) to the next in X: L, or the padded size
   int logMf, logMa, logMb, logTm, logTt; // freq_res = Ma*Mb ; m2 columns per k_inv_a tile ; t1 columns per k_inv_b tile
   int real_input, npol;
-  int logFb2;                            // two-pass path (FB_HAS(6)): L = 2^14 * 2^logFb2, the inverse tile holds 2^logFb2 channels x 2 pols
+  int logFb2, logFa2;                    // two-pass path (FB_HAS(6)): L = 2^logFa2 * 2^logFb2 (Fa <= 2^14), the inverse tile holds
+                                         // 2^logFb2 channels x 2 pols
   uint32_t C, nfilt_pos, nkeep;
   int dbg;   // DSPSR_AMD_DEBUG ablation bits (timing experiments only; results are wrong when set)
   const float2* tw_lo;   // exp(-2*pi*i*j/L), j < L/TWN : fine part of the pass-1 twiddle (L > TWN)
@@ -1173,6 +1174,26 @@ __global__ __launch_bounds__(512) void k_fwd_rows(const FbGeom g, const cf* __re
 
 #endif  // FB_HAS(2)
 
+// LDS-DMA of one 16-byte plan entry per lane, global -> LDS without passing through registers (lane l of the wave lands at
+// `lds_wave_base` + 16*l), issued from inline assembly: the compiler does not see a vector-memory operation, so it does NOT put
+// `s_waitcnt vmcnt(0)` in front of the next barrier.  With __builtin_amdgcn_global_load_lds it did -- in the middle of the
+// transform, where that wait also drained the whole prefetch of the next tile, issued just before (ISA of round 3's
+// k_inv_chan<12,true,2>: global_load_lds_dwordx4 ... s_waitcnt vmcnt(0); s_barrier between the second and the third stage;
+// the stamps of profiles/r03_experiments.txt item 4 show the transform phase 1.8k cycles longer for it).  The hardware needs
+// no such wait: a barrier does not drain vector memory (MI355X_MICROARCH.md, "Two waves per SIMD" item 7); what orders a reader
+// behind the DMA is the issuing wave's covering vmcnt wait plus a barrier, and the callers have both: every tile begins with an
+// explicit `s_waitcnt vmcnt(0)` and the entries are read behind the tile's first exchange barrier.  An operation the compiler
+// does not count only makes its own counted waits more conservative (the counter is in order).  m0 (the LDS base of the DMA)
+// is saved and restored inside the block.
+DEV void lds_dma_b128(const void* gsrc, const uint32_t lds_wave_base)
+{
+  const uint32_t sb = __builtin_amdgcn_readfirstlane(lds_wave_base);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(sb) : "memory");
+}
+DEV uint32_t lds_byte_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+
 DEV void detect4(const cf p, const cf q, const int state, float (&r)[4])
 {
   // cross_detect.ic:23-43 / stokes_detect.ic:21-44
@@ -1325,11 +1346,6 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   if constexpr (FOLD) {
     psl = (uint32_t*)&lds[plan_off + 4 * out.plan_cap];
     fent_all = (const uint4*)(out.pstart + ((out.nparts_plan + 1 + 3) & ~3u));
-    use_psl = out.plan_cap > 0 && nparts + 1 <= FB_PSL_MAX;
-    if (use_psl) {
-      for (uint32_t q = tid; q <= nparts; q += blockDim.x) psl[q] = out.pstart[part0 + q];
-      __syncthreads();
-    }
   }
   uint32_t jt = 0;                                              // tiles done by this workgroup
   Item item, next;
@@ -1349,6 +1365,14 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   if (fnseg > 1) fold_b -= fseg * fntg;
   if constexpr (FOLD) {
     if (fnp == 0) return;
+    // the offsets of the parts THIS workgroup walks (its run of a segmented launch: launches of up to 256 parts are cut into
+    // runs of at most FB_PSL_MAX - 1; the whole launch's offsets did not fit, and every entry and accumulator of such launches
+    // -- the sub-band and -F 256:D geometries -- then came from global memory in the fold phase), psl[lp - fp0]
+    use_psl = out.plan_cap > 0 && fnp + 1 <= FB_PSL_MAX;
+    if (use_psl) {
+      for (uint32_t q = tid; q <= fnp; q += blockDim.x) psl[q] = out.pstart[part0 + fp0 + q];
+      __syncthreads();
+    }
     // tiles that share an X layout block (2^(logX3-logT3) of them) go to blocks b, b+8, ... : one XCD under the
     // observed round-robin placement, at the same time, so the block's lines are fetched once (speed only)
     const int lr = logX3 - logT3;
@@ -1393,7 +1417,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   auto plan_fetch = [&](const Item it) {
     if constexpr (FOLD) {
       const uint32_t lp = it.lp;
-      if (use_psl) { fe0_cur = psl[lp]; fn_cur = psl[lp + 1] - fe0_cur; }
+      if (use_psl) { fe0_cur = psl[lp - fp0]; fn_cur = psl[lp - fp0 + 1] - fe0_cur; }
       else { fe0_cur = out.pstart[part0 + lp]; fn_cur = out.pstart[part0 + lp + 1] - fe0_cur; }
       if (FB_DBG(g) & 16) fn_cur = 0;
     }
@@ -1411,11 +1435,9 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   const bool plan_dma_ok = FOLD && FftPlan<LOGF>::NS >= 2 && use_psl;
   auto plan_dma = [&](const Item it, const uint32_t buf) {
     if constexpr (FOLD) {
-      const uint32_t fe0 = psl[it.lp], fn = (FB_DBG(g) & 16) ? 0u : psl[it.lp + 1] - fe0;
+      const uint32_t fe0 = psl[it.lp - fp0], fn = (FB_DBG(g) & 16) ? 0u : psl[it.lp - fp0 + 1] - fe0;
       if (fn <= out.plan_cap && tid < fn)
-        __builtin_amdgcn_global_load_lds((const void*)(fent_all + fe0 + tid),
-                                         (__attribute__((address_space(3))) void*)((uint4*)&lds[plan_off] + buf * out.plan_cap + (tid & ~63u)),
-                                         16, 0, 0);
+        lds_dma_b128((const void*)(fent_all + fe0 + tid), lds_byte_addr((const uint4*)&lds[plan_off] + buf * out.plan_cap + (tid & ~63u)));
     }
   };
   if (plan_dma_ok) plan_dma(item, 0);
@@ -1696,8 +1718,10 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 // ------------------------------------------------------------------------------------ two-pass path (short responses)
 // A part needs log2 L forward and log2 M inverse radix-2 levels; a workgroup tile holds 14.  When log2 L + log2 M <= 27
 // (complex dual-pol input; the 50 MHz sub-band geometry -F 512:D -x 512 is 18 + 9) TWO tiles cover them, and the spectrum
-// never makes its round trip through HBM:  L = Fa * Fb with Fa = 2^14 (one whole column per tile) and Fb = 2^13 / M,
-// sample n = nb + Fb*na, bin k = ka + Fa*kb -- and with ka = a*M + j that bin is bin j of channel c = a + (Fa/M)*kb.
+// never makes its round trip through HBM:  L = Fa * Fb with Fb = 2^13 / M and Fa = L / Fb <= 2^14 (at 2^14 one whole column per
+// tile), sample n = nb + Fb*na, bin k = ka + Fa*kb -- and with ka = a*M + j that bin is bin j of channel c = a + (Fa/M)*kb.
+// Fa < 2^14 (fewer channels): pass 1 is the ordinary k_raw_transpose + k_fwd_cols on a geometry of its own (M = Fa, Rr = Fb,
+// T2 = freq_res: the A layout below is exactly theirs); only Fa = 2^14 needs P0' / P1'.
 //   P0' k_raw_cols   the 8-bit block regrouped per column and polarisation: Rt[part][pol][nb][na]
 //   P1' k_fwd_col1   ONE Fa = 2^14-point FFT per tile (column nb of one polarisation): the even and the odd samples are the
 //                    two interleaved columns of a 2^13-point wgfft, combined by one radix-2 step in registers;
@@ -1889,8 +1913,9 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
   uint32_t tid = threadIdx.x;
   constexpr int logT3 = LOGFB, logT = LOGFB + 1;
   constexpr uint32_t Fb = 1u << LOGFB, T3 = Fb, NJ = 16 / Fb;
-  constexpr int logCa = 14 - LOGM;                                  // Fa / M: channel stride between the rows kb of a tile
-  const uint64_t L = 1ull << (14 + LOGFB);
+  const int logCa = g.logFa2 - LOGM;                                // Fa / M: channel stride between the rows kb of a tile
+  const int logL = g.logFa2 + LOGFB;
+  const uint64_t L = 1ull << logL;
   const uint32_t ntile = 1u << logCa;
   struct Abk { cf a, b; };
   struct Item { uint32_t tile, lp; };
@@ -1937,11 +1962,6 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
   if constexpr (FOLD) {
     psl = (uint32_t*)&lds[plan_off + 4 * out.plan_cap];
     fent_all = (const uint4*)(out.pstart + ((out.nparts_plan + 1 + 3) & ~3u));
-    use_psl = out.plan_cap > 0 && nparts + 1 <= FB_PSL_MAX;
-    if (use_psl) {
-      for (uint32_t q = tid; q <= nparts; q += blockDim.x) psl[q] = out.pstart[part0 + q];
-      __syncthreads();
-    }
   }
   uint32_t jt = 0;
   Item item, next;
@@ -1956,6 +1976,11 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
   if (fnseg > 1) fold_b -= fseg * fntg;
   if constexpr (FOLD) {
     if (fnp == 0) return;
+    use_psl = out.plan_cap > 0 && fnp + 1 <= FB_PSL_MAX;          // offsets of this workgroup's run of parts: psl[lp - fp0]
+    if (use_psl) {
+      for (uint32_t q = tid; q <= fnp; q += blockDim.x) psl[q] = out.pstart[part0 + fp0 + q];
+      __syncthreads();
+    }
   }
   const bool tile_major = FOLD || (ntile >= gridDim.x && ntile % gridDim.x == 0);
   auto next_item = [&](const uint32_t jj, Item& it) -> bool {
@@ -1989,18 +2014,16 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
   auto plan_fetch = [&](const Item it) {
     if constexpr (FOLD) {
       const uint32_t lp = it.lp;
-      if (use_psl) { fe0_cur = psl[lp]; fn_cur = psl[lp + 1] - fe0_cur; }
+      if (use_psl) { fe0_cur = psl[lp - fp0]; fn_cur = psl[lp - fp0 + 1] - fe0_cur; }
       else { fe0_cur = out.pstart[part0 + lp]; fn_cur = out.pstart[part0 + lp + 1] - fe0_cur; }
     }
   };
   const bool plan_dma_ok = FOLD && FftPlan<LOGM>::NS >= 2 && use_psl;
   auto plan_dma = [&](const Item it, const uint32_t buf) {
     if constexpr (FOLD) {
-      const uint32_t fe0 = psl[it.lp], fn = psl[it.lp + 1] - fe0;
+      const uint32_t fe0 = psl[it.lp - fp0], fn = psl[it.lp - fp0 + 1] - fe0;
       if (fn <= out.plan_cap && tid < fn)
-        __builtin_amdgcn_global_load_lds((const void*)(fent_all + fe0 + tid),
-                                         (__attribute__((address_space(3))) void*)((uint4*)&lds[plan_off] + buf * out.plan_cap + (tid & ~63u)),
-                                         16, 0, 0);
+        lds_dma_b128((const void*)(fent_all + fe0 + tid), lds_byte_addr((const uint4*)&lds[plan_off] + buf * out.plan_cap + (tid & ~63u)));
     }
   };
   if (plan_dma_ok) plan_dma(item, 0);
@@ -2042,7 +2065,7 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
         cf t[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) jw[q] = (ka << q) & (uint32_t)(L - 1);
-        twiddles_big(t, jw, 14 + LOGFB, tw, g.tw_lo);
+        twiddles_big(t, jw, logL, tw, g.tw_lo);
         apply_powers<Fb>(v, t[0], t[1], t[2], t[3]);
         fftR<Fb, -1>(v);
 #pragma unroll
@@ -2865,6 +2888,10 @@ struct dspsr_amd_filterbank_impl {
   size_t lds3f = 0;          // dynamic LDS of the fused inverse pass
   // two-pass path of short responses (complex dual-pol 8-bit input, nchan_subband * freq_res^2 == 2^27): see FB_HAS(6)
   bool two_pass = false;
+  FbGeom g1t;                 // ... pass 1 of Fa < 2^14 through k_raw_transpose + k_fwd_cols: their geometry (M = Fa, Rr = Fb, T2 = freq_res)
+  k1_t k1t = nullptr;
+  uint32_t nt1t = 0;
+  size_t lds1t = 0;
   k1c_t k1c = nullptr;
   k3_t k2r = nullptr, k2rf = nullptr;
   size_t lds1c = 0, lds2r = 0, lds2rf = 0;
@@ -2927,7 +2954,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   g.xblock = g.kblock = 0;
   g.xstride = fb->L;
   g.logMa = g.logMb = g.logTm = g.logTt = 0;
-  g.logFb2 = 0;
+  g.logFb2 = g.logFa2 = 0;
   g.tw_lo = g.tw_lo_m = nullptr;
   g.real_input = cfg->real_input ? 1 : 0;
   g.npol = cfg->npol;
@@ -3070,30 +3097,54 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
                   : fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: geometry not in this (experiment) build");
     }
   }
-  // Two-pass path: forward and inverse levels together fit two workgroup tiles (FB_HAS(6)).  Complex dual-pol input with
-  // nchan_subband * freq_res^2 == 2^27 and 512 <= freq_res <= 4096 (the 50 MHz sub-band geometry -F 512:D -x 512); taken per call
-  // when the input is the generic 8-bit block (fb_run), the three-pass kernels above serve every other input form.
+  // Two-pass path: forward and inverse levels together fit two workgroup tiles (FB_HAS(6)).  Complex dual-pol input,
+  // 512 <= freq_res <= 4096, Fb = 2^13 / freq_res channels per inverse tile, Fa = L / Fb with freq_res <= Fa <= 2^14, i.e.
+  // Fb <= nchan_subband <= 2^27 / freq_res^2 (the 50 MHz sub-band geometry -F 512:D -x 512 is the upper end).  Taken per call
+  // when the input is the generic 8-bit block (fb_run); the three-pass kernels above serve every other input form.
   // force_four_pass == 2 switches it off (comparison runs and tests).
-  if (!g.four_pass && !cfg->real_input && cfg->npol == 2 && cfg->force_four_pass != 2 && logMf >= 9 && logMf <= 12 &&
-      logC + 2 * logMf == 27 && ctx->ncu > 0 && FB_ENV_INT("DSPSR_AMD_NO_TWO_PASS", 0) == 0) {
-    fb->k1c = fb_pick_col1();
-    fb->k2r = fb_pick_rinv(logMf, false);
-    fb->k2rf = fb_pick_rinv(logMf, true);
-    if (fb->k1c && fb->k2r && fb->k2rf) {
-      g.logFb2 = 13 - logMf;
-      fb->lds1c = lds_total_words_host(1u << 14, 13) * sizeof(cf);
-      fb->lds2r = lds_total_words_host(1u << 14, logMf) * sizeof(cf);
-      const size_t psl_bytes = FB_PSL_MAX * sizeof(uint32_t);
-      const size_t spare = 160 * 1024 - 64 - fb->lds2r - 16 - psl_bytes;
-      uint32_t cap = fb->lds2r + 64 + 16 + psl_bytes < 160 * 1024 ? (uint32_t)(spare / 32) : 0;
-      if (cap > 512) cap = 512;
-      if (cap < 16) cap = 0;
-      fb->plan_cap2 = cap;
-      fb->lds2rf = fb->lds2r + 16 + (size_t)cap * 32 + psl_bytes;
-      hipError_t e2 = allow_lds(fb->k1c, fb->lds1c);
-      if (e2 == hipSuccess) e2 = allow_lds(fb->k2r, fb->lds2r);
-      if (e2 == hipSuccess) e2 = allow_lds(fb->k2rf, fb->lds2rf);
-      fb->two_pass = e2 == hipSuccess;
+  {
+    const int lfb = 13 - logMf, lfa = logL - lfb;
+    if (!g.four_pass && !cfg->real_input && cfg->npol == 2 && cfg->force_four_pass != 2 && logMf >= 9 && logMf <= 12 &&
+        lfa >= logMf && lfa <= 14 && ctx->ncu > 0 && FB_ENV_INT("DSPSR_AMD_NO_TWO_PASS", 0) == 0) {
+      hipError_t e2 = hipSuccess;
+      bool have1 = false;
+      if (lfa == 14) {
+        fb->k1c = fb_pick_col1();
+        fb->lds1c = lds_total_words_host(1u << 14, 13) * sizeof(cf);
+        have1 = fb->k1c != nullptr;
+        if (have1) e2 = allow_lds(fb->k1c, fb->lds1c);
+      } else {
+        // pass 1 = the ordinary column pass on a geometry of its own: T1 adjacent columns nb per tile, A blocked by T2 = freq_res
+        FbGeom& q = fb->g1t;
+        q = g;
+        q.logM = lfa; q.logR = lfb;
+        q.logT1 = imin(lfb, LOG_POINTS_DEFAULT - lfa);
+        q.logT2 = logMf;
+        const uint64_t p1t = (1ull << lfa) << q.logT1;
+        fb->nt1t = (uint32_t)(p1t / PTS);
+        fb->lds1t = lds_total_words_host((uint32_t)p1t, lfa) * sizeof(cf);
+        fb->k1t = fb_pick1(lfa, 1, q.logT1 == full_logt(lfa));
+        have1 = fb->k1t != nullptr && q.logT1 >= 1 && p1t >= 32;
+        if (have1) e2 = allow_lds(fb->k1t, fb->lds1t);
+      }
+      fb->k2r = fb_pick_rinv(logMf, false);
+      fb->k2rf = fb_pick_rinv(logMf, true);
+      if (have1 && fb->k2r && fb->k2rf) {
+        g.logFb2 = lfb;
+        g.logFa2 = lfa;
+        fb->g1t.logFb2 = lfb; fb->g1t.logFa2 = lfa;
+        fb->lds2r = lds_total_words_host(1u << 14, logMf) * sizeof(cf);
+        const size_t psl_bytes = FB_PSL_MAX * sizeof(uint32_t);
+        const size_t spare = 160 * 1024 - 64 - fb->lds2r - 16 - psl_bytes;
+        uint32_t cap = fb->lds2r + 64 + 16 + psl_bytes < 160 * 1024 ? (uint32_t)(spare / 32) : 0;
+        if (cap > 512) cap = 512;
+        if (cap < 16) cap = 0;
+        fb->plan_cap2 = cap;
+        fb->lds2rf = fb->lds2r + 16 + (size_t)cap * 32 + psl_bytes;
+        if (e2 == hipSuccess) e2 = allow_lds(fb->k2r, fb->lds2r);
+        if (e2 == hipSuccess) e2 = allow_lds(fb->k2rf, fb->lds2rf);
+        fb->two_pass = e2 == hipSuccess;
+      }
     }
   }
   fb->max_parts = cfg->max_parts ? cfg->max_parts : 1;
@@ -3280,8 +3331,10 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
                      ((uintptr_t)in.base % 16) == 0 && (in.part_step % 4) == 0 && g.logR >= 3;
   // the two-pass path of short responses takes exactly this input form (and out.kind 0..3; the four-pass segment sums never
   // apply: freq_res <= 4096)
-  const bool two = fb->two_pass && in.kind == 1 && !g.real_input && g.npol == 2 && out.kind != 4 &&
-                   ((uintptr_t)in.base % (fb->cfg.input_nchan == 1 ? 16 : 4)) == 0 && (in.part_step % 4) == 0;
+  // (whole columns, Fa = 2^14: k_raw_cols also takes blocks of several input channels; Fa < 2^14 goes through k_raw_transpose)
+  const bool two = fb->two_pass && in.kind == 1 && !g.real_input && g.npol == 2 && out.kind != 4 && (in.part_step % 4) == 0 &&
+                   (fb->k1c ? ((uintptr_t)in.base % (fb->cfg.input_nchan == 1 ? 16 : 4)) == 0
+                            : (fb->cfg.input_nchan == 1 && ((uintptr_t)in.base % 16) == 0));
   bool pret = two || ((fast8 || fastc) && g.logR >= 2 && g.logT1 <= 5 && !FB_ENV_SET("DSPSR_AMD_NO_PRETRANSPOSE"));   // rows of >= 128 B need no regrouping
   if (pret && in.kind == 2 && (in.part_step % 4) != 0) pret = false;
   if (pret && !fb->Rt) {
@@ -3337,12 +3390,21 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         // Two passes (FB_HAS(6)): regroup per column, whole-column forward pass, rows + inverse pass -- the spectrum never
         // leaves the chip.  Launches are whole groups (the segmented fused fold pays a memset and a combine pass per launch).
         const uint32_t Fb = 1u << g.logFb2;
-        fb_launch_raw_cols(dim3((uint32_t)(fb->L / 8192), nb), ctx->stream, g, ci, fb->Rt, part0);
         FbIn cr = ci;
         cr.kind = 3;
         cr.base = fb->Rt;
-        const uint64_t n1c = (uint64_t)Fb * 2 * nb;
-        hipLaunchKernelGGL(fb->k1c, dim3(grid_for(n1c, fb->ncu)), dim3(512), fb->lds1c, ctx->stream, g, cr, fb->A, ctx->tw, nb, 2u, 32u);
+        if (fb->k1c) {
+          fb_launch_raw_cols(dim3((uint32_t)(fb->L / 8192), nb), ctx->stream, g, ci, fb->Rt, part0);
+          const uint64_t n1c = (uint64_t)Fb * 2 * nb;
+          hipLaunchKernelGGL(fb->k1c, dim3(grid_for(n1c, fb->ncu)), dim3(512), fb->lds1c, ctx->stream, g, cr, fb->A, ctx->tw, nb, 2u, 32u);
+        } else {
+          const FbGeom& q = fb->g1t;
+          const uint32_t Fa = 1u << q.logM;
+          fb_launch_raw_transpose(dim3((Fb + 255) / 256, (Fa + 63) / 64, nb * 2), ctx->stream, q, ci, fb->Rt, part0);
+          const uint64_t n1t = (uint64_t)(Fb >> q.logT1) * 2 * nb;
+          hipLaunchKernelGGL(fb->k1t, dim3(grid_for(n1t, fb->ncu)), dim3(fb->nt1t), fb->lds1t, ctx->stream, q, cr, fb->A, ctx->tw, part0,
+                             nb, 2u, 32u);
+        }
         const uint32_t tiles = g.C >> g.logFb2;
         if (co.kind == 3) {
           const int rc = fb_launch_fused(fb, fb->k2rf, fb->A, kern, co, part0, nb, fused_segmented, true);

@@ -86,7 +86,7 @@ typedef struct {
   uint32_t max_parts;       /* parts processed per launch group (scratch is sized for this); 0 => default */
   uint32_t force_four_pass; /* 0 => passes chosen from the geometry; 1: two-pass inverse (the path of freq_res > 8192 and of
                                dsp::Convolution) also where the single-pass inverse would do; 2: never the two-pass path of
-                               short responses (complex dual-pol input, nchan_subband * freq_res^2 == 2^27: forward and
+                               short responses (complex dual-pol input, nchan_subband * freq_res^2 <= 2^27: forward and
                                inverse transforms in two tiles); same results to rounding in every case */
   uint32_t fused_fold;      /* dspsr_amd_filterbank_perform_fold: DSPSR_AMD_FUSED_AUTO (fold inside the last filterbank
                                pass when the channel tiles fill the chip), _ALWAYS, _NEVER -- same sums bit for bit */
@@ -166,8 +166,9 @@ int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb);
 /* How many transform passes (trips of the part through HBM scratch + 1) a call makes -- the role of the plan choice inside
  * CUDA::FilterbankEngine::setup (FilterbankCUDA.cu:92-116: one forward and one batched backward cuFFT plan).  raw_input != 0:
  * the answer for dspsr_amd_filterbank_perform_raw / _detect / _fold on a generic 8-bit block, else for float32 rows.
- *   2  short responses: complex dual-pol 8-bit input with nchan_subband * freq_res^2 == 2^27 (one 50 MHz sub-band, -F 512:D
- *      -x 512): whole-column forward pass, then rows + chirp + inverse transforms in ONE tile -- the spectrum stays on chip;
+ *   2  short responses: complex dual-pol 8-bit input with 512 <= freq_res <= 4096 and 2^13 / freq_res <= nchan_subband <=
+ *      2^27 / freq_res^2 (upper end: one 50 MHz sub-band with -F 512:D -x 512): column forward pass, then rows + chirp + inverse
+ *      transforms in ONE tile -- the spectrum stays on chip;
  *   3  forward columns, forward rows, inverse per channel (freq_res <= 8192);
  *   4  two-pass inverse (freq_res > 8192, dsp::Convolution shapes, force_four_pass = 1). */
 int dspsr_amd_filterbank_npass(const dspsr_amd_filterbank* fb, int raw_input);

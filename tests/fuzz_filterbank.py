@@ -42,6 +42,18 @@ for i in range(ncases):
     if rng.integers(0, 4) == 0 and logN <= 18 and "layout" not in kw:      # (the CASPSR byte order is single channel)
         kw["input_nchan"] = int(rng.integers(2, 4))
     npart = int(rng.integers(1, 4)) if logN <= 19 else int(rng.integers(1, 3))
+    if rng.integers(0, 6) == 0:
+        # the two-pass family of short responses (complex dual-pol, nchan_subband * freq_res^2 == 2^27): 8-bit blocks take the
+        # two-pass kernels (or, four_pass = 2, the three-pass ones), float32 rows always the three-pass ones
+        logM = int(rng.integers(9, 13))
+        logC = int(rng.integers(13 - logM, 27 - 2 * logM + 1))            # Fb <= C <= 2^27 / M^2
+        C, M = 1 << logC, 1 << logM
+        pos, neg = int(rng.integers(0, M // 3)), int(rng.integers(0, M // 3))
+        kw = dict(npol=2, real=False, use_raw=bool(rng.integers(0, 4) != 0), max_parts=int(rng.integers(1, 4)),
+                  four_pass=int(rng.choice([0, 0, 2, 1])), seed=int(rng.integers(1, 1000)))
+        if rng.integers(0, 4) == 0 and logM <= 10 and logC + logM <= 17:
+            kw["input_nchan"] = 2
+        npart = int(rng.integers(1, 5))
     desc = "C=%d M=%d nfilt=(%d,%d) npart=%d %s" % (C, M, pos, neg, npart, kw)
     try:
         _fb_case(oracle, (dspsr_amd, ctx), C, M, (pos, neg), npart, **kw)

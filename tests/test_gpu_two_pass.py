@@ -20,8 +20,11 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
-# (nchan_subband, freq_res, (nfilt_pos, nfilt_neg)): C * M^2 == 2^27, Fb = 2^13 / M rows per inverse tile
-GEOMETRIES = [(512, 512, (27, 27)), (128, 1024, (100, 61)), (32, 2048, (200, 301)), (8, 4096, (422, 400))]
+# (nchan_subband, freq_res, (nfilt_pos, nfilt_neg)): Fb = 2^13 / M rows per inverse tile, Fa = C * M / Fb columns of pass 1.
+# C * M^2 == 2^27 (Fa = 2^14): whole columns (k_raw_cols + k_fwd_col1); fewer channels (M <= Fa < 2^14): k_raw_transpose +
+# k_fwd_cols on a geometry of their own, down to ONE tile of Fb channels (Fa = M)
+GEOMETRIES = [(512, 512, (27, 27)), (128, 1024, (100, 61)), (32, 2048, (200, 301)), (8, 4096, (422, 400)),
+              (256, 512, (27, 27)), (64, 512, (5, 90)), (16, 512, (40, 3)), (64, 1024, (100, 61)), (8, 2048, (2, 700)), (2, 4096, (422, 400))]
 
 
 @pytest.mark.parametrize("C,M,nfilt", GEOMETRIES)
@@ -32,7 +35,16 @@ def test_two_pass_filterbank_against_oracle(oracle, gpu, C, M, nfilt):
     got3, _ = _fb_case(oracle, gpu, C, M, nfilt, 3, npol=2, real=False, max_parts=2, seed=11, four_pass=2)
     rms = math.sqrt(np.mean(np.abs(ref) ** 2))
     d = np.abs(got2 - got3)
-    assert d.max() > 0, "force_four_pass = 2 must take other kernels than the default (identical bits: the two-pass path did not run)"
+    # (M = 4096: Fb = 2, and twiddle + radix-2 butterfly + chirp + the same inverse wgfft<12> are the very operations of
+    #  k_fwd_rows<1> + k_inv_chan<12> in the same order: bit-identical by construction; that the path is taken is checked below)
+    if M < 4096:
+        assert d.max() > 0, "force_four_pass = 2 must take other kernels than the default (identical bits: the two-pass path did not run)"
+    dspsr_amd, ctx = gpu
+    e2 = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, 2, False, None, max_parts=2)
+    e3 = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, 2, False, None, max_parts=2, force_four_pass=2)
+    assert (e2.npass(True), e2.npass(False), e3.npass(True)) == (2, 3, 3)
+    e2.close()
+    e3.close()
     assert math.sqrt(np.mean(d ** 2)) <= 4e-6 * rms and d.max() <= 4e-5 * rms
 
 
@@ -78,7 +90,8 @@ def test_two_pass_detected_output(oracle, gpu, ndim, state):
 
 
 @pytest.mark.parametrize("C,M,nfilt,nbin,period_samples", [(512, 512, (27, 27), 64, 71.3), (128, 1024, (100, 61), 128, 300.7),
-                                                           (8, 4096, (422, 400), 32, 97.1)])
+                                                           (8, 4096, (422, 400), 32, 97.1), (64, 512, (27, 27), 64, 33.3),
+                                                           (16, 1024, (100, 61), 16, 450.2)])
 def test_two_pass_fused_fold_bit_identical(oracle, gpu, C, M, nfilt, nbin, period_samples):
     """perform_fold through k_rows_inv<., ., true> with one workgroup per tile for all parts of a launch (FUSED_ALWAYS: exact
     time order) == perform_detect + FoldEngine.fold (Fold.C:835-891), bit for bit, over several calls and launch groups."""

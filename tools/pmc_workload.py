@@ -62,7 +62,7 @@ def main():
             fold.set_bins(polyco.phase_frac(day, sec0 + t0), (1.0 / rate) * polyco.frequency(day, sec0 + t0), ndat, 0, hits)
             fold.fold(det)
         torch.cuda.synchronize()
-        rec.update(parts_per_block=1, parts_per_launch_group=1, algorithmic_bytes_per_block=det.numel() * 4, roofline_kernel="k_fold_chunked")
+        rec.update(parts_per_block=1, parts_per_launch_group=1, algorithmic_bytes_per_block=det.numel() * 4, roofline_kernel="k_fold_")
         fold.close()
         ctx.close()
     else:
