@@ -343,8 +343,9 @@ template <int W> DEV void decode_pair(const FbGeom& g, const FbIn& in, const Raw
 // table (the remaining low bits of j), both correctly rounded -> about 1.2e-7 relative error.
 // NT twiddles exp(-2*pi*i*j[q]/2^logL) at once: all table loads are issued back to back (one memory round trip)
 // and only then combined -- evaluating them one by one costs a dependent L1/L2 round trip each
-#ifndef FB_FT_ROWS             // tile of k_float_transpose (rows x columns of 8-byte elements through LDS).  Only 64 x 64 is
-                               // validated: experiment builds with 32 x 128 and 16 x 256 faulted on the device (r03_experiments.txt)
+#ifndef FB_FT_ROWS             // tile of k_float_transpose (rows x columns of 8-byte elements through LDS).  64 x 64 is the shipped
+                               // one; 32 x 128 and 16 x 256 run too (r04_experiments.txt item 8: what round 3 saw as a device fault
+                               // was a refused launch -- grid.x = Rr / COLS = 0 for Rr < COLS -- under an LD_PRELOAD of two libraries)
 #define FB_FT_ROWS 64
 #define FB_FT_COLS 64
 #endif
@@ -3427,7 +3428,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         ci.kind = 3;
         ci.base = fb->Rt;
       } else if (pretf) {
-        fb_launch_float_transpose(dim3(Rr / FB_FT_COLS, (M + FB_FT_ROWS - 1) / FB_FT_ROWS, nb * fb->nseq), ctx->stream, g, ci, fb->X, part0);
+        fb_launch_float_transpose(dim3((Rr + FB_FT_COLS - 1) / FB_FT_COLS, (M + FB_FT_ROWS - 1) / FB_FT_ROWS, nb * fb->nseq), ctx->stream, g, ci, fb->X, part0);
         ci.kind = 5;
         ci.base = fb->X;
       }
