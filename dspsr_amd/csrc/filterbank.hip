@@ -1900,6 +1900,115 @@ __global__ __launch_bounds__(512) void k_fwd_col1(const FbGeom g, const FbIn in,
 #endif
 }
 
+// P1', three exchanged stages (round 4, second form).  2^14 = 16^3 * 4: the column as FOUR interleaved sub-sequences
+// y_c[m] = y[4m + c] -- the four columns of a 2^12-point wgfft (three radix-16 stages, none of them a remainder stage) -- and
+// the last radix-4 level in registers:  Y[P + 2^12 q] = sum_c (-i)^(c q) W^(c P) F_c[P],  W = exp(-2 pi i / 2^14).
+// The last stage leaves a thread the pair (F_c, F_c+1)[P_k], P_k = p + 256 k, with c = 0 in even lanes and c = 2 in odd lanes of
+// the same p: each lane twiddles its own pair (apply_pass_twiddle: W^(c P) for the columns c, c + 1), the two lanes swap pairs
+// (DPP) and each computes two of the four outputs -- even lanes rows P and P + 2^13, odd lanes P + 2^12 and P + 3*2^12.
+// Against k_fwd_col1 (even / odd halves + radix-2 step) one whole exchanged stage -- 16 b128 reads and 16 b128 writes per
+// thread, two barriers -- is replaced by about 350 vector instructions.
+struct Col1qOut {
+  cf* img;
+  const cf* tw;
+  const cf* tw_lo;
+  int h;
+  template <int R> DEV void operator()(const uint32_t col, const uint32_t p, const uint32_t pstride, cx2 (&v)[R])
+  {
+    static_assert(R == 16, "k_fwd_col1q: radix-16 last stage");
+    apply_pass_twiddle<R>(v, col, p, pstride, 14, tw, tw_lo);            // v[k] = (G_c, G_c+1)[p + k*pstride], G_c = W^(c P) F_c
+    const bool odd = col != 0;                                            // col = 0 (c = 0, 1) or 2 (c = 2, 3)
+    const float sg = odd ? -1.0f : 1.0f;
+    auto swp = [](const float a) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xf, 0xf, false)); };
+    // staged image: natural order of ka, 8-byte elements, rows of odd q moved by 8 elements (XOR of bit 3) so that the even
+    // and the odd lanes of a store fall on different banks (their rows differ by a multiple of 2^12 elements)
+    const uint32_t q1 = odd ? 1u : 0u;
+    const uint32_t b1 = lds_pad((p ^ (q1 << 3)) + (q1 << 12)), b2 = lds_pad((p ^ (q1 << 3)) + ((q1 + 2) << 12));
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      const cx2 own = v[k];
+      cx2 rc;
+      rc.x = (v2f){swp(own.x[0]), swp(own.x[1])};
+      rc.y = (v2f){swp(own.y[0]), swp(own.y[1])};
+      // even: (G0 + G2, G1 + G3) = (A, C) ; odd: (G0 - G2, G1 - G3) = (B, D)
+      cx2 sm;
+      sm.x = own.x * sg + rc.x;
+      sm.y = own.y * sg + rc.y;
+      const cf sa = cx2_lo(sm), sb = cx2_hi(sm);
+      const cf r = odd ? make_float2(sb.y, -sb.x) : sb;                   // odd: -i D
+      const uint32_t c = k * pstride;                                     // multiple of 64: the padding carries over
+      const uint32_t o = c + ((c >> 6) << 2);
+      img[b1 + o] = make_float2(sa.x + r.x, sa.y + r.y);                  // even: Y[P] = A + C          odd: Y[P + 2^12] = B - i D
+      img[b2 + o] = make_float2(sa.x - r.x, sa.y - r.y);                  // even: Y[P + 2^13] = A - C   odd: Y[P + 3*2^12] = B + i D
+    }
+  }
+};
+
+template <int RAWW>
+__global__ __launch_bounds__(512) void k_fwd_col1q(const FbGeom g, const FbIn in, cf* __restrict__ A,
+                                                   const cf* __restrict__ tw, const uint32_t nparts,
+                                                   const uint32_t nseq, const uint32_t run)
+{
+  constexpr int LOGF = 12, LOGT = 2;
+  typedef FftPlan<LOGF> P;
+  static_assert(P::REM == 0 && P::R1 == 16 && P::G1 == 2, "k_fwd_col1q: 16 x 16 x 16");
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  uint32_t tid = threadIdx.x;
+  const int logFb = g.logFb2, logMi = g.logMf;
+  const uint32_t Mi = 1u << logMi;
+  const uint32_t total = (nseq * nparts) << logFb;
+  auto fetch = [&](const uint32_t item, RawW<RAWW> (&raw)[PTS / 2]) {
+    const uint64_t t0 = (uint64_t)item << 14;
+#pragma unroll
+    for (int i = 0; i < P::R1; i++) raw[i] = fetch_pair<RAWW>(g, in, 0, t0 + 2 * tid + 1024u * i);   // samples 4*pos + c, c = 2*(tid & 1) + {0, 1}
+  };
+  const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;
+  ltw_fill<LOGF>(lds, ltw_off, tw, tid, blockDim.x);
+  const uint32_t co_lds0 = lds_pad(2 * threadIdx.x), co_lds1 = lds_pad((2 * threadIdx.x) ^ 8u);
+  uint32_t item, next;
+  uint32_t j = 0;
+  if (!persistent_item(blockIdx.x, gridDim.x, j, run, total, item)) return;
+  RawW<RAWW> raw[PTS / 2];
+  fetch(item, raw);
+  for (;;) {
+    asm volatile("" : "+v"(tid));
+    cx2 x[NPAIR];
+#pragma unroll
+    for (int h = 0; h < NPAIR; h++) {
+      cf a, b;
+      decode_pair<RAWW>(g, in, raw[h], a, b, 0);
+      x[h] = make_cx2(a, b);
+    }
+    const bool more = persistent_item(blockIdx.x, gridDim.x, ++j, run, total, next);
+    if (more) fetch(next, raw);
+    Col1qOut out;
+    out.img = lds;
+    out.tw = tw;
+    out.tw_lo = g.tw_lo;
+    out.h = 0;
+    wgfft<LOGF, -1, true>(lds, ltw_off, tid, LOGT, x, out);
+    __syncthreads();
+    const uint32_t nb = item & ((1u << logFb) - 1);
+    cf* __restrict__ Aseq = A + ((uint64_t)(item >> logFb) << (14 + logFb));
+#pragma unroll
+    for (int j4 = 0; j4 < PTS / 2; j4 += 4) {
+      float4 pr[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++)                                        // row block jj holds q = jj / 4: rows of odd q are XOR-8 swizzled
+        pr[q] = *(const float4*)&lds[((((j4 + q) >> 2) & 1) ? co_lds1 : co_lds0) + (j4 + q) * (1024u + 64u)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t ka = 2 * tid + 1024u * (j4 + q);
+        st_stream((float4*)&Aseq[((((ka >> logMi) << logFb) + nb) << logMi) + (ka & (Mi - 1))], pr[q]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!more) break;
+    item = next;
+  }
+}
+
 // P2': see the head of this section.  LOGM + LOGFB == 13: a tile is Fb channels x 2 polarisations x M bins = 2^14 points;
 // a thread holds, for NJ = 16 / Fb bins j = tid + 512*jq, the Fb rows nb of both polarisations (pair = (pol 0, pol 1)).
 // Items, the fused fold (exact time order per tile, or segmented over part runs) and the output forms are k_inv_chan's.
@@ -1912,7 +2021,16 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
   static_assert(LOGM + LOGFB == 13 && LOGFB >= 1 && LOGFB <= 4, "k_rows_inv: Fb channels x 2 pols x M bins = 2^14 points");
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
-  constexpr int logT3 = LOGFB, logT = LOGFB + 1;
+  // HALF (M = 512 = 16 * 16 * 2): the inverse transform as the 256-point transforms of the even and of the odd bins -- two
+  // more "columns" per (channel, pol), two radix-16 stages, no remainder stage -- and the last radix-2 level in registers:
+  // y[m] = E[m] + W^-m O[m], y[m + 256] = E[m] - W^-m O[m].  The last stage leaves E in even lanes and O in odd lanes of the
+  // same (channel, m): the odd lane's twiddle, one DPP swap and one packed fma per element replace a whole exchanged stage.
+  // Measured (profiles/r04_experiments.txt item 10): fused 430.7 -> 417.3 us per 256 parts (-3 %), but the form that writes
+  // its output 497.6 -> 635.8 (+28 %): with 64 columns a wave of the last stage spans all channels and both halves of the
+  // transform, two consecutive samples per (channel, half) -- 32-byte store runs.  Off; fused and unfused keep one association.
+  constexpr bool HALF = false && (LOGM % 4) == 1;
+  constexpr int LOGFI = HALF ? LOGM - 1 : LOGM;                      // length of the exchanged inverse transform
+  constexpr int logT3 = LOGFB, logT = LOGFB + 1 + (HALF ? 1 : 0);    // columns: (kb, [bin parity,] pol)
   constexpr uint32_t Fb = 1u << LOGFB, T3 = Fb, NJ = 16 / Fb;
   const int logCa = g.logFa2 - LOGM;                                // Fa / M: channel stride between the rows kb of a tile
   const int logL = g.logFa2 + LOGFB;
@@ -1955,8 +2073,8 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
   };
 
   const uint32_t ltw_off = lds_pad(PTS * blockDim.x) + 8;
-  ltw_fill<LOGM>(lds, ltw_off, tw, tid, blockDim.x);
-  const uint32_t plan_off = (ltw_off + ltw_entries_dev<LOGM>() + 1) & ~1u;
+  ltw_fill<LOGFI>(lds, ltw_off, tw, tid, blockDim.x);
+  const uint32_t plan_off = (ltw_off + ltw_entries_dev<LOGM>() + 1) & ~1u;     // (the host sizes the tables for LOGM)
   uint32_t* psl = nullptr;
   const uint4* __restrict__ fent_all = nullptr;
   bool use_psl = false;
@@ -2019,7 +2137,7 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
       else { fe0_cur = out.pstart[part0 + lp]; fn_cur = out.pstart[part0 + lp + 1] - fe0_cur; }
     }
   };
-  const bool plan_dma_ok = FOLD && FftPlan<LOGM>::NS >= 2 && use_psl;
+  const bool plan_dma_ok = FOLD && FftPlan<LOGFI>::NS >= 2 && use_psl;
   auto plan_dma = [&](const Item it, const uint32_t buf) {
     if constexpr (FOLD) {
       const uint32_t fe0 = psl[it.lp - fp0], fn = psl[it.lp - fp0 + 1] - fe0;
@@ -2085,11 +2203,13 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
     __syncthreads();                     // every wave has finished with the previous tile's image (last stage / fold phase)
 #pragma unroll
     for (uint32_t jq = 0; jq < NJ; jq++) {
-      const uint32_t e0 = (tid + 512u * jq) << logT;
+      const uint32_t jb = tid + 512u * jq;
+      // HALF: position j / 2, column 4*kb + 2*(j & 1) + pol
+      const uint32_t e0 = HALF ? (((jb >> 1) << logT) + 2 * (jb & 1u)) : (jb << logT);
 #pragma unroll
       for (uint32_t kb = 0; kb < Fb; kb++) {
         const cx2 q = x[jq * Fb + kb];
-        *(float4*)&lds[lds_pad(e0 + 2 * kb)] = make_float4(q.x[0], q.x[1], q.y[0], q.y[1]);
+        *(float4*)&lds[lds_pad(e0 + (HALF ? 4 : 2) * kb)] = make_float4(q.x[0], q.x[1], q.y[0], q.y[1]);
       }
     }
     __syncthreads();
@@ -2164,7 +2284,7 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
     bool in_lds = false;
     uint4 en_pre = make_uint4(0, 0, 0, 0), en_pre2 = make_uint4(0, 0, 0, 0);
     float4 acc_pre = make_float4(0.f, 0.f, 0.f, 0.f), acc_pre2 = acc_pre;
-    constexpr bool PRE = FOLD && FftPlan<LOGM>::NS >= 2;
+    constexpr bool PRE = FOLD && FftPlan<LOGFI>::NS >= 2;
     constexpr bool PRE2 = PRE && LOGFB >= 3;              // >= 8 channels per tile: a thread may fold a second item
     if constexpr (FOLD) {
       f_e0 = fe0_cur;
@@ -2212,7 +2332,29 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
         if (phase == 2 && plan_dma_ok && more) plan_dma(next, (jt + 1) & 1);
       }
     };
-    wgfft<LOGM, +1, FOLD, true>(lds, ltw_off, tid, logT, x, store, mid);
+    if constexpr (HALF) {
+      // last stage of the half-length transforms -> radix-2 step in registers -> the ordinary store
+      auto store_half = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
+        constexpr int R = sizeof(v) / sizeof(v[0]);
+        const uint32_t odd = (col >> 1) & 1u;                               // bin parity of this lane's pair (even lanes E, odd lanes O)
+        apply_pass_twiddle_inv<R>(v, odd, p, pstride, LOGM, tw, g.tw_lo_m);   // O[m] *= exp(+2 pi i m / M), m = p + k*pstride (E: x 1)
+        const float sg = odd ? -1.0f : 1.0f;
+        auto swp = [](const float a) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xf, 0xf, false)); };
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          const cx2 own = v[k];
+          cx2 rc;
+          rc.x = (v2f){swp(own.x[0]), swp(own.x[1])};
+          rc.y = (v2f){swp(own.y[0]), swp(own.y[1])};
+          v[k].x = own.x * sg + rc.x;                                       // even: E + W O = y[m]   odd: E - W O = y[m + M/2]
+          v[k].y = own.y * sg + rc.y;
+        }
+        store((col >> 2) << 1, p + (odd << (LOGM - 1)), pstride, v);
+      };
+      wgfft<LOGFI, +1, FOLD, true>(lds, ltw_off, tid, logT, x, store_half, mid);
+    } else {
+      wgfft<LOGM, +1, FOLD, true>(lds, ltw_off, tid, logT, x, store, mid);
+    }
 #if defined(FB_STAMPS) && FB_STAMPS == 7
     STAMP(ts3);
 #endif
@@ -2728,7 +2870,7 @@ k3a_t fb_pick3a(int logf, bool blocked);
 k3b_t fb_pick3b(int logf, bool foldb = false);
 // two-pass path (FB_HAS(6)): pass 1 on whole columns, rows + inverse pass (M = 2^logm, Fb = 2^(13 - logm)), the 8-bit regroup
 typedef void (*k1c_t)(FbGeom, FbIn, cf*, const cf*, uint32_t, uint32_t, uint32_t);
-k1c_t fb_pick_col1();
+k1c_t fb_pick_col1(int variant = 1);     // 1: four sub-sequences + radix-4 in registers (three exchanged stages), 0: even / odd + radix-2
 k3_t fb_pick_rinv(int logm, bool fold);
 void fb_launch_raw_cols(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
@@ -2761,7 +2903,7 @@ k3a_t fb_pick3a(int, bool) { return nullptr; }
 k3b_t fb_pick3b(int, bool) { return nullptr; }
 #endif
 #if FB_HAS(6)
-k1c_t fb_pick_col1() { return nullptr; }
+k1c_t fb_pick_col1(int) { return nullptr; }
 k3_t fb_pick_rinv(int, bool) { return nullptr; }
 void fb_launch_raw_cols(dim3, hipStream_t, const FbGeom&, const FbIn&, uint16_t*, uint64_t) {}
 #endif
@@ -2823,7 +2965,7 @@ k3a_t fb_pick3a(int logf, bool blocked) { return pick3a(logf, blocked, seq_t());
 k3b_t fb_pick3b(int logf, bool foldb) { return pick3b(logf, foldb, seq_t()); }
 #endif
 #if FB_HAS(6)
-k1c_t fb_pick_col1() { return k_fwd_col1<1>; }
+k1c_t fb_pick_col1(int variant) { return variant ? k_fwd_col1q<1> : k_fwd_col1<1>; }
 k3_t fb_pick_rinv(int logm, bool fold)
 {
   switch (logm) {
@@ -3110,8 +3252,9 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
       hipError_t e2 = hipSuccess;
       bool have1 = false;
       if (lfa == 14) {
-        fb->k1c = fb_pick_col1();
-        fb->lds1c = lds_total_words_host(1u << 14, 13) * sizeof(cf);
+        const int c1v = FB_ENV_INT("DSPSR_AMD_COL1_V", 1);
+        fb->k1c = fb_pick_col1(c1v);
+        fb->lds1c = lds_total_words_host(1u << 14, c1v ? 12 : 13) * sizeof(cf);
         have1 = fb->k1c != nullptr;
         if (have1) e2 = allow_lds(fb->k1c, fb->lds1c);
       } else {
