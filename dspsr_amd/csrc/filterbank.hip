@@ -114,8 +114,8 @@ struct FbOut {
                    // the translation unit of the instrumented kernel (single-TU builds, or the FB_PART that holds it)
 #define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define FB_STAMPS_PART (FB_STAMPS == 1 ? 1 : FB_STAMPS == 2 ? 2 : FB_STAMPS == 3 ? 5 : 6)
+static __device__ unsigned long long g_stamps[1024][8];     // (one per translation unit; the exported reader sees FB_STAMPS_PART's)
 #if !defined(FB_PART) || FB_PART == FB_STAMPS_PART
-__device__ unsigned long long g_stamps[1024][8];
 extern "C" int dspsr_amd_debug_stamps(unsigned long long* out_host, int zero)
 {
   if (zero) { static unsigned long long z[1024][8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }

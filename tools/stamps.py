@@ -7,9 +7,10 @@ import dspsr_amd
 from dspsr_amd import pipeline
 import bench
 lib = C.CDLL(os.environ["DSPSR_AMD_LIB"])
-wl = bench.WORKLOADS["target"]
+wl = bench.WORKLOADS[os.environ.get("WL", "target")]           # WL=cfg2|cfg3|target (three-pass, single-channel input)
 info = pipeline.InputInfo(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=1, npol=2, ndim=1, tsamp_us=wl["tsamp_us"], machine="CASPSR")
-cfg = pipeline.Config(nchan=1024, dispersion_measure=1000.0, nbin=1024, folding_period=0.0893, freq_res=4096, parts_per_block=16, max_parts=8,
+cfg = pipeline.Config(nchan=wl["nchan"], dispersion_measure=wl["dm"], nbin=wl["nbin"], folding_period=0.0893, freq_res=wl["freq_res"],
+                      parts_per_block=int(os.environ.get("PPB", "16")), max_parts=int(os.environ.get("MAXP", "8")),
                       fused_fold=os.environ.get("FUSED", "1") == "1")
 lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
 raw = (torch.randn(lt.block_bytes(), device="cuda") * 24).round().clamp(-128, 127).to(torch.int8)
