@@ -59,6 +59,9 @@ struct FbGeom {
   uint64_t xstride;                      // elements from one spectrum (sequence) to the next in X: L, or the padded size
   int logMf, logMa, logMb, logTm, logTt; // freq_res = Ma*Mb ; m2 columns per k_inv_a tile ; t1 columns per k_inv_b tile
   int real_input, npol;
+  uint32_t nsub;                         // 1, or 3 / 5: nchan_subband = nsub * 2^k -- the forward transform of L = nsub * L' points as nsub
+                                         //   interleaved sub-sequences of L' = M << logR points each (passes 0-2 on the power-of-two geometry,
+                                         //   k_sub_combine), the inverse pass on nsub << logR spectrum rows
   int logFb2, logFa2;                    // two-pass path (FB_HAS(6)): L = 2^logFa2 * 2^logFb2 (Fa <= 2^14), the inverse tile holds
                                          // 2^logFb2 channels x 2 pols
   uint32_t C, nfilt_pos, nkeep;
@@ -107,6 +110,19 @@ struct FbOut {
   const Interval* piv;                          // kind 3: intervals (offset within the part, hits), time ordered per bin
   const uint32_t* blk_first;                    // kind 4: interval that holds sample 1024*i of the block
   const uint32_t* bin_start;                    // kind 4 (host side only): the intervals bucketed by phase bin (with piv)
+};
+
+// nchan_subband = 3 * 2^k / 5 * 2^k: arguments of k_sub_split (see the section in front of pass 2)
+struct SubSplit {
+  int kind;                   // FbIn::kind of the source: 0 float rows, 1 generic 8-bit, 2 CASPSR
+  const void* base;
+  uint64_t chan_off;          // float: floats to this input channel's rows
+  uint64_t pol_stride;        // float: floats between polarisation rows
+  uint32_t nchan, ichan, npol, ndim;
+  uint64_t t_first;           // first sample of the group
+  uint64_t nper;              // samples per sub-sequence
+  uint32_t R;
+  uint64_t sub_stride;        // bytes from one sub-block to the next
 };
 
 #ifdef FB_STAMPS   // diagnostic build only (-DFB_STAMPS=1|2|3|6|7: pass to instrument -- 6 = k_fwd_col1, 7 = k_rows_inv): where a
@@ -992,6 +1008,82 @@ __global__ __launch_bounds__(512) void k_fwd_cols_dual(const FbGeom g, const FbI
     item = next;
   }
 }
+// ------------------------------------------------------------------------------------ nchan_subband = 3 * 2^k, 5 * 2^k
+// dsp::Filterbank takes whatever length FFTW / cuFFT plans (Filterbank.C:107-155, FilterbankCUDA.cu:92-116), e.g. -F 96:D.
+// Here the transform tiles are powers of two; a forward transform of L = R * L' points (R = 3 or 5) is computed as R
+// interleaved sub-sequences w_c[m] = w[R m + c] -- each an ordinary power-of-two forward transform F_c (passes 0-2 unchanged) --
+// and one radix-R step:  X[k + q L'] = sum_c W_R^(c q) W_L^(c k) F_c[k],  k < L', q < R.  Bin k + q L' lies in spectrum row
+// q * Rr' + k / M: the R combined bands, stored one after the other in the power-of-two X layout, ARE the R * Rr' rows the
+// inverse pass walks (k_inv_chan: rows nsub << logR).
+//   k_sub_split   : the launch group's samples de-interleaved into R contiguous single-channel blocks (generic byte order /
+//                   float rows), so that passes 0-2 see ordinary inputs
+//   k_sub_combine : the radix-R step in place on the R sub-spectra of every (part, sequence)
+__global__ __launch_bounds__(256) void k_sub_split(const SubSplit p, uint8_t* __restrict__ out)
+{
+  const uint64_t n = p.nper * p.R;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t j = i / p.R;
+    const uint32_t c = (uint32_t)(i - j * p.R);
+    const uint64_t t = p.t_first + i;                                       // = t_first + R*j + c
+    uint8_t* __restrict__ o = out + (uint64_t)c * p.sub_stride;
+    if (p.kind == 0) {                                                      // float rows -> [pol][j][ndim] floats
+      const float* __restrict__ x = (const float*)p.base + p.chan_off;
+      float* __restrict__ of = (float*)o;
+      for (uint32_t q = 0; q < p.npol; q++)
+        for (uint32_t d = 0; d < p.ndim; d++) of[(q * p.nper + j) * p.ndim + d] = x[q * p.pol_stride + t * p.ndim + d];
+    } else if (p.kind == 2) {                                               // CASPSR 4 B pol0 | 4 B pol1 -> (p0, p1) pairs
+      const uint8_t* __restrict__ b = (const uint8_t*)p.base + (t >> 2) * 8 + (t & 3);
+      o[2 * j] = b[0];
+      o[2 * j + 1] = b[4];
+    } else {                                                                // generic: byte ((t*nchan + c)*npol + p)*ndim + d
+      const uint32_t es = p.npol * p.ndim;
+      const uint8_t* __restrict__ b = (const uint8_t*)p.base + (t * p.nchan + p.ichan) * es;
+      for (uint32_t q = 0; q < es; q++) o[j * es + q] = b[q];
+    }
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_sub_combine(const FbGeom g, cf* __restrict__ X, const uint32_t nseqs /* parts x sequences */)
+{
+  const int logLs = g.logM + g.logR;                     // sub-sequence length L'
+  const uint32_t Ls = 1u << logLs, L = Ls * R;
+  const uint32_t X3m = (1u << g.logX3) - 1, Mm = (1u << g.logM) - 1;
+  cf wr[R];                                              // W_R^j
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    const float x = (float)j / (float)R;
+    wr[j] = make_float2(__builtin_amdgcn_cosf(x), -__builtin_amdgcn_sinf(x));
+  }
+  const uint64_t n = (uint64_t)nseqs << logLs;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t o = (uint32_t)(i & (Ls - 1));
+    cf* __restrict__ base = X + (i >> logLs) * (uint64_t)L + o;
+    // X layout: offset o = ((s' >> logX3) * M + m) << logX3 | s' % X3  ->  bin k = s' * M + m
+    const uint32_t t = o >> g.logX3, m = t & Mm, sp = ((t >> g.logM) << g.logX3) | (o & X3m);
+    const uint32_t k = (sp << g.logM) + m;
+    cf gq[R];
+    gq[0] = base[0];
+#pragma unroll
+    for (int c = 1; c < R; c++) {
+      // W_L^(c k): c k mod L = a L' + b -> a / R + (b / L') / R revolutions (b / L' is exact)
+      const uint32_t ck = (uint32_t)(((uint64_t)c * k) % L), a = ck >> logLs, b = ck & (Ls - 1);
+      const float x = ((float)a + (float)b * __uint_as_float((uint32_t)(127 - logLs) << 23)) / (float)R;
+      const cf w = make_float2(__builtin_amdgcn_cosf(x), -__builtin_amdgcn_sinf(x));
+      gq[c] = cmul(base[(uint64_t)c << logLs], w);
+    }
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      cf acc = gq[0];
+#pragma unroll
+      for (int c = 1; c < R; c++) {
+        const cf v = cmul(gq[c], wr[(c * q) % R]);
+        acc.x += v.x; acc.y += v.y;
+      }
+      base[(uint64_t)q << logLs] = acc;
+    }
+  }
+}
 #endif  // FB_HAS(1)
 
 #if FB_HAS(2)
@@ -1233,8 +1325,8 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   uint32_t tid = threadIdx.x;
   const int logT3 = LOGT >= 1 ? LOGT - 1 : g.logT3;
   const int logT = logT3 + 1;
-  const uint32_t T = 1u << logT, T3 = 1u << logT3, M = 1u << LOGF, Rr = 1u << g.logR;
-  const uint64_t L = (uint64_t)M << g.logR;
+  const uint32_t T = 1u << logT, T3 = 1u << logT3, M = 1u << LOGF, Rr = g.nsub << g.logR;     // (nsub = 3, 5: not a power of two)
+  const uint64_t L = (uint64_t)M * Rr;
   const uint32_t nseq = g.real_input ? 1 : g.npol;
   const int logX3 = g.logX3;                    // X layout: element (row, m) at ((row >> logX3)*M + m) << logX3 | row % X3
   const uint32_t X3 = 1u << logX3;
@@ -1292,7 +1384,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
           raw[2 * u].b = make_float2(B.x, B.y); raw[2 * u + 1].b = make_float2(B.z, B.w);
         }
         const uint32_t s = tile * T3 + q;
-        special = ld_stream(mb == 0 ? X0s + xi((Rr - s) & (Rr - 1), 0) : X0s + xi(Rr - 1 - s, M - mb));
+        special = ld_stream(mb == 0 ? X0s + xi(s ? Rr - s : 0u, 0) : X0s + xi(Rr - 1 - s, M - mb));
         return;
       }
     }
@@ -1304,7 +1396,7 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       const cf* __restrict__ pa = X0s + xi(s, mb);
       const cf* __restrict__ pb = g.real_input ? X0s + xi(Rr - 1 - s, M - mb) : pa + (g.npol == 2 ? L : 0);
       const int64_t stepb = g.real_input ? -step : step;
-      const cf* __restrict__ pb0 = (g.real_input && mb == 0) ? X0s + xi((Rr - s) & (Rr - 1), 0) : pb;
+      const cf* __restrict__ pb0 = (g.real_input && mb == 0) ? X0s + xi(s ? Rr - s : 0u, 0) : pb;
 #pragma unroll
       for (int i = 0; i < P::R1; i++) {
         if (chunk >= 0 && i % NCHUNK != chunk) continue;
@@ -2873,6 +2965,8 @@ typedef void (*k1c_t)(FbGeom, FbIn, cf*, const cf*, uint32_t, uint32_t, uint32_t
 k1c_t fb_pick_col1(int variant = 1);     // 1: four sub-sequences + radix-4 in registers (three exchanged stages), 0: even / odd + radix-2
 k3_t fb_pick_rinv(int logm, bool fold);
 void fb_launch_raw_cols(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
+void fb_launch_sub_split(hipStream_t stream, const SubSplit& p, uint8_t* out, uint32_t ncu);
+void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu);
 void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, cf* Rt, uint64_t part0);
 
@@ -2991,6 +3085,15 @@ void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, c
 {
   hipLaunchKernelGGL(k_float_transpose, grid, dim3(256), 0, stream, g, in, Rt, part0);
 }
+void fb_launch_sub_split(hipStream_t stream, const SubSplit& p, uint8_t* out, uint32_t ncu)
+{
+  hipLaunchKernelGGL(k_sub_split, dim3(8 * ncu), dim3(256), 0, stream, p, out);
+}
+void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu)
+{
+  if (g.nsub == 3) hipLaunchKernelGGL(k_sub_combine<3>, dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs);
+  else hipLaunchKernelGGL(k_sub_combine<5>, dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs);
+}
 #endif
 
 #if FB_HAS(0)
@@ -3030,6 +3133,8 @@ struct dspsr_amd_filterbank_impl {
   uint32_t plan_cap = 0;     // fused fold: plan entries per LDS buffer behind the twiddle tables
   size_t lds3f = 0;          // dynamic LDS of the fused inverse pass
   // two-pass path of short responses (complex dual-pol 8-bit input, nchan_subband * freq_res^2 == 2^27): see FB_HAS(6)
+  uint8_t* dsub = nullptr;    // nsub > 1: the launch group's samples de-interleaved into nsub blocks (k_sub_split)
+  size_t dsub_bytes = 0;
   bool two_pass = false;
   FbGeom g1t;                 // ... pass 1 of Fa < 2^14 through k_raw_transpose + k_fwd_cols: their geometry (M = Fa, Rr = Fb, T2 = freq_res)
   k1_t k1t = nullptr;
@@ -3072,9 +3177,19 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     return fb_fail(ctx, DSPSR_AMD_EINVAL,
                    "dspsr_amd_filterbank_create: freq_res=%u must be a power of two >= 2 "
                    "(freq_res=1 is the non-convolving filterbank, not built yet)", cfg->freq_res);
-  if (!ispow2(cfg->nchan_subband))
-    return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u must be a power of two",
-                   cfg->nchan_subband);
+  // nchan_subband: a power of two, or 3 or 5 times one (the forward transform then runs as 3 / 5 interleaved sub-sequences,
+  // k_sub_split / k_sub_combine).  freq_res -- the length of the transforms INSIDE a tile -- stays a power of two.
+  uint32_t nsub = 1;
+  if (!ispow2(cfg->nchan_subband)) {
+    if (cfg->nchan_subband % 3 == 0 && ispow2(cfg->nchan_subband / 3)) nsub = 3;
+    else if (cfg->nchan_subband % 5 == 0 && ispow2(cfg->nchan_subband / 5)) nsub = 5;
+    else
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u must be 2^k, 3*2^k or 5*2^k",
+                     cfg->nchan_subband);
+    if (cfg->force_four_pass == 1)
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u (not a power of two) has no four-pass form",
+                     cfg->nchan_subband);
+  }
   if (cfg->nfilt_pos + cfg->nfilt_neg >= cfg->freq_res)
     return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nfilt_pos+nfilt_neg=%u >= freq_res=%u",
                    cfg->nfilt_pos + cfg->nfilt_neg, cfg->freq_res);
@@ -3084,11 +3199,13 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   fb->ctx = ctx;
   fb->cfg = *cfg;
   FbGeom& g = fb->g;
-  const uint64_t M = cfg->freq_res, C = cfg->nchan_subband;
-  fb->N = C * M;
+  // (C, Rr, logL, logC describe the power-of-two geometry passes 0-2 run on: one of nsub sub-sequences; fb->N, fb->L and g.C
+  //  are the whole transform's)
+  const uint64_t M = cfg->freq_res, C = cfg->nchan_subband / nsub;
+  fb->N = (uint64_t)cfg->nchan_subband * M;
   fb->L = cfg->real_input ? 2 * fb->N : fb->N;
-  const uint64_t Rr = fb->L / M;
-  const int logMf = ilog2(M), logL = ilog2(fb->L), logC = ilog2(C);
+  const uint64_t Rr = fb->L / nsub / M;
+  const int logMf = ilog2(M), logL = ilog2(fb->L / nsub), logC = ilog2(C);
   g.logM = logMf;
   g.logR = ilog2(Rr);
   g.logMf = logMf;
@@ -3098,10 +3215,12 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   g.xstride = fb->L;
   g.logMa = g.logMb = g.logTm = g.logTt = 0;
   g.logFb2 = g.logFa2 = 0;
+  g.nsub = 1;
   g.tw_lo = g.tw_lo_m = nullptr;
   g.real_input = cfg->real_input ? 1 : 0;
   g.npol = cfg->npol;
-  g.C = (uint32_t)C;
+  g.C = cfg->nchan_subband;
+  g.nsub = nsub;
   g.nfilt_pos = cfg->nfilt_pos;
   g.nkeep = cfg->freq_res - cfg->nfilt_pos - cfg->nfilt_neg;
   g.dbg = FB_ENV_INT("DSPSR_AMD_DEBUG", 0);
@@ -3133,6 +3252,11 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   }
   // ... otherwise four: L = Fa*Fb forward (whole spectrum, blocked by pass-2 tile), freq_res = Ma*Mb inverse in two passes.
   // This also covers nchan_subband = 1 (dsp::Convolution) and freq_res up to 2^26.
+  if (nsub > 1 && !three_ok) {
+    delete fb;
+    return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u (not a power of two) needs freq_res <= 8192 "
+                   "and a sub-geometry of at least 32 points per pass", cfg->nchan_subband);
+  }
   if (cfg->force_four_pass == 1 || !three_ok) {
     int la = (logL + 1) / 2;
     if (la > MAX_LOGF) la = MAX_LOGF;
@@ -3247,7 +3371,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   // force_four_pass == 2 switches it off (comparison runs and tests).
   {
     const int lfb = 13 - logMf, lfa = logL - lfb;
-    if (!g.four_pass && !cfg->real_input && cfg->npol == 2 && cfg->force_four_pass != 2 && logMf >= 9 && logMf <= 12 &&
+    if (nsub == 1 && !g.four_pass && !cfg->real_input && cfg->npol == 2 && cfg->force_four_pass != 2 && logMf >= 9 && logMf <= 12 &&
         lfa >= logMf && lfa <= 14 && ctx->ncu > 0 && FB_ENV_INT("DSPSR_AMD_NO_TWO_PASS", 0) == 0) {
       hipError_t e2 = hipSuccess;
       bool have1 = false;
@@ -3345,6 +3469,7 @@ extern "C" void dspsr_amd_filterbank_destroy(dspsr_amd_filterbank* fb)
   if (fb->det) (void)hipFree(fb->det);
   if (fb->fpart) (void)hipFree(fb->fpart);
   if (fb->msum) (void)hipFree(fb->msum);
+  if (fb->dsub) (void)hipFree(fb->dsub);
   if (fb->tw_lo) (void)hipFree(fb->tw_lo);
   if (fb->tw_lo_m) (void)hipFree(fb->tw_lo_m);
   delete fb;
@@ -3529,6 +3654,71 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         if (i3b > per_part_items) per_part_items = i3b;
         while (nb > 1 && per_part_items * nb >= (1ull << 31)) nb /= 2;
         nb_step = nb;
+      }
+      if (g.nsub > 1) {
+        // nchan_subband = 3 * 2^k / 5 * 2^k: the group's samples as nsub interleaved sub-sequences, passes 0-2 on each (the
+        // power-of-two geometry), one radix-nsub step on the sub-spectra, then the inverse pass on nsub << logR rows
+        const uint32_t R = g.nsub;
+        const uint32_t ndim = g.real_input ? 1u : 2u;
+        const uint64_t step = in.part_step, nper = ((uint64_t)(nb - 1) * step + fb->L) / R;       // (step and L are multiples of nsub)
+        const size_t es = in.kind == 0 ? (size_t)g.npol * ndim * sizeof(float) : (size_t)g.npol * ndim;   // bytes per sample, all pols
+        const size_t sub_stride = (nper * es + 15) & ~(size_t)15;
+        if (sub_stride * R > fb->dsub_bytes) {
+          (void)hipStreamSynchronize(ctx->stream);
+          if (fb->dsub) (void)hipFree(fb->dsub);
+          fb->dsub = nullptr; fb->dsub_bytes = 0;
+          if (hipMalloc((void**)&fb->dsub, sub_stride * R) != hipSuccess)
+            return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of %zu sub-sequence bytes failed", sub_stride * R);
+          fb->dsub_bytes = sub_stride * R;
+        }
+        SubSplit sp = {in.kind, in.base, in.kind == 0 ? (uint64_t)ichan * in_chan_stride_bytes_or_floats : 0, in.pol_stride,
+                       fb->cfg.input_nchan, ichan, (uint32_t)g.npol, ndim, part0 * step, nper, R, sub_stride};
+        fb_launch_sub_split(ctx->stream, sp, fb->dsub, fb->ncu);
+        const uint64_t Ls = fb->L / R;
+        for (uint32_t c = 0; c < R; c++) {
+          FbIn cs = in;
+          cs.kind = in.kind == 0 ? 0 : 1;                           // (the split writes the generic byte order)
+          cs.base = fb->dsub + (size_t)c * sub_stride;
+          cs.pol_stride = in.kind == 0 ? nper * ndim : 0;
+          cs.part_step = step / R;
+          cs.nchan = 1; cs.ichan = 0;
+          const bool f8 = cs.kind == 1 && g.real_input && g.npol == 2;
+          const bool fc = cs.kind == 1 && !g.real_input && g.npol == 2 && (cs.part_step % 4) == 0 && g.logR >= 3;
+          const bool prt = (f8 || fc) && g.logR >= 2 && g.logT1 <= 5 && (cs.part_step % 4) == 0;
+          const bool prf = cs.kind == 0 && g.npol == 2 && g.logR >= 6 && g.logT1 >= 1 && g.logT1 <= 4 && (cs.part_step % 4) == 0 &&
+                           (cs.pol_stride % 4) == 0;
+          if (prt && !fb->Rt && hipMalloc((void**)&fb->Rt, (size_t)fb->max_parts * fb->nseq * fb->L * sizeof(uint16_t)) != hipSuccess)
+            return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of the 8-bit regroup buffer failed");
+          const int rw = (prt || f8) ? 1 : 4;
+          k1_t k1s = rw == 1 ? fb->k1_w1 : fb->k1_w4;
+          if (!k1s) return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: geometry not in this (experiment) build");
+          FbIn cr = cs;
+          if (prt) {
+            fb_launch_raw_transpose(dim3((Rr + 255) / 256, (M + 63) / 64, nb * fb->nseq), ctx->stream, g, cs, fb->Rt, 0);
+            cr.kind = 3; cr.base = fb->Rt;
+          } else if (prf) {
+            // (the float regroup buffer is the X scratch in the power-of-two path; X holds finished sub-spectra here: use Rt's
+            //  place in A's idle upper half -- A needs nseq * L' of its nseq * L elements per part)
+            cf* ft = fb->A + (size_t)nb * fb->nseq * Ls;
+            fb_launch_float_transpose(dim3((Rr + FB_FT_COLS - 1) / FB_FT_COLS, (M + FB_FT_ROWS - 1) / FB_FT_ROWS, nb * fb->nseq), ctx->stream, g, cs, ft, 0);
+            cr.kind = 5; cr.base = ft;
+          }
+          const uint64_t n1s = (uint64_t)(Rr >> g.logT1) * fb->nseq * nb, n2s = (uint64_t)(M >> g.logT2) * fb->nseq * nb;
+          hipLaunchKernelGGL(k1s, dim3(grid_for(n1s, fb->ncu * fb->wg1)), dim3(fb->nt1), fb->lds1, ctx->stream, g, cr, fb->A, ctx->tw, 0ull,
+                             nb, fb->nseq, 32u);
+          hipLaunchKernelGGL(k2, dim3(grid_for(n2s, fb->ncu * fb->wg_per_cu)), dim3(fb->nt2), fb->lds2, ctx->stream, g, fb->A, fb->X + c * Ls,
+                             ctx->tw, nb, fb->nseq, 4u);
+        }
+        fb_launch_sub_combine(ctx->stream, g, fb->X, nb * fb->nseq, fb->ncu);
+        const uint64_t n3s = (uint64_t)(g.C >> g.logT3) * nb;
+        if (co.kind == 3) {
+          const int rc = fb_launch_fused(fb, k3, fb->X, kern, co, part0, nb, fused_segmented);
+          if (rc != DSPSR_AMD_OK) return rc;
+        } else {
+          hipLaunchKernelGGL(k3, dim3(grid_for(n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern, co, ctx->tw,
+                             part0, nb, nb);
+        }
+        continue;
       }
       if (two) {
         // Two passes (FB_HAS(6)): regroup per column, whole-column forward pass, rows + inverse pass -- the spectrum never

@@ -76,8 +76,11 @@ int dspsr_amd_add_fpt(dspsr_amd_ctx* ctx, float* to_dev, uint64_t to_chan_stride
  *   (FilterbankCUDA.cu:73-168 reads freq_res, nchan_subband, input state, response nchan/ndat/
  *    impulse_pos/neg and copies the host-built, already swapped kernel to the device) */
 typedef struct {
-  uint32_t nchan_subband;   /* output channels per input channel          Filterbank.C:68  */
-  uint32_t freq_res;        /* response ndat = backward FFT length (>= 2) Filterbank.C:93  */
+  uint32_t nchan_subband;   /* output channels per input channel          Filterbank.C:68
+                               2^k, 3 * 2^k or 5 * 2^k (dspsr -F 96:D, -F 320:D: the reference plans any length,
+                               Filterbank.C:107-155; here the forward transform of 3 / 5 interleaved sub-sequences + one
+                               radix-3 / radix-5 step; freq_res <= 8192 then) */
+  uint32_t freq_res;        /* response ndat = backward FFT length, a power of two >= 2       Filterbank.C:93  */
   uint32_t nfilt_pos;       /* response impulse_pos                       Filterbank.C:90  */
   uint32_t nfilt_neg;       /* response impulse_neg                       Filterbank.C:91  */
   uint32_t input_nchan;     /* input channels (kernel has input_nchan*nchan_subband*freq_res bins) */

@@ -42,6 +42,11 @@ for i in range(ncases):
     if rng.integers(0, 4) == 0 and logN <= 18 and "layout" not in kw:      # (the CASPSR byte order is single channel)
         kw["input_nchan"] = int(rng.integers(2, 4))
     npart = int(rng.integers(1, 4)) if logN <= 19 else int(rng.integers(1, 3))
+    if rng.integers(0, 6) == 0 and logN - logM >= 3 and logM <= 13:
+        # nchan_subband = 3 * 2^k / 5 * 2^k: interleaved sub-sequences + one radix-3 / radix-5 step (three-pass geometries)
+        R = int(rng.choice([3, 5]))
+        C = R * (C >> 2) if C >= 8 else C
+        kw["four_pass"] = 0
     if rng.integers(0, 6) == 0:
         # the two-pass family of short responses (complex dual-pol, nchan_subband * freq_res^2 == 2^27): 8-bit blocks take the
         # two-pass kernels (or, four_pass = 2, the three-pass ones), float32 rows always the three-pass ones

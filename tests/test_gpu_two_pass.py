@@ -156,3 +156,59 @@ def test_two_pass_segmented_fused_fold_and_pipeline(oracle, gpu):
     for key in ("two_unfused", "three_fused"):
         assert np.array_equal(res[key][0], h), key
         assert np.abs(res[key][1] - p).max() <= 2e-6 * np.abs(p).max(), (key, np.abs(res[key][1] - p).max() / np.abs(p).max())
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# nchan_subband = 3 * 2^k / 5 * 2^k (dspsr -F 96:D, -F 320:D; Filterbank.C:107-155 plans any length): the forward transform as 3 / 5
+# interleaved power-of-two sub-sequences + one radix-3 / radix-5 step (k_sub_split, k_sub_combine), the inverse pass on
+# nsub << logR rows.  Same oracle (numpy's FFT takes any length), same bounds.
+@pytest.mark.parametrize("C,M,nfilt,kw", [
+    (96, 256, (20, 21), dict()),                                   # real dual-pol 8-bit, -F 96:D
+    (96, 256, (20, 21), dict(use_raw=False)),                      # float32 rows
+    (80, 512, (40, 30), dict(real=False)),                         # complex dual-pol, 5 * 16 channels
+    (48, 1024, (100, 101), dict(layout="caspsr")),                 # CASPSR byte order
+    (12, 4096, (422, 400), dict(max_parts=2)),                     # few channels, long response
+    (192, 64, (5, 7), dict(real=False, use_raw=False)),            # complex float rows
+    (24, 128, (9, 10), dict(real=False, input_nchan=2)),           # two input channels
+    (320, 128, (9, 10), dict(npol=1)),                             # single polarisation, 5 * 64
+])
+def test_filterbank_three_and_five_times_power_of_two_channels(oracle, gpu, C, M, nfilt, kw):
+    _fb_case(oracle, gpu, C, M, nfilt, 3, max_parts=kw.pop("max_parts", 2), seed=9, **kw)
+
+
+def test_non_power_of_two_channels_fused_fold_bit_identical(oracle, gpu):
+    """perform_fold == perform_detect + fold, bit for bit, with 96 channels (fused kernel, one workgroup per tile)."""
+    dspsr_amd, ctx = gpu
+    o = oracle
+    C, M, nfilt, nbin, npart = 96, 512, (40, 30), 64, 4
+    N, nkeep = C * M, M - sum(nfilt)
+    step, ovl = 2 * (N - sum(nfilt) * C), 2 * sum(nfilt) * C
+    rng = np.random.default_rng(5)
+    kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, N)).astype(np.complex64)
+    eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt[0], nfilt[1], 1, 2, True, kernel, max_parts=3, fused_fold=dspsr_amd.FUSED_ALWAYS)
+    assert (eng.nsamp_fft, eng.nkeep) == (2 * N, nkeep)
+    folds = [dspsr_amd.FoldEngine(ctx), dspsr_amd.FoldEngine(ctx)]
+    hits = [np.zeros(nbin, np.uint32), np.zeros(nbin, np.uint32)]
+    for f in folds:
+        f.set_shape(C, 1, 4, nbin)
+    det = torch.zeros((C, 1, 4 * npart * nkeep), dtype=torch.float32, device="cuda")
+    raw = torch.from_numpy(_raw(npart * step + ovl, seed=3)).cuda()
+    for k, f in enumerate(folds):
+        f.set_nbin(nbin)
+        f.set_ndat(npart * nkeep, 0)
+        f.set_bins(0.21, 1.0 / 45.3, npart * nkeep, 0, hits[k])
+    eng.perform_detect(det, npart, dspsr_amd.COHERENCE, 4, raw=raw, scale=float(o.S8))
+    folds[0].fold(det)
+    eng.perform_fold(folds[1], npart, dspsr_amd.COHERENCE, raw=raw, scale=float(o.S8))
+    a, b = folds[0].synch(), folds[1].synch()
+    assert np.abs(a).max() > 0 and np.array_equal(a, b) and np.array_equal(hits[0], hits[1])
+    eng.close()
+    for f in folds:
+        f.close()
+
+
+def test_rejected_channel_counts(gpu):
+    dspsr_amd, ctx = gpu
+    for C in (7, 9, 100, 6 * 7):
+        with pytest.raises(dspsr_amd.DspsrAmdError):
+            dspsr_amd.FilterbankEngine(ctx).setup(C, 256, 5, 5, 1, 2, True, None)
