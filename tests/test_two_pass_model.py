@@ -39,3 +39,22 @@ def test_two_pass_decomposition_equals_direct(logFa, logM, logFb):
             assert np.allclose(S[kb], np.fft.fft(x)[c * M:(c + 1) * M])
             got[c] = np.fft.ifft(S[kb] * H[c * M:(c + 1) * M]) * M
     assert np.allclose(got, want)
+
+
+@pytest.mark.parametrize("R,logLs,logM", [(3, 7, 3), (5, 6, 2), (3, 9, 4)])
+def test_sub_sequence_decomposition_equals_direct(R, logLs, logM):
+    """nchan_subband = 3 * 2^k / 5 * 2^k (csrc/filterbank.hip k_sub_split / k_sub_combine): L = R * L' points as R interleaved
+    sub-sequences, X[k + q L'] = sum_c W_R^(c q) W_L^(c k) F_c[k]; band q of the combined spectrum = rows q*Rr' .. of the full one."""
+    Ls, M = 1 << logLs, 1 << logM
+    L = R * Ls
+    rng = np.random.default_rng(2)
+    w = rng.standard_normal(L) + 1j * rng.standard_normal(L)
+    F = [np.fft.fft(w[c::R]) for c in range(R)]
+    k = np.arange(Ls)
+    X = np.zeros(L, complex)
+    for q in range(R):
+        X[q * Ls:(q + 1) * Ls] = sum(np.exp(-2j * np.pi * c * q / R) * np.exp(-2j * np.pi * c * k / L) * F[c] for c in range(R))
+    assert np.allclose(X, np.fft.fft(w))
+    # spectrum rows of M bins: row of bin k + q L' is q * (L'/M) + k // M
+    rows = (np.arange(L) // M).reshape(R, Ls // M, M)
+    assert np.array_equal(rows[:, :, 0], np.arange(R)[:, None] * (Ls // M) + np.arange(Ls // M)[None, :])
