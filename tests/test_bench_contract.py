@@ -37,4 +37,15 @@ def test_default_bench_line_contract():
     eb = cfg["engine_boundary"]
     assert eb["raw_deferred"] >= 0.9 * d["value"] and eb["raw_deferred_fused_blocks"] > 0 and eb["float_eager_fused_blocks"] == 0
     assert d["subband_shard"]["workload"] == "cfg4" and d["subband_shard"]["value"] > 0
+    # round 4: which transport carried the dumps is a top-level field; the PCIe-inclusive companion and the PMC traffic ratio of
+    # EVERY workload are part of the default line
+    assert d["exchange"] == "none" and cfg["exchange"] == "none" and cfg["reduce_ms_per_dump"] is None
+    assert d["subband_shard"]["exchange"] == "none" and d["subband_shard"]["reduce_ms_per_dump"] is None
+    pc = cfg["pcie_inclusive"]
+    assert pc["unit"] == "Msamples/s" and 0 < pc["value"] < d["value"] and pc["steps"] >= 5
+    assert r["traffic_ratio"] is not None and abs(r["traffic_ratio"] - r["traffic"] / (r["algorithmic_bytes_per_part"] * cfg["max_parts"])) < 1e-2
+    assert "profiles/" in r["traffic_source"]
+    assert d["subband_shard"]["roofline_traffic_ratio"] > 1.0 and cfg["transform_passes"] == 3
+    for w in d["other_workloads"]:
+        assert w["roofline_traffic_ratio"] is not None and w["roofline_traffic_ratio"] >= 1.0, w["workload"]
     assert {w["workload"] for w in d["other_workloads"]} >= {"cfg1", "cfg1opt", "cfg2", "cfg3", "cfg5"}
