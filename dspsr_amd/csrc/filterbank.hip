@@ -159,7 +159,7 @@ DEV void fb_stagger()
 #endif
 }
 
-[[maybe_unused]] constexpr uint32_t FB_PSL_MAX = 128;   // fused fold: part offsets of one launch kept in LDS (launches hold <= 64 parts)
+[[maybe_unused]] constexpr uint32_t FB_PSL_MAX = 128;   // fused fold: offsets of the parts a workgroup walks (its run of a launch), kept in LDS
 
 // (int8 + 0.5) * scale (GenericEightBitUnpackerCUDA.cu:45).  int8 + 0.5 is exact in float, so the one rounding of the product
 // is the rounding of the exact value (v + 0.5)*scale -- which fma(v, scale, scale/2) rounds likewise (scale/2 is exact):
