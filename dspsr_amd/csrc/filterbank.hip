@@ -125,11 +125,11 @@ struct SubSplit {
   uint64_t sub_stride;        // bytes from one sub-block to the next
 };
 
-#ifdef FB_STAMPS   // diagnostic build only (-DFB_STAMPS=1|2|3|6|7: pass to instrument -- 6 = k_fwd_col1, 7 = k_rows_inv): where a
+#ifdef FB_STAMPS   // diagnostic build only (-DFB_STAMPS=1|2|3|4|6|7: pass to instrument -- 4 = k_inv_a, 6 = k_fwd_col1, 7 = k_rows_inv): where a
                    // tile spends its cycles (s_memtime per phase, lane 0 of wave 0 of every workgroup).  The counters live in
                    // the translation unit of the instrumented kernel (single-TU builds, or the FB_PART that holds it)
 #define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define FB_STAMPS_PART (FB_STAMPS == 1 ? 1 : FB_STAMPS == 2 ? 2 : FB_STAMPS == 3 ? 5 : 6)
+#define FB_STAMPS_PART (FB_STAMPS == 1 ? 1 : FB_STAMPS == 2 ? 2 : FB_STAMPS == 3 ? 5 : FB_STAMPS == 4 ? 4 : 6)
 static __device__ unsigned long long g_stamps[1024][8];     // (one per translation unit; the exported reader sees FB_STAMPS_PART's)
 #if !defined(FB_PART) || FB_PART == FB_STAMPS_PART
 extern "C" int dspsr_amd_debug_stamps(unsigned long long* out_host, int zero)
@@ -2518,7 +2518,13 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
 //   P3b k_inv_b : inverse Mb-point FFTs over m2 for Tt adjacent t1 (one contiguous block of U)
 //                 -> keep window on t = t1 + Ma*t2 -> complex output or fused detection
 // Columns of both tiles are (column, pol) pairs, so the thread's two butterflies are the two polarisations.
-template <int LOGF, bool BLOCKED>
+// REAL: real input (one packed sequence per part, the polarisations separated by the Hermitian split) or complex input
+// (npol sequences), fixed at compile time: the split loop and the mirror addresses are then free of per-element branches
+// (the run-time form cost one uniform branch per element and load, 5577 ISA lines per tile at -x 262144).
+// FULL: the tile is the whole workgroup tile (Ma * 2*Tm = 2^14 elements, 512 threads): the column count is then a
+// compile-time constant and the exchange addresses of the transform fold (wgfft_stage's uniform selects otherwise cost
+// two branches per element: 107 per tile in the -x 262144 listing).
+template <int LOGF, bool BLOCKED, bool REAL, bool FULL>
 __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restrict__ X, const cf* __restrict__ kernel,
                                                cf* __restrict__ U, const cf* __restrict__ tw, const uint32_t nparts,
                                                const uint32_t run)
@@ -2526,10 +2532,11 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
   typedef FftPlan<LOGF> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
-  const int logTm = g.logTm, logT = logTm + 1, logTt = g.logTt;
+  const int logTm = FULL ? 13 - LOGF : g.logTm, logT = logTm + 1, logTt = g.logTt;
   const uint32_t Tm = 1u << logTm, Tt = 1u << logTt;
   const uint64_t L = 1ull << (g.logM + g.logR);
-  const uint32_t nseq = g.real_input ? 1 : g.npol;
+  const uint32_t nseq = REAL ? 1 : g.npol;
+  const bool npol2 = g.npol == 2;
   const uint32_t ntile = 1u << (g.logMb - logTm);          // m2 tiles per channel
   const uint32_t per_part = ntile * g.C;
   const uint32_t total = per_part * nparts;
@@ -2594,42 +2601,54 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
     return ((i & 1) ? D[0] : 0u) + ((i & 2) ? D[1] : 0u) + ((i & 4) ? D[2] : 0u) + ((i & 8) ? D[3] : 0u);
   };
 
-  auto fetch = [&](const uint32_t item, Abk (&raw)[PTS / 2]) {
+  // The prefetch of the next tile is issued in NCH groups spread over the tile -- behind the split, inside the order
+  // exchange, behind the butterflies of the first stages (wgfft's `mid` hook) -- instead of one burst of 32 loads per thread:
+  // the burst blocked every wave in its load instructions for a quarter of the tile while the memory pipeline, still
+  // draining the previous tile's stores, accepted them (stamps: 11.6k of 45.7k cycles, and as many again at the next barrier).
+  // chunk < 0: all elements; otherwise the elements i with i % NCH == chunk.
+  constexpr int NMID = P::NS >= 3 ? 2 : (P::NS == 2 ? 1 : 0);
+  constexpr int NCH = 1 + (BLOCKED ? 1 : 0) + NMID;
+  auto fetch = [&](const uint32_t item, Abk (&raw)[PTS / 2], const int chunk) {
     const uint32_t r = (FB_DBG(g) & 256) ? item % per_part : item / nparts, part = (FB_DBG(g) & 256) ? item / per_part : item - r * nparts;
     const uint32_t c = r >> logNt, tile = r & (ntile - 1);
     const cf* __restrict__ X0s = X + (uint64_t)part * nseq * g.xstride;
     if (FB_DBG(g) & 2) {
+      if (chunk <= 0) {
 #pragma unroll
-      for (int i = 0; i < NPAIR; i++) { raw[i].a = make_float2(tid, i); raw[i].b = raw[i].a; }
+        for (int i = 0; i < NPAIR; i++) { raw[i].a = make_float2(tid, i); raw[i].b = raw[i].a; }
+      }
       return;
     }
     if constexpr (BLOCKED) {
       const uint32_t kt = (c << g.logMf) + tile * Tm;
       const uint32_t k0 = kt + thr_k, a0 = xa(kt) + thr_xa;
-      const cf* __restrict__ X1s = X0s + g.xstride;
-      if (g.real_input) {
+      if constexpr (REAL) {
         const uint32_t lowT = k0 & maskT, lowA = k0 & maskA;
-        const uint32_t E1 = XAM + (lowT ? 1u : dCarryA);                               // increment reaches into ka
         const uint32_t E2 = XAM + (lowT ? 1u : (lowA ? dCarryA : dCarryB));            // increment in kb only
+        const uint32_t dE = XAM + (lowT ? 1u : dCarryA) - E2;                          // increment reaches into ka: E2 + dE
 #pragma unroll
         for (int i = 0; i < PTS / 2; i++) {
+          if (chunk >= 0 && i % NCH != chunk) continue;
           const uint32_t ia = a0 + inc(Dxa, i);
-          uint32_t ib = ((inc(Dk, i) & maskA) ? E1 : E2) - ia;
+          const uint32_t into_ka = (inc(Dk, i) & maskA) ? 1u : 0u;                     // uniform: a scalar, no branch
+          uint32_t ib = E2 + into_ka * dE - ia;
           if (i == 0) ib = k0 == 0 ? 0u : ib;                                          // bin 0 is its own mirror
           Abk q;
           q.a = ld_stream(X0s + ia);
           q.b = ld_stream(X0s + ib);
           raw[i] = q;
         }
-        return;
-      }
+      } else {
+        const cf* __restrict__ X1s = npol2 ? X0s + g.xstride : X0s;                    // (one polarisation: loaded twice, zeroed below)
 #pragma unroll
-      for (int i = 0; i < PTS / 2; i++) {
-        const uint32_t ia = a0 + inc(Dxa, i);
-        Abk q;
-        q.a = ld_stream(X0s + ia);
-        q.b = g.npol == 2 ? ld_stream(X1s + ia) : make_float2(0.f, 0.f);
-        raw[i] = q;
+        for (int i = 0; i < PTS / 2; i++) {
+          if (chunk >= 0 && i % NCH != chunk) continue;
+          const uint32_t ia = a0 + inc(Dxa, i);
+          Abk q;
+          q.a = ld_stream(X0s + ia);
+          q.b = ld_stream(X1s + ia);
+          raw[i] = q;
+        }
       }
       return;
     }
@@ -2643,11 +2662,12 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
       const uint32_t j = (eb & ((1u << logT) - 1)) >> 1, m1b = eb >> logT;
       const uint64_t k0 = ((uint64_t)c << g.logMf) + ((uint64_t)m1b << g.logMb) + tile * Tm + j;
       const cf* __restrict__ pa = X0s + k0;
-      const cf* __restrict__ pb = g.real_input ? X0s + (L - k0) : pa + (g.npol == 2 ? L : 0);
-      const int64_t stepb = g.real_input ? -step : step;
-      const cf* __restrict__ pb0 = (g.real_input && k0 == 0) ? X0s : pb;
+      const cf* __restrict__ pb = REAL ? X0s + (L - k0) : pa + (npol2 ? L : 0);
+      const int64_t stepb = REAL ? -step : step;
+      const cf* __restrict__ pb0 = (REAL && k0 == 0) ? X0s : pb;
 #pragma unroll
       for (int i = 0; i < P::R1; i++) {
+        if (chunk >= 0 && ((g2 / 2) * P::R1 + i) % NCH != chunk) continue;
         Abk q;
         q.a = ld_stream(pa + i * step);
         q.b = ld_stream(i == 0 ? pb0 : pb + i * stepb);
@@ -2666,18 +2686,26 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
   if (item >= item_end) return;
   uint32_t next;
   Abk raw[PTS / 2];
-  fetch(item, raw);
+  fetch(item, raw, -1);
+#if defined(FB_STAMPS) && FB_STAMPS == 4
+  unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, ts6, acc_s[7] = {0, 0, 0, 0, 0, 0, 0};
+  STAMP(ts5);
+#endif
   for (;;) {
     asm volatile("" : "+v"(tid));
     const uint32_t r = (FB_DBG(g) & 256) ? item % per_part : item / nparts, part = (FB_DBG(g) & 256) ? item / per_part : item - r * nparts;
     const uint32_t c = r >> logNt, tile = r & (ntile - 1);
     cx2 x[NPAIR];
+#if defined(FB_STAMPS) && FB_STAMPS == 4
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(ts0);
+#endif
     {
       // (the chirp is re-read for every part of the tile -- from the L2, the workgroup has just used it: keeping it in
       //  registers across the parts costs 32 registers that the 256-register budget does not have; the spills then wait
       //  on the in-order vector-memory counter behind the prefetched tile: 1379 -> 1767 us)
       cf kk[PTS / 2];
-      if (BLOCKED && kernel && !(FB_DBG(g) & 2)) {
+      if (BLOCKED && kernel && !(FB_DBG(g) & (2 | 4))) {
         const uint32_t c0 = xk((c << g.logMf) + tile * Tm) + thr_xk;
 #pragma unroll
         for (int i = 0; i < PTS / 2; i++) kk[i] = kernel[c0 + inc(Dxk, i)];
@@ -2699,25 +2727,36 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
       for (int i = 0; i < PTS / 2; i++) {
         const Abk q = raw[i];
         cf x0, x1;
-        if (g.real_input) {
+        if constexpr (REAL) {
           x0 = make_float2(0.5f * (q.a.x + q.b.x), 0.5f * (q.a.y - q.b.y));
           x1 = make_float2(0.5f * (q.a.y + q.b.y), 0.5f * (q.b.x - q.a.x));
         } else {
           x0 = q.a;
-          x1 = g.npol == 2 ? q.b : make_float2(0.f, 0.f);
+          x1 = npol2 ? q.b : make_float2(0.f, 0.f);
         }
         x[i] = cmuls(make_cx2(x0, x1), kk[i]);
       }
     }
     next = item + 1;
     const bool more = next < item_end;
-    if (more) fetch(next, raw);
+#if defined(FB_STAMPS) && FB_STAMPS == 4
+    STAMP(ts1);
+#endif
+    // unconditional (the last item of the range is fetched again and dropped: 1/64 of the reads at 8 parts per launch).  Under
+    // `if (more)` the loads went to fresh registers and the copies into `raw` at the end of the conditional block waited for
+    // them (`s_waitcnt vmcnt(0)` straight behind the 32 loads in the ISA): the prefetch overlapped nothing.
+    const uint32_t nitem = more ? next : item;
+    fetch(nitem, raw, 0);
+#if defined(FB_STAMPS) && FB_STAMPS == 4
+    STAMP(ts2);
+#endif
     if constexpr (BLOCKED) {
       // memory order -> butterfly order: element (m1, j) of the tile (both polarisations, 16 bytes) at word pair m1*Tm + j
       __syncthreads();                         // the previous tile's copy-out has finished with the buffer
 #pragma unroll
       for (int i = 0; i < PTS / 2; i++)
         *(float4*)&lds[thr_st + inc(Dst, i)] = make_float4(x[i].x[0], x[i].x[1], x[i].y[0], x[i].y[1]);
+      fetch(nitem, raw, 1);
       __syncthreads();
 #pragma unroll
       for (int g2 = 0; g2 < P::G1; g2 += 2)
@@ -2730,6 +2769,9 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
       __syncthreads();                         // before the first stage's exchange overwrites the buffer
     }
 
+#if defined(FB_STAMPS) && FB_STAMPS == 4
+    STAMP(ts6);
+#endif
     cf* __restrict__ Uc = U + ((uint64_t)part * g.C + c) * (2ull << g.logMf);
     // staged image order [t1/Tt][j][t1%Tt][pol]: whole runs of Tm*Tt*2 elements go out with 16-byte stores
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
@@ -2743,8 +2785,14 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
         *(float4*)&lds[lds_pad(l)] = make_float4(v[k].x[0], v[k].y[0], v[k].x[1], v[k].y[1]);
       }
     };
-    wgfft<LOGF, +1, true>(lds, ltw_off, tid, logT, x, store);
+    auto mid = [&](const int phase) {
+      if (phase >= 1 && phase <= NMID) fetch(nitem, raw, (BLOCKED ? 1 : 0) + phase);
+    };
+    wgfft<LOGF, +1, true>(lds, ltw_off, tid, logT, x, store, mid);
     __syncthreads();
+#if defined(FB_STAMPS) && FB_STAMPS == 4
+    STAMP(ts3);
+#endif
     {
       const uint32_t nthr = blockDim.x;
       const int logRun = logTm + logTt + 1;
@@ -2762,7 +2810,8 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
           for (int q = 0; q < 4; q++) pr[q] = *(const float4*)&lds[lb + (j4 + q) * lstep];
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int q = 0; q < 4; q++) st_stream((float4*)(gb + (uint64_t)(j4 + q) * gstep + goff), pr[q]);
+          for (int q = 0; q < 4; q++)
+            if (!(FB_DBG(g) & 1)) st_stream((float4*)(gb + (uint64_t)(j4 + q) * gstep + goff), pr[q]);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -2775,9 +2824,18 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
         }
       }
     }
+#if defined(FB_STAMPS) && FB_STAMPS == 4
+    STAMP(ts4);
+    acc_s[0] += ts0 - ts5; acc_s[1] += ts1 - ts0; acc_s[2] += ts2 - ts1; acc_s[3] += ts6 - ts2; acc_s[4] += ts3 - ts6; acc_s[6] += ts4 - ts3; acc_s[5] += 1;
+    ts5 = ts4;
+#endif
     if (!more) break;
     item = next;
   }
+#if defined(FB_STAMPS) && FB_STAMPS == 4
+  if (threadIdx.x == 0 && blockIdx.x < 1024)
+    for (int q = 0; q < 7; q++) atomicAdd(&g_stamps[blockIdx.x][q], acc_s[q]);
+#endif
 }
 
 // FOLDB (FbOut kind 4): the tile holds, for one channel, Mb runs of Tt consecutive output samples (run t2 = samples
@@ -2958,7 +3016,7 @@ k1_t fb_pick1_dual(int raww);      // pass 1 on pairs of two-column tiles (2^13-
 k2_t fb_pick2(int logf, bool full);
 k3_t fb_pick3(int logf, bool full);       // plain
 k3_t fb_pick3f(int logf, bool full);      // fused fold
-k3a_t fb_pick3a(int logf, bool blocked);
+k3a_t fb_pick3a(int logf, bool blocked, bool real, bool full);
 k3b_t fb_pick3b(int logf, bool foldb = false);
 // two-pass path (FB_HAS(6)): pass 1 on whole columns, rows + inverse pass (M = 2^logm, Fb = 2^(13 - logm)), the 8-bit regroup
 typedef void (*k1c_t)(FbGeom, FbIn, cf*, const cf*, uint32_t, uint32_t, uint32_t);
@@ -2993,7 +3051,7 @@ k3_t fb_pick3(int logf, bool full) { return logf != 12 ? nullptr : (full ? k_inv
 k3_t fb_pick3f(int logf, bool full) { return logf != 12 ? nullptr : (full ? k_inv_chan<12, true, 2> : k_inv_chan<12, true, -1>); }
 #endif
 #if FB_HAS(4)
-k3a_t fb_pick3a(int, bool) { return nullptr; }
+k3a_t fb_pick3a(int, bool, bool, bool) { return nullptr; }
 k3b_t fb_pick3b(int, bool) { return nullptr; }
 #endif
 #if FB_HAS(6)
@@ -3043,11 +3101,18 @@ template <int... I> static k3_t pick3f(int logf, bool full, iseq<I...>)
 k3_t fb_pick3f(int logf, bool full) { return pick3f(logf, full, seq_t()); }
 #endif
 #if FB_HAS(4)
-template <int... I> static k3a_t pick3a(int logf, bool blocked, iseq<I...>)
+template <int... I> static k3a_t pick3a(int logf, bool blocked, bool real, bool full, iseq<I...>)
 {
-  static const k3a_t tn[] = {k_inv_a<I, false>...};
-  static const k3a_t tb[] = {k_inv_a<I, true>...};
-  return blocked ? tb[logf] : tn[logf];
+  static const k3a_t tn[] = {k_inv_a<I, false, false, false>...};
+  static const k3a_t tb[] = {k_inv_a<I, true, false, false>...};
+  static const k3a_t rn[] = {k_inv_a<I, false, true, false>...};
+  static const k3a_t rb[] = {k_inv_a<I, true, true, false>...};
+  static const k3a_t tnf[] = {k_inv_a<I, false, false, true>...};
+  static const k3a_t tbf[] = {k_inv_a<I, true, false, true>...};
+  static const k3a_t rnf[] = {k_inv_a<I, false, true, true>...};
+  static const k3a_t rbf[] = {k_inv_a<I, true, true, true>...};
+  if (full) return real ? (blocked ? rbf[logf] : rnf[logf]) : (blocked ? tbf[logf] : tnf[logf]);
+  return real ? (blocked ? rb[logf] : rn[logf]) : (blocked ? tb[logf] : tn[logf]);
 }
 template <int... I> static k3b_t pick3b(int logf, bool foldb, iseq<I...>)
 {
@@ -3055,7 +3120,7 @@ template <int... I> static k3b_t pick3b(int logf, bool foldb, iseq<I...>)
   static const k3b_t f[] = {k_inv_b<I, true>...};
   return foldb ? f[logf] : t[logf];
 }
-k3a_t fb_pick3a(int logf, bool blocked) { return pick3a(logf, blocked, seq_t()); }
+k3a_t fb_pick3a(int logf, bool blocked, bool real, bool full) { return pick3a(logf, blocked, real, full, seq_t()); }
 k3b_t fb_pick3b(int logf, bool foldb) { return pick3b(logf, foldb, seq_t()); }
 #endif
 #if FB_HAS(6)
@@ -3328,7 +3393,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     }
     fb->k2 = fb_pick2(g.logR, full2);
     if (g.four_pass) {
-      fb->k3a = fb_pick3a(g.logMa, g.xblocked != 0);
+      fb->k3a = fb_pick3a(g.logMa, g.xblocked != 0, g.real_input != 0, !notfixed && g.logTm == 13 - g.logMa && g.logMa <= 12 && fb->nt3 == 512);
       fb->k3b = fb_pick3b(g.logMb);
       fb->k3bf = fb_pick3b(g.logMb, true);
     } else {
