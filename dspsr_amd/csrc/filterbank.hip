@@ -2687,6 +2687,13 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
   uint32_t next;
   Abk raw[PTS / 2];
   fetch(item, raw, -1);
+  // The chirp of a tile stays in registers while the workgroup walks the tile's parts (loaded when the tile changes: 16
+  // loads per thread less on 7 of 8 items; cfg1opt +2.5 %).  32 registers: the full-tile kernels fit them with 0-7 spilled
+  // registers, except the blocked ones whose stages are all radix 16 (13-18 spills: those re-read the chirp per part from the
+  // L2, as the generic kernels do).
+  constexpr bool KEEPK = FULL && !(BLOCKED && LOGF % 4 == 0 && LOGF > 0);
+  cf kk[PTS / 2];
+  uint32_t kk_r = ~0u;
 #if defined(FB_STAMPS) && FB_STAMPS == 4
   unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, ts6, acc_s[7] = {0, 0, 0, 0, 0, 0, 0};
   STAMP(ts5);
@@ -2701,10 +2708,8 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
     STAMP(ts0);
 #endif
     {
-      // (the chirp is re-read for every part of the tile -- from the L2, the workgroup has just used it: keeping it in
-      //  registers across the parts costs 32 registers that the 256-register budget does not have; the spills then wait
-      //  on the in-order vector-memory counter behind the prefetched tile: 1379 -> 1767 us)
-      cf kk[PTS / 2];
+      if (!KEEPK || r != kk_r) {
+      kk_r = r;
       if (BLOCKED && kernel && !(FB_DBG(g) & (2 | 4))) {
         const uint32_t c0 = xk((c << g.logMf) + tile * Tm) + thr_xk;
 #pragma unroll
@@ -2722,6 +2727,7 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
       } else {
 #pragma unroll
         for (int i = 0; i < PTS / 2; i++) kk[i] = make_float2(1.f, 0.f);
+      }
       }
 #pragma unroll
       for (int i = 0; i < PTS / 2; i++) {
@@ -2846,7 +2852,8 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
 // 1/16 of the detected bytes instead of all of them.  fold_segment_combine (fold.hip) then adds, per (channel, bin), the
 // pieces of the bin's intervals in time order.  Deterministic; equal to the time-order sum to float rounding like the
 // long-run fold itself (other micro-block boundaries, so not bit-equal to it).
-template <int LOGF, bool FOLDB>
+// FULL: whole workgroup tile (Mb * 2*Tt = 2^14 elements, 512 threads), column count fixed at compile time (see k_inv_a).
+template <int LOGF, bool FOLDB, bool FULL>
 __global__ __launch_bounds__(512) void k_inv_b(const FbGeom g, const cf* __restrict__ U, const FbOut out,
                                                const cf* __restrict__ tw, const uint64_t part0, const uint32_t nparts,
                                                const uint32_t run)
@@ -2854,7 +2861,7 @@ __global__ __launch_bounds__(512) void k_inv_b(const FbGeom g, const cf* __restr
   typedef FftPlan<LOGF> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
-  const int logTt = g.logTt, logT = logTt + 1;
+  const int logTt = FULL ? 13 - LOGF : g.logTt, logT = logTt + 1;
   const uint32_t ntile = 1u << (g.logMa - logTt);          // t1 blocks per channel
   const uint32_t per_part = ntile * g.C;
   const uint32_t total = per_part * nparts;
@@ -3017,7 +3024,7 @@ k2_t fb_pick2(int logf, bool full);
 k3_t fb_pick3(int logf, bool full);       // plain
 k3_t fb_pick3f(int logf, bool full);      // fused fold
 k3a_t fb_pick3a(int logf, bool blocked, bool real, bool full);
-k3b_t fb_pick3b(int logf, bool foldb = false);
+k3b_t fb_pick3b(int logf, bool foldb, bool full);
 // two-pass path (FB_HAS(6)): pass 1 on whole columns, rows + inverse pass (M = 2^logm, Fb = 2^(13 - logm)), the 8-bit regroup
 typedef void (*k1c_t)(FbGeom, FbIn, cf*, const cf*, uint32_t, uint32_t, uint32_t);
 k1c_t fb_pick_col1(int variant = 1);     // 1: four sub-sequences + radix-4 in registers (three exchanged stages), 0: even / odd + radix-2
@@ -3052,7 +3059,7 @@ k3_t fb_pick3f(int logf, bool full) { return logf != 12 ? nullptr : (full ? k_in
 #endif
 #if FB_HAS(4)
 k3a_t fb_pick3a(int, bool, bool, bool) { return nullptr; }
-k3b_t fb_pick3b(int, bool) { return nullptr; }
+k3b_t fb_pick3b(int, bool, bool) { return nullptr; }
 #endif
 #if FB_HAS(6)
 k1c_t fb_pick_col1(int) { return nullptr; }
@@ -3114,14 +3121,19 @@ template <int... I> static k3a_t pick3a(int logf, bool blocked, bool real, bool 
   if (full) return real ? (blocked ? rbf[logf] : rnf[logf]) : (blocked ? tbf[logf] : tnf[logf]);
   return real ? (blocked ? rb[logf] : rn[logf]) : (blocked ? tb[logf] : tn[logf]);
 }
-template <int... I> static k3b_t pick3b(int logf, bool foldb, iseq<I...>)
+template <int... I> static k3b_t pick3b(int logf, bool foldb, bool full, iseq<I...>)
 {
-  static const k3b_t t[] = {k_inv_b<I, false>...};
-  static const k3b_t f[] = {k_inv_b<I, true>...};
+  static const k3b_t t[] = {k_inv_b<I, false, false>...};
+  static const k3b_t f[] = {k_inv_b<I, true, false>...};
+  static const k3b_t tf[] = {k_inv_b<I, false, true>...};
+  static const k3b_t ff[] = {k_inv_b<I, true, true>...};
+  // (FOLDB with a radix-2 / radix-4 remainder stage -- LOGF % 4 == 1, 2 -- spills 12-20 registers in the full-tile form and
+  //  none in the generic one: those lengths keep the generic kernel)
+  if (full && !(foldb && (logf % 4 == 1 || logf % 4 == 2))) return foldb ? ff[logf] : tf[logf];
   return foldb ? f[logf] : t[logf];
 }
 k3a_t fb_pick3a(int logf, bool blocked, bool real, bool full) { return pick3a(logf, blocked, real, full, seq_t()); }
-k3b_t fb_pick3b(int logf, bool foldb) { return pick3b(logf, foldb, seq_t()); }
+k3b_t fb_pick3b(int logf, bool foldb, bool full) { return pick3b(logf, foldb, full, seq_t()); }
 #endif
 #if FB_HAS(6)
 k1c_t fb_pick_col1(int variant) { return variant ? k_fwd_col1q<1> : k_fwd_col1<1>; }
@@ -3394,8 +3406,9 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     fb->k2 = fb_pick2(g.logR, full2);
     if (g.four_pass) {
       fb->k3a = fb_pick3a(g.logMa, g.xblocked != 0, g.real_input != 0, !notfixed && g.logTm == 13 - g.logMa && g.logMa <= 12 && fb->nt3 == 512);
-      fb->k3b = fb_pick3b(g.logMb);
-      fb->k3bf = fb_pick3b(g.logMb, true);
+      const bool full4 = !notfixed && g.logTt == 13 - g.logMb && g.logMb <= 12 && fb->nt4 == 512;
+      fb->k3b = fb_pick3b(g.logMb, false, full4);
+      fb->k3bf = fb_pick3b(g.logMb, true, full4);
     } else {
       fb->k3 = fb_pick3(g.logM, full3);
       fb->k3f = fb_pick3f(g.logM, full3);
