@@ -2524,6 +2524,22 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
 // FULL: the tile is the whole workgroup tile (Ma * 2*Tm = 2^14 elements, 512 threads): the column count is then a
 // compile-time constant and the exchange addresses of the transform fold (wgfft_stage's uniform selects otherwise cost
 // two branches per element: 107 per tile in the -x 262144 listing).
+#ifndef FB_INVA_NT_LD
+#define FB_INVA_NT_LD 1        // experiment (0): k_inv_a reads the spectrum with plain loads
+#endif
+#ifndef FB_INVA_NT_ST
+#define FB_INVA_NT_ST 1        // experiment (0): k_inv_a writes U with plain stores
+#endif
+#if FB_INVA_NT_LD
+#define INVA_LD(p) ld_stream(p)
+#else
+#define INVA_LD(p) (*(p))
+#endif
+#if FB_INVA_NT_ST
+#define INVA_ST(p, v) st_stream(p, v)
+#else
+#define INVA_ST(p, v) (*(p) = (v))
+#endif
 template <int LOGF, bool BLOCKED, bool REAL, bool FULL>
 __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restrict__ X, const cf* __restrict__ kernel,
                                                cf* __restrict__ U, const cf* __restrict__ tw, const uint32_t nparts,
@@ -2634,8 +2650,8 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
           uint32_t ib = E2 + into_ka * dE - ia;
           if (i == 0) ib = k0 == 0 ? 0u : ib;                                          // bin 0 is its own mirror
           Abk q;
-          q.a = ld_stream(X0s + ia);
-          q.b = ld_stream(X0s + ib);
+          q.a = INVA_LD(X0s + ia);
+          q.b = INVA_LD(X0s + ib);
           raw[i] = q;
         }
       } else {
@@ -2645,8 +2661,8 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
           if (chunk >= 0 && i % NCH != chunk) continue;
           const uint32_t ia = a0 + inc(Dxa, i);
           Abk q;
-          q.a = ld_stream(X0s + ia);
-          q.b = ld_stream(X1s + ia);
+          q.a = INVA_LD(X0s + ia);
+          q.b = INVA_LD(X1s + ia);
           raw[i] = q;
         }
       }
@@ -2669,8 +2685,8 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
       for (int i = 0; i < P::R1; i++) {
         if (chunk >= 0 && ((g2 / 2) * P::R1 + i) % NCH != chunk) continue;
         Abk q;
-        q.a = ld_stream(pa + i * step);
-        q.b = ld_stream(i == 0 ? pb0 : pb + i * stepb);
+        q.a = INVA_LD(pa + i * step);
+        q.b = INVA_LD(i == 0 ? pb0 : pb + i * stepb);
         raw[(g2 / 2) * P::R1 + i] = q;
       }
     }
@@ -2817,7 +2833,7 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int q = 0; q < 4; q++)
-            if (!(FB_DBG(g) & 1)) st_stream((float4*)(gb + (uint64_t)(j4 + q) * gstep + goff), pr[q]);
+            if (!(FB_DBG(g) & 1)) INVA_ST((float4*)(gb + (uint64_t)(j4 + q) * gstep + goff), pr[q]);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -2826,7 +2842,7 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
           const uint32_t l = 2 * (tid + jj * nthr);
           const uint32_t tb = l >> logRun, within = l & ((1u << logRun) - 1);
           const float4 pr = *(const float4*)&lds[lds_pad(l)];
-          st_stream((float4*)&Uc[((((uint64_t)tb << g.logMb) + tile * Tm) << (logTt + 1)) + within], pr);
+          INVA_ST((float4*)&Uc[((((uint64_t)tb << g.logMb) + tile * Tm) << (logTt + 1)) + within], pr);
         }
       }
     }
