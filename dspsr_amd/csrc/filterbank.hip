@@ -1606,10 +1606,12 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
     STAMP(ts1);
 #endif
     const bool more = next_item(++j, next);
-    // One burst: spreading the loads over the transform (wgfft's `mid` hook) or loading the chirp one tile early
-    // was measured and does not pay -- the wave time goes to ISSUING the 8-byte loads (about 6k cycles per tile,
-    // profiles/r01d_p3_phase_stamps.txt), wherever they are placed.
-    if (more) fetch(next, raw, -1);
+    // One burst, and unconditional: the last item of a workgroup is fetched again and dropped.  Under `if (more)` the generic
+    // (8-byte) form's loads went to fresh registers and the copies into the loop-carried `raw` sat at the end of the conditional
+    // block behind `s_waitcnt vmcnt(16) ... (0)` -- the prefetch was waited for at once (profiles/r04_experiments.txt item 13;
+    // what rounds 1-3 read as "the wave time goes to ISSUING the 8-byte loads").  The 16-byte pair form of the headline
+    // geometry was not affected.
+    fetch(more ? next : item, raw, -1);
 #if defined(FB_STAMPS) && FB_STAMPS == 3
     STAMP(ts2);
 #endif
