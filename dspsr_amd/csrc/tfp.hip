@@ -66,7 +66,9 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
   const uint32_t nt = blockDim.x;
-  const int logT = p.logT, logTp = logT - 1;                   // columns; parts per tile
+  // columns of the tile: always 14 - LOGC (dspsr_amd_tfp_filterbank sets p.logT so), a compile-time constant here: with the
+  // run-time value every exchange address of the transform carried two uniform branches (150-171 per tile at 4096 channels)
+  constexpr int logT = 14 - LOGC, logTp = logT - 1;            // columns; parts per tile
   const uint32_t Tp = 1u << logTp, C = 1u << LOGC;             // C = nchan complex points per polarisation and part
   const uint32_t npol_out = p.pscrunch ? 1 : 2;
   const uint64_t nout = p.npart / p.sfactor;
