@@ -391,6 +391,21 @@ template <int NT, typename IDX> DEV void twiddles_big(cf (&t)[NT], const IDX (&j
       const float x = (float)(uint32_t)j[q] * sc;
       t[q] = make_float2(__builtin_amdgcn_cosf(x), -__builtin_amdgcn_sinf(x));
     }
+  } else if (logL <= 32 && !FB_TABLE_TWIDDLES) {   // uniform (32-bit indices)
+    // L > 2^24: j / L is no longer exact in float -- two exact arguments instead, hi = j >> s (13 bits) in revolutions of 2^13
+    // and lo = j mod 2^s in revolutions of L, and one product: 2.4e-7 max against double (tools/sincos_probe.hip; coarse x fine
+    // tables 1.3e-7).  The table form cost pass 2 ten dependent L2 round trips at the top of EVERY tile (the compiler sinks each
+    // load to its use: `global_load; s_waitcnt vmcnt(0)` chains in the listing), with nothing else in flight: cfg1opt's
+    // k_fwd_rows 821 -> see profiles/r04_experiments.txt item 13.
+    const int s = logL - 13;
+    const float scl = __uint_as_float((uint32_t)(127 - logL) << 23);
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+      const uint32_t jq = (uint32_t)j[q];
+      const float xh = (float)(jq >> s) * (1.0f / 8192.0f), xl = (float)(jq & ((1u << s) - 1)) * scl;
+      const float ch = __builtin_amdgcn_cosf(xh), sh = __builtin_amdgcn_sinf(xh), cl = __builtin_amdgcn_cosf(xl), sl = __builtin_amdgcn_sinf(xl);
+      t[q] = make_float2(ch * cl - sh * sl, -(ch * sl + sh * cl));
+    }
   } else if (logL <= LOG_TWN) {                // uniform
 #pragma unroll
     for (int q = 0; q < NT; q++) t[q] = tw[j[q] << (LOG_TWN - logL)];
