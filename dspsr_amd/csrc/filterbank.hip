@@ -124,6 +124,14 @@ struct SubSplit {
   uint32_t R;
   uint64_t sub_stride;        // bytes from one sub-block to the next
 };
+// parameters of k_time_combine (freq_res = 3 * 2^k / 5 * 2^k)
+struct TimeCombine {
+  const cf* Y;
+  uint64_t y_chan_stride, y_pol_stride;     // complex elements; parts M' apart
+  uint32_t logMi, mo, nfilt_pos, nkeep, C, npol;
+  uint64_t part0;
+  uint32_t nparts;
+};
 
 #ifdef FB_STAMPS   // diagnostic build only (-DFB_STAMPS=1|2|3|4|6|7: pass to instrument -- 4 = k_inv_a, 6 = k_fwd_col1, 7 = k_rows_inv): where a
                    // tile spends its cycles (s_memtime per phase, lane 0 of wave 0 of every workgroup).  The counters live in
@@ -1058,8 +1066,12 @@ __global__ __launch_bounds__(256) void k_sub_split(const SubSplit p, uint8_t* __
   }
 }
 
-template <int R>
-__global__ __launch_bounds__(256) void k_sub_combine(const FbGeom g, cf* __restrict__ X, const uint32_t nseqs /* parts x sequences */)
+// MSUB (freq_res = R * 2^k): the combined spectrum goes to a second buffer in PSEUDO-CHANNEL order -- bin R m' + r of channel c is
+// bin m' of row c*R + r -- and, for real input, the mirror bins L - k where the inverse pass looks for them: row Rr-1-s, bin
+// M' - m' (m' >= 1), row Rr - s, bin 0 (m' = 0).  mo = the caller's freq_res (R * M').
+template <int R, bool MSUB>
+__global__ __launch_bounds__(256) void k_sub_combine(const FbGeom g, cf* __restrict__ X, const uint32_t nseqs /* parts x sequences */,
+                                                     cf* __restrict__ Xout, const uint32_t mo)
 {
   const int logLs = g.logM + g.logR;                     // sub-sequence length L'
   const uint32_t Ls = 1u << logLs, L = Ls * R;
@@ -1095,7 +1107,21 @@ __global__ __launch_bounds__(256) void k_sub_combine(const FbGeom g, cf* __restr
         const cf v = cmul(gq[c], wr[(c * q) % R]);
         acc.x += v.x; acc.y += v.y;
       }
-      base[(uint64_t)q << logLs] = acc;
+      if constexpr (!MSUB) {
+        base[(uint64_t)q << logLs] = acc;
+      } else {
+        const uint32_t kk = k + ((uint32_t)q << logLs);                      // natural bin of the whole transform
+        const uint32_t Rr = (uint32_t)R << g.logR, N = g.real_input ? L >> 1 : L;
+        const bool up = kk > N;                                               // (real input) a mirror bin
+        const uint32_t kq = up ? L - kk : kk;
+        const uint32_t cc = kq / mo, mm = kq - cc * mo, mi = mm / R, r = mm - mi * R, s = cc * R + r;
+        uint32_t row, bin;
+        if (kk == N && g.real_input) { row = Rr >> 1; bin = 0; }              // (never read: the slot nothing else uses)
+        else if (!up) { row = s; bin = mi; }
+        else if (mi) { row = Rr - 1 - s; bin = (1u << g.logM) - mi; }
+        else { row = Rr - s; bin = 0; }
+        Xout[(i >> logLs) * (uint64_t)L + (((((uint64_t)(row >> g.logX3) << g.logM) + bin) << g.logX3) | (row & X3m))] = acc;
+      }
     }
   }
 }
@@ -1312,6 +1338,60 @@ DEV void detect4(const cf p, const cf q, const int state, float (&r)[4])
   if (state == DSPSR_AMD_STOKES) { r[0] = pp + qq; r[1] = pp - qq; r[2] = 2.0f * re; r[3] = 2.0f * im; }
   else { r[0] = pp; r[1] = qq; r[2] = re; r[3] = im; }
 }
+
+#if FB_HAS(3)
+// freq_res = R * 2^k, last step: y[n] = sum_r exp(+2 pi i r n / freq_res) y_r[n mod M'] for the kept samples n of every channel and
+// part, from the pseudo-channels' whole transforms Y[c*R + r][pol][part][M'] (written by the inverse pass as complex rows), into
+// the caller's output: complex rows (kind 1) or detected samples (kind 2; Detection.C:423-474 layouts as in k_inv_chan).
+template <int R>
+__global__ __launch_bounds__(256) void k_time_combine(const TimeCombine p, const FbOut out)
+{
+  const uint32_t Mi = 1u << p.logMi;
+  const uint64_t n = (uint64_t)p.nparts * p.C * p.nkeep;
+  const float inv_mo = 1.0f / (float)p.mo;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t t = (uint32_t)(i % p.nkeep);
+    const uint64_t pc = i / p.nkeep;
+    const uint32_t c = (uint32_t)(pc % p.C), lp = (uint32_t)(pc / p.C);
+    const uint32_t nn = p.nfilt_pos + t, ni = nn & (Mi - 1);
+    cf a = make_float2(0.f, 0.f), b = a;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const cf* __restrict__ y = p.Y + (uint64_t)(c * R + r) * p.y_chan_stride + ((uint64_t)lp << p.logMi) + ni;
+      cf w = make_float2(1.f, 0.f);
+      if (r) {
+        const float x = (float)((uint32_t)((uint64_t)r * nn % p.mo)) * inv_mo;       // revolutions
+        w = make_float2(__builtin_amdgcn_cosf(x), __builtin_amdgcn_sinf(x));
+      }
+      const cf v0 = cmul(y[0], w);
+      a.x += v0.x; a.y += v0.y;
+      if (p.npol == 2) { const cf v1 = cmul(y[p.y_pol_stride], w); b.x += v1.x; b.y += v1.y; }
+    }
+    const uint64_t part = p.part0 + lp;
+    const uint32_t chan = out.chan0 + c;
+    float* __restrict__ row = out.base + chan * out.chan_stride;
+    if (out.kind == 1) {
+      float2* __restrict__ o = (float2*)(row + part * out.part_step) + t;
+      *o = a;
+      if (p.npol == 2) *(float2*)((float*)o + out.pol_stride) = b;
+    } else if (out.kind == 2) {
+      float q[4];
+      detect4(a, b, out.state, q);
+      const uint64_t idat = part * p.nkeep + t;
+      if (out.ndim == 4) ((float4*)row)[idat] = make_float4(q[0], q[1], q[2], q[3]);
+      else if (out.ndim == 2) {
+        ((float2*)row)[idat] = make_float2(q[0], q[1]);
+        ((float2*)(row + out.pol_stride))[idat] = make_float2(q[2], q[3]);
+      } else {
+        row[idat] = q[0];
+        row[out.pol_stride + idat] = q[1];
+        row[2 * out.pol_stride + idat] = q[2];
+        row[3 * out.pol_stride + idat] = q[3];
+      }
+    }
+  }
+}
+#endif
 
 #if FB_HAS(3) || FB_HAS(5)
 // ------------------------------------------------------------------------------------ P3
@@ -3064,7 +3144,8 @@ k1c_t fb_pick_col1(int variant = 1);     // 1: four sub-sequences + radix-4 in r
 k3_t fb_pick_rinv(int logm, bool fold);
 void fb_launch_raw_cols(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_sub_split(hipStream_t stream, const SubSplit& p, uint8_t* out, uint32_t ncu);
-void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu);
+void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu, cf* Xout = nullptr, uint32_t mo = 0);
+void fb_launch_time_combine(hipStream_t stream, const TimeCombine& p, const FbOut& out, uint32_t R, uint32_t ncu);
 void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, cf* Rt, uint64_t part0);
 
@@ -3086,6 +3167,11 @@ k2_t fb_pick2(int logf, bool full) { return logf == 11 ? (full ? k_fwd_rows<11, 
 #endif
 #if FB_HAS(3)
 k3_t fb_pick3(int logf, bool full) { return logf != 12 ? nullptr : (full ? k_inv_chan<12, false, 2> : k_inv_chan<12, false, -1>); }
+void fb_launch_time_combine(hipStream_t stream, const TimeCombine& p, const FbOut& out, uint32_t R, uint32_t ncu)
+{
+  if (R == 3) hipLaunchKernelGGL(k_time_combine<3>, dim3(8 * ncu), dim3(256), 0, stream, p, out);
+  else hipLaunchKernelGGL(k_time_combine<5>, dim3(8 * ncu), dim3(256), 0, stream, p, out);
+}
 #endif
 #if FB_HAS(5)
 k3_t fb_pick3f(int logf, bool full) { return logf != 12 ? nullptr : (full ? k_inv_chan<12, true, 2> : k_inv_chan<12, true, -1>); }
@@ -3130,6 +3216,11 @@ template <int... I> static k3_t pick3(int logf, bool full, iseq<I...>)
   return full ? f[logf] : t[logf];
 }
 k3_t fb_pick3(int logf, bool full) { return pick3(logf, full, seq_t()); }
+void fb_launch_time_combine(hipStream_t stream, const TimeCombine& p, const FbOut& out, uint32_t R, uint32_t ncu)
+{
+  if (R == 3) hipLaunchKernelGGL(k_time_combine<3>, dim3(8 * ncu), dim3(256), 0, stream, p, out);
+  else hipLaunchKernelGGL(k_time_combine<5>, dim3(8 * ncu), dim3(256), 0, stream, p, out);
+}
 #endif
 #if FB_HAS(5)
 template <int... I> static k3_t pick3f(int logf, bool full, iseq<I...>)
@@ -3199,10 +3290,15 @@ void fb_launch_sub_split(hipStream_t stream, const SubSplit& p, uint8_t* out, ui
 {
   hipLaunchKernelGGL(k_sub_split, dim3(8 * ncu), dim3(256), 0, stream, p, out);
 }
-void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu)
+void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu, cf* Xout, uint32_t mo)
 {
-  if (g.nsub == 3) hipLaunchKernelGGL(k_sub_combine<3>, dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs);
-  else hipLaunchKernelGGL(k_sub_combine<5>, dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs);
+  if (!Xout) {
+    if (g.nsub == 3) hipLaunchKernelGGL((k_sub_combine<3, false>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, X, 0u);
+    else hipLaunchKernelGGL((k_sub_combine<5, false>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, X, 0u);
+  } else {
+    if (g.nsub == 3) hipLaunchKernelGGL((k_sub_combine<3, true>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, Xout, mo);
+    else hipLaunchKernelGGL((k_sub_combine<5, true>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, Xout, mo);
+  }
 }
 #endif
 
@@ -3257,6 +3353,12 @@ struct dspsr_amd_filterbank_impl {
   k3b_t k3bf = nullptr;      // four-pass fused fold: second inverse pass that leaves segment sums (FbOut kind 4)
   float* msum = nullptr;     // ... [chan][part][tile][t2][2] float4 of one input channel's sub-band and one block
   size_t msum_floats = 0;
+  // freq_res = 3 * 2^k / 5 * 2^k (msub = 3, 5; see k_time_combine): g and everything above describe the INNER filterbank of
+  // nchan_subband * msub pseudo-channels with freq_res / msub bins and the whole transform kept; cfg and these the caller's
+  uint32_t msub = 0, out_C = 0, out_M = 0, out_nfilt_pos = 0, out_nkeep = 0;
+  cf* Xp = nullptr;          // the combined spectrum in pseudo-channel order (k_sub_combine writes it there)
+  cf* Y = nullptr;           // the pseudo-channels' time series of one launch group [pseudo-channel][pol][part][freq_res / msub]
+  size_t Xp_elems = 0, Y_elems = 0;
 };
 
 }  // namespace dspsr_amd
@@ -3283,16 +3385,34 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   *out = nullptr;
   if (cfg->npol != 1 && cfg->npol != 2)
     return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: npol=%u not 1 or 2", cfg->npol);
-  if (!ispow2(cfg->freq_res) || cfg->freq_res < 2)
+  // freq_res: a power of two, or 3 or 5 times one with a power-of-two nchan_subband (dspsr -x 12288).  The transforms inside a
+  // tile stay powers of two: bins m = R m' + r of a channel are R pseudo-channels of freq_res / R bins (the inner filterbank of
+  // nchan_subband * R channels below, whole transforms kept), whose time series k_time_combine adds with the twiddles
+  // exp(+2 pi i r n / freq_res) -- the decimation-in-frequency form of the freq_res-point backward transform.
+  uint32_t msub = 0;
+  if (!ispow2(cfg->freq_res)) {
+    if (cfg->freq_res % 3 == 0 && ispow2(cfg->freq_res / 3)) msub = 3;
+    else if (cfg->freq_res % 5 == 0 && ispow2(cfg->freq_res / 5)) msub = 5;
+    if (!msub || !ispow2(cfg->nchan_subband) || cfg->freq_res / msub < 2 || cfg->force_four_pass == 1)
+      return fb_fail(ctx, DSPSR_AMD_EINVAL,
+                     "dspsr_amd_filterbank_create: freq_res=%u must be 2^k >= 2, or 3*2^k / 5*2^k (k >= 1) with a power-of-two "
+                     "nchan_subband (freq_res=1 is the non-convolving filterbank, not built yet)", cfg->freq_res);
+  } else if (cfg->freq_res < 2)
     return fb_fail(ctx, DSPSR_AMD_EINVAL,
-                   "dspsr_amd_filterbank_create: freq_res=%u must be a power of two >= 2 "
+                   "dspsr_amd_filterbank_create: freq_res=%u must be >= 2 "
                    "(freq_res=1 is the non-convolving filterbank, not built yet)", cfg->freq_res);
+  if (cfg->nfilt_pos + cfg->nfilt_neg >= cfg->freq_res)
+    return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nfilt_pos+nfilt_neg=%u >= freq_res=%u",
+                   cfg->nfilt_pos + cfg->nfilt_neg, cfg->freq_res);
+  // (the geometry below is built from these: the caller's values, or the inner filterbank's)
+  const uint32_t nchan_sb = msub ? cfg->nchan_subband * msub : cfg->nchan_subband, fres = msub ? cfg->freq_res / msub : cfg->freq_res,
+                 nfpos = msub ? 0u : cfg->nfilt_pos, nfneg = msub ? 0u : cfg->nfilt_neg;
   // nchan_subband: a power of two, or 3 or 5 times one (the forward transform then runs as 3 / 5 interleaved sub-sequences,
-  // k_sub_split / k_sub_combine).  freq_res -- the length of the transforms INSIDE a tile -- stays a power of two.
+  // k_sub_split / k_sub_combine).
   uint32_t nsub = 1;
-  if (!ispow2(cfg->nchan_subband)) {
-    if (cfg->nchan_subband % 3 == 0 && ispow2(cfg->nchan_subband / 3)) nsub = 3;
-    else if (cfg->nchan_subband % 5 == 0 && ispow2(cfg->nchan_subband / 5)) nsub = 5;
+  if (!ispow2(nchan_sb)) {
+    if (nchan_sb % 3 == 0 && ispow2(nchan_sb / 3)) nsub = 3;
+    else if (nchan_sb % 5 == 0 && ispow2(nchan_sb / 5)) nsub = 5;
     else
       return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u must be 2^k, 3*2^k or 5*2^k",
                      cfg->nchan_subband);
@@ -3300,9 +3420,6 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
       return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u (not a power of two) has no four-pass form",
                      cfg->nchan_subband);
   }
-  if (cfg->nfilt_pos + cfg->nfilt_neg >= cfg->freq_res)
-    return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nfilt_pos+nfilt_neg=%u >= freq_res=%u",
-                   cfg->nfilt_pos + cfg->nfilt_neg, cfg->freq_res);
   if (cfg->input_nchan == 0) return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: input_nchan=0");
 
   dspsr_amd_filterbank* fb = new dspsr_amd_filterbank;
@@ -3311,8 +3428,11 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   FbGeom& g = fb->g;
   // (C, Rr, logL, logC describe the power-of-two geometry passes 0-2 run on: one of nsub sub-sequences; fb->N, fb->L and g.C
   //  are the whole transform's)
-  const uint64_t M = cfg->freq_res, C = cfg->nchan_subband / nsub;
-  fb->N = (uint64_t)cfg->nchan_subband * M;
+  const uint64_t M = fres, C = nchan_sb / nsub;
+  fb->msub = msub;
+  fb->out_C = cfg->nchan_subband; fb->out_M = cfg->freq_res; fb->out_nfilt_pos = cfg->nfilt_pos;
+  fb->out_nkeep = cfg->freq_res - cfg->nfilt_pos - cfg->nfilt_neg;
+  fb->N = (uint64_t)nchan_sb * M;
   fb->L = cfg->real_input ? 2 * fb->N : fb->N;
   const uint64_t Rr = fb->L / nsub / M;
   const int logMf = ilog2(M), logL = ilog2(fb->L / nsub), logC = ilog2(C);
@@ -3329,10 +3449,10 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   g.tw_lo = g.tw_lo_m = nullptr;
   g.real_input = cfg->real_input ? 1 : 0;
   g.npol = cfg->npol;
-  g.C = cfg->nchan_subband;
+  g.C = nchan_sb;
   g.nsub = nsub;
-  g.nfilt_pos = cfg->nfilt_pos;
-  g.nkeep = cfg->freq_res - cfg->nfilt_pos - cfg->nfilt_neg;
+  g.nfilt_pos = nfpos;
+  g.nkeep = fres - nfpos - nfneg;
   g.dbg = FB_ENV_INT("DSPSR_AMD_DEBUG", 0);
   fb->nseq = cfg->real_input ? 1 : cfg->npol;
   // tiles: every workgroup holds min(2^14, available) points = 32 per thread
@@ -3581,6 +3701,8 @@ extern "C" void dspsr_amd_filterbank_destroy(dspsr_amd_filterbank* fb)
   if (fb->fpart) (void)hipFree(fb->fpart);
   if (fb->msum) (void)hipFree(fb->msum);
   if (fb->dsub) (void)hipFree(fb->dsub);
+  if (fb->Xp) (void)hipFree(fb->Xp);
+  if (fb->Y) (void)hipFree(fb->Y);
   if (fb->tw_lo) (void)hipFree(fb->tw_lo);
   if (fb->tw_lo_m) (void)hipFree(fb->tw_lo_m);
   delete fb;
@@ -3615,6 +3737,17 @@ extern "C" int dspsr_amd_filterbank_set_kernel(dspsr_amd_filterbank* fb, const f
       }
     src = perm.data();
   }
+  if (fb->msub) {
+    // the inner filterbank's channels are the pseudo-channels (c, r): bin m' of pseudo-channel c*R + r is bin R*m' + r of channel c
+    const uint64_t N = fb->N, R = fb->msub, Mo = fb->out_M, Mi = Mo / R;
+    perm.resize(expect);
+    for (uint64_t ic = 0; ic < fb->cfg.input_nchan; ic++)
+      for (uint64_t k = 0; k < N; k++) {
+        const uint64_t c = k / Mo, m = k - c * Mo, mi = m / R, r = m - mi * R;
+        perm[ic * N + (c * R + r) * Mi + mi] = src[ic * N + k];
+      }
+    src = perm.data();
+  }
   hipError_t e = hipMemcpyAsync(fb->kernel, src, expect * sizeof(cf), hipMemcpyHostToDevice, fb->ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(fb->ctx->stream);
   if (e != hipSuccess)
@@ -3633,7 +3766,7 @@ extern "C" int dspsr_amd_filterbank_sizes(const dspsr_amd_filterbank* fb, uint64
   if (nsamp_fft) *nsamp_fft = fft;
   if (nsamp_overlap) *nsamp_overlap = ovl;
   if (nsamp_step) *nsamp_step = fft - ovl;
-  if (nkeep) *nkeep = fb->g.nkeep;
+  if (nkeep) *nkeep = fb->msub ? fb->out_nkeep : fb->g.nkeep;
   return DSPSR_AMD_OK;
 }
 
@@ -3693,6 +3826,11 @@ static int fb_launch_fused(dspsr_amd_filterbank* fb, k3_t k3, const cf* X, const
   if (nseg > 1) return fold_combine_partials(co.fold, fb->fpart, nseg - 1, co.chan0, g.C);
   return DSPSR_AMD_OK;
 }
+
+// output channels per input channel / kept samples per part as the caller sees them (freq_res = 3 * 2^k / 5 * 2^k: g describes the
+// inner filterbank of pseudo-channels)
+static inline uint32_t fb_out_C(const dspsr_amd_filterbank* fb) { return fb->msub ? fb->out_C : fb->g.C; }
+static inline uint32_t fb_out_nkeep(const dspsr_amd_filterbank* fb) { return fb->msub ? fb->out_nkeep : fb->g.nkeep; }
 
 static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, uint64_t in_chan_stride_bytes_or_floats)
 {
@@ -3764,6 +3902,9 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         if (i3a > per_part_items) per_part_items = i3a;
         if (i3b > per_part_items) per_part_items = i3b;
         while (nb > 1 && per_part_items * nb >= (1ull << 31)) nb /= 2;
+        // (the sub-sequences of a launch group share one de-interleaved block: the parts must start a multiple of nsub samples
+        //  apart -- always so for nchan_subband = nsub * 2^k, for freq_res = nsub * 2^k only when the kept length allows it)
+        if (g.nsub > 1 && in.part_step % g.nsub) nb = 1;
         nb_step = nb;
       }
       if (g.nsub > 1) {
@@ -3820,8 +3961,29 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
           hipLaunchKernelGGL(k2, dim3(grid_for(n2s, fb->ncu * fb->wg_per_cu)), dim3(fb->nt2), fb->lds2, ctx->stream, g, fb->A, fb->X + c * Ls,
                              ctx->tw, nb, fb->nseq, 4u);
         }
-        fb_launch_sub_combine(ctx->stream, g, fb->X, nb * fb->nseq, fb->ncu);
         const uint64_t n3s = (uint64_t)(g.C >> g.logT3) * nb;
+        if (fb->msub) {
+          // freq_res = R * 2^k: the spectrum in pseudo-channel order (second buffer), the inverse pass on the R * nchan_subband
+          // pseudo-channels keeping whole transforms (complex rows into Y), then the radix-R step in time into the caller's output
+          const uint64_t Mi = 1ull << g.logM, xe = (uint64_t)fb->max_parts * fb->nseq * fb->L,
+                         ye = (uint64_t)g.C * g.npol * fb->max_parts * Mi;
+          if (!fb->Xp && hipMalloc((void**)&fb->Xp, xe * sizeof(cf)) != hipSuccess)
+            return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of the pseudo-channel spectrum failed");
+          if (!fb->Y && hipMalloc((void**)&fb->Y, ye * sizeof(cf)) != hipSuccess)
+            return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of the pseudo-channel time series failed");
+          fb_launch_sub_combine(ctx->stream, g, fb->X, nb * fb->nseq, fb->ncu, fb->Xp, fb->out_M);
+          // Y[pseudo-channel][pol][part of the group][Mi] complex: rows (pseudo-channel, pol), parts 2*Mi floats apart
+          FbOut yo = {1, (float*)fb->Y, (uint64_t)g.npol * fb->max_parts * Mi * 2, (uint64_t)fb->max_parts * Mi * 2, Mi * 2, 0, 2, 0};
+          hipLaunchKernelGGL(fb->k3, dim3(grid_for(n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->Xp, kern, yo, ctx->tw,
+                             0ull, nb, nb);
+          TimeCombine tc = {fb->Y, (uint64_t)g.npol * fb->max_parts * Mi, (uint64_t)fb->max_parts * Mi, (uint32_t)g.logM, fb->out_M,
+                            fb->out_nfilt_pos, fb->out_nkeep, fb->out_C, (uint32_t)g.npol, part0, nb};
+          FbOut cu = co;
+          cu.chan0 = ichan * fb->out_C;
+          if (cu.kind == 1 || cu.kind == 2) fb_launch_time_combine(ctx->stream, tc, cu, fb->msub, fb->ncu);
+          continue;
+        }
+        fb_launch_sub_combine(ctx->stream, g, fb->X, nb * fb->nseq, fb->ncu);
         if (co.kind == 3) {
           const int rc = fb_launch_fused(fb, k3, fb->X, kern, co, part0, nb, fused_segmented);
           if (rc != DSPSR_AMD_OK) return rc;
@@ -3970,11 +4132,11 @@ extern "C" int dspsr_amd_filterbank_perform(dspsr_amd_filterbank* fb, const floa
   if (in_step % ndim)
     return fb_fail(fb->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: in_step=%llu not a multiple of ndim",
                    (unsigned long long)in_step);
-  if (out_dev && out_step < 2ull * fb->g.nkeep)
+  if (out_dev && out_step < 2ull * fb_out_nkeep(fb))
     return fb_fail(fb->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: out_step=%llu < 2*nkeep=%u",
-                   (unsigned long long)out_step, 2 * fb->g.nkeep);
-  const uint64_t nchan_out = (uint64_t)fb->cfg.input_nchan * fb->g.C;
-  const uint64_t row = npart ? (npart - 1) * out_step + 2ull * fb->g.nkeep : 0;      // floats one output row spans
+                   (unsigned long long)out_step, 2 * fb_out_nkeep(fb));
+  const uint64_t nchan_out = (uint64_t)fb->cfg.input_nchan * fb_out_C(fb);
+  const uint64_t row = npart ? (npart - 1) * out_step + 2ull * fb_out_nkeep(fb) : 0;      // floats one output row spans
   if (out_dev && npart && ((fb->cfg.npol > 1 && out_pol_stride < row) || (nchan_out > 1 && out_chan_stride < row)))
     return fb_fail(fb->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: output rows of %llu floats overlap "
                    "(chan stride %llu, pol stride %llu)", (unsigned long long)row, (unsigned long long)out_chan_stride,
@@ -4041,7 +4203,7 @@ extern "C" int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, con
   }
   {
     // rows must not overlap: channel-major (TimeSeries FPT order) or plane-major layouts are accepted
-    const uint64_t nchan_out = (uint64_t)fb->cfg.input_nchan * fb->g.C, row = npart * fb->g.nkeep * ndim, planes = 4 / ndim;
+    const uint64_t nchan_out = (uint64_t)fb->cfg.input_nchan * fb_out_C(fb), row = npart * fb_out_nkeep(fb) * ndim, planes = 4 / ndim;
     const bool chan_major = (planes == 1 || det_pol_stride >= row) &&
                             (nchan_out == 1 || det_chan_stride >= (planes - 1) * det_pol_stride + row);
     const bool plane_major = planes > 1 && (nchan_out == 1 || det_chan_stride >= row) &&
@@ -4064,7 +4226,7 @@ extern "C" int dspsr_amd_filterbank_npass(const dspsr_amd_filterbank* fb, int ra
 
 extern "C" int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb)
 {
-  if (!fb) return 0;
+  if (!fb || fb->msub) return 0;            // (freq_res = 3 * 2^k / 5 * 2^k: the last step is a pass of its own, k_time_combine)
   // (segment sums pay when most of the transform is kept: at -F 64:D -x 16384 only 1817 of 16384 samples are, the unfused pass
   //  writes just those, and the fused one measured 541 against 458 us per 8 parts)
   if (fb->g.four_pass)
@@ -4089,7 +4251,7 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
     return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_fold: Cannot detect polarization when npol != 2");
   if (state != DSPSR_AMD_COHERENCE && state != DSPSR_AMD_STOKES)
     return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_fold: invalid state=%d", state);
-  const uint32_t nchan = fb->cfg.input_nchan * fb->g.C;
+  const uint32_t nchan = fb->cfg.input_nchan * fb_out_C(fb);
   // profile shapes: npol 1 x ndim 4 (one float4 per bin, the CPU default, LoadToFoldConfig.C:104) or npol 2 x ndim 2 (rows
   // (PP, QQ) and (Re, Im): what the reference's GPU pipeline detects and folds, LoadToFold1.C:1105-1109)
   const bool planes2 = fold->npol == 2 && fold->ndim == 2;
@@ -4159,7 +4321,7 @@ extern "C" int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const
   }
   const int fmode = dspsr_amd_filterbank_fold_is_fused(fb);
   if ((fmode != 1 && fmode != 2) || !prof_vec4 || fold_plan_max_run(fold) >= (uint32_t)FB_ENV_INT("DSPSR_AMD_FUSED_MAX_RUN", (int)FOLD_FUSED_MAX_RUN)) {
-    const uint64_t row = npart * fb->g.nkeep * 4;                       // floats per channel
+    const uint64_t row = npart * fb_out_nkeep(fb) * 4;                       // floats per channel
     const size_t need = (size_t)row * nchan;
     if (!need) return DSPSR_AMD_OK;
     if (need > fb->det_floats) {

@@ -80,7 +80,10 @@ typedef struct {
                                2^k, 3 * 2^k or 5 * 2^k (dspsr -F 96:D, -F 320:D: the reference plans any length,
                                Filterbank.C:107-155; here the forward transform of 3 / 5 interleaved sub-sequences + one
                                radix-3 / radix-5 step; freq_res <= 8192 then) */
-  uint32_t freq_res;        /* response ndat = backward FFT length, a power of two >= 2       Filterbank.C:93  */
+  uint32_t freq_res;        /* response ndat = backward FFT length                            Filterbank.C:93
+                               2^k >= 2, or 3 * 2^k / 5 * 2^k with a power-of-two nchan_subband (dspsr -x 12288): bins R m' + r of
+                               a channel are R pseudo-channels of freq_res / R bins through the power-of-two passes, one radix-R
+                               step in time adds their transforms (a pass of its own: fold_is_fused() == 0; freq_res / R <= 8192) */
   uint32_t nfilt_pos;       /* response impulse_pos                       Filterbank.C:90  */
   uint32_t nfilt_neg;       /* response impulse_neg                       Filterbank.C:91  */
   uint32_t input_nchan;     /* input channels (kernel has input_nchan*nchan_subband*freq_res bins) */

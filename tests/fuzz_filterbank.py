@@ -47,6 +47,12 @@ for i in range(ncases):
         R = int(rng.choice([3, 5]))
         C = R * (C >> 2) if C >= 8 else C
         kw["four_pass"] = 0
+    elif rng.integers(0, 6) == 0 and 3 <= logM <= 15 and logN - logM <= 12:
+        # freq_res = 3 * 2^k / 5 * 2^k: pseudo-channels of freq_res / R bins + one radix-R step in time (k_time_combine)
+        R = int(rng.choice([3, 5]))
+        M = R * (M >> 2)
+        pos, neg = int(rng.integers(0, max(1, M // 3))), int(rng.integers(0, max(1, M // 3)))
+        kw["four_pass"] = 0
     if rng.integers(0, 6) == 0:
         # the two-pass family of short responses (complex dual-pol, nchan_subband * freq_res^2 == 2^27): 8-bit blocks take the
         # two-pass kernels (or, four_pass = 2, the three-pass ones), float32 rows always the three-pass ones

@@ -212,3 +212,76 @@ def test_rejected_channel_counts(gpu):
     for C in (7, 9, 100, 6 * 7):
         with pytest.raises(dspsr_amd.DspsrAmdError):
             dspsr_amd.FilterbankEngine(ctx).setup(C, 256, 5, 5, 1, 2, True, None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# freq_res = 3 * 2^k / 5 * 2^k (dspsr -x 12288; the reference plans any length, Filterbank.C:107-155): R pseudo-channels of
+# freq_res / R bins per channel through the power-of-two passes, then one radix-R step in time (k_time_combine)
+@pytest.mark.parametrize("C,M,nfilt,npart,kw", [
+    (16, 3 * 256, (50, 41), 3, dict(max_parts=2)),                      # real dual-pol 8-bit
+    (8, 5 * 128, (33, 20), 2, dict()),                                  # radix 5
+    (64, 3 * 512, (100, 101), 2, dict(real=False)),                     # complex dual-pol: no mirror rows
+    (32, 3 * 64, (7, 9), 2, dict(npol=1)),                              # one polarisation
+    (4, 3 * 4096, (1000, 900), 2, dict(layout="caspsr")),               # -x 12288, CASPSR byte order
+    (16, 5 * 256, (60, 60), 3, dict(use_raw=False, max_parts=2)),       # float32 rows, ragged launch groups
+    (8, 3 * 128, (20, 21), 2, dict(input_nchan=2, real=False)),         # two input channels
+    (128, 3 * 2, (1, 1), 2, dict()),                                    # the shortest inner transform
+])
+def test_filterbank_freq_res_three_five_times_power_of_two(oracle, gpu, C, M, nfilt, npart, kw):
+    _fb_case(oracle, gpu, C, M, nfilt, npart, **kw)
+
+
+def test_freq_res_not_power_of_two_detected_and_folded(oracle, gpu):
+    """The same geometry through perform_detect (every ndim / state) and perform_fold (separate Detection + Fold launches:
+    fold_is_fused() == 0) against the oracle's filterbank + detection + fold."""
+    dspsr_amd, ctx = gpu
+    o = oracle
+    C, M, nfilt_pos, nfilt_neg, npart = 16, 3 * 256, 50, 41, 3
+    N = C * M
+    rng = np.random.default_rng(5)
+    kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, N)).astype(np.complex64)
+    obs = o.Observation(nchan=1, npol=2, ndim=1, machine="DADA")
+    plan = o.FilterbankPlan(C, 1, C, M, N, nfilt_pos, nfilt_neg, nfilt_pos + nfilt_neg, 2 * N, 2 * (nfilt_pos + nfilt_neg) * C, 0,
+                            M - nfilt_pos - nfilt_neg, float(N) * M, True)
+    plan.nsamp_step = plan.nsamp_fft - plan.nsamp_overlap
+    ndat = npart * plan.nsamp_step + plan.nsamp_overlap
+    raw = np.clip(np.rint(rng.standard_normal(ndat * 2) * 24.0), -128, 127).astype(np.int8)
+    ref = o.filterbank(o.unpack_8bit(raw, obs), plan, kernel, npart=npart, dtype=np.float64)       # [chan][pol][t] complex
+    eng = dspsr_amd.FilterbankEngine(ctx).setup(C, M, nfilt_pos, nfilt_neg, 1, 2, True, kernel, max_parts=2)
+    assert eng.fold_is_fused() == 0 and eng.nkeep == plan.nkeep
+    d_raw = torch.from_numpy(raw).cuda()
+    nout = npart * plan.nkeep
+    p, q = ref[:, 0, :], ref[:, 1, :]
+    coh = np.stack([np.abs(p) ** 2, np.abs(q) ** 2, (p * np.conj(q)).real, -(p * np.conj(q)).imag], axis=-1)     # cross_detect.ic:23-43
+    scale = np.abs(coh).max()
+    for ndim in (4, 2, 1):
+        det = torch.zeros((C, 4 // ndim, nout * ndim), dtype=torch.float32, device="cuda")
+        eng.perform_detect(det, npart, dspsr_amd.COHERENCE, ndim, raw=d_raw, scale=float(o.S8))
+        eng.finish()
+        g = det.cpu().numpy().reshape(C, 4 // ndim, nout, ndim).transpose(0, 2, 1, 3).reshape(C, nout, 4)
+        assert np.abs(g - coh).max() <= 2e-5 * scale, (ndim, np.abs(g - coh).max() / scale)
+    # fold: 64 bins, against the time-order sums of the oracle's detected samples
+    nbin = 64
+    fold = dspsr_amd.FoldEngine(ctx)
+    fold.set_shape(C, 1, 4, nbin)
+    fold.set_nbin(nbin)
+    fold.set_ndat(nout, 0)
+    hits = np.zeros(nbin, np.uint32)
+    fold.set_bins(0.3, 1.0 / 97.3, nout, 0, hits)
+    eng.perform_fold(fold, npart, dspsr_amd.COHERENCE, raw=d_raw, scale=float(o.S8))
+    binplan = o.fold_binplan(0.3, 1.0 / 97.3, nbin, nout)
+    want = np.zeros((C, nbin, 4))
+    for i in range(nout):
+        want[:, binplan[i], :] += coh[:, i, :]
+    got = fold.synch().reshape(C, nbin, 4)
+    assert np.array_equal(hits, np.bincount(binplan, minlength=nbin).astype(np.uint32))
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+    fold.close()
+    eng.close()
+
+
+def test_freq_res_other_lengths_are_refused(gpu):
+    dspsr_amd, ctx = gpu
+    for C, M in ((16, 7 * 64), (16, 9 * 64), (24, 3 * 64), (16, 3)):
+        with pytest.raises(dspsr_amd.DspsrAmdError):
+            dspsr_amd.FilterbankEngine(ctx).setup(C, M, 1, 1, 1, 2, True, None)
