@@ -285,3 +285,26 @@ def test_freq_res_other_lengths_are_refused(gpu):
     for C, M in ((16, 7 * 64), (16, 9 * 64), (24, 3 * 64), (16, 3)):
         with pytest.raises(dspsr_amd.DspsrAmdError):
             dspsr_amd.FilterbankEngine(ctx).setup(C, M, 1, 1, 1, 2, True, None)
+
+
+def test_freq_res_not_power_of_two_through_the_pipeline(gpu):
+    """LoadToFold with -F 16:D -x 3072 (Detection and Fold as separate launches): every output sample lands in a phase bin and the
+    folded profile equals the sum of the detected block the pipeline keeps, bin by bin in time order."""
+    dspsr_amd, ctx = gpu
+    from dspsr_amd import pipeline
+    info = pipeline.InputInfo(centre_frequency=1382.0, bandwidth=-64.0, nchan=1, npol=2, ndim=1, tsamp_us=1.0 / 128.0, machine="DADA")
+    cfg = pipeline.Config(nchan=16, dispersion_measure=10.0, nbin=64, folding_period=0.00123, freq_res=3072, ndim=4, parts_per_block=6, max_parts=4)
+    lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    assert not lt.fused_fold and lt.fb.npass(True) == 3 and lt.nkeep == 3072 - lt.response.impulse_pos - lt.response.impulse_neg
+    raw = torch.from_numpy(_raw(lt.block_bytes() // 2, 2, 1, 1, seed=21)).cuda()
+    lt.process_block(raw)
+    lt.finish_subint()
+    lt.synchronize()
+    sub = lt.subints[-1]
+    ndat = 6 * lt.nkeep
+    assert int(sub["hits"].sum()) == ndat
+    prof = sub["profile_dev"].cpu().numpy().reshape(16, 64, 4)
+    det = lt.detected.view(16, ndat, 4).cpu().numpy()
+    assert np.isfinite(prof).all() and np.abs(prof).max() > 0
+    assert np.allclose(prof.sum(axis=1), det.sum(axis=1), rtol=2e-4, atol=1e-3 * np.abs(det).max())
+    lt.close()
