@@ -226,6 +226,8 @@ def test_rejected_channel_counts(gpu):
     (16, 5 * 256, (60, 60), 3, dict(use_raw=False, max_parts=2)),       # float32 rows, ragged launch groups
     (8, 3 * 128, (20, 21), 2, dict(input_nchan=2, real=False)),         # two input channels
     (128, 3 * 2, (1, 1), 2, dict()),                                    # the shortest inner transform
+    (1, 3 * 4096, (500, 400), 2, dict()),                               # one channel (dsp::Convolution shape)
+    (2, 5 * 8192, (3000, 2000), 1, dict(real=False)),                   # the longest inner transform
 ])
 def test_filterbank_freq_res_three_five_times_power_of_two(oracle, gpu, C, M, nfilt, npart, kw):
     _fb_case(oracle, gpu, C, M, nfilt, npart, **kw)
