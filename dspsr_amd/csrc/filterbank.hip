@@ -1069,9 +1069,10 @@ __global__ __launch_bounds__(256) void k_sub_split(const SubSplit p, uint8_t* __
 // MSUB (freq_res = R * 2^k): the combined spectrum goes to a second buffer in PSEUDO-CHANNEL order -- bin R m' + r of channel c is
 // bin m' of row c*R + r -- and, for real input, the mirror bins L - k where the inverse pass looks for them: row Rr-1-s, bin
 // M' - m' (m' >= 1), row Rr - s, bin 0 (m' = 0).  mo = the caller's freq_res (R * M').
+// rm = the factor of freq_res (the radix R of this kernel is nsub = rm times the odd factor of nchan_subband).
 template <int R, bool MSUB>
 __global__ __launch_bounds__(256) void k_sub_combine(const FbGeom g, cf* __restrict__ X, const uint32_t nseqs /* parts x sequences */,
-                                                     cf* __restrict__ Xout, const uint32_t mo)
+                                                     cf* __restrict__ Xout, const uint32_t mo, const uint32_t rm)
 {
   const int logLs = g.logM + g.logR;                     // sub-sequence length L'
   const uint32_t Ls = 1u << logLs, L = Ls * R;
@@ -1114,7 +1115,7 @@ __global__ __launch_bounds__(256) void k_sub_combine(const FbGeom g, cf* __restr
         const uint32_t Rr = (uint32_t)R << g.logR, N = g.real_input ? L >> 1 : L;
         const bool up = kk > N;                                               // (real input) a mirror bin
         const uint32_t kq = up ? L - kk : kk;
-        const uint32_t cc = kq / mo, mm = kq - cc * mo, mi = mm / R, r = mm - mi * R, s = cc * R + r;
+        const uint32_t cc = kq / mo, mm = kq - cc * mo, mi = mm / rm, r = mm - mi * rm, s = cc * rm + r;
         uint32_t row, bin;
         if (kk == N && g.real_input) { row = Rr >> 1; bin = 0; }              // (never read: the slot nothing else uses)
         else if (!up) { row = s; bin = mi; }
@@ -3144,7 +3145,8 @@ k1c_t fb_pick_col1(int variant = 1);     // 1: four sub-sequences + radix-4 in r
 k3_t fb_pick_rinv(int logm, bool fold);
 void fb_launch_raw_cols(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_sub_split(hipStream_t stream, const SubSplit& p, uint8_t* out, uint32_t ncu);
-void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu, cf* Xout = nullptr, uint32_t mo = 0);
+void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu, cf* Xout = nullptr, uint32_t mo = 0,
+                           uint32_t rm = 1);
 void fb_launch_time_combine(hipStream_t stream, const TimeCombine& p, const FbOut& out, uint32_t R, uint32_t ncu);
 void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, cf* Rt, uint64_t part0);
@@ -3169,8 +3171,14 @@ k2_t fb_pick2(int logf, bool full) { return logf == 11 ? (full ? k_fwd_rows<11, 
 k3_t fb_pick3(int logf, bool full) { return logf != 12 ? nullptr : (full ? k_inv_chan<12, false, 2> : k_inv_chan<12, false, -1>); }
 void fb_launch_time_combine(hipStream_t stream, const TimeCombine& p, const FbOut& out, uint32_t R, uint32_t ncu)
 {
-  if (R == 3) hipLaunchKernelGGL(k_time_combine<3>, dim3(8 * ncu), dim3(256), 0, stream, p, out);
-  else hipLaunchKernelGGL(k_time_combine<5>, dim3(8 * ncu), dim3(256), 0, stream, p, out);
+  switch (R) {
+    case 3: hipLaunchKernelGGL(k_time_combine<3>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+    case 5: hipLaunchKernelGGL(k_time_combine<5>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+    case 7: hipLaunchKernelGGL(k_time_combine<7>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+    case 9: hipLaunchKernelGGL(k_time_combine<9>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+    case 15: hipLaunchKernelGGL(k_time_combine<15>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+    default: break;
+  }
 }
 #endif
 #if FB_HAS(5)
@@ -3218,8 +3226,14 @@ template <int... I> static k3_t pick3(int logf, bool full, iseq<I...>)
 k3_t fb_pick3(int logf, bool full) { return pick3(logf, full, seq_t()); }
 void fb_launch_time_combine(hipStream_t stream, const TimeCombine& p, const FbOut& out, uint32_t R, uint32_t ncu)
 {
-  if (R == 3) hipLaunchKernelGGL(k_time_combine<3>, dim3(8 * ncu), dim3(256), 0, stream, p, out);
-  else hipLaunchKernelGGL(k_time_combine<5>, dim3(8 * ncu), dim3(256), 0, stream, p, out);
+  switch (R) {
+    case 3: hipLaunchKernelGGL(k_time_combine<3>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+    case 5: hipLaunchKernelGGL(k_time_combine<5>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+    case 7: hipLaunchKernelGGL(k_time_combine<7>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+    case 9: hipLaunchKernelGGL(k_time_combine<9>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+    case 15: hipLaunchKernelGGL(k_time_combine<15>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+    default: break;
+  }
 }
 #endif
 #if FB_HAS(5)
@@ -3290,15 +3304,15 @@ void fb_launch_sub_split(hipStream_t stream, const SubSplit& p, uint8_t* out, ui
 {
   hipLaunchKernelGGL(k_sub_split, dim3(8 * ncu), dim3(256), 0, stream, p, out);
 }
-void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu, cf* Xout, uint32_t mo)
+void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu, cf* Xout, uint32_t mo, uint32_t rm)
 {
-  if (!Xout) {
-    if (g.nsub == 3) hipLaunchKernelGGL((k_sub_combine<3, false>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, X, 0u);
-    else hipLaunchKernelGGL((k_sub_combine<5, false>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, X, 0u);
-  } else {
-    if (g.nsub == 3) hipLaunchKernelGGL((k_sub_combine<3, true>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, Xout, mo);
-    else hipLaunchKernelGGL((k_sub_combine<5, true>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, Xout, mo);
-  }
+#define FB_SUBC(R)                                                                                                              \
+  case R:                                                                                                                       \
+    if (!Xout) hipLaunchKernelGGL((k_sub_combine<R, false>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, X, 0u, 1u);        \
+    else hipLaunchKernelGGL((k_sub_combine<R, true>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, Xout, mo, rm);          \
+    break;
+  switch (g.nsub) { FB_SUBC(3) FB_SUBC(5) FB_SUBC(7) FB_SUBC(9) FB_SUBC(15) default: break; }
+#undef FB_SUBC
 }
 #endif
 
@@ -3389,14 +3403,18 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   // tile stay powers of two: bins m = R m' + r of a channel are R pseudo-channels of freq_res / R bins (the inner filterbank of
   // nchan_subband * R channels below, whole transforms kept), whose time series k_time_combine adds with the twiddles
   // exp(+2 pi i r n / freq_res) -- the decimation-in-frequency form of the freq_res-point backward transform.
+  // (odd factors 3, 5, 7, 9, 15 of either length; both lengths at once as long as the product of the two factors is one of those)
+  auto odd_part = [](uint32_t v) { while (v && !(v & 1)) v >>= 1; return v; };
+  auto radix_ok = [](uint32_t r) { return r == 3 || r == 5 || r == 7 || r == 9 || r == 15; };
   uint32_t msub = 0;
   if (!ispow2(cfg->freq_res)) {
-    if (cfg->freq_res % 3 == 0 && ispow2(cfg->freq_res / 3)) msub = 3;
-    else if (cfg->freq_res % 5 == 0 && ispow2(cfg->freq_res / 5)) msub = 5;
-    if (!msub || !ispow2(cfg->nchan_subband) || cfg->freq_res / msub < 2 || cfg->force_four_pass == 1)
+    msub = odd_part(cfg->freq_res);
+    if (!radix_ok(msub) || cfg->nchan_subband == 0 || !(ispow2(cfg->nchan_subband) || radix_ok(odd_part(cfg->nchan_subband) * msub)) ||
+        cfg->freq_res / msub < 2 || cfg->force_four_pass == 1)
       return fb_fail(ctx, DSPSR_AMD_EINVAL,
-                     "dspsr_amd_filterbank_create: freq_res=%u must be 2^k >= 2, or 3*2^k / 5*2^k (k >= 1) with a power-of-two "
-                     "nchan_subband (freq_res=1 is the non-convolving filterbank, not built yet)", cfg->freq_res);
+                     "dspsr_amd_filterbank_create: freq_res=%u must be 2^k >= 2, or 2^k (k >= 1) times 3, 5, 7, 9 or 15 (times the odd "
+                     "factor of nchan_subband=%u: again one of those; freq_res=1 is the non-convolving filterbank, not built yet)",
+                     cfg->freq_res, cfg->nchan_subband);
   } else if (cfg->freq_res < 2)
     return fb_fail(ctx, DSPSR_AMD_EINVAL,
                    "dspsr_amd_filterbank_create: freq_res=%u must be >= 2 "
@@ -3411,10 +3429,9 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   // k_sub_split / k_sub_combine).
   uint32_t nsub = 1;
   if (!ispow2(nchan_sb)) {
-    if (nchan_sb % 3 == 0 && ispow2(nchan_sb / 3)) nsub = 3;
-    else if (nchan_sb % 5 == 0 && ispow2(nchan_sb / 5)) nsub = 5;
-    else
-      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u must be 2^k, 3*2^k or 5*2^k",
+    nsub = nchan_sb ? odd_part(nchan_sb) : 0;
+    if (!radix_ok(nsub))
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u must be 2^k or 2^k times 3, 5, 7, 9 or 15",
                      cfg->nchan_subband);
     if (cfg->force_four_pass == 1)
       return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u (not a power of two) has no four-pass form",
@@ -3971,7 +3988,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
             return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of the pseudo-channel spectrum failed");
           if (!fb->Y && hipMalloc((void**)&fb->Y, ye * sizeof(cf)) != hipSuccess)
             return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of the pseudo-channel time series failed");
-          fb_launch_sub_combine(ctx->stream, g, fb->X, nb * fb->nseq, fb->ncu, fb->Xp, fb->out_M);
+          fb_launch_sub_combine(ctx->stream, g, fb->X, nb * fb->nseq, fb->ncu, fb->Xp, fb->out_M, fb->msub);
           // Y[pseudo-channel][pol][part of the group][Mi] complex: rows (pseudo-channel, pol), parts 2*Mi floats apart
           FbOut yo = {1, (float*)fb->Y, (uint64_t)g.npol * fb->max_parts * Mi * 2, (uint64_t)fb->max_parts * Mi * 2, Mi * 2, 0, 2, 0};
           hipLaunchKernelGGL(fb->k3, dim3(grid_for(n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->Xp, kern, yo, ctx->tw,

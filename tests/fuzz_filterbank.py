@@ -44,13 +44,13 @@ for i in range(ncases):
     npart = int(rng.integers(1, 4)) if logN <= 19 else int(rng.integers(1, 3))
     if rng.integers(0, 6) == 0 and logN - logM >= 3 and logM <= 13:
         # nchan_subband = 3 * 2^k / 5 * 2^k: interleaved sub-sequences + one radix-3 / radix-5 step (three-pass geometries)
-        R = int(rng.choice([3, 5]))
-        C = R * (C >> 2) if C >= 8 else C
+        R = int(rng.choice([3, 5, 7, 9, 15]))
+        C = R * (C >> (2 if R < 7 else 3 if R < 15 else 4)) if C >= 16 else C
         kw["four_pass"] = 0
     elif rng.integers(0, 6) == 0 and 3 <= logM <= 15 and logN - logM <= 12:
         # freq_res = 3 * 2^k / 5 * 2^k: pseudo-channels of freq_res / R bins + one radix-R step in time (k_time_combine)
-        R = int(rng.choice([3, 5]))
-        M = R * (M >> 2)
+        R = int(rng.choice([3, 5, 7, 9, 15]))
+        M = R * (M >> (2 if R < 7 else 3))
         pos, neg = int(rng.integers(0, max(1, M // 3))), int(rng.integers(0, max(1, M // 3)))
         kw["four_pass"] = 0
     if rng.integers(0, 6) == 0:

@@ -209,7 +209,7 @@ def test_non_power_of_two_channels_fused_fold_bit_identical(oracle, gpu):
 
 def test_rejected_channel_counts(gpu):
     dspsr_amd, ctx = gpu
-    for C in (7, 9, 100, 6 * 7):
+    for C in (11, 13, 100, 6 * 11, 25):
         with pytest.raises(dspsr_amd.DspsrAmdError):
             dspsr_amd.FilterbankEngine(ctx).setup(C, 256, 5, 5, 1, 2, True, None)
 
@@ -228,6 +228,14 @@ def test_rejected_channel_counts(gpu):
     (128, 3 * 2, (1, 1), 2, dict()),                                    # the shortest inner transform
     (1, 3 * 4096, (500, 400), 2, dict()),                               # one channel (dsp::Convolution shape)
     (2, 5 * 8192, (3000, 2000), 1, dict(real=False)),                   # the longest inner transform
+    (16, 7 * 64, (30, 21), 2, dict()),                                  # other small odd factors: 7, 9, 15
+    (8, 9 * 128, (100, 50), 2, dict(real=False)),
+    (32, 15 * 32, (40, 41), 3, dict(max_parts=2)),
+    (56, 256, (20, 21), 2, dict()),                                     # ... of the channel count (-F 56:D, -F 36:D, -F 60:D)
+    (36, 512, (40, 30), 2, dict(real=False)),
+    (60, 128, (9, 10), 3, dict(layout="caspsr", max_parts=2)),
+    (96, 3 * 256, (50, 41), 2, dict()),                                 # both lengths at once: -F 96:D -x 768 (9 sub-sequences)
+    (80, 3 * 128, (20, 21), 2, dict(real=False)),                       # 5 x 3
 ])
 def test_filterbank_freq_res_three_five_times_power_of_two(oracle, gpu, C, M, nfilt, npart, kw):
     _fb_case(oracle, gpu, C, M, nfilt, npart, **kw)
@@ -284,7 +292,7 @@ def test_freq_res_not_power_of_two_detected_and_folded(oracle, gpu):
 
 def test_freq_res_other_lengths_are_refused(gpu):
     dspsr_amd, ctx = gpu
-    for C, M in ((16, 7 * 64), (16, 9 * 64), (24, 3 * 64), (16, 3)):
+    for C, M in ((16, 11 * 64), (16, 13 * 64), (24, 5 * 64 * 3), (80, 5 * 64), (16, 3)):
         with pytest.raises(dspsr_amd.DspsrAmdError):
             dspsr_amd.FilterbankEngine(ctx).setup(C, M, 1, 1, 1, 2, True, None)
 
