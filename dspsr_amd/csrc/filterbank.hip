@@ -3928,6 +3928,9 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         // nchan_subband = 3 * 2^k / 5 * 2^k: the group's samples as nsub interleaved sub-sequences, passes 0-2 on each (the
         // power-of-two geometry), one radix-nsub step on the sub-spectra, then the inverse pass on nsub << logR rows
         const uint32_t R = g.nsub;
+        if (in.kind == 4)
+          return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: 16-bit UWB blocks need power-of-two nchan_subband and "
+                         "freq_res (k_sub_split de-interleaves 8-bit and float32 input)");
         const uint32_t ndim = g.real_input ? 1u : 2u;
         const uint64_t step = in.part_step, nper = ((uint64_t)(nb - 1) * step + fb->L) / R;       // (step and L are multiples of nsub)
         const size_t es = in.kind == 0 ? (size_t)g.npol * ndim * sizeof(float) : (size_t)g.npol * ndim;   // bytes per sample, all pols
