@@ -58,3 +58,66 @@ def test_sub_sequence_decomposition_equals_direct(R, logLs, logM):
     # spectrum rows of M bins: row of bin k + q L' is q * (L'/M) + k // M
     rows = (np.arange(L) // M).reshape(R, Ls // M, M)
     assert np.array_equal(rows[:, :, 0], np.arange(R)[:, None] * (Ls // M) + np.arange(Ls // M)[None, :])
+
+
+@pytest.mark.parametrize("R,C,logMi,real", [(3, 4, 4, True), (5, 2, 3, True), (3, 8, 3, False), (9, 2, 2, True), (15, 1, 3, False)])
+def test_pseudo_channel_decomposition_equals_direct(R, C, logMi, real):
+    """freq_res = R * 2^k (csrc/filterbank.hip, k_sub_combine<R, true> + k_inv_chan + k_time_combine<R>): bin R m' + r of channel c
+    is bin m' of pseudo-channel row c*R + r; for real input (two polarisations packed as one complex sequence of L = 2N points)
+    the mirror bin L - k goes where the inverse pass looks for it -- row Rr-1-s, bin M'-m' (m' >= 1), row Rr-s, bin 0 (m' = 0);
+    whole M'-point backward transforms per row, then y[n] = sum_r exp(+2 pi i r n / M) y_r[n mod M'].  Equals the direct
+    formulation of Filterbank.C:561-662 with freq_res = M = R * M'."""
+    Mi = 1 << logMi
+    M = R * Mi
+    N = C * M
+    rng = np.random.default_rng(3)
+    H = np.exp(1j * rng.uniform(-np.pi, np.pi, N))
+    if real:
+        p0, p1 = rng.standard_normal(2 * N), rng.standard_normal(2 * N)
+        X0, X1 = np.fft.rfft(p0)[:N] * H, np.fft.rfft(p1)[:N] * H
+        L, Rr = 2 * N, 2 * C * R
+        Z = np.fft.fft(p0 + 1j * p1)
+    else:
+        z0 = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+        X0 = np.fft.fft(z0) * H
+        X1 = X0
+        L, Rr = N, C * R
+        Z = np.fft.fft(z0)
+    want = [np.stack([np.fft.ifft(X[c * M:(c + 1) * M]) * M for c in range(C)]) for X in (X0, X1)]
+    # the permuted spectrum rows[row][bin] and chirp
+    rows = np.zeros((Rr, Mi), complex)
+    Hp = np.zeros((C * R, Mi), complex)
+    for kk in range(L):
+        up = real and kk > N
+        if real and kk == N:
+            continue
+        kq = L - kk if up else kk
+        c, mm = divmod(kq, M)
+        mi, r = divmod(mm, R)
+        s = c * R + r
+        if not up:
+            rows[s, mi] = Z[kk]
+            Hp[s, mi] = H[kq]
+        elif mi:
+            rows[Rr - 1 - s, Mi - mi] = Z[kk]
+        else:
+            rows[Rr - s, 0] = Z[kk]
+    # the inverse pass on pseudo-channel row s: Hermitian split exactly as k_inv_chan reads its mirror, chirp, backward transform
+    got0, got1 = np.zeros((C, M), complex), np.zeros((C, M), complex)
+    n = np.arange(M)
+    for c in range(C):
+        for r in range(R):
+            s = c * R + r
+            a = rows[s]
+            if real:
+                b = np.empty(Mi, complex)
+                b[1:] = rows[Rr - 1 - s, Mi - np.arange(1, Mi)]
+                b[0] = rows[Rr - s, 0] if s else rows[0, 0]
+                x0, x1 = 0.5 * (a + np.conj(b)), -0.5j * (a - np.conj(b))
+            else:
+                x0 = x1 = a
+            y0, y1 = np.fft.ifft(x0 * Hp[s]) * Mi, np.fft.ifft(x1 * Hp[s]) * Mi
+            w = np.exp(2j * np.pi * r * n / M)
+            got0[c] += w * y0[n % Mi]
+            got1[c] += w * y1[n % Mi]
+    assert np.allclose(got0, want[0]) and np.allclose(got1, want[1])
