@@ -2720,8 +2720,19 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
   // the burst blocked every wave in its load instructions for a quarter of the tile while the memory pipeline, still
   // draining the previous tile's stores, accepted them (stamps: 11.6k of 45.7k cycles, and as many again at the next barrier).
   // chunk < 0: all elements; otherwise the elements i with i % NCH == chunk.
-  constexpr int NMID = P::NS >= 3 ? 2 : (P::NS == 2 ? 1 : 0);
-  constexpr int NCH = 1 + (BLOCKED ? 1 : 0) + NMID;
+#ifndef FB_INVA_NMID_MAX
+#define FB_INVA_NMID_MAX 2     // experiment: 0 = the prefetch behind the split and inside the order exchange only
+#endif
+  // (measured at cfg1opt / cfg1, same box: one burst 63.7k / 10.0k Msamples/s, two groups 67.2k / 9.9k, four 77.3k / 10.3-10.6k,
+  //  five 75.1k, six 77.1k: four it is -- the natural order has no exchange to hide a group in and takes one in front of the
+  //  copy-out stores instead)
+  constexpr int CO_CHUNK = BLOCKED ? 0 : 1;
+  constexpr int NMID0 = P::NS, NMID = NMID0 < FB_INVA_NMID_MAX ? NMID0 : FB_INVA_NMID_MAX;
+#ifdef FB_INVA_ONE_BURST
+  constexpr int NCH = 1;
+#else
+  constexpr int NCH = 1 + (BLOCKED ? 1 : 0) + NMID + CO_CHUNK;
+#endif
   auto fetch = [&](const uint32_t item, Abk (&raw)[PTS / 2], const int chunk) {
     const uint32_t r = (FB_DBG(g) & 256) ? item % per_part : item / nparts, part = (FB_DBG(g) & 256) ? item / per_part : item - r * nparts;
     const uint32_t c = r >> logNt, tile = r & (ntile - 1);
@@ -2876,7 +2887,7 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
 #pragma unroll
       for (int i = 0; i < PTS / 2; i++)
         *(float4*)&lds[thr_st + inc(Dst, i)] = make_float4(x[i].x[0], x[i].x[1], x[i].y[0], x[i].y[1]);
-      fetch(nitem, raw, 1);
+      if (NCH > 1) fetch(nitem, raw, 1);
       __syncthreads();
 #pragma unroll
       for (int g2 = 0; g2 < P::G1; g2 += 2)
@@ -2906,10 +2917,11 @@ __global__ __launch_bounds__(512) void k_inv_a(const FbGeom g, const cf* __restr
       }
     };
     auto mid = [&](const int phase) {
-      if (phase >= 1 && phase <= NMID) fetch(nitem, raw, (BLOCKED ? 1 : 0) + phase);
+      if (NCH > 1 && phase >= 1 && phase <= NMID) fetch(nitem, raw, (BLOCKED ? 1 : 0) + phase);
     };
     wgfft<LOGF, +1, true>(lds, ltw_off, tid, logT, x, store, mid);
     __syncthreads();
+    if (CO_CHUNK && NCH > 1) fetch(nitem, raw, NCH - 1);
 #if defined(FB_STAMPS) && FB_STAMPS == 4
     STAMP(ts3);
 #endif
