@@ -250,15 +250,22 @@ def algorithmic_bytes_per_part(npol, nsamp_fft, nbit, N, nchan_subband, nkeep):
 
 def measured_traffic(workload, max_parts, key="hbm_bytes_per_launch_group"):
     """HBM bytes per launch group (or, cfg5 / fold: per launch of the roofline kernel) from the committed PMC profile
-    (tools/pmc_traffic.sh; rocprofv3 cannot run inside the bench); None when the newest profile of the workload was taken
-    for another grouping."""
+    (tools/pmc_traffic.sh; rocprofv3 cannot run inside the bench).  Only a profile taken with THIS library counts: the file
+    carries the build id of the library it was collected on (dspsr_amd_build_id(): sha256 of the sources), and a file whose
+    id differs from the loaded library's -- or that has none -- is refused (traffic: null, the reason in traffic_source)."""
     import glob
-    measured_traffic.source = None
+    import dspsr_amd
+    have = dspsr_amd.build_id()
+    measured_traffic.source = "no profiles/r*_traffic.json for workload %s taken with library build %s" % (workload, have)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):   # newest round first
         try:
             d = json.load(open(path))
             if d["workload"] == workload and (max_parts is None or d["parts_per_launch_group"] == max_parts) and key in d:
-                measured_traffic.source = "%s (commit %s)" % (os.path.relpath(path, ROOT), d.get("commit"))
+                if d.get("build_id") != have:
+                    measured_traffic.source = "%s refused: taken with library build %s, loaded build %s" % (
+                        os.path.relpath(path, ROOT), d.get("build_id"), have)
+                    continue
+                measured_traffic.source = "%s (library build %s)" % (os.path.relpath(path, ROOT), d["build_id"])
                 return d[key]
         except Exception:
             pass
@@ -858,7 +865,7 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
                        "n_fft": N, "nfilt_pos": r.impulse_pos, "nfilt_neg": r.impulse_neg, "nkeep": lt.nkeep,
                        "nsamp_step": lt.nsamp_step, "dm": cfg.dispersion_measure, "nbin": cfg.nbin,
                        "parts_per_block": cfg.parts_per_block, "max_parts": cfg.max_parts,
-                       "input": "8-bit dual-pol, resident in HBM",
+                       "input": "8-bit dual-pol, resident in HBM", "library_build": dspsr_amd.build_id(),
                        "detected_ndim": cfg.ndim, "fused_fold": bool(fused), "transform_passes": npass, "parallelism": par,
                        "realtime_factor": round(value / world / (info.rate / 1e6), 3)},
             "parity_gate": gate,
@@ -867,10 +874,8 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
                          "traffic": measured_traffic(name, cfg.max_parts),
                          "traffic_source": measured_traffic.source,
                          "traffic_unit": "HBM bytes per launch group of %d parts (PMC counters of a separate rocprofv3 run on the "
-                                         "commit named in %s -- not measured in this run); "
-                                         "algorithmic bytes for the same group: %d"
-                                         % (cfg.max_parts, measured_traffic.source or "profiles/r*_traffic.json: none for this shape",
-                                            b_alg * cfg.max_parts),
+                                         "same library build, see traffic_source -- not measured in this run); "
+                                         "algorithmic bytes for the same group: %d" % (cfg.max_parts, b_alg * cfg.max_parts),
                          "kernel": "filterbank launch group %s (FFT+chirp+detect, detected output written)" % group[0],
                          "algorithmic_bytes_per_part": b_alg, "group_ms_per_block": round(fb_ms, 4),
                          "traffic_ratio": None,

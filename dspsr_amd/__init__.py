@@ -8,4 +8,9 @@ from .engine import (Communicator, Context, ConvolutionEngine, Dedispersion, Det
                      eight_bit_scale, fold_binplan, optimal_fft_length, tfp_filterbank)
 
 __all__ = ["Communicator", "Context", "ConvolutionEngine", "Dedispersion", "DetectionEngine", "DspsrAmdError", "FilterbankEngine", "FoldEngine", "Rescale", "SampleDelay", "add_fpt", "copy_data_fpt", "dedispersion_sample_delays", "pscrunch_tfp", "sigproc_digitize",
-           "eight_bit_scale", "fold_binplan", "optimal_fft_length", "tfp_filterbank", "lib", "LIB_PATH"]
+           "eight_bit_scale", "fold_binplan", "optimal_fft_length", "tfp_filterbank", "lib", "LIB_PATH", "build_id"]
+
+
+def build_id() -> str:
+    """sha256 (12 hex digits) of the sources the loaded library was built from (csrc/Makefile: BUILD_ID)."""
+    return lib.dspsr_amd_build_id().decode()

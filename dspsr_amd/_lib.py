@@ -53,6 +53,7 @@ SYMBOLS = {
     "dspsr_amd_last_error": (C.c_char_p, [_vp]),
     "dspsr_amd_stream_sync": (_i, [_vp]),
     "dspsr_amd_version": (C.c_char_p, []),
+    "dspsr_amd_build_id": (C.c_char_p, []),
     "dspsr_amd_malloc": (_i, [_vp, _sz, _pp]),
     "dspsr_amd_free": (_i, [_vp, _vp]),
     "dspsr_amd_zero": (_i, [_vp, _vp, _sz]),

@@ -8,7 +8,11 @@
 
 using namespace dspsr_amd;
 
-extern "C" const char* dspsr_amd_version(void) { return "dspsr_amd 0.1 (gfx950)"; }
+#ifndef DSPSR_AMD_BUILD_ID
+#define DSPSR_AMD_BUILD_ID "unknown"     // (the Makefile passes the sha256 of the sources, see there)
+#endif
+extern "C" const char* dspsr_amd_version(void) { return "dspsr_amd 0.5 (gfx950) build " DSPSR_AMD_BUILD_ID; }
+extern "C" const char* dspsr_amd_build_id(void) { return DSPSR_AMD_BUILD_ID; }
 
 extern "C" int dspsr_amd_ctx_create(int device, void* hip_stream, dspsr_amd_ctx** out)
 {

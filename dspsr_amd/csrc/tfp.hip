@@ -11,6 +11,7 @@
 // transform, the Hermitian split + |.|^2 is applied while reading the transform back from LDS, and each
 // thread keeps the running time-scrunch sums of the bins it owns in registers (added in time order).
 #include "engine_internal.h"
+#include "stamps.h"
 
 namespace dspsr_amd {
 
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
     if constexpr (COAL) fetch_pieces((uint64_t)blockIdx.x * groups_per_out);
     else fetch((uint64_t)blockIdx.x * groups_per_out);
   }
+  FB_ST_BEGIN(8);
   for (uint64_t item = blockIdx.x; item < nitem; item += gridDim.x) {
     float acc[NB][2][2];                                        // [bin pair][k / C-k][pol]
 #pragma unroll
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
       const uint64_t group = item * groups_per_out + gi;
       asm volatile("" : "+v"(tid));
       cx2 x[NPAIR];
+      FB_ST(8, 0);
       if constexpr (COAL) {
         // the tile's bytes, in file order, into the exchange buffer (the previous tile's read-back ended with a barrier)
         uint8_t* img = (uint8_t*)lds;
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
         x[h].x = (v2f){__builtin_fmaf((float)(int8_t)(w & 0xff), p.scale, hs), __builtin_fmaf((float)(int8_t)((w >> 8) & 0xff), p.scale, hs)};
         x[h].y = (v2f){__builtin_fmaf((float)(int8_t)((w >> 16) & 0xff), p.scale, hs), __builtin_fmaf((float)(int8_t)(w >> 24), p.scale, hs)};
       }
+      FB_ST(8, 1);                               // image through LDS + decode
       {
         const uint64_t next = gi + 1 < groups_per_out ? group + 1 : (item + gridDim.x) * groups_per_out;
         if (gi + 1 < groups_per_out || item + gridDim.x < nitem) {
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
         }
       }
       if constexpr (COAL) __syncthreads();      // every thread has taken its words: the exchanges may overwrite the image
+      FB_ST(8, 2);                               // next tile's loads issued
       // staged transform: one plane of C float4 per part (column pair), (Re p0, Re p1, Im p0, Im p1) -- the register order of
       // the pair and what the read-back wants for packed arithmetic; the planes are 8 float4 apart modulo the bank period, so the
       // lanes of a store (two parts, consecutive positions) and of a read-back (consecutive bins of one part) fall on
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
       };
       wgfft<LOGC, -1, true>(lds, ltw_off, tid, logT, x, store);
       __syncthreads();
+      FB_ST(8, 3);                               // transform + staging
       // real-transform post-processing, power, time scrunch (parts added in time order)
       const uint64_t part_first = group << logTp, part_end = nout * p.sfactor;
       const uint32_t phase_first = (uint32_t)(part_first % p.sfactor);       // wave-uniform: no division per bin
@@ -265,8 +271,11 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
         }
       }
       __syncthreads();    // LDS is overwritten by the next tile's exchanges
+      FB_ST(8, 4);                               // split, powers, time scrunch, stores
+      FB_ST_TILE(8, 5);
     }
   }
+  FB_ST_END(8);
 }
 
 typedef void (*ktfp_t)(TfpParams, const cf*);
@@ -285,6 +294,8 @@ template <int... I> static ktfp_t pick_tfp(int logf, bool caspsr, bool coal, ise
 }  // namespace dspsr_amd
 
 using namespace dspsr_amd;
+
+FB_ST_READER(tfp)
 
 extern "C" int dspsr_amd_tfp_filterbank(dspsr_amd_ctx* ctx, const dspsr_amd_tfp_config* cfg, const int8_t* raw_dev,
                                         int raw_layout, float scale, float* out_dev, uint64_t npart)

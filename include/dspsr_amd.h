@@ -46,6 +46,9 @@ void dspsr_amd_ctx_destroy(dspsr_amd_ctx* ctx);
 const char* dspsr_amd_last_error(const dspsr_amd_ctx* ctx);
 int dspsr_amd_stream_sync(dspsr_amd_ctx* ctx);            /* FilterbankEngine::finish / check_error_stream */
 const char* dspsr_amd_version(void);
+/* sha256 (12 hex digits) of the sources the loaded library was built from (dspsr_amd/csrc/Makefile: BUILD_ID); the evidence files
+ * under profiles/ and the bench line name it, so that a counter profile can be matched to the library that was timed */
+const char* dspsr_amd_build_id(void);
 
 /* ---- dsp::Memory (Memory.h:18-34): do_allocate / do_free / do_zero / do_copy ---- */
 int dspsr_amd_malloc(dspsr_amd_ctx* ctx, size_t nbytes, void** ptr_dev);

@@ -29,15 +29,37 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == names
 
 
+def test_shipped_library_matches_the_sources():
+    """dspsr_amd_build_id() = sha256 of the sources the library was built from (csrc/Makefile: BUILD_ID), recomputed here from the
+    tree: a stale libdspsr_amd.so -- a source edited without `make` -- fails the CPU suite, and the evidence files under profiles/
+    that carry the id can be matched to a library."""
+    import hashlib
+    import dspsr_amd
+    from dspsr_amd import _lib
+    csrc = os.path.join(ROOT, "dspsr_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    units = re.search(r"^UNITS = (.*)$", mk, re.M).group(1).split()
+    hdr = re.search(r"^HDR = (.*)$", mk, re.M).group(1).split()
+    files = sorted([u + ".hip" for u in units] + ["host_prep.cpp"] + hdr) + ["Makefile"]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    assert _lib.lib.dspsr_amd_build_id().decode() == h.hexdigest()[:12], "libdspsr_amd.so is older than its sources: run make -C dspsr_amd/csrc"
+    assert h.hexdigest()[:12] in _lib.lib.dspsr_amd_version().decode()
+    assert dspsr_amd.build_id() == h.hexdigest()[:12]
+
+
 def test_shipped_library_reads_no_environment():
-    """Ablation bits ('results are wrong when set') and geometry overrides exist only in -DDSPSR_AMD_EXPERIMENT builds
-    (tools/build_variant.sh): the shipped library neither imports getenv nor holds any of the knob names."""
+    """The library's behaviour depends on the configuration structs of the C-ABI alone: it neither imports getenv nor holds any
+    of the knob names earlier rounds' experiment builds read; the phase-stamp diagnostics (csrc/stamps.h) are not in it."""
     import subprocess
     import dspsr_amd
     blob = open(dspsr_amd.LIB_PATH, "rb").read()
     assert b"DSPSR_AMD_DEBUG" not in blob and b"DSPSR_AMD_FUSED_MIN_TILES" not in blob and b"DSPSR_AMD_WG_PER_CU" not in blob
     undefined = subprocess.run(["nm", "-D", "--undefined-only", dspsr_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in undefined
+    exported = subprocess.run(["nm", "-D", "--defined-only", dspsr_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "debug_stamps" not in exported
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

@@ -80,10 +80,8 @@ for m in modes:
             e = ker[k[0]]
             out["hbm_bytes_per_launch"] = int((2 * e["fetch_KB_per_block"] + e["write_KB_per_block"]) * 1024 / max(e["calls_per_block"], 1e-9))
             out["roofline_kernel"] = k[0]
-try:
-    out["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
-except Exception:
-    out["commit"] = None
+# the library the counters were collected on (the GPU box has no .git: the id is baked into the library at make time)
+out["build_id"] = line.get("build_id")
 json.dump(out, open("gpurun_out/%s/%s_traffic.json" % (tag, wl), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("kernels") and k != "source"}))
 for m in modes:

@@ -24,7 +24,8 @@ def main():
     import bench
     wl = bench.WORKLOADS[name]
     args = argparse.Namespace(parts_per_block=0, max_parts=0, ndim=4, no_fused_fold=(mode != "fused"), dump_steps=8)
-    rec = {"workload": name, "mode": mode, "blocks": K}
+    import dspsr_amd
+    rec = {"workload": name, "mode": mode, "blocks": K, "build_id": dspsr_amd.build_id()}
     if name == "cfg5":
         from dspsr_amd import pipeline
         info = pipeline.InputInfo(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=1, npol=2, ndim=1, tsamp_us=wl["tsamp_us"],
