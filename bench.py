@@ -595,8 +595,10 @@ def engine_boundary(torch):
 RCCL_SETUP_TIMEOUT_S = 120.0
 
 
-def _bounded(what, fn, rank, timeout=None):
-    """Runs fn() on a helper thread and waits at most RCCL_SETUP_TIMEOUT_S for it.  ncclCommInitRank and the trial exchange
+def _bounded(what, fn, rank, timeout=None, device=None):
+    """Runs fn() on a helper thread and waits at most RCCL_SETUP_TIMEOUT_S for it.  The HIP (and torch) current device is a
+    per-thread setting and a new thread starts on device 0: `device` is made current on the helper first, so that allocations
+    and launches of rank r >= 1 land on ITS GPU, where its stream and communicator live.  ncclCommInitRank and the trial exchange
     are collectives: a rank whose peers never arrive would block for ever (ctypes releases the GIL, so this thread can watch).
     A rank that is stuck EXITS non-zero with a message -- the launcher then tears the job down -- instead of hanging the run.
     Returns (result, exception)."""
@@ -605,6 +607,9 @@ def _bounded(what, fn, rank, timeout=None):
 
     def run():
         try:
+            if device is not None:
+                import torch
+                torch.cuda.set_device(device)
             box["r"] = fn()
         except BaseException as e:                                        # noqa: BLE001 -- handed to the caller
             box["e"] = e
@@ -628,6 +633,7 @@ def open_rccl_exchange(ctx, torch, dist, rank, world):
     Returns (communicator or None, reason or None)."""
     import dspsr_amd
     state = {"ok": 1, "note": None}
+    dev = torch.cuda.current_device()               # this rank's GPU: made current on the helper threads below as well
 
     def agree(stage):
         t = torch.tensor([state["ok"]], dtype=torch.int32, device="cuda")
@@ -660,19 +666,19 @@ def open_rccl_exchange(ctx, torch, dist, rank, world):
     ids = [uid if rank == 0 else None]
     dist.broadcast_object_list(ids, src=0)
     # 2. ncclCommInitRank: collective, all ranks enter it (they all passed step 1)
-    rccl, err = _bounded("dspsr_amd_comm_create (ncclCommInitRank)", lambda: dspsr_amd.Communicator(ctx, world, rank, ids[0]), rank)
+    rccl, err = _bounded("dspsr_amd_comm_create (ncclCommInitRank)", lambda: dspsr_amd.Communicator(ctx, world, rank, ids[0]), rank, device=dev)
     if err is not None:
         state["ok"], state["note"] = 0, "%s" % err
     if not agree("comm_create"):
         return give_up(rccl)
     # 3. one tiny exchange: collective again, entered by all (they all hold a communicator)
     def trial():
-        t = torch.full((4, 8), float(rank + 1), dtype=torch.float32, device="cuda")
+        t = torch.full((4, 8), float(rank + 1), dtype=torch.float32, device="cuda:%d" % dev)
         rccl.start(rccl.SUM, t.data_ptr(), 8, 4, 8, np.ones(4, np.uint32), 1.0, 4, check_hits=True)
         got = rccl.finish()
         if rank == 0 and (float(got[0][0]) != world * (world + 1) / 2 or int(got[1][0]) != world or not got[4]):
             raise RuntimeError("trial exchange returned %r" % (got[0][:2],))
-    _, err = _bounded("the trial exchange", trial, rank)
+    _, err = _bounded("the trial exchange", trial, rank, device=dev)
     if err is not None:
         state["ok"], state["note"] = 0, "%s" % err
     if not agree("trial exchange"):

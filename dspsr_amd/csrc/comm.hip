@@ -220,6 +220,9 @@ extern "C" int dspsr_amd_reduce_profiles_start(dspsr_amd_comm* c, int mode, int 
   if (mode != DSPSR_AMD_REDUCE_SUM && mode != DSPSR_AMD_REDUCE_GATHER)
     return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_reduce_profiles_start: unknown mode %d", mode);
   if (c->pending) return ctx_fail(ctx, DSPSR_AMD_ESTATE, "dspsr_amd_reduce_profiles_start: the previous exchange was not finished");
+  // the current device is a per-thread setting: a caller thread that has not selected this context's GPU (a fresh helper thread
+  // starts on device 0) would place the staging buffers below on another device than the stream and the communicator
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_reduce_profiles_start: hipSetDevice failed");
   const uint64_t n = nrow * row_floats;
   const bool sum = mode == DSPSR_AMD_REDUCE_SUM, is_root = c->rank == root;
   const size_t nmeta = (size_t)nbin + 2;                                   // SUM: hits, ndat_total, integration_length as doubles
@@ -308,6 +311,7 @@ extern "C" int dspsr_amd_reduce_profiles_finish(dspsr_amd_comm* c, float* profil
   if (!c) return DSPSR_AMD_EINVAL;
   dspsr_amd_ctx* ctx = c->ctx;
   if (!c->pending) return ctx_fail(ctx, DSPSR_AMD_ESTATE, "dspsr_amd_reduce_profiles_finish: no exchange in flight");
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_reduce_profiles_finish: hipSetDevice failed");
   const hipError_t e = hipEventSynchronize(c->done);
   c->pending = false;
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_reduce_profiles_finish: %s", hipGetErrorString(e));

@@ -104,6 +104,28 @@ struct SubSplit {
   uint32_t R;
   uint64_t sub_stride;        // bytes from one sub-block to the next
 };
+// Twiddles of the radix-R steps outside the tiles (R = 3, 5, 7, 9, 15): exp(-2 pi i t / (R 2^logP)), t < R 2^logP.  With
+// t = a 2^logP + b the twiddle is W_R^a -- R values, built in double on the host and handed over in this table -- times
+// (cos, -sin)(b / 2^logP / R revolutions): b / 2^logP is exact in float for logP <= 24 and the one division by R leaves
+// an argument error below 2e-8 revolutions, so the product is as accurate as the hi / lo split of twiddles_big (2.4e-7; the
+// single-argument form it replaces, (a + b / 2^logP) / R, rounded the whole angle: up to 4e-7, and the time-domain step's
+// t * (1 / freq_res) up to 7.5e-7).
+struct OddTw { float2 w[16]; };                       // w[a] = exp(-2 pi i a / R), a < R
+template <int R> DEV cf twiddle_odd(const uint32_t t, const int logP, const OddTw& tab)
+{
+  const uint32_t a = (t >> logP) % (uint32_t)R, b = t & ((1u << logP) - 1);
+  const float x = (float)b * __uint_as_float((uint32_t)(127 - logP) << 23) / (float)R;
+  return cmul(tab.w[a], make_float2(__builtin_amdgcn_cosf(x), -__builtin_amdgcn_sinf(x)));
+}
+inline OddTw make_odd_tw(const uint32_t R)
+{
+  OddTw t;
+  for (uint32_t a = 0; a < 16; a++) {
+    const double ang = -2.0 * M_PI * (double)(a % R) / (double)R;
+    t.w[a] = make_float2((float)cos(ang), (float)sin(ang));
+  }
+  return t;
+}
 // parameters of k_time_combine (freq_res = 3 * 2^k / 5 * 2^k)
 struct TimeCombine {
   const cf* Y;
@@ -111,6 +133,7 @@ struct TimeCombine {
   uint32_t logMi, mo, nfilt_pos, nkeep, C, npol;
   uint64_t part0;
   uint32_t nparts;
+  OddTw tw;                                 // W_R^a of the radix-R step in time
 };
 
 

@@ -491,17 +491,11 @@ __global__ __launch_bounds__(256) void k_sub_split(const SubSplit p, uint8_t* __
 // rm = the factor of freq_res (the radix R of this kernel is nsub = rm times the odd factor of nchan_subband).
 template <int R, bool MSUB>
 __global__ __launch_bounds__(256) void k_sub_combine(const FbGeom g, cf* __restrict__ X, const uint32_t nseqs /* parts x sequences */,
-                                                     cf* __restrict__ Xout, const uint32_t mo, const uint32_t rm)
+                                                     cf* __restrict__ Xout, const uint32_t mo, const uint32_t rm, const OddTw wr)
 {
   const int logLs = g.logM + g.logR;                     // sub-sequence length L'
   const uint32_t Ls = 1u << logLs, L = Ls * R;
   const uint32_t X3m = (1u << g.logX3) - 1, Mm = (1u << g.logM) - 1;
-  cf wr[R];                                              // W_R^j
-#pragma unroll
-  for (int j = 0; j < R; j++) {
-    const float x = (float)j / (float)R;
-    wr[j] = make_float2(__builtin_amdgcn_cosf(x), -__builtin_amdgcn_sinf(x));
-  }
   const uint64_t n = (uint64_t)nseqs << logLs;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t o = (uint32_t)(i & (Ls - 1));
@@ -513,18 +507,15 @@ __global__ __launch_bounds__(256) void k_sub_combine(const FbGeom g, cf* __restr
     gq[0] = base[0];
 #pragma unroll
     for (int c = 1; c < R; c++) {
-      // W_L^(c k): c k mod L = a L' + b -> a / R + (b / L') / R revolutions (b / L' is exact)
-      const uint32_t ck = (uint32_t)(((uint64_t)c * k) % L), a = ck >> logLs, b = ck & (Ls - 1);
-      const float x = ((float)a + (float)b * __uint_as_float((uint32_t)(127 - logLs) << 23)) / (float)R;
-      const cf w = make_float2(__builtin_amdgcn_cosf(x), -__builtin_amdgcn_sinf(x));
-      gq[c] = cmul(base[(uint64_t)c << logLs], w);
+      // W_L^(c k), L = R L' (c k < 15 * 2^27: 32 bits; the multiple of L in it drops out of twiddle_odd's a = ... mod R)
+      gq[c] = cmul(base[(uint64_t)c << logLs], twiddle_odd<R>((uint32_t)c * k, logLs, wr));
     }
 #pragma unroll
     for (int q = 0; q < R; q++) {
       cf acc = gq[0];
 #pragma unroll
       for (int c = 1; c < R; c++) {
-        const cf v = cmul(gq[c], wr[(c * q) % R]);
+        const cf v = cmul(gq[c], wr.w[(c * q) % R]);
         acc.x += v.x; acc.y += v.y;
       }
       if constexpr (!MSUB) {
@@ -574,8 +565,8 @@ void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t 
 {
 #define FB_SUBC(R)                                                                                                              \
   case R:                                                                                                                       \
-    if (!Xout) hipLaunchKernelGGL((k_sub_combine<R, false>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, X, 0u, 1u);        \
-    else hipLaunchKernelGGL((k_sub_combine<R, true>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, Xout, mo, rm);          \
+    if (!Xout) hipLaunchKernelGGL((k_sub_combine<R, false>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, X, 0u, 1u, make_odd_tw(R)); \
+    else hipLaunchKernelGGL((k_sub_combine<R, true>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, Xout, mo, rm, make_odd_tw(R));   \
     break;
   switch (g.nsub) { FB_SUBC(3) FB_SUBC(5) FB_SUBC(7) FB_SUBC(9) FB_SUBC(15) default: break; }
 #undef FB_SUBC

@@ -11,7 +11,6 @@ __global__ __launch_bounds__(256) void k_time_combine(const TimeCombine p, const
 {
   const uint32_t Mi = 1u << p.logMi;
   const uint64_t n = (uint64_t)p.nparts * p.C * p.nkeep;
-  const float inv_mo = 1.0f / (float)p.mo;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t t = (uint32_t)(i % p.nkeep);
     const uint64_t pc = i / p.nkeep;
@@ -22,9 +21,9 @@ __global__ __launch_bounds__(256) void k_time_combine(const TimeCombine p, const
     for (int r = 0; r < R; r++) {
       const cf* __restrict__ y = p.Y + (uint64_t)(c * R + r) * p.y_chan_stride + ((uint64_t)lp << p.logMi) + ni;
       cf w = make_float2(1.f, 0.f);
-      if (r) {
-        const float x = (float)((uint32_t)((uint64_t)r * nn % p.mo)) * inv_mo;       // revolutions
-        w = make_float2(__builtin_amdgcn_cosf(x), __builtin_amdgcn_sinf(x));
+      if (r) {                                                   // exp(+2 pi i r n / freq_res), freq_res = R M' (r n < 15 * 2^26)
+        w = twiddle_odd<R>((uint32_t)r * nn, p.logMi, p.tw);
+        w.y = -w.y;
       }
       const cf v0 = cmul(y[0], w);
       a.x += v0.x; a.y += v0.y;

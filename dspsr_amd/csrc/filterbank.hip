@@ -662,7 +662,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
           hipLaunchKernelGGL(fb->k3, dim3(grid_for(n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->Xp, kern, yo, ctx->tw,
                              0ull, nb, nb);
           TimeCombine tc = {fb->Y, (uint64_t)g.npol * fb->max_parts * Mi, (uint64_t)fb->max_parts * Mi, (uint32_t)g.logM, fb->out_M,
-                            fb->out_nfilt_pos, fb->out_nkeep, fb->out_C, (uint32_t)g.npol, part0, nb};
+                            fb->out_nfilt_pos, fb->out_nkeep, fb->out_C, (uint32_t)g.npol, part0, nb, make_odd_tw(fb->msub)};
           FbOut cu = co;
           cu.chan0 = ichan * fb->out_C;
           if (cu.kind == 1 || cu.kind == 2) fb_launch_time_combine(ctx->stream, tc, cu, fb->msub, fb->ncu);
@@ -915,6 +915,8 @@ extern "C" int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb
   if (fb->g.nkeep >= 65536) return 0;
   if (fb->cfg.fused_fold == DSPSR_AMD_FUSED_ALWAYS) return 1;
   if (fb->cfg.fused_fold == DSPSR_AMD_FUSED_NEVER) return 0;
+  // (a call that takes the two-pass path has the same tile count: Fb = 2^13 / freq_res channels per tile is the three-pass T3
+  //  whenever nchan_subband >= Fb, which the two-pass path requires)
   const uint64_t tiles = (uint64_t)(fb->g.C >> fb->g.logT3);
   if (tiles >= fb->ncu) return 1;           // one workgroup per tile fills the chip: exact time-order sums
   return tiles >= 8 ? 2 : 0;                // fewer tiles: the parts of a launch are folded in runs (re-associated sums)

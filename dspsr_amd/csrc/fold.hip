@@ -795,13 +795,28 @@ static int fold_fold_impl(dspsr_amd_fold* f, const float* in_dev, uint64_t in_ch
   uint32_t max_run = 0;
   for (const RunBin& r : f->binplan) if (r.hits > max_run) max_run = r.hits;
   const bool lng = aligned && nbin <= (uint32_t)FOLD_BPT * 1024 && max_run >= FOLD_LONG_RUN;   // re-associated sums (see FOLD_LONG_RUN)
-  // Dense per-chunk table (k_fold_dense): at most one run per (chunk, phase bin), runs cut at the chunk ends
+  // Dense per-chunk table (k_fold_dense): at most one run per (chunk, phase bin), runs cut at the chunk ends.
+  // Whether the plan qualifies is decided BEFORE the table is touched, in one walk over the runs with a scratch of nbin words
+  // (the chunk in which each bin last had a piece): a plan with two runs of a bin inside a chunk -- a folding period shorter than
+  // the chunk -- used to be discovered half way through filling up to 64 MB of pinned table.  The table is also refused when it
+  // would be more than a quarter of the bytes it helps to fold (few channels, many bins).
   bool dense = false;
   size_t ntab = 0;
   if (aligned && !lng && nbin <= (uint32_t)FOLD_BPT * 1024) {
     const uint64_t nchunk = (last - first + FOLD_CHUNK - 1) / FOLD_CHUNK;
     ntab = (size_t)nchunk * nbin;
-    if (ntab <= ((size_t)1 << 24)) {
+    const uint64_t data_words = (last - first) * (uint64_t)f->nchan * f->npol * f->ndim;
+    if (ntab <= ((size_t)1 << 24) && 4 * (uint64_t)ntab <= data_words) {
+      dense = true;
+      f->cursor.assign(nbin, ~0u);                          // (scratch: chunk of the bin's previous piece)
+      for (const RunBin& r : f->binplan) {
+        if (r.hits == 0) continue;
+        const uint64_t c0 = (r.offset - first) / FOLD_CHUNK, c1 = (r.offset - first + r.hits - 1) / FOLD_CHUNK;
+        if (f->cursor[r.ibin] == (uint32_t)c0) { dense = false; break; }     // a second run of this bin in the chunk
+        f->cursor[r.ibin] = (uint32_t)c1;
+      }
+    }
+    if (dense) {
       if (ntab > sl.aux_cap) {
         if (sl.h_aux) (void)hipHostFree(sl.h_aux);
         if (sl.d_aux) (void)hipFree(sl.d_aux);
@@ -812,20 +827,16 @@ static int fold_fold_impl(dspsr_amd_fold* f, const float* in_dev, uint64_t in_ch
         sl.aux_cap = n;
       }
       ::memset((void*)sl.h_aux, 0, ntab * sizeof(uint32_t));
-      dense = true;
       for (const RunBin& r : f->binplan) {
         uint64_t off = r.offset - first;
         uint32_t left = r.hits;
         while (left) {
           const uint64_t c = off / FOLD_CHUNK;
           const uint32_t s0 = (uint32_t)(off % FOLD_CHUNK), n = left < FOLD_CHUNK - s0 ? left : FOLD_CHUNK - s0;
-          uint32_t& t = sl.h_aux[c * nbin + r.ibin];
-          if (t) { dense = false; break; }               // a second run of this bin in the chunk: the interval walk handles it
-          t = s0 | (n << 11);
+          sl.h_aux[c * nbin + r.ibin] = s0 | (n << 11);
           off += n;
           left -= n;
         }
-        if (!dense) break;
       }
     }
   }

@@ -30,8 +30,11 @@
 // What a fused block leaves behind is a detected TimeSeries that was NEVER WRITTEN.  Any later engine call that reads it
 // before the next perform() -- a FoldEngine that was not registered on the chain, a second Detection, copy_data_fpt --
 // throws Error (InvalidState) instead of returning stale data.  A recorded block that reaches the next perform() without
-// having been folded (Fold skipped it) cannot be executed any more -- DSPSR has refilled its input -- and is an
-// Error (InvalidState) too unless the caller has accepted that with set_drop_unfolded (true) (counted in get_dropped_blocks).
+// having been folded cannot be executed any more (DSPSR has refilled its input).  The reference skips Fold for a block
+// legitimately -- Subint<Fold>::transformation: `if (!divider.get_is_valid()) continue;` in front of Op::transformation()
+// (Signal/Pulsar/dsp/Subint.h:270), e.g. data before the requested start -- and nobody else reads the intermediates in the
+// pipelines deferred mode is for, so such a block is DROPPED and counted (get_dropped_blocks); set_drop_unfolded (false)
+// makes it an Error (InvalidState) instead, for callers that want to hear about it.
 // A consumer of the intermediate TimeSeries that bypasses the engines (dsp::Dump, a TransferCUDA to the host) cannot be
 // seen from here: deferred mode is for pipelines in which Detection is the only reader of the Filterbank output and the
 // Folds on the chain the only readers of the Detection output (dspsr's default fold pipeline); it is opt-in for that reason.
@@ -67,7 +70,7 @@ namespace HIP
   {
   public:
     Chain (dspsr_amd_ctx* _ctx) : ctx (_ctx), deferred (false), fused_blocks (0), eager_blocks (0), dropped_blocks (0),
-                                  nfold (0), drop_unfolded (false), consumed_fb (0), consumed_det (0)
+                                  nfold (0), drop_unfolded (true), consumed_fb (0), consumed_det (0)
     { fbk.pending = false; det.pending = false; fbk.raw = 0; }
 
     void set_deferred (bool flag) { if (!flag) flush (); deferred = flag; }
@@ -123,7 +126,7 @@ namespace HIP
       if (!drop_unfolded)
         throw Error (InvalidState, "HIP::FilterbankEngine::perform", "the block recorded by the deferred HIP::Chain was never "
                      "folded and cannot be executed any more (its input has been refilled): another reader of the Filterbank / "
-                     "Detection output would see stale data.  Chain::set_drop_unfolded (true) accepts the loss");
+                     "Detection output would see stale data (strict mode, Chain::set_drop_unfolded (false))");
       dropped_blocks ++;
     }
 
@@ -298,7 +301,7 @@ namespace HIP
       {
         Chain::FilterbankCall& c = chain->fbk;
         chain->clear_consumed ();                                    // `out` is about to be written (or recorded) anew
-        if (c.pending) chain->unfolded_block ();                     // never folded: Error, or dropped if the caller opted in
+        if (c.pending) chain->unfolded_block ();                     // never folded (Subint.h:270): dropped and counted; Error in strict mode
         c.fb = fb; c.in = in; c.out = out;
         c.ibase = ibase; c.ics = ics; c.ips = ips; c.obase = obase; c.ocs = ocs; c.ops = ops;
         c.npart = npart; c.in_step = in_step; c.out_step = out_step;

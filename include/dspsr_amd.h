@@ -180,7 +180,11 @@ int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb);
  *      2^27 / freq_res^2 (upper end: one 50 MHz sub-band with -F 512:D -x 512): column forward pass, then rows + chirp + inverse
  *      transforms in ONE tile -- the spectrum stays on chip;
  *   3  forward columns, forward rows, inverse per channel (freq_res <= 8192);
- *   4  two-pass inverse (freq_res > 8192, dsp::Convolution shapes, force_four_pass = 1). */
+ *   4  two-pass inverse (freq_res > 8192, dsp::Convolution shapes, force_four_pass = 1).
+ * The count is that of the TILE passes.  Lengths with an odd factor run the three tile passes per power-of-two sub-sequence and
+ * add trips through HBM outside the tiles: nchan_subband = R * 2^k a de-interleave of the input (k_sub_split) and one radix-R pass
+ * over the spectrum (k_sub_combine); freq_res = R * 2^k a radix-R pass over the pseudo-channels' time series as well
+ * (k_time_combine, with Detection and Fold as launches of their own: fold_is_fused() == 0). */
 int dspsr_amd_filterbank_npass(const dspsr_amd_filterbank* fb, int raw_input);
 int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const float* in_f32_dev, uint64_t in_chan_stride,
                                       uint64_t in_pol_stride, uint64_t in_step, const int8_t* raw_dev, int raw_layout,

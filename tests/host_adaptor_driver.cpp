@@ -226,14 +226,21 @@ static int deferred_section (dspsr_amd_ctx* ctx, dsp::Memory* dmem)
       out_d.set_state (Signal::Coherence);
       if (do_fold) { fold.prepare_output (); fold.fold (0.3, 37.7 / out_d.get_rate (), 0, ndat); }
     };
+    // a block Fold skipped (Subint.h:270: `if (!divider.get_is_valid()) continue;`) is dropped and counted by default ...
+    REQUIRE (chain->get_drop_unfolded (), "dropping unfolded blocks is the default");
     block (false);                                         // recorded, never folded
+    block (true);
+    REQUIRE (chain->get_dropped_blocks () == 1 && chain->get_fused_blocks () == 1, "default: %llu dropped / %llu fused",
+             (unsigned long long) chain->get_dropped_blocks (), (unsigned long long) chain->get_fused_blocks ());
+    // ... and an Error in strict mode
+    chain->set_drop_unfolded (false);
+    block (false);
     bool threw = false;
     try { block (true); } catch (Error& e) { threw = true; }
-    REQUIRE (threw, "an unfolded recorded block must be an Error at the next perform()");
+    REQUIRE (threw, "strict mode: an unfolded recorded block must be an Error at the next perform()");
     chain->set_drop_unfolded (true);
-    block (false);
     block (true);
-    REQUIRE (chain->get_dropped_blocks () == 1 && chain->get_fused_blocks () == 1, "drop_unfolded: %llu dropped / %llu fused",
+    REQUIRE (chain->get_dropped_blocks () == 1 && chain->get_fused_blocks () == 2, "after strict mode: %llu dropped / %llu fused",
              (unsigned long long) chain->get_dropped_blocks (), (unsigned long long) chain->get_fused_blocks ());
     // the last block was fused: out_d was never written; a reader that goes through an engine of the chain is refused
     HIP::TimeSeriesEngine tse (ctx, chain);
