@@ -410,26 +410,6 @@ template <int R> DEV void apply_pass_twiddle_inv(cx2 (&v)[R], const uint32_t nb,
   for (int k = 0; k < R; k++) v[k] = cmuls(v[k], t[0]);
 }
 
-// LDS-DMA of one 16-byte plan entry per lane, global -> LDS without passing through registers (lane l of the wave lands at
-// `lds_wave_base` + 16*l), issued from inline assembly: the compiler does not see a vector-memory operation, so it does NOT put
-// `s_waitcnt vmcnt(0)` in front of the next barrier.  With __builtin_amdgcn_global_load_lds it did -- in the middle of the
-// transform, where that wait also drained the whole prefetch of the next tile, issued just before (ISA of round 3's
-// k_inv_chan<12,true,2>: global_load_lds_dwordx4 ... s_waitcnt vmcnt(0); s_barrier between the second and the third stage;
-// the stamps of profiles/r03_experiments.txt item 4 show the transform phase 1.8k cycles longer for it).  The hardware needs
-// no such wait: a barrier does not drain vector memory (MI355X_MICROARCH.md, "Two waves per SIMD" item 7); what orders a reader
-// behind the DMA is the issuing wave's covering vmcnt wait plus a barrier, and the callers have both: every tile begins with an
-// explicit `s_waitcnt vmcnt(0)` and the entries are read behind the tile's first exchange barrier.  An operation the compiler
-// does not count only makes its own counted waits more conservative (the counter is in order).  m0 (the LDS base of the DMA)
-// is saved and restored inside the block.
-DEV void lds_dma_b128(const void* gsrc, const uint32_t lds_wave_base)
-{
-  const uint32_t sb = __builtin_amdgcn_readfirstlane(lds_wave_base);
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(sb) : "memory");
-}
-DEV uint32_t lds_byte_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
-
 DEV void detect4(const cf p, const cf q, const int state, float (&r)[4])
 {
   // cross_detect.ic:23-43 / stokes_detect.ic:21-44

@@ -278,6 +278,175 @@ __global__ __launch_bounds__(512) void k_tfp(const TfpParams p, const cf* __rest
   FB_ST_END(8);
 }
 
+// nchan = 4096 (digifil -F 4096, BASELINE config 5) with an even time-scrunch factor: the real-transform post-processing on the LAST
+// STAGE'S REGISTERS.  k_tfp stages the transform in LDS (16 ds_write_b128 per thread), passes a barrier and reads every bin with
+// its Hermitian mirror back (16 ds_read_b128): a fourth 128 KB round trip through LDS per tile, 23 % of its cycles together with
+// the arithmetic (stamps, profiles/r05_experiments.txt item 1).  Here the last stage runs in wgfft's MIRROR form: thread
+// (j = tid / 4, column c = tid % 4) holds, for k < 16, Z[256 k + pa] and Z[256 k + pb] of ITS column (pa = j, pb = 256 - j; j = 0:
+// pa = 0, pb = 128) -- and the mirror C - (256 k + pa) = 256 (15 - k) + pb is the other half of its register 15 - k.  The pair
+// (v[k], halves of v[15-k] swapped) gives X at four bins per packed evaluation; nothing is staged.  The four lanes of a quad are
+// the tile's (part, polarisation) columns of one position pair, so the polarisation sum and the time sum over the tile's two
+// parts are DPP adds inside the quad, in the reference's order: (p0 + p1) per part (TFPFilterbank.C:79-80), parts in time order
+// (TScrunch.C:193-200).  Lanes c = 0 (and 1 without pscrunch) carry the running sums of their 33 bins across the sfactor / 2
+// tiles of an output sample.  Lanes j = 0 hold the self-mirrored columns p = 0 (mirror of 256 k: 256 (16 - k)) and p = 128: their
+// mirror operands are picked per lane (v_cndmask), bin C/2 = 2048 is one extra scalar evaluation.
+template <bool CASPSR, bool PSC>
+__global__ __launch_bounds__(512) void k_tfp4k(const TfpParams p, const cf* __restrict__ tw)
+{
+  constexpr int LOGC = 12, logT = 2, logTp = 1;
+  typedef FftPlan<LOGC> P;
+  static_assert(P::NS == 3 && P::R1 == 16 && P::G1 == 2 && P::REM == 0, "k_tfp4k: 16 x 16 x 16");
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  uint32_t tid = threadIdx.x;
+  constexpr uint32_t nt = 512, C = 1u << LOGC;
+  constexpr uint32_t npol_out = PSC ? 1 : 2;
+  const uint64_t nout = p.npart / p.sfactor;
+  const uint32_t ltw_off = lds_pad(PTS * nt) + 8;
+  ltw_fill<LOGC>(lds, ltw_off, tw, tid, nt);
+  const uint32_t col = threadIdx.x & 3u, jp = threadIdx.x >> 2, pa = jp, pb = jp ? 256u - jp : 128u;
+  const bool j0 = jp == 0;
+  // w^pa, w^pb, w = exp(-i pi / C) = (c, -s): argument p / 2C revolutions, exact in float.  The twiddle of bin 256 k + p is
+  // w^p times exp(-i pi k / 16), a compile-time constant: 4 packed operations per k and tile instead of 32 registers held
+  // across the transform (which spilled)
+  const v2f wpc = {__builtin_amdgcn_cosf((float)pa * (1.0f / 8192.0f)), __builtin_amdgcn_cosf((float)pb * (1.0f / 8192.0f))};
+  const v2f wps = {__builtin_amdgcn_sinf((float)pa * (1.0f / 8192.0f)), __builtin_amdgcn_sinf((float)pb * (1.0f / 8192.0f))};
+  // samples decoded at HALF scale: A = (Z[k] + conj Z[C-k]) / 2, B = (Z[k] - conj Z[C-k]) / 2i then need no factor 1/2, and a
+  // power-of-two scale commutes with every rounding -- the same bits as k_tfp's 0.5f * (...)
+  const float sc2 = 0.5f * p.scale, hs2 = 0.5f * sc2;
+  const uint32_t groups_per_out = p.sfactor >> logTp;            // sfactor is even (host)
+  const uint64_t nitem = nout;
+  auto elem = [&](const int g2, const int i, uint32_t& pl, uint32_t& n) {
+    const uint32_t e = first_stage_elem<LOGC>(tid, logT, g2, i);
+    pl = (e & ((1u << logT) - 1)) >> 1;
+    n = e >> logT;
+  };
+  // The tile's 2^15 bytes travel global -> LDS by LDS-DMA (16 bytes per lane, 1 KB per wave instruction, four per wave), straight
+  // into the head of the exchange buffer in file order: no staging registers, no ds_write, and the request for tile i + 1 is
+  // issued behind tile i's last exchange read, so it lands while the post-processing runs.  Every part of a launch is whole
+  // (nout * sfactor <= npart): no bounds to check.
+  constexpr uint32_t NCH = (PTS * 2) / 16, IMG_SKEW = 64;       // 16-byte pieces per thread (pieces 0, 1: part 0; 2, 3: part 1)
+  auto fetch_image = [&](const uint64_t group) {
+    const uint8_t* src = p.raw + (group << logTp) * (uint64_t)C * 4 + 16u * threadIdx.x;
+    // (the second part's 16 KB lie IMG_SKEW bytes further on: the lanes of a first-stage read alternate between the two parts at
+    //  the same offset -- the same LDS bank 16 KB apart)
+#pragma unroll
+    for (uint32_t r = 0; r < NCH; r++)
+      lds_dma_b128(src + 16u * nt * r, lds_byte_addr((const uint8_t*)lds + 16u * ((threadIdx.x & ~63u) + r * nt) + (r >> 1) * IMG_SKEW));
+  };
+  auto dpp_pol = [](const float a) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xf, 0xf, false)); };    // lane ^ 1
+  auto dpp_part1 = [](const float a) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xEE, 0xf, 0xf, false)); };  // quad_perm [2,3,2,3]
+  if (blockIdx.x < nitem) fetch_image((uint64_t)blockIdx.x * groups_per_out);      // (ltw_fill ended with a barrier)
+  FB_ST_BEGIN(8);
+  for (uint64_t item = blockIdx.x; item < nitem; item += gridDim.x) {
+    v2f accK[8], accM[8];                                       // running sums: bins 256 k + (pa | pb); 256 (15 - k) + (pb | pa)
+    float accH = 0.f;                                           // bin C/2 (lanes j = 0)
+#pragma unroll
+    for (int k = 0; k < 8; k++) accK[k] = accM[k] = (v2f){0.f, 0.f};
+    for (uint32_t gi = 0; gi < groups_per_out; gi++) {
+      const uint64_t group = item * groups_per_out + gi;
+      asm volatile("" : "+v"(tid));
+      cx2 x[NPAIR];
+      FB_ST(8, 0);
+      {
+        // this tile's image has been requested one tile ago (or in front of the loop): each wave waits for its own pieces, the
+        // barrier for everybody's; each thread then picks the 16 words of its first-stage butterflies.  The first exchange
+        // write of the transform sits behind a barrier of its own (wgfft), which also ends these reads.
+        const uint8_t* img = (const uint8_t*)lds;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < P::R1; i++) {
+          uint32_t pl, n;
+          elem(0, i, pl, n);
+          const uint32_t w = tfp_word_aligned<CASPSR>(img + (pl << (LOGC + 2)) + pl * IMG_SKEW, 2 * n);     // (p0[2n], p1[2n], p0[2n+1], p1[2n+1])
+          x[i].x = (v2f){__builtin_fmaf((float)(int8_t)(w & 0xff), sc2, hs2), __builtin_fmaf((float)(int8_t)((w >> 8) & 0xff), sc2, hs2)};
+          x[i].y = (v2f){__builtin_fmaf((float)(int8_t)((w >> 16) & 0xff), sc2, hs2), __builtin_fmaf((float)(int8_t)(w >> 24), sc2, hs2)};
+        }
+      }
+      FB_ST(8, 1);                               // image wait + decode
+      const bool more = gi + 1 < groups_per_out || item + gridDim.x < nitem;
+      const uint64_t next = gi + 1 < groups_per_out ? group + 1 : (item + gridDim.x) * groups_per_out;
+      FB_ST(8, 2);
+      auto post = [&](const uint32_t, const uint32_t, const uint32_t, cx2 (&v)[16]) {
+        __syncthreads();                         // every wave has read the last exchange: the next tile's image may land
+        if (more) fetch_image(next);
+        FB_ST(8, 3);                             // transform
+        v2f wpc_t = wpc, wps_t = wps;            // opaque copies: the per-bin twiddles below are loop invariant and would
+        asm volatile("" : "+v"(wpc_t), "+v"(wps_t));   // otherwise be hoisted out of the tile loop (32 registers, spilled)
+        // one packed evaluation: (Z[k], mirror operands) of bins 256 k + (pa | pb) -> their powers and those of the mirror bins, added
+        // to the running sums.  The accumulators start an output sample at zero (0 + x == x: the sums of TScrunch.C:193-200 bit for bit)
+        auto eval = [&](const int k, const v2f mr, const v2f mi) {
+          const v2f zr = v[k].x, zi = v[k].y;
+          const v2f ar = zr + mr, ai = zi - mi;                       // A = Z[k] + conj Z[C-k]           (halved by the input scale)
+          const v2f br = zi + mi, bi = mr - zr;                       // B = (Z[k] - conj Z[C-k]) / i
+          // cos / sin(pi k / 16), k < 8
+          constexpr float C16[8] = {1.0f, 0.98078528040323043f, C16_1, 0.83146961230254524f, C16_2, 0.55557023301960218f, S16_1, 0.19509032201612825f};
+          constexpr float S16[8] = {0.0f, 0.19509032201612825f, S16_1, 0.55557023301960218f, C16_2, 0.83146961230254524f, C16_1, 0.98078528040323043f};
+          const v2f wck = k ? C16[k] * wpc_t - S16[k] * wps_t : wpc_t, wsk = k ? S16[k] * wpc_t + C16[k] * wps_t : wps_t;
+          const v2f wr = wck * br + wsk * bi, wi = wck * bi - wsk * br;           // w^bin B,  w^bin = (c, -s)
+          const v2f xr = ar + wr, xi = ai + wi, yr = ar - wr, yi = ai - wi;       // X[k] = A + w^k B,  X[C-k] = conj(A - w^k B)
+          v2f pk = xr * xr; pk += xi * xi;                            // TFPFilterbank.C:56-59: Re^2 then += Im^2
+          v2f pm = yr * yr; pm += yi * yi;
+          if constexpr (PSC) {                                        // :79-80 pol sum BEFORE the time sum
+            pk += (v2f){dpp_pol(pk[0]), dpp_pol(pk[1])};
+            pm += (v2f){dpp_pol(pm[0]), dpp_pol(pm[1])};
+          }
+          // time order: part 0 of the tile (this quad's lanes 0, 1), then part 1 (lanes 2, 3)
+          accK[k] = (accK[k] + pk) + (v2f){dpp_part1(pk[0]), dpp_part1(pk[1])};
+          accM[k] = (accM[k] + pm) + (v2f){dpp_part1(pm[0]), dpp_part1(pm[1])};
+        };
+        if (threadIdx.x >= 64) {                 // (wave uniform)
+          // mirror operands: the other half of v[15 - k]
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const cx2 g = v[15 - k];
+            eval(k, __builtin_shufflevector(g.x, g.x, 1, 0), __builtin_shufflevector(g.y, g.y, 1, 0));
+          }
+        } else {
+          // wave 0 holds the lanes j = 0 (columns p = 0 and p = 128, their own mirrors): low half Z[256 (16 - k)] (k = 0: Z[0]
+          // itself), high half Z[256 (15 - k) + 128] (the same half), picked per lane
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const cx2 g = v[15 - k], sp = v[(16 - k) & 15];
+            eval(k, (v2f){j0 ? sp.x[0] : g.x[1], j0 ? g.x[1] : g.x[0]}, (v2f){j0 ? sp.y[0] : g.y[1], j0 ? g.y[1] : g.y[0]});
+          }
+          // bin C/2 = 2048 = 256 * 8 + 0: its own mirror, w = -i: A = 2 Re Z, w B = -i 2 Im Z  (meaningful in lanes j = 0 only)
+          const float xr = v[8].x[0] + v[8].x[0], xi = -(v[8].y[0] + v[8].y[0]);
+          float ph = xr * xr; ph += xi * xi;
+          if constexpr (PSC) ph += dpp_pol(ph);
+          accH = (accH + ph) + dpp_part1(ph);
+        }
+      };
+      wgfft<LOGC, -1, false, false, true>(lds, ltw_off, tid, logT, x, post);
+      if (gi + 1 == groups_per_out && col < npol_out) {
+        // lanes c = 0 (pol 0 / the pol sum) and, without pscrunch, c = 1 (pol 1) hold the output sample's sums
+        // (offsets from an opaque copy of the position pair: they are loop invariant, and hoisted out of the tile loop the 33
+        //  addresses spilled the kernel)
+        uint32_t qa = pa, qb = pb;
+        asm volatile("" : "+v"(qa), "+v"(qb));
+        float* const o = p.out + item * (uint64_t)C * npol_out + col;
+        const uint32_t oa = qa * npol_out, ob = qb * npol_out, ks = 256u * npol_out;     // bin 256 k + p at o[p * npol + k * ks]
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          o[oa + k * ks] = accK[k][0];
+          o[ob + k * ks] = accK[k][1];
+          if (!j0) {
+            o[ob + (15 - k) * ks] = accM[k][0];
+            o[oa + (15 - k) * ks] = accM[k][1];
+          } else {
+            if (k) o[(16 - k) * ks] = accM[k][0];
+            o[ob + (15 - k) * ks] = accM[k][1];                // (pb = 128)
+          }
+        }
+        if (j0) o[8 * ks] = accH;
+      }
+      FB_ST(8, 4);                               // split, powers, time scrunch, stores
+      FB_ST_TILE(8, 5);
+    }
+  }
+  FB_ST_END(8);
+}
+
 typedef void (*ktfp_t)(TfpParams, const cf*);
 template <int... I> struct iseq_t {};
 template <int N, int... I> struct mkseq_t : mkseq_t<N - 1, N - 1, I...> {};
@@ -326,6 +495,9 @@ extern "C" int dspsr_amd_tfp_filterbank(dspsr_amd_ctx* ctx, const dspsr_amd_tfp_
   // whole-range 16-byte loads need an aligned block, at least two columns per group (T >= 2) and full-size workgroups
   const bool coal = ((uintptr_t)raw_dev & 15) == 0;
   ktfp_t k = pick_tfp(logC, p.caspsr != 0, coal, mkseq_t<14>::type());
+  // digifil's own geometry (-F 4096 with an even -t): post-processing on the last stage's registers, see k_tfp4k
+  if (nchan == 4096 && coal && (sf % 2) == 0)
+    k = p.caspsr ? (p.pscrunch ? k_tfp4k<true, true> : k_tfp4k<true, false>) : (p.pscrunch ? k_tfp4k<false, true> : k_tfp4k<false, false>);
   const size_t lds = lds_total_words_host(16384, logC) * sizeof(cf);
   hipError_t e = dspsr_amd_allow_lds((const void*)k, lds);      // raised once per kernel, not per call
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_tfp_filterbank: %s", hipGetErrorString(e));

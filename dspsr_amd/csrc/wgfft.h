@@ -254,10 +254,18 @@ template <class O> DEV void out_set_h(O&, const int, long) {}
 // `mid(0)` before the first stage).  The passes use it to issue the global loads of their NEXT tile in
 // NS + 1 small groups spread over the transform instead of one burst that blocks the wave while the
 // memory pipeline accepts it.
-template <int LOGR, int SIGN, bool FIRST, bool LAST, bool STAGED, class Out, class Mid>
+// MIRROR (last stage only, real-input transforms): the thread's butterfly pair is not (column c, c + 1) of one position but the
+// positions (p, P - p) of ONE column -- p = 0 goes with P/2 --, read as two 8-byte elements.  Its outputs are then bins k*P + p in
+// the low halves and k*P + (P - p) in the high halves of v[k]: the Hermitian mirror C - (k*P + p) = (R-1-k)*P + (P - p) of every
+// bin lies in the SAME thread (high half of v[R-1-k]), so the real-transform post-processing (X[k] from Z[k], Z[C-k]) needs no
+// further exchange.  Pair q = H*tid + h is column q % T, position pair q / T; out(col, p, pstride, v) gets that column and p.
+// ILV (the stage in FRONT of a MIRROR stage): its exchange writes the pair as (re, im) of column c, (re, im) of column c + 1 --
+// whole 8-byte elements per column -- instead of the split form (re c, re c+1, im c, im c+1) every other stage reads back.
+template <int LOGR, int SIGN, bool FIRST, bool LAST, bool STAGED, bool MIRROR = false, bool ILV = false, class Out, class Mid>
 DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const int logT, const int logF,
                      const int logP, cx2 (&x)[NPAIR], Out& out, Mid& mid, const int phase)
 {
+  static_assert(!MIRROR || (LAST && !FIRST && !STAGED), "MIRROR: a last stage fed from the exchange buffer, outputs kept in registers");
   constexpr int R = 1 << LOGR;
   constexpr int G = PTS / R;          // butterflies per thread
   constexpr int H = G / 2;            // pairs of butterflies
@@ -277,6 +285,14 @@ DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const 
     for (int i = 0; i < R; i++) {
       if constexpr (FIRST) {
         v[h][i] = x[h * R + i];
+      } else if constexpr (MIRROR) {
+        const uint32_t q = H * tid + h, c = q & ((1u << logT) - 1), j = q >> logT;
+        const uint32_t pb = j ? (1u << logP) - j : (1u << (logP - 1));
+        const uint32_t ea = (j << logT) + c, eb = (pb << logT) + c, cc = i * stride;     // (stride = P*T)
+        const cf a = lds[raff ? lds_pad(ea) + cc + ((cc >> 6) << 2) : lds_pad(ea + cc)];
+        const cf b = lds[raff ? lds_pad(eb) + cc + ((cc >> 6) << 2) : lds_pad(eb + cc)];
+        v[h][i].x = (v2f){a.x, b.x};
+        v[h][i].y = (v2f){a.y, b.y};
       } else {
         const uint32_t c = i * stride;
         const float4 pr = *(const float4*)&lds[raff ? rbase + c + ((c >> 6) << 2) : lds_pad(u + c)];
@@ -311,7 +327,11 @@ DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const 
     const uint32_t rest = u >> logT;
     const uint32_t p = rest & ((1u << logP) - 1);
     const uint32_t s = rest >> logP;
-    if constexpr (LAST) {
+    if constexpr (LAST && MIRROR) {
+      const uint32_t q = H * tid + h;
+      out_set_h(out, h, 0);
+      out(q & ((1u << logT) - 1), q >> logT, 1u << logP, v[h]);
+    } else if constexpr (LAST) {
       out_set_h(out, h, 0);
       out(col, p, 1u << logP, v[h]);     // Q == 1, s == 0
     } else {
@@ -323,7 +343,8 @@ DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const 
       for (int k = 0; k < R; k++) {
         const uint32_t c = k * step;
         *(float4*)&lds[waff2 ? wbase + c + ((c >> 6) << 2) : lds_pad(e0 + c)] =
-            make_float4(v[h][k].x[0], v[h][k].x[1], v[h][k].y[0], v[h][k].y[1]);
+            ILV ? make_float4(v[h][k].x[0], v[h][k].y[0], v[h][k].x[1], v[h][k].y[1])
+                : make_float4(v[h][k].x[0], v[h][k].x[1], v[h][k].y[0], v[h][k].y[1]);
       }
     }
   }
@@ -338,9 +359,10 @@ DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const 
 // lds_pad(pos*T + col), column pairs in split form as the stages write them -- and passed a barrier; the first stage then
 // reads its inputs there like every later stage (x is not used).  This is how a pass chains two transforms over different
 // axes of one tile without leaving the workgroup (k_rows_inv: FFT over the rows in registers, inverse FFT over the bins here).
-template <int LOGF, int SIGN, bool STAGED = false, bool FROM_LDS = false, class Out, class Mid>
+template <int LOGF, int SIGN, bool STAGED = false, bool FROM_LDS = false, bool MIRROR = false, class Out, class Mid>
 DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx2 (&x)[NPAIR], Out& out, Mid& mid)
 {
+  static_assert(!MIRROR || FftPlan<LOGF>::NS >= 2, "MIRROR needs a last stage behind an exchange (P >= 2)");
   typedef FftPlan<LOGF> P;
   // opaque copy: LDS addresses and twiddle indices are loop-invariant in a persistent workgroup and
   // would otherwise be hoisted out of the tile loop and spilled (hundreds of registers)
@@ -349,44 +371,52 @@ DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx
   if constexpr (P::NS <= 1) {
     wgfft_stage<P::LOGR1, SIGN, !FROM_LDS, true, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out, mid, 1);
   } else {
-    wgfft_stage<4, SIGN, !FROM_LDS, false, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out, mid, 1);
+    // radix-16 stages between the first and the last: at most two (LOGF <= 13); the one in front of a MIRROR stage writes ILV
+    constexpr int NMID = P::NQ - (P::REM ? 0 : 1) - 1;
+    static_assert(NMID >= 0 && NMID <= 2, "wgfft: at most four stages");
+    wgfft_stage<4, SIGN, !FROM_LDS, false, STAGED, false, MIRROR && NMID == 0>(lds, ltw_off, tid, logT, LOGF, 0, x, out, mid, 1);
     int logP = 4;
     uint32_t toff = ltw_off + (4u << (LOGF - 4));
-#pragma unroll
-    for (int j = 1; j < P::NQ - (P::REM ? 0 : 1); j++) {
-      wgfft_stage<4, SIGN, false, false, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out, mid, j + 1);
+    if constexpr (NMID >= 1) {
+      wgfft_stage<4, SIGN, false, false, STAGED, false, MIRROR && NMID == 1>(lds, toff, tid, logT, LOGF, logP, x, out, mid, 2);
       logP += 4;
       toff += 4u << (LOGF - logP);
     }
-    if constexpr (P::REM != 0) wgfft_stage<P::REM, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out, mid, P::NS);
-    else wgfft_stage<4, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out, mid, P::NS);
+    if constexpr (NMID >= 2) {
+      wgfft_stage<4, SIGN, false, false, STAGED, false, MIRROR>(lds, toff, tid, logT, LOGF, logP, x, out, mid, 3);
+      logP += 4;
+      toff += 4u << (LOGF - logP);
+    }
+    if constexpr (P::REM != 0) wgfft_stage<P::REM, SIGN, false, true, STAGED, MIRROR>(lds, toff, tid, logT, LOGF, logP, x, out, mid, P::NS);
+    else wgfft_stage<4, SIGN, false, true, STAGED, MIRROR>(lds, toff, tid, logT, LOGF, logP, x, out, mid, P::NS);
   }
 }
-template <int LOGF, int SIGN, bool STAGED = false, bool FROM_LDS = false, class Out>
+template <int LOGF, int SIGN, bool STAGED = false, bool FROM_LDS = false, bool MIRROR = false, class Out>
 DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx2 (&x)[NPAIR], Out& out)
 {
   NoMid mid;
-  wgfft<LOGF, SIGN, STAGED, FROM_LDS>(lds, ltw_off, tid, logT, x, out, mid);
+  wgfft<LOGF, SIGN, STAGED, FROM_LDS, MIRROR>(lds, ltw_off, tid, logT, x, out, mid);
 }
 
-// Ablation only (DSPSR_AMD_DEBUG bit 4): hands the first-stage registers straight to `out` in the shape
-// of the last stage, i.e. a tile with its global loads and stores but without the transform.
-template <int LOGF, class Out>
-DEV void wgfft_passthrough(uint32_t tid, const int logT, cx2 (&x)[NPAIR], Out& out)
+// LDS-DMA of 16 bytes per lane (a plan entry, a piece of an 8-bit block), global -> LDS without passing through registers (lane l of the wave lands at
+// `lds_wave_base` + 16*l), issued from inline assembly: the compiler does not see a vector-memory operation, so it does NOT put
+// `s_waitcnt vmcnt(0)` in front of the next barrier.  With __builtin_amdgcn_global_load_lds it did -- in the middle of the
+// transform, where that wait also drained the whole prefetch of the next tile, issued just before (ISA of round 3's
+// k_inv_chan<12,true,2>: global_load_lds_dwordx4 ... s_waitcnt vmcnt(0); s_barrier between the second and the third stage;
+// the stamps of profiles/r03_experiments.txt item 4 show the transform phase 1.8k cycles longer for it).  The hardware needs
+// no such wait: a barrier does not drain vector memory (MI355X_MICROARCH.md, "Two waves per SIMD" item 7); what orders a reader
+// behind the DMA is the issuing wave's covering vmcnt wait plus a barrier, and the callers have both: every tile begins with an
+// explicit `s_waitcnt vmcnt(0)` and the entries are read behind the tile's first exchange barrier.  An operation the compiler
+// does not count only makes its own counted waits more conservative (the counter is in order).  m0 (the LDS base of the DMA)
+// is saved and restored inside the block.
+DEV void lds_dma_b128(const void* gsrc, const uint32_t lds_wave_base)
 {
-  typedef FftPlan<LOGF> P;
-  constexpr int LOGRL = P::NS <= 1 ? P::LOGR1 : (P::REM ? P::REM : 4);
-  constexpr int R = 1 << LOGRL, G = PTS / R, H = G / 2;
-  const int logP = LOGF - LOGRL;
-#pragma unroll
-  for (int h = 0; h < H; h++) {
-    const uint32_t u = G * tid + 2 * h;
-    cx2 v[R];
-#pragma unroll
-    for (int k = 0; k < R; k++) v[k] = x[h * R + k];
-    out(u & ((1u << logT) - 1), (u >> logT) & ((1u << logP) - 1), 1u << logP, v);
-  }
+  const uint32_t sb = __builtin_amdgcn_readfirstlane(lds_wave_base);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(sb) : "memory");
 }
+DEV uint32_t lds_byte_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
 
 // Work distribution of a persistent grid.  Items are dealt to the 8 XCDs in runs of `run`
 // consecutive items (blocks b and b+8 share an XCD under the observed round-robin placement;

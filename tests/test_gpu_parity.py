@@ -759,6 +759,39 @@ def test_tfp_filterbank_search_mode(oracle, gpu, nchan, tscrunch, pscrunch, npar
     assert np.sqrt(np.mean((got - want).astype(np.float64) ** 2)) <= 2e-6 * rms
 
 
+@pytest.mark.parametrize("pscrunch", [True, False])
+@pytest.mark.parametrize("layout_name,tscrunch,npart", [("generic", 16, 80), ("caspsr", 2, 14), ("generic", 6, 37)])
+def test_tfp_4096_register_split_equals_generic_kernel(gpu, pscrunch, layout_name, tscrunch, npart):
+    """nchan = 4096 with an even tscrunch takes k_tfp4k (Hermitian split, powers, pol and time sums on the last stage's registers,
+    DPP adds inside the quad); tscrunch = 1 takes the generic k_tfp (staged transform).  Summing the generic kernel's per-part
+    powers in time order (float32, sequentially: TScrunch.C:193-200) must reproduce k_tfp4k up to the two kernels' twiddle
+    rounding (1e-6 of the rms), for both raw layouts, with and without pscrunch, and with a ragged last output sample dropped.
+    An unaligned block (generic kernel for any tscrunch) gives the same answer."""
+    dspsr_amd, ctx = gpu
+    from dspsr_amd import _lib
+    rng = np.random.default_rng(77)
+    nchan = 4096
+    layout = _lib.RAW_CASPSR if layout_name == "caspsr" else _lib.RAW_GENERIC
+    raw = torch.from_numpy(np.clip(np.rint(rng.standard_normal(npart * 2 * nchan * 2) * 24.0), -128, 127).astype(np.int8)).cuda()
+    npol = 1 if pscrunch else 2
+    nout = npart // tscrunch
+    one = torch.zeros((npart, nchan, npol), dtype=torch.float32, device="cuda")
+    dspsr_amd.tfp_filterbank(ctx, raw, nchan, npart, one, pscrunch, 1, layout=layout, scale=0.0123)
+    want = one[0:nout * tscrunch:tscrunch].clone()
+    for i in range(1, tscrunch):
+        want = want + one[i:nout * tscrunch:tscrunch]
+    got = torch.full((nout, nchan, npol), -1.0, dtype=torch.float32, device="cuda")
+    dspsr_amd.tfp_filterbank(ctx, raw, nchan, npart, got, pscrunch, tscrunch, layout=layout, scale=0.0123)
+    rms = float(want.double().pow(2).mean().sqrt())
+    assert float((got - want).abs().max()) <= 1e-6 * rms * 8 and float(got.min()) >= 0.0
+    if layout_name == "generic":
+        shifted = torch.zeros(raw.numel() + 2, dtype=torch.int8, device="cuda")
+        shifted[2:] = raw                                               # 2-byte aligned only: no 16-byte pieces, generic kernel
+        got2 = torch.zeros_like(got)
+        dspsr_amd.tfp_filterbank(ctx, shifted[2:], nchan, npart, got2, pscrunch, tscrunch, layout=layout, scale=0.0123)
+        assert float((got2 - want).abs().max()) <= 1e-6 * rms * 8
+
+
 @pytest.mark.parametrize("nchan,npol,ndat,interval,constant,blocks", [
     (1024, 1, 4096, 0, False, 1), (256, 2, 3000, 1000, False, 3), (64, 4, 2500, 700, True, 2), (4096, 1, 1024, 512, False, 2),
     (16, 1, 100000, 0, False, 1), (33, 2, 777, 100, False, 2)])
