@@ -66,6 +66,12 @@ WORKLOADS = {
     "cfg5": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=4096, dm=0.0, freq_res=1,
                  nbin=0, machine="DADA", tscrunch=16, nparts=32768,
                  cmd="digifil -F 4096 -t 16 -b 8 (TFP filterbank + square law + tscrunch, Rescale, PScrunch, 8-bit digitizer; no fold)"),
+    # the other branch of digifil (LoadToFil.C:185-222): convolving filterbank with coherent dedispersion in search mode -- the headline
+    # geometry, detected (Intensity), time scrunched, rescaled and digitised instead of folded
+    "cfg5c": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=1024, dm=1000.0, freq_res=4096, nbin=0,
+                  machine="DADA", tscrunch=16, nparts=64, max_parts=32,
+                  cmd="digifil -F 1024:D -x 4096 -D 1000 -t 16 -b 8 (convolving filterbank + square law + tscrunch in one launch group, "
+                      "Rescale + 8-bit digitizer; no fold)"),
     # the reference's fold benchmark (Benchmark/fold.csh on Benchmark/fold_header.dada): already-detected input, 1024
     # channels x 4 polarisation products at 32 us, folded with vela.polyco -- dsp::Fold alone
     "fold": dict(freq=1382.0, bw=-400.0, in_nchan=1024, ndim=1, tsamp_us=32.0, nchan=1024, dm=0.0, freq_res=1, nbin=0,
@@ -252,6 +258,69 @@ def bench_search_mode(args, wl, torch):
         dt = time.perf_counter() - t1
         res["cpu_baseline"] = {"value": n * 2 * nchan / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
                                "sample": "%d FFT blocks of the same workload, numpy oracle, %.1f s" % (n, dt)}
+    lf.close()
+    return res
+
+
+def make_search_coherent(wl, torch):
+    """The pipeline object and the synthetic block of the cfg5c workload (shared with tools/pmc_workload.py)."""
+    from dspsr_amd import pipeline
+    info = pipeline.InputInfo(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=1, npol=2, ndim=1, tsamp_us=wl["tsamp_us"],
+                              machine=wl["machine"])
+    cfg = pipeline.SearchConfig(nchan=wl["nchan"], tscrunch=wl["tscrunch"], nbit=8, dispersion_measure=wl["dm"], freq_res=wl["freq_res"],
+                                parts_per_block=wl["nparts"], max_parts=wl["max_parts"], rescale_seconds=10.0)
+    lf = pipeline.LoadToFilCoherent(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    nbytes = lf.block_bytes()
+    gen = torch.Generator(device="cuda").manual_seed(20100413)
+    raw = torch.empty(nbytes, dtype=torch.int8, device="cuda")
+    for s0 in range(0, nbytes, 1 << 26):
+        e = min(nbytes, s0 + (1 << 26))
+        raw[s0:e] = torch.randn(e - s0, generator=gen, device="cuda").mul_(24.0).round_().clamp_(-128, 127).to(torch.int8)
+    return lf, raw, cfg
+
+
+def bench_search_coherent(args, wl, torch):
+    """cfg5c: one step = one block of nparts overlap-save parts through digifil's convolving branch (dspsr_amd.pipeline.LoadToFilCoherent):
+    Filterbank + chirp + Detection::square_law + TScrunch [one launch group, the roofline group] -> Rescale + 8-bit SigProcDigitizer
+    [one pass over the 16x smaller scrunched rows], everything resident in HBM."""
+    import dspsr_amd
+    lf, raw, cfg = make_search_coherent(wl, torch)
+    npart = wl["nparts"]
+    for _ in range(args.warmup):
+        lf.process_block(raw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lf.process_block(raw)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(3, args.steps // 2))]
+    for a, b in ev:                                   # the filterbank + detection + scrunch launch group alone
+        a.record()
+        lf.detect_scrunch(raw)
+        b.record()
+    torch.cuda.synchronize()
+    g_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    r = lf.response
+    N = cfg.nchan * r.ndat
+    # SURVEY 8(d) with the output term of this path: each input byte once, the chirp once, each SCRUNCHED sample written once
+    b_alg = 2 * (2 * N) + 8 * N + cfg.nchan * cfg.npol * 4 * lf.nkeep / cfg.tscrunch
+    achieved = b_alg * npart / (g_ms * 1e-3) / 1e9
+    samples = npart * lf.nsamp_step
+    res = {"metric": "Msamples/s dedispersed+folded", "value": round(samples * args.steps / elapsed / 1e6, 2), "unit": "Msamples/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "cfg5c", "command": wl["cmd"], "nchan": cfg.nchan, "freq_res": r.ndat, "n_fft": N, "nkeep": lf.nkeep,
+                      "tscrunch": cfg.tscrunch, "parts_per_block": npart, "max_parts": cfg.max_parts, "input": "8-bit dual-pol, resident in HBM",
+                      "search_fused": bool(lf.fused and lf.fb.search_is_fused()), "library_build": dspsr_amd.build_id(),
+                      "note": "search mode: dedispersed coherently, detected, scrunched and digitised, NOT folded"},
+           "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": measured_traffic("cfg5c", cfg.max_parts), "traffic_source": measured_traffic.source,
+                        "kernel": "filterbank launch group k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,2> (FFT + chirp + square law + "
+                                  "time scrunch)",
+                        "algorithmic_bytes_per_part": int(b_alg), "group_ms_per_block": round(g_ms, 4)}}
+    if res["roofline"]["traffic"]:
+        res["roofline"]["traffic_ratio"] = round(res["roofline"]["traffic"] / (b_alg * cfg.max_parts), 3)
     lf.close()
     return res
 
@@ -1035,10 +1104,11 @@ def main():
             dist.destroy_process_group()
 
     name = args.workload or "target"
-    if name in ("cfg5", "fold"):
+    if name in ("cfg5", "cfg5c", "fold"):
         if world > 1:
             sys.exit("bench.py: the %s workload runs as independent replicas; use --gpus 1" % name)
-        return finish(bench_search_mode(args, WORKLOADS[name], torch) if name == "cfg5" else bench_fold_only(args, WORKLOADS[name], torch))
+        fn = {"cfg5": bench_search_mode, "cfg5c": bench_search_coherent, "fold": bench_fold_only}[name]
+        return finish(fn(args, WORKLOADS[name], torch))
     ctx = (torch, dist, rank, world, local_rank, single)
     out = run_fold_workload(name, args, *ctx, steps=args.steps, warmup=args.warmup, full=True)
     if args.workload is None and not args.no_companions and not (args.parts_per_block or args.max_parts):
@@ -1065,6 +1135,11 @@ def main():
                            "roofline_frac": rec5["roofline"]["frac"], "roofline_kernel": rec5["roofline"]["kernel"],
                            "roofline_traffic_ratio": rec5["roofline"].get("traffic_ratio"), "roofline_traffic_source": rec5["roofline"].get("traffic_source"),
                            "command": rec5["config"]["command"]})
+            rec5c = bench_search_coherent(sm, WORKLOADS["cfg5c"], torch)
+            others.append({"workload": "cfg5c", "value": rec5c["value"], "unit": rec5c["unit"], "ms_per_step": rec5c["ms_per_step"], "steps": rec5c["steps"],
+                           "roofline_frac": rec5c["roofline"]["frac"], "roofline_kernel": rec5c["roofline"]["kernel"],
+                           "roofline_traffic_ratio": rec5c["roofline"].get("traffic_ratio"), "roofline_traffic_source": rec5c["roofline"].get("traffic_source"),
+                           "command": rec5c["config"]["command"]})
             fo = argparse.Namespace(**vars(args))
             fo.steps, fo.warmup, fo.no_cpu_baseline = 2 * ssteps, swarm, True
             recf = bench_fold_only(fo, WORKLOADS["fold"], torch)                 # BASELINE.md benchmark B (Benchmark/fold.csh): dsp::Fold alone

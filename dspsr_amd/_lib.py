@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("DSPSR_AMD_LIB") or os.path.join(_HERE, "libdspsr_amd.
 OK, EINVAL, EHIP, ENOMEM, ESTATE = 0, -1, -2, -3, -4
 H2D, D2H, D2D = 1, 2, 3
 RAW_GENERIC, RAW_CASPSR, RAW_UWB16 = 0, 1, 2
-COHERENCE, STOKES = 0, 1
+COHERENCE, STOKES, INTENSITY, PPQQ = 0, 1, 2, 3
 FUSED_AUTO, FUSED_ALWAYS, FUSED_NEVER = 0, 1, 2
 REDUCE_SUM, REDUCE_GATHER = 0, 1
 UNIQUE_ID_BYTES = 128
@@ -71,6 +71,12 @@ SYMBOLS = {
     "dspsr_amd_filterbank_fold_is_fused": (_i, [_vp]),
     "dspsr_amd_filterbank_npass": (_i, [_vp, _i]),
     "dspsr_amd_filterbank_perform_fold": (_i, [_vp, _vp, _u64, _u64, _u64, _vp, _i, _f, _i, _vp, _u64]),
+    "dspsr_amd_filterbank_perform_search": (_i, [_vp, _vp, _u64, _u64, _u64, _vp, _i, _f, _i, _u32, _vp, _u64, _u64, _vp,
+                                                 C.POINTER(_u32), _u64, C.POINTER(_u64)]),
+    "dspsr_amd_filterbank_search_is_fused": (_i, [_vp]),
+    "dspsr_amd_tscrunch_fpt": (_i, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u32, _u64, _u32, _vp, C.POINTER(_u32),
+                                    C.POINTER(_u64)]),
+    "dspsr_amd_fscrunch_fpt": (_i, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u32, _u64, _u32]),
     "dspsr_amd_sample_delay_create": (_i, [_vp, _u32, _u32, _vp, _i, _pp]),
     "dspsr_amd_sample_delay_destroy": (None, [_vp]),
     "dspsr_amd_sample_delay_zero_delay": (C.c_int64, [_vp]),
@@ -84,6 +90,9 @@ SYMBOLS = {
     "dspsr_amd_rescale_get": (_i, [_vp, _vp, _vp]),
     "dspsr_amd_rescale_pscrunch_digitize": (_i, [_vp, _vp, _u64, _i, _f, _i, _i, _vp]),
     "dspsr_amd_sigproc_digitize": (_i, [_vp, _vp, _u64, _u32, _u32, _i, _i, _d, _f, _i, _i, _vp]),
+    "dspsr_amd_rescale_transform_fpt": (_i, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _u64]),
+    "dspsr_amd_sigproc_digitize_fpt": (_i, [_vp, _vp, _u64, _u64, _u64, _u32, _u32, _i, _i, _d, _f, _i, _i, _vp]),
+    "dspsr_amd_rescale_digitize_fpt": (_i, [_vp, _vp, _u64, _u64, _u64, _i, _f, _i, _i, _vp]),
     "dspsr_amd_detect_polarimetry": (_i, [_vp, _i, _u32, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u64]),
     "dspsr_amd_detect_square_law": (_i, [_vp, _i, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u32, _u64]),
     "dspsr_amd_tfp_filterbank": (_i, [_vp, C.POINTER(TfpConfig), _vp, _i, _f, _vp, _u64]),

@@ -78,9 +78,10 @@ __global__ void k_square_law(const int intensity, const uint32_t npol, const flo
     float acc = 0.f;
     for (uint32_t ipol = 0; ipol < npol; ipol++) {
       const float2 a = ((const float2*)(in + chan * in_chan_stride + ipol * in_pol_stride))[i];
-      float v = a.x * a.x;   // Detection.C:273-279: Re*Re then += Im*Im
-      v += a.y * a.y;
-      if (intensity) acc = ipol ? acc + v : v;          // Detection.C:285-300: *p0 += *p1
+      // Detection.C:273-279: `*out = re*re; *out += im*im;` -- two roundings, as the reference's x86 host code (no fused
+      // multiply-add), and the same expression as the search-mode epilogue of the filterbank (fb_common.h sqld)
+      const float v = __fadd_rn(__fmul_rn(a.x, a.x), __fmul_rn(a.y, a.y));
+      if (intensity) acc = ipol ? __fadd_rn(acc, v) : v;          // Detection.C:285-300: *p0 += *p1
       else out[chan * out_chan_stride + ipol * out_pol_stride + i] = v;
     }
     if (intensity) out[chan * out_chan_stride + i] = acc;

@@ -90,7 +90,81 @@ struct FbOut {
   const Interval* piv;                          // kind 3: intervals (offset within the part, hits), time ordered per bin
   const uint32_t* blk_first;                    // kind 4: interval that holds sample 1024*i of the block
   const uint32_t* bin_start;                    // kind 4 (host side only): the intervals bucketed by phase bin (with piv)
+  // kind 5: search mode (digifil -F N:D): square-law detection (state = DSPSR_AMD_INTENSITY | DSPSR_AMD_PPQQ) and the time
+  // scrunch of the detected STREAM inside the inverse pass; base = FPT rows [chan][npol_out] of scrunched samples, chan_stride /
+  // pol_stride in floats.  See ts_part / the search epilogue below.
+  uint32_t ts_sf;                               //   scrunch factor
+  uint32_t ts_magic;                            //   ceil(2^32 / sf): t / sf = umulhi(t, magic) for t * sf < 2^32 (host checks)
+  uint32_t ts_phase0;                           //   samples of output 0 already summed into the carry when the call begins
+  uint32_t ts_G;                                //   groups per staged row (odd, >= the most groups a part can touch)
+  float* ts_carry;                              //   [chan][npol_out] partial sums of the output sample still open
 };
+
+// Search-mode epilogue (FbOut kind 5): the detected samples of a channel form a stream over the parts of a call (and over calls:
+// the carry).  Output sample o is the sum, in time order, of stream samples [o*sf, (o+1)*sf) (TScrunch.C:148-178).  A part's nkeep
+// samples start at stream index s = phase0 + part * nkeep: they touch groups ofirst .. ofirst + ng - 1, the first one from its
+// element phi on, the last one up to element rlast - 1.
+struct TsPart { uint32_t phi, ng, rlast, ofirst; };
+DEV TsPart ts_part(const FbOut& out, const uint32_t part_in_call, const uint32_t nkeep)
+{
+  const uint32_t s = out.ts_phase0 + part_in_call * nkeep;       // (< 2^32: the host bounds npart * nkeep)
+  TsPart p;
+  p.ofirst = s / out.ts_sf;
+  p.phi = s - p.ofirst * out.ts_sf;
+  const uint32_t e = p.phi + nkeep;
+  p.ng = (e + out.ts_sf - 1) / out.ts_sf;
+  p.rlast = e - (p.ng - 1) * out.ts_sf;
+  return p;
+}
+// Square-law detection as the reference's host code rounds it (Detection.C:273-279: `*out = re*re; *out += im*im;` -- two
+// roundings, no fused multiply-add on its x86 builds)
+DEV float sqld(const cf a) { return __fadd_rn(__fmul_rn(a.x, a.x), __fmul_rn(a.y, a.y)); }
+// The tile's detected samples are staged as [channel * npol_out + q][element r of the group][group] floats (G groups per row, G
+// odd): the scrunch then reads element r of consecutive groups from consecutive words (conflict free), and the last stage's writes
+// -- consecutive samples of a lane pair's channels -- fall G words apart.
+DEV void ts_stage(float* __restrict__ stg, const FbOut& out, const TsPart& tp, const uint32_t slo, const uint32_t t, const cf a, const cf b)
+{
+  const uint32_t tr = t + tp.phi, gq = out.ts_sf == 1 ? tr : __umulhi(tr, out.ts_magic), r = tr - gq * out.ts_sf;
+  const float pp = sqld(a), qq = sqld(b);
+  if (out.state == DSPSR_AMD_PPQQ) {
+    const uint32_t base = ((2 * slo) * out.ts_sf + r) * out.ts_G + gq;
+    stg[base] = pp;
+    stg[base + out.ts_sf * out.ts_G] = qq;
+  } else {
+    stg[(slo * out.ts_sf + r) * out.ts_G + gq] = __fadd_rn(pp, qq);          // Detection.C:285-300: *p0 += *p1
+  }
+}
+// carry of row `row` (channel * npol_out + q), read past the L1 (the previous part's store of this workgroup went to L2)
+DEV float ts_carry_load(const FbOut& out, const uint32_t row) { return __hip_atomic_load(out.ts_carry + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The scrunch of one staged tile: nrow = channels * npol_out staged rows; chan_of(row / npo) = output channel (without chan0).
+// Thread w < nrow takes the FIRST group of row w (the one that may continue the carry, pre-loaded into `carry_pre` by that same
+// thread), the others the remaining (row, group) items.  Sums are sequential in time: out = in[0]; out += in[1]; ...
+template <class ChanOf>
+DEV void ts_reduce(const float* __restrict__ stg, const FbOut& out, const TsPart& tp, const uint32_t nrow, const float carry_pre,
+                   const bool have_pre, const uint32_t tid, const uint32_t nthr, ChanOf&& chan_of)
+{
+  const uint32_t sf = out.ts_sf, G = out.ts_G, npo = out.state == DSPSR_AMD_PPQQ ? 2u : 1u;
+  const uint32_t ng1 = tp.ng - 1, nitem = nrow * tp.ng;
+  for (uint32_t w = tid; w < nitem; w += nthr) {
+    uint32_t row, gq;
+    if (w < nrow) { row = w; gq = 0; }
+    else { const uint32_t x = w - nrow; row = x / ng1; gq = 1 + (x - row * ng1); }
+    const uint32_t r1 = gq == ng1 ? tp.rlast : sf;
+    uint32_t r = gq == 0 ? tp.phi : 0;
+    const float* __restrict__ src = stg + (row * sf) * G + gq;
+    float acc;
+    if (gq == 0 && tp.phi) acc = (have_pre && w == tid) ? carry_pre : ts_carry_load(out, (out.chan0 + chan_of(row / npo)) * npo + row % npo);
+    else { acc = src[r * G]; r++; }
+    for (; r + 4 <= r1; r += 4) {                                  // loads ahead, adds in time order
+      const float a0 = src[r * G], a1 = src[(r + 1) * G], a2 = src[(r + 2) * G], a3 = src[(r + 3) * G];
+      acc = __fadd_rn(acc, a0); acc = __fadd_rn(acc, a1); acc = __fadd_rn(acc, a2); acc = __fadd_rn(acc, a3);
+    }
+    for (; r < r1; r++) acc = __fadd_rn(acc, src[r * G]);
+    const uint32_t chan = out.chan0 + chan_of(row / npo), q = row % npo;
+    if (r1 < sf) out.ts_carry[chan * npo + q] = acc;                // the group is still open: the next part (or call) continues it
+    else out.base[chan * out.chan_stride + q * out.pol_stride + tp.ofirst + gq] = acc;
+  }
+}
 
 // nchan_subband = 3 * 2^k / 5 * 2^k: arguments of k_sub_split (see the section in front of pass 2)
 struct SubSplit {
@@ -442,12 +516,13 @@ k1_t fb_pick1_dual(int raww);      // pass 1 on pairs of two-column tiles (2^13-
 k2_t fb_pick2(int logf, bool full);
 k3_t fb_pick3(int logf, bool full);       // plain
 k3_t fb_pick3f(int logf, bool full);      // fused fold
+k3_t fb_pick3s(int logf, bool full);      // search mode (detection + time scrunch)
 k3a_t fb_pick3a(int logf, bool blocked, bool real, bool full);
 k3b_t fb_pick3b(int logf, bool foldb, bool full);
 // two-pass path (fb_two_pass.hip): pass 1 on whole columns, rows + inverse pass (M = 2^logm, Fb = 2^(13 - logm)), the 8-bit regroup
 typedef void (*k1c_t)(FbGeom, FbIn, cf*, const cf*, uint32_t, uint32_t, uint32_t);
 k1c_t fb_pick_col1();
-k3_t fb_pick_rinv(int logm, bool fold);
+k3_t fb_pick_rinv(int logm, int epi);      // epilogue: 0 output written, 1 fused fold, 2 search mode
 void fb_launch_raw_cols(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_sub_split(hipStream_t stream, const SubSplit& p, uint8_t* out, uint32_t ncu);
 void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu, cf* Xout = nullptr, uint32_t mo = 0,

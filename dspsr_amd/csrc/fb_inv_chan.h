@@ -20,13 +20,17 @@ namespace dspsr_amd {
 // order and launches are stream ordered, so every (chan, bin) sum has the association order of the CPU loop
 // Fold.C:844-852, exactly as the stand-alone fold kernel (fold.hip) -- bit-identical results, without the
 // 16 B/sample round trip of the detected time series through HBM.
-template <int LOGF, bool FOLD, int LOGT>
+// EPI: 0 = complex or detected output written by the last stage; 1 (FOLD) = fused fold; 2 = search mode (FbOut kind 5): square-law
+// detection + time scrunch of the detected stream (digifil -F N:D, LoadToFil.C:185-222,250-304), staged like the fold's samples and
+// reduced by ts_reduce (fb_common.h).  Both walk the parts of a tile in order (the fold's profile, the scrunch's carry).
+template <int LOGF, int EPI, int LOGT>
 __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __restrict__ X,
                                                   const cf* __restrict__ kernel, const FbOut out,
                                                   const cf* __restrict__ tw, const uint64_t part0,
                                                   const uint32_t nparts, const uint32_t run)
 {
   typedef FftPlan<LOGF> P;
+  constexpr bool FOLD = EPI == 1, SEARCH = EPI == 2;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
   const int logT3 = LOGT >= 1 ? LOGT - 1 : g.logT3;
@@ -172,9 +176,9 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
   // Without the fold the order of the items is free.  When every workgroup gets the same number of tiles it also walks the
   // parts of a tile one after the other, so that the tile's chirp stays in registers (one chirp read per launch, not per
   // part); otherwise the items are dealt XCD-wise as in the other passes.
-  const bool tile_major = FOLD || (ntile >= gridDim.x && ntile % gridDim.x == 0);
+  const bool tile_major = EPI != 0 || (ntile >= gridDim.x && ntile % gridDim.x == 0);
   auto next_item = [&](const uint32_t jj, Item& it) -> bool {
-    if (FOLD || tile_major) {
+    if (EPI != 0 || tile_major) {
       const uint32_t q = jj / fnp;                     // (32-bit; jj counts this workgroup's items)
       it.tile = fold_b + q * fntg;
       it.lp = fp0 + (jj - q * fnp);
@@ -303,6 +307,9 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
 
     const uint32_t tile = item.tile;
     const uint64_t part = part0 + item.lp;
+    [[maybe_unused]] TsPart tsp = {0, 0, 0, 0};
+    [[maybe_unused]] float ts_carry_pre = 0.f;
+    if constexpr (SEARCH) tsp = ts_part(out, (uint32_t)part, g.nkeep);
     // FOLD: the tile's detected samples are staged UNPADDED, channel after channel (16 bytes per sample), so that the
     // samples of a phase bin's run are read at constant offsets from one base (the padded image cost four integer
     // instructions per sample in a phase that only three of eight waves work in).  The channel stride is nkeep rounded up
@@ -322,6 +329,16 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
           float r[4];
           detect4(cx2_lo(v[k]), cx2_hi(v[k]), out.state, r);
           *(float4*)&lds[2 * (slo * fcs + (uint32_t)t)] = make_float4(r[0], r[1], r[2], r[3]);
+        }
+        return;
+      }
+      if constexpr (SEARCH) {
+        const int32_t t0 = (int32_t)p - (int32_t)g.nfilt_pos;
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          const int32_t t = t0 + (int32_t)(k * pstride);
+          if ((uint32_t)t >= g.nkeep) continue;
+          ts_stage((float*)lds, out, tsp, col >> 1, (uint32_t)t, cx2_lo(v[k]), cx2_hi(v[k]));
         }
         return;
       }
@@ -415,6 +432,13 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
       }
     };
     auto mid = [&](const int phase) {
+      if constexpr (SEARCH) {
+        // the open output sample's partial sum (written by this workgroup at the end of the previous part, two barriers ago)
+        const uint32_t npo = out.state == DSPSR_AMD_PPQQ ? 2u : 1u;
+        // (behind the tile's first barrier: that store has been waited for; single-stage transforms load it in ts_reduce)
+        if (FftPlan<LOGF>::NS >= 2 && phase == 2 && tsp.phi && tid < (npo << logT3))
+          ts_carry_pre = ts_carry_load(out, (out.chan0 + tile * T3 + tid / npo) * npo + tid % npo);
+      }
       if constexpr (PRE) {
         // only when the part's plan entries are in LDS: the accumulator's address then depends on an LDS read alone.  With
         // the entry possibly coming from global memory (a select, or two branches that the compiler merges again) the
@@ -429,8 +453,14 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         if (phase == 2 && plan_dma_ok && more) plan_dma(next, (jt + 1) & 1);
       }
     };
-    wgfft<LOGF, +1, FOLD>(lds, ltw_off, tid, logT, x, store, mid);
+    wgfft<LOGF, +1, EPI != 0>(lds, ltw_off, tid, logT, x, store, mid);
     FB_ST(3, 3);
+    if constexpr (SEARCH) {
+      __syncthreads();                       // the tile's detected samples are staged
+      const uint32_t npo = out.state == DSPSR_AMD_PPQQ ? 2u : 1u;
+      ts_reduce((const float*)lds, out, tsp, npo << logT3, ts_carry_pre, FftPlan<LOGF>::NS >= 2, tid, blockDim.x, [&](const uint32_t slo) { return tile * T3 + slo; });
+      // (the barrier in front of the next tile's first exchange write also ends this read phase)
+    }
     if constexpr (FOLD) {
       __syncthreads();                       // the tile's detected samples are staged
       // the samples of an interval are fetched from LDS eight at a time (independent loads) and then added one after

@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void k_time_combine(const TimeCombine p, const
 
 template <int... I> static k3_t pick3(int logf, bool full, iseq<I...>)
 {
-  static const k3_t t[] = {k_inv_chan<I, false, -1>...};
-  static const k3_t f[] = {k_inv_chan<I, false, full_logt(I)>...};
+  static const k3_t t[] = {k_inv_chan<I, 0, -1>...};
+  static const k3_t f[] = {k_inv_chan<I, 0, full_logt(I)>...};
   return full ? f[logf] : t[logf];
 }
 k3_t fb_pick3(int logf, bool full) { return pick3(logf, full, seq_t()); }

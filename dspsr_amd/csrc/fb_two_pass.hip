@@ -187,13 +187,14 @@ __global__ __launch_bounds__(512) void k_fwd_col1q(const FbGeom g, const FbIn in
 // P2': see the head of this section.  LOGM + LOGFB == 13: a tile is Fb channels x 2 polarisations x M bins = 2^14 points;
 // a thread holds, for NJ = 16 / Fb bins j = tid + 512*jq, the Fb rows nb of both polarisations (pair = (pol 0, pol 1)).
 // Items, the fused fold (exact time order per tile, or segmented over part runs) and the output forms are k_inv_chan's.
-template <int LOGM, int LOGFB, bool FOLD>
+template <int LOGM, int LOGFB, int EPI>
 __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __restrict__ A,
                                                   const cf* __restrict__ kernel, const FbOut out,
                                                   const cf* __restrict__ tw, const uint64_t part0,
                                                   const uint32_t nparts, const uint32_t run)
 {
   static_assert(LOGM + LOGFB == 13 && LOGFB >= 1 && LOGFB <= 4, "k_rows_inv: Fb channels x 2 pols x M bins = 2^14 points");
+  constexpr bool FOLD = EPI == 1, SEARCH = EPI == 2;         // (the epilogues of k_inv_chan)
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
   // (the inverse 512-point transforms as even / odd 256-point halves + a radix-2 step in registers measured -3 % fused but +28 %
@@ -269,9 +270,9 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
       __syncthreads();
     }
   }
-  const bool tile_major = FOLD || (ntile >= gridDim.x && ntile % gridDim.x == 0);
+  const bool tile_major = EPI != 0 || (ntile >= gridDim.x && ntile % gridDim.x == 0);
   auto next_item = [&](const uint32_t jj, Item& it) -> bool {
-    if (FOLD || tile_major) {
+    if (EPI != 0 || tile_major) {
       const uint32_t q = jj / fnp;
       it.tile = fold_b + q * fntg;
       it.lp = fp0 + (jj - q * fnp);
@@ -374,6 +375,9 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
 
     const uint32_t tile = item.tile;
     const uint64_t part = part0 + item.lp;
+    [[maybe_unused]] TsPart tsp = {0, 0, 0, 0};
+    [[maybe_unused]] float ts_carry_pre = 0.f;
+    if constexpr (SEARCH) tsp = ts_part(out, (uint32_t)part, g.nkeep);
     const uint32_t fcr = (16u >> logT3) & 15u, fcs_r = ((g.nkeep + 15u - fcr) & ~15u) + fcr;
     const uint32_t fcs = ((2u * fcs_r) << logT3) <= PTS * blockDim.x ? fcs_r : g.nkeep;
     auto store = [&](const uint32_t col, const uint32_t p, const uint32_t pstride, auto& v) {
@@ -388,6 +392,16 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
           float r[4];
           detect4(cx2_lo(v[k]), cx2_hi(v[k]), out.state, r);
           *(float4*)&lds[2 * (slo * fcs + (uint32_t)t)] = make_float4(r[0], r[1], r[2], r[3]);
+        }
+        return;
+      }
+      if constexpr (SEARCH) {
+        const int32_t t0 = (int32_t)p - (int32_t)g.nfilt_pos;
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          const int32_t t = t0 + (int32_t)(k * pstride);
+          if ((uint32_t)t >= g.nkeep) continue;
+          ts_stage((float*)lds, out, tsp, col >> 1, (uint32_t)t, cx2_lo(v[k]), cx2_hi(v[k]));
         }
         return;
       }
@@ -471,6 +485,13 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
       }
     };
     auto mid = [&](const int phase) {
+      if constexpr (SEARCH) {
+        // the open output sample's partial sum (this workgroup's store at the end of the previous part; FROM_LDS: the rows -> bins
+        // exchange in front of the transform has passed two barriers since)
+        const uint32_t npo = out.state == DSPSR_AMD_PPQQ ? 2u : 1u;
+        if (phase == 1 && tsp.phi && tid < (npo << logT3))
+          ts_carry_pre = ts_carry_load(out, (out.chan0 + chan_of(tile, tid / npo)) * npo + tid % npo);
+      }
       if constexpr (PRE) {
         if (phase == 2 && in_lds && tid < (f_nact << logT3)) {
           en_pre = planl[tid >> logT3];
@@ -487,8 +508,13 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
         if (phase == 2 && plan_dma_ok && more) plan_dma(next, (jt + 1) & 1);
       }
     };
-    wgfft<LOGM, +1, FOLD, true>(lds, ltw_off, tid, logT, x, store, mid);
+    wgfft<LOGM, +1, EPI != 0, true>(lds, ltw_off, tid, logT, x, store, mid);
     FB_ST(7, 4);
+    if constexpr (SEARCH) {
+      __syncthreads();                       // the tile's detected samples are staged
+      const uint32_t npo = out.state == DSPSR_AMD_PPQQ ? 2u : 1u;
+      ts_reduce((const float*)lds, out, tsp, npo << logT3, ts_carry_pre, true, tid, blockDim.x, [&](const uint32_t slo) { return chan_of(tile, slo); });
+    }
     if constexpr (FOLD) {
       __syncthreads();
       const bool pre = PRE && in_lds;
@@ -540,15 +566,17 @@ __global__ __launch_bounds__(512) void k_rows_inv(const FbGeom g, const cf* __re
 }
 
 k1c_t fb_pick_col1() { return k_fwd_col1q<1>; }
-k3_t fb_pick_rinv(int logm, bool fold)
+k3_t fb_pick_rinv(int logm, int epi)
 {
+#define FB_RINV(M, B) (epi == 1 ? k_rows_inv<M, B, 1> : epi == 2 ? k_rows_inv<M, B, 2> : k_rows_inv<M, B, 0>)
   switch (logm) {
-    case 9: return fold ? k_rows_inv<9, 4, true> : k_rows_inv<9, 4, false>;
-    case 10: return fold ? k_rows_inv<10, 3, true> : k_rows_inv<10, 3, false>;
-    case 11: return fold ? k_rows_inv<11, 2, true> : k_rows_inv<11, 2, false>;
-    case 12: return fold ? k_rows_inv<12, 1, true> : k_rows_inv<12, 1, false>;
+    case 9: return FB_RINV(9, 4);
+    case 10: return FB_RINV(10, 3);
+    case 11: return FB_RINV(11, 2);
+    case 12: return FB_RINV(12, 1);
     default: return nullptr;
   }
+#undef FB_RINV
 }
 void fb_launch_raw_cols(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0)
 {

@@ -32,7 +32,7 @@ struct dspsr_amd_filterbank_impl {
   // kernels of this geometry, chosen and given their dynamic-LDS limit once, at create time
   k1_t k1_w1 = nullptr, k1_w4 = nullptr;                     // pass 1: one word per sample pair / generic loads
   k2_t k2 = nullptr;
-  k3_t k3 = nullptr, k3f = nullptr;                          // inverse pass: plain, fused fold
+  k3_t k3 = nullptr, k3f = nullptr, k3s = nullptr;           // inverse pass: plain, fused fold, search mode (FbOut kind 5)
   k3a_t k3a = nullptr;
   k3b_t k3b = nullptr;
   float* fpart = nullptr;    // segmented fused fold: partial profiles of the part runs 1 .. nseg-1 of a launch
@@ -48,7 +48,7 @@ struct dspsr_amd_filterbank_impl {
   uint32_t nt1t = 0;
   size_t lds1t = 0;
   k1c_t k1c = nullptr;
-  k3_t k2r = nullptr, k2rf = nullptr;
+  k3_t k2r = nullptr, k2rf = nullptr, k2rs = nullptr;
   size_t lds1c = 0, lds2r = 0, lds2rf = 0;
   uint32_t plan_cap2 = 0;
   k3b_t k3bf = nullptr;      // four-pass fused fold: second inverse pass that leaves segment sums (FbOut kind 4)
@@ -255,6 +255,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     } else {
       fb->k3 = fb_pick3(g.logM, full3);
       fb->k3f = fb_pick3f(g.logM, full3);
+      fb->k3s = fb_pick3s(g.logM, full3);
       // fused fold: the LDS left over behind the twiddle tables holds the part's fold plan (two buffers)
       const size_t psl_bytes = FB_PSL_MAX * sizeof(uint32_t);
       const size_t spare = 160 * 1024 - 64 - fb->lds3 - 16 - psl_bytes;
@@ -274,6 +275,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
       if (e == hipSuccess) e = allow_lds(fb->k2, fb->lds2);
       if (e == hipSuccess && fb->k3) e = allow_lds(fb->k3, fb->lds3);
       if (e == hipSuccess && fb->k3f) e = allow_lds(fb->k3f, fb->lds3f);
+      if (e == hipSuccess && fb->k3s) e = allow_lds(fb->k3s, fb->lds3);
       if (e == hipSuccess && fb->k3a) e = allow_lds(fb->k3a, fb->lds3);
       if (e == hipSuccess && fb->k3b) e = allow_lds(fb->k3b, fb->lds4);
       if (e == hipSuccess && fb->k3bf) e = allow_lds(fb->k3bf, fb->lds4);
@@ -314,8 +316,9 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
         have1 = fb->k1t != nullptr && q.logT1 >= 1 && p1t >= 32;
         if (have1) e2 = allow_lds(fb->k1t, fb->lds1t);
       }
-      fb->k2r = fb_pick_rinv(logMf, false);
-      fb->k2rf = fb_pick_rinv(logMf, true);
+      fb->k2r = fb_pick_rinv(logMf, 0);
+      fb->k2rf = fb_pick_rinv(logMf, 1);
+      fb->k2rs = fb_pick_rinv(logMf, 2);
       if (have1 && fb->k2r && fb->k2rf) {
         g.logFb2 = lfb;
         g.logFa2 = lfa;
@@ -330,6 +333,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
         fb->lds2rf = fb->lds2r + 16 + (size_t)cap * 32 + psl_bytes;
         if (e2 == hipSuccess) e2 = allow_lds(fb->k2r, fb->lds2r);
         if (e2 == hipSuccess) e2 = allow_lds(fb->k2rf, fb->lds2rf);
+        if (e2 == hipSuccess && fb->k2rs) e2 = allow_lds(fb->k2rs, fb->lds2r);
         fb->two_pass = e2 == hipSuccess;
       }
     }
@@ -555,7 +559,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   k1_t k1 = raww == 1 ? fb->k1_w1 : fb->k1_w4;
   const k1_t k1d = raww == 1 ? fb->k1d_w1 : fb->k1d_w4;
   k2_t k2 = fb->k2;
-  k3_t k3 = out.kind == 3 ? fb->k3f : fb->k3;
+  k3_t k3 = out.kind == 3 ? fb->k3f : out.kind == 5 ? fb->k3s : fb->k3;
   k3a_t k3a = fb->k3a;
   k3b_t k3b = out.kind == 4 ? fb->k3bf : fb->k3b;
   if (!k1 || !k2 || (g.four_pass ? (!k3a || !k3b) : !k3))
@@ -673,8 +677,9 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
           const int rc = fb_launch_fused(fb, k3, fb->X, kern, co, part0, nb, fused_segmented);
           if (rc != DSPSR_AMD_OK) return rc;
         } else {
-          hipLaunchKernelGGL(k3, dim3(grid_for(n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X, kern, co, ctx->tw,
-                             part0, nb, nb);
+          // (search mode: one workgroup per tile of channels, walking the group's parts in order)
+          hipLaunchKernelGGL(k3, dim3(grid_for(co.kind == 5 ? n3s / nb : n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X,
+                             kern, co, ctx->tw, part0, nb, nb);
         }
         continue;
       }
@@ -701,6 +706,9 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         if (co.kind == 3) {
           const int rc = fb_launch_fused(fb, fb->k2rf, fb->A, kern, co, part0, nb, fused_segmented, true);
           if (rc != DSPSR_AMD_OK) return rc;
+        } else if (co.kind == 5) {
+          hipLaunchKernelGGL(fb->k2rs, dim3(grid_for(tiles, fb->ncu)), dim3(512), fb->lds2r, ctx->stream, g, fb->A, kern, co, ctx->tw, part0,
+                             nb, nb);
         } else {
           hipLaunchKernelGGL(fb->k2r, dim3(grid_for((uint64_t)tiles * nb, fb->ncu)), dim3(512), fb->lds2r, ctx->stream, g, fb->A, kern, co,
                              ctx->tw, part0, nb, nb);
@@ -749,7 +757,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
           const uint32_t ns = nb - s0 < p23sub ? nb - s0 : p23sub;
           const uint64_t off = (uint64_t)s0 * fb->part_elems;
           const uint64_t n2s = (uint64_t)(M >> g.logT2) * fb->nseq * ns;
-          const uint64_t n3s = co.kind == 3 ? (uint64_t)(g.C >> g.logT3) : (uint64_t)(g.C >> g.logT3) * ns;
+          const uint64_t n3s = (co.kind == 3 || co.kind == 5) ? (uint64_t)(g.C >> g.logT3) : (uint64_t)(g.C >> g.logT3) * ns;
           hipLaunchKernelGGL(k2, dim3(grid_for(n2s, fb->ncu)), dim3(fb->nt2), fb->lds2, ctx->stream, g, fb->A + off,
                              fb->X + off, ctx->tw, ns, fb->nseq, run2);
           if (co.kind == 3) {
@@ -766,7 +774,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
                          ctx->tw, nb, fb->nseq, run2);
       if (!g.four_pass) {
         // fused fold: one workgroup owns a tile (T3 channels) for all parts of the launch
-        const uint64_t items3 = co.kind == 3 ? (uint64_t)(g.C >> g.logT3) : n3;
+        const uint64_t items3 = (co.kind == 3 || co.kind == 5) ? (uint64_t)(g.C >> g.logT3) : n3;
         const size_t lds3 = co.kind == 3 ? fb->lds3f : fb->lds3;
         if (co.kind == 3) co.plan_cap = fb->plan_cap;       // LDS left over behind the twiddle tables holds the part's fold plan
         if (co.kind == 3) {
@@ -895,6 +903,109 @@ extern "C" int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, con
   }
   FbOut out = {2, det_dev, det_chan_stride, det_pol_stride, 0, state, ndim, 0};
   return fb_run(fb, in, out, npart, in_chan_stride);
+}
+
+// search mode inside the inverse pass: the staged tile (fb_common.h ts_stage) must fit the exchange buffer and the 32-bit index
+// arithmetic of the epilogue must hold
+static bool fb_search_fits(const dspsr_amd_filterbank* fb, uint32_t npo, uint32_t sf, uint32_t* G_out)
+{
+  const FbGeom& g = fb->g;
+  if (g.four_pass || fb->msub || !fb->k3s || g.nkeep >= 65536 || sf >= 32768) return false;
+  const uint64_t ngmax = ((uint64_t)g.nkeep + 2ull * sf - 2) / sf;
+  const uint32_t G = (uint32_t)ngmax | 1u;
+  const uint64_t floats = ((uint64_t)npo << g.logT3) * sf * G;
+  if (floats > 2ull * fb->nt3 * PTS) return false;                       // (the buffer's padding is slack)
+  if (((uint64_t)g.nkeep + sf) * sf >= (1ull << 32)) return false;       // t / sf by multiplication (ts_magic)
+  if (G_out) *G_out = G;
+  return true;
+}
+
+extern "C" int dspsr_amd_filterbank_search_is_fused(const dspsr_amd_filterbank* fb)
+{
+  return fb && fb_search_fits(fb, 2, 1, nullptr) ? 1 : 0;
+}
+
+extern "C" int dspsr_amd_filterbank_perform_search(dspsr_amd_filterbank* fb, const float* in_f32_dev, uint64_t in_chan_stride,
+                                                   uint64_t in_pol_stride, uint64_t in_step, const int8_t* raw_dev, int raw_layout,
+                                                   float scale, int out_state, uint32_t tscrunch, float* out_dev, uint64_t out_chan_stride,
+                                                   uint64_t out_pol_stride, float* carry_dev, uint32_t* carry_count, uint64_t npart,
+                                                   uint64_t* nout)
+{
+  if (!fb || (!in_f32_dev == !raw_dev) || !carry_count || !nout) return DSPSR_AMD_EINVAL;
+  dspsr_amd_ctx* ctx = fb->ctx;
+  if (out_state != DSPSR_AMD_INTENSITY && out_state != DSPSR_AMD_PPQQ)
+    return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_search: out_state=%d is neither Intensity nor PPQQ", out_state);
+  if (out_state == DSPSR_AMD_PPQQ && fb->cfg.npol != 2)
+    return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_search: PPQQ needs two polarisations (npol=%u)", fb->cfg.npol);
+  if (!tscrunch) return fb_fail(ctx, DSPSR_AMD_EINVAL, "dsp::TScrunch::get_factor scrunch factor not set");
+  if (*carry_count >= tscrunch)
+    return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_search: carry_count=%u must be < tscrunch=%u", *carry_count, tscrunch);
+  const uint32_t npo = out_state == DSPSR_AMD_PPQQ ? 2u : 1u, nkeep = fb_out_nkeep(fb);
+  const uint64_t ndat = npart * nkeep, total = (uint64_t)*carry_count + ndat;
+  if (total + tscrunch >= (1ull << 32))
+    return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_search: %llu parts x %u samples exceed the 32-bit sample index of a call",
+                   (unsigned long long)npart, nkeep);
+  *nout = total / tscrunch;
+  const uint32_t rem = (uint32_t)(total % tscrunch);
+  if (!npart) return DSPSR_AMD_OK;
+  if ((!out_dev && *nout) || !carry_dev) return DSPSR_AMD_EINVAL;
+  const uint64_t nchan_out = (uint64_t)fb->cfg.input_nchan * fb_out_C(fb);
+  if (*nout && ((npo > 1 && out_pol_stride < *nout) || (nchan_out > 1 && out_chan_stride < (npo - 1) * out_pol_stride + *nout)))
+    return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_search: output rows of %llu floats overlap (chan stride %llu, pol "
+                   "stride %llu)", (unsigned long long)*nout, (unsigned long long)out_chan_stride, (unsigned long long)out_pol_stride);
+  uint64_t step;
+  dspsr_amd_filterbank_sizes(fb, nullptr, nullptr, &step, nullptr);
+  FbIn in;
+  if (in_f32_dev) {
+    const uint32_t idim = fb->cfg.real_input ? 1 : 2;
+    if (in_step % idim)
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_search: in_step=%llu not a multiple of ndim", (unsigned long long)in_step);
+    in = {0, in_f32_dev, in_pol_stride, in_step / idim, fb->cfg.input_nchan, 0, 1.0f};
+  } else {
+    if (raw_layout == DSPSR_AMD_RAW_CASPSR && !(fb->cfg.real_input && fb->cfg.npol == 2 && fb->cfg.input_nchan == 1))
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_search: CASPSR layout needs real dual-pol single-channel input");
+    if (raw_layout == DSPSR_AMD_RAW_UWB16 && (fb->cfg.real_input || fb->cfg.input_nchan != 1))
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_search: UWB 16-bit layout needs complex single-channel input");
+    if (raw_layout != DSPSR_AMD_RAW_CASPSR && raw_layout != DSPSR_AMD_RAW_GENERIC && raw_layout != DSPSR_AMD_RAW_UWB16)
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform_search: unknown raw layout %d", raw_layout);
+    in = {raw_kind(raw_layout), raw_dev, 0, step, fb->cfg.input_nchan, 0, scale};
+  }
+  uint32_t G = 0;
+  if (fb_search_fits(fb, npo, tscrunch, &G)) {
+    // Filterbank + Detection::square_law + TScrunch in one launch group: the detected stream never reaches HBM
+    FbOut out = {};
+    out.kind = 5; out.base = out_dev; out.chan_stride = out_chan_stride; out.pol_stride = out_pol_stride;
+    out.state = out_state; out.ndim = 1;
+    out.ts_sf = tscrunch; out.ts_magic = (uint32_t)(((1ull << 32) + tscrunch - 1) / tscrunch); out.ts_phase0 = *carry_count;
+    out.ts_G = G; out.ts_carry = carry_dev;
+    if (tscrunch == 1) out.ts_magic = 0xffffffffu;                       // (2^32 does not fit: t / 1 = t is the special case below)
+    const int rc = fb_run(fb, in, out, npart, in_chan_stride);
+    if (rc != DSPSR_AMD_OK) return rc;
+    *carry_count = rem;
+    return DSPSR_AMD_OK;
+  }
+  // Other geometries (freq_res > 8192, freq_res with an odd factor, tiles the staged samples do not fit): the three operations one
+  // after the other on a block owned by the object -- complex rows [chan][pol], detected rows behind them
+  const uint64_t crow = 2 * ndat, drow = ndat;
+  const size_t need = (size_t)nchan_out * (fb->cfg.npol * crow + npo * drow);
+  if (need > fb->det_floats) {
+    (void)hipStreamSynchronize(ctx->stream);
+    if (fb->det) (void)hipFree(fb->det);
+    fb->det = nullptr; fb->det_floats = 0;
+    if (hipMalloc((void**)&fb->det, need * sizeof(float)) != hipSuccess)
+      return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform_search: hipMalloc of %zu bytes failed", need * sizeof(float));
+    fb->det_floats = need;
+  }
+  float* cplx = fb->det;
+  float* det = fb->det + (size_t)nchan_out * fb->cfg.npol * crow;
+  FbOut cout = {1, cplx, fb->cfg.npol * crow, crow, 2ull * nkeep, 0, 2, 0};
+  int rc = fb_run(fb, in, cout, npart, in_chan_stride);
+  if (rc != DSPSR_AMD_OK) return rc;
+  rc = dspsr_amd_detect_square_law(ctx, out_state == DSPSR_AMD_INTENSITY, cplx, fb->cfg.npol * crow, crow, det, npo * drow, drow,
+                                   (uint32_t)nchan_out, fb->cfg.npol, ndat);
+  if (rc != DSPSR_AMD_OK) return rc;
+  return dspsr_amd_tscrunch_fpt(ctx, det, npo * drow, drow, out_dev, out_chan_stride, out_pol_stride, (uint32_t)nchan_out, npo, ndat,
+                                tscrunch, carry_dev, carry_count, nout);
 }
 
 extern "C" int dspsr_amd_filterbank_npass(const dspsr_amd_filterbank* fb, int raw_input)

@@ -162,6 +162,99 @@ __global__ __launch_bounds__(256) void k_pscrunch_tfp(const float* __restrict__ 
     out[i] = __fmul_rn(__fadd_rn(in[i * npol], in[i * npol + 1]), scale);
 }
 
+
+// ---- FPT order: rows [chan][pol] of ndat floats (Rescale.C:232-262,330-347; SigProcDigitizer.C:238-290,346-358) ----------------------
+// partial sums of one time slice of one row: block (x: slice, y: row = chan * npol + pol); fixed-order tree in LDS (deterministic)
+__global__ __launch_bounds__(256) void k_rescale_sums_fpt(const float* __restrict__ in, const uint64_t ics, const uint64_t ips, const uint32_t npol,
+                                                          const uint64_t ndat, const uint32_t per_block, const uint32_t ncol,
+                                                          double* __restrict__ part_sum, double* __restrict__ part_sq)
+{
+  __shared__ double ss[256], sq[256];
+  const uint32_t col = blockIdx.y, chan = col / npol, pol = col % npol;
+  const float* __restrict__ x = in + chan * ics + pol * ips;
+  const uint64_t i0 = (uint64_t)blockIdx.x * per_block, i1 = i0 + per_block < ndat ? i0 + per_block : ndat;
+  double s = 0.0, q = 0.0;
+  for (uint64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float v = x[i];
+    s += (double)v;
+    q += (double)__fmul_rn(v, v);                      // the reference squares in float and accumulates in double (:243-244)
+  }
+  ss[threadIdx.x] = s; sq[threadIdx.x] = q;
+  __syncthreads();
+  for (uint32_t w = 128; w; w >>= 1) {
+    if (threadIdx.x < w) { ss[threadIdx.x] += ss[threadIdx.x + w]; sq[threadIdx.x] += sq[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part_sum[(uint64_t)blockIdx.x * ncol + col] = ss[0]; part_sq[(uint64_t)blockIdx.x * ncol + col] = sq[0]; }
+}
+
+__global__ __launch_bounds__(256) void k_rescale_apply_fpt(const float* in, const uint64_t ics, const uint64_t ips, float* out /* may alias in */,
+                                                           const uint64_t ocs, const uint64_t ops, const uint32_t npol, const uint64_t n,
+                                                           const float* __restrict__ offset, const float* __restrict__ scale)
+{
+  const uint32_t col = blockIdx.y, chan = col / npol, pol = col % npol;
+  const float o = offset[col], sc = scale[col];
+  const float* x = in + chan * ics + pol * ips;
+  float* y = out + chan * ocs + pol * ops;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    y[i] = __fmul_rn(__fadd_rn(x[i], o), sc);          // Rescale.C:343
+}
+
+// SigProcDigitizer::pack, FPT branch, optionally behind Rescale's apply (RESC): a block transposes 64 time samples x 64 output
+// channels of one polarisation through LDS -- rows are read along time (coalesced), bytes leave along the channels, in the TPF
+// order of the file (outidx = idat*nchan*npol + ipol*nchan + ichan).  nbit -32: floats divided by the input scale (pack_float).
+template <bool RESC>
+__global__ __launch_bounds__(256) void k_digitize_fpt(const float* __restrict__ in, const uint64_t ics, const uint64_t ips, uint8_t* __restrict__ out,
+                                                      const uint64_t ndat, const uint32_t nchan, const uint32_t npol, const int nbit,
+                                                      const float* __restrict__ offset, const float* __restrict__ scale,
+                                                      const float digi_scale, const float digi_mean, const float xpol_offset,
+                                                      const int digi_max, const float fscale, const int flip_band, const int swap_band)
+{
+  __shared__ float tile[64][65];
+  const uint32_t k0 = blockIdx.x * 64, ipol = blockIdx.z;
+  const uint64_t t0 = (uint64_t)blockIdx.y * 64;
+  const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // read: tx = time, ty + 4 j = channel of the tile
+  for (uint32_t j = 0; j < 16; j++) {
+    const uint32_t k = k0 + ty + 4 * j;
+    float v = 0.f;
+    if (k < nchan && t0 + tx < ndat) {
+      uint32_t ic = k;                                               // ChannelSort, SigProcDigitizer.C:52-65
+      if (swap_band) ic = (ic + nchan / 2) % nchan;
+      if (flip_band) ic = nchan - ic - 1;
+      v = in[ic * ics + ipol * ips + t0 + tx];
+      if (RESC) v = __fmul_rn(__fadd_rn(v, offset[ic * npol + ipol]), scale[ic * npol + ipol]);      // Rescale.C:343
+    }
+    tile[ty + 4 * j][tx] = v;
+  }
+  __syncthreads();
+  const float mean = digi_mean + (ipol > 1 ? xpol_offset : 0.0f);
+  auto level = [&](const float x) {
+    // :253  float multiply, float add, then + 0.5 in double (the literal is a double), truncation; out-of-range and NaN
+    // conversions yield INT_MIN on the reference's x86 hosts (cvttsd2si), i.e. clip to 0
+    const double d = (double)__fadd_rn(__fmul_rn(x, digi_scale), mean) + 0.5;
+    int r = (d >= 2147483648.0 || d <= -2147483649.0 || d != d) ? (int)0x80000000 : (int)d;
+    r = r < 0 ? 0 : r;
+    return r > digi_max ? digi_max : r;
+  };
+  if (nbit == -32) {
+    for (uint32_t j = 0; j < 16; j++) {                              // write: tx = channel, ty + 4 j = time
+      const uint32_t tt = ty + 4 * j, k = k0 + tx;
+      if (k < nchan && t0 + tt < ndat) ((float*)out)[(t0 + tt) * nchan * npol + (uint64_t)ipol * nchan + k] = __fdiv_rn(tile[tx][tt], fscale);
+    }
+    return;
+  }
+  const uint32_t spb = nbit >= 8 ? 1 : 8 / nbit, units = 64 / spb;  // bytes (16-bit: samples) of the tile per time sample
+  for (uint32_t u = threadIdx.x; u < 64 * units; u += 256) {
+    const uint32_t tt = u / units, w = u % units, k = k0 + w * spb;
+    if (k >= nchan || t0 + tt >= ndat) continue;
+    uint32_t byte = 0;
+    for (uint32_t j = 0; j < spb; j++) byte |= (uint32_t)level(tile[w * spb + j][tt]) << (j * (nbit >= 8 ? 0 : nbit));
+    const uint64_t oidx = ((t0 + tt) * nchan * npol + (uint64_t)ipol * nchan + k) / spb;
+    if (nbit == 16) ((uint16_t*)out)[oidx] = (uint16_t)byte;
+    else out[oidx] = (uint8_t)byte;
+  }
+}
+
 }  // namespace dspsr_amd
 
 using namespace dspsr_amd;
@@ -231,8 +324,10 @@ extern "C" void dspsr_amd_rescale_destroy(dspsr_amd_rescale* r)
 
 // Rescale::transformation over one block: statistics per interval segment, then `apply(start, n)` for the segment's samples
 // with the offset / scale in force for it (the plain apply pass, or the fused apply + PScrunch + digitiser)
+// fpt != nullptr: FPT rows (strides in floats) instead of a TFP block
+struct FptRows { const float* base; uint64_t cs, ps; };
 template <class Apply>
-static int rescale_block(dspsr_amd_rescale* r, const float* in_tfp_dev, uint64_t ndat, const char* who, Apply&& apply)
+static int rescale_block(dspsr_amd_rescale* r, const float* in_tfp_dev, uint64_t ndat, const char* who, Apply&& apply, const FptRows* fpt = nullptr)
 {
   dspsr_amd_ctx* ctx = r->ctx;
   if (!r->nsample) r->nsample = ndat;                       // Rescale::init: nsample = input->get_ndat()
@@ -245,7 +340,7 @@ static int rescale_block(dspsr_amd_rescale* r, const float* in_tfp_dev, uint64_t
     if (interval_end < end) end = interval_end;
     const uint64_t n = end - start;
     // sums over [start, end): slices of time so that the chip is filled, then a fixed-order accumulation
-    uint32_t rows_per_block = 64;
+    uint32_t rows_per_block = fpt ? 4096 : 64;
     uint32_t nslice = (uint32_t)((n + rows_per_block - 1) / rows_per_block);
     while (nslice > 4096) { rows_per_block *= 2; nslice = (uint32_t)((n + rows_per_block - 1) / rows_per_block); }
     if (nslice > r->part_cap) {
@@ -258,9 +353,14 @@ static int rescale_block(dspsr_amd_rescale* r, const float* in_tfp_dev, uint64_t
         return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "%s: hipMalloc of the partial sums failed", who);
       r->part_cap = nslice;
     }
-    const float* seg = in_tfp_dev + start * ncol;
-    hipLaunchKernelGGL(k_rescale_sums, dim3(gx, nslice), dim3(256), 0, ctx->stream, seg, n, ncol, rows_per_block,
-                       r->part_sum, r->part_sq);
+    if (fpt) {
+      hipLaunchKernelGGL(k_rescale_sums_fpt, dim3(nslice, ncol), dim3(256), 0, ctx->stream, fpt->base + start, fpt->cs, fpt->ps, r->npol, n,
+                         rows_per_block, ncol, r->part_sum, r->part_sq);
+    } else {
+      const float* seg = in_tfp_dev + start * ncol;
+      hipLaunchKernelGGL(k_rescale_sums, dim3(gx, nslice), dim3(256), 0, ctx->stream, seg, n, ncol, rows_per_block,
+                         r->part_sum, r->part_sq);
+    }
     hipLaunchKernelGGL(k_rescale_accumulate, dim3(gx), dim3(256), 0, ctx->stream, r->part_sum, r->part_sq, nslice, ncol,
                        r->total, r->totalsq);
     r->isample += n;
@@ -430,4 +530,78 @@ extern "C" int dspsr_amd_sigproc_digitize(dspsr_amd_ctx* ctx, const float* in_tf
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_sigproc_digitize: %s", hipGetErrorString(e));
   return DSPSR_AMD_OK;
+}
+
+
+static hipError_t launch_digitize_fpt(dspsr_amd_ctx* ctx, bool resc, const float* in, uint64_t ics, uint64_t ips, uint8_t* out, uint64_t ndat,
+                                      uint32_t nchan, uint32_t npol, int nbit, const float* offset, const float* scale, const DigiParams& d,
+                                      float fscale, int flip_band, int swap_band)
+{
+  const dim3 grid((nchan + 63) / 64, (uint32_t)((ndat + 63) / 64), npol);
+  if (resc) hipLaunchKernelGGL(k_digitize_fpt<true>, grid, dim3(256), 0, ctx->stream, in, ics, ips, out, ndat, nchan, npol, nbit, offset, scale,
+                               d.scale, d.mean, d.xpol_offset, d.max, fscale, flip_band, swap_band);
+  else hipLaunchKernelGGL(k_digitize_fpt<false>, grid, dim3(256), 0, ctx->stream, in, ics, ips, out, ndat, nchan, npol, nbit, offset, scale,
+                          d.scale, d.mean, d.xpol_offset, d.max, fscale, flip_band, swap_band);
+  return hipGetLastError();
+}
+
+extern "C" int dspsr_amd_rescale_transform_fpt(dspsr_amd_rescale* r, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
+                                               float* out_dev, uint64_t out_chan_stride, uint64_t out_pol_stride, uint64_t ndat)
+{
+  if (!r || ((!in_dev || !out_dev) && ndat)) return DSPSR_AMD_EINVAL;
+  if (!ndat) return DSPSR_AMD_OK;
+  if (r->ncol > 65535) return ctx_fail(r->ctx, DSPSR_AMD_EINVAL, "dspsr_amd_rescale_transform_fpt: nchan*npol=%u exceeds the grid limit", r->ncol);
+  const FptRows rows = {in_dev, in_chan_stride, in_pol_stride};
+  return rescale_block(r, nullptr, ndat, "dspsr_amd_rescale_transform_fpt", [&](const uint64_t start, const uint64_t n) {
+    uint64_t gb = (n + 255) / 256;
+    if (gb > 256) gb = 256;
+    hipLaunchKernelGGL(k_rescale_apply_fpt, dim3((uint32_t)gb, r->ncol), dim3(256), 0, r->ctx->stream, in_dev + start, in_chan_stride,
+                       in_pol_stride, out_dev + start, out_chan_stride, out_pol_stride, r->npol, n, r->offset, r->scale);
+  }, &rows);
+}
+
+static int digitize_fpt_check(dspsr_amd_ctx* ctx, const char* who, uint32_t nchan, uint32_t npol, int nbit, uint64_t ndat)
+{
+  if (nbit != 1 && nbit != 2 && nbit != 4 && nbit != 8 && nbit != 16 && nbit != -32)
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dsp::SigProcDigitizer::set_nbit nbit=%i not understood", nbit);
+  if (nbit > 0 && nbit < 8 && nchan % (8 / nbit))
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "%s: nchan=%u not a multiple of %d samples per byte", who, nchan, 8 / nbit);
+  if ((ndat + 63) / 64 > 65535 || npol > 65535)
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "%s: ndat=%llu / npol=%u exceed the grid limits (digitise the block in pieces)", who,
+                    (unsigned long long)ndat, npol);
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_sigproc_digitize_fpt(dspsr_amd_ctx* ctx, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
+                                              uint64_t ndat, uint32_t nchan, uint32_t npol, int nbit, int use_digi_scales, double input_scale,
+                                              float scale_fac, int flip_band, int swap_band, void* out_dev)
+{
+  if (!ctx || ((!in_dev || !out_dev) && ndat)) return DSPSR_AMD_EINVAL;
+  const int rc = digitize_fpt_check(ctx, "dspsr_amd_sigproc_digitize_fpt", nchan, npol, nbit, ndat);
+  if (rc != DSPSR_AMD_OK) return rc;
+  if (!ndat || !nchan || !npol) return DSPSR_AMD_OK;
+  const DigiParams d = nbit == -32 ? DigiParams{0.f, 0.f, 0.f, 0} : digi_params(nbit, use_digi_scales, input_scale, scale_fac);
+  const hipError_t e = launch_digitize_fpt(ctx, false, in_dev, in_chan_stride, in_pol_stride, (uint8_t*)out_dev, ndat, nchan, npol, nbit, nullptr,
+                                           nullptr, d, (float)input_scale, flip_band, swap_band);
+  if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_sigproc_digitize_fpt: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}
+
+extern "C" int dspsr_amd_rescale_digitize_fpt(dspsr_amd_rescale* r, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
+                                              uint64_t ndat, int nbit, float scale_fac, int flip_band, int swap_band, void* out_dev)
+{
+  if (!r || ((!in_dev || !out_dev) && ndat)) return DSPSR_AMD_EINVAL;
+  dspsr_amd_ctx* ctx = r->ctx;
+  if (nbit == -32) return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_rescale_digitize_fpt: nbit -32 takes the separate operations");
+  const int rc = digitize_fpt_check(ctx, "dspsr_amd_rescale_digitize_fpt", r->nchan, r->npol, nbit, ndat);
+  if (rc != DSPSR_AMD_OK) return rc;
+  if (!ndat) return DSPSR_AMD_OK;
+  if (r->ncol > 65535) return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_rescale_digitize_fpt: nchan*npol=%u exceeds the grid limit", r->ncol);
+  const DigiParams d = digi_params(nbit, 1, 1.0, scale_fac);        // behind Rescale the input scale is 1 (Rescale.C:204)
+  const size_t out_row = (size_t)r->nchan * r->npol * (nbit == 16 ? 2 : 1) / (nbit >= 8 ? 1 : 8 / nbit);
+  const FptRows rows = {in_dev, in_chan_stride, in_pol_stride};
+  return rescale_block(r, nullptr, ndat, "dspsr_amd_rescale_digitize_fpt", [&](const uint64_t start, const uint64_t n) {
+    (void)launch_digitize_fpt(ctx, true, in_dev + start, in_chan_stride, in_pol_stride, (uint8_t*)out_dev + start * out_row, n, r->nchan, r->npol,
+                              nbit, r->offset, r->scale, d, 1.0f, flip_band, swap_band);
+  }, &rows);
 }

@@ -233,6 +233,38 @@ class FilterbankEngine:
                                                        state, ndim, det.data_ptr(), dcs, dps, npart),
                "dspsr_amd_filterbank_perform_detect")
 
+    def perform_search(self, out, carry, carry_count, npart, tscrunch, state=_lib.INTENSITY, inp=None, in_step=0, raw=None,
+                       layout=_lib.RAW_GENERIC, scale=1.0):
+        """digifil's convolving branch in one launch group (LoadToFil.C:185-222,250-304): Filterbank -> Detection::square_law
+        (Intensity / PPQQ) -> TScrunch on the detected stream.  out: device float32 rows [nchan][npol_out][>= nout]; carry:
+        device float32 [nchan][npol_out] (the open output sample's partial sums); carry_count: samples already in it.
+        Returns (nout, carry_count_after)."""
+        ocs, ops = _strides3(out)
+        npo = 2 if state == _lib.PPQQ else 1
+        if out.shape[1] != npo or carry.numel() < out.shape[0] * npo:
+            raise DspsrAmdError("dspsr_amd.FilterbankEngine.perform_search: out needs %d polarisation rows per channel and carry "
+                                "[nchan][%d] floats" % (npo, npo))
+        if npart:
+            self._need("scrunched block", out.shape[2], (carry_count + npart * self.nkeep) // max(1, tscrunch))
+            if raw is not None and layout != _lib.RAW_UWB16:
+                self._need("raw block", raw.numel(), self._raw_bytes(npart, layout))
+        if inp is not None:
+            ics, ips = _strides3(inp)
+            iptr = inp.data_ptr()
+        else:
+            ics = ips = 0
+            iptr = None
+        cc, nout = C.c_uint32(carry_count), C.c_uint64(0)
+        _check(self.ctx.handle,
+               lib.dspsr_amd_filterbank_perform_search(self.handle, iptr, ics, ips, in_step, raw.data_ptr() if raw is not None else None,
+                                                       layout, scale, state, tscrunch, out.data_ptr(), ocs, ops, carry.data_ptr(),
+                                                       C.byref(cc), npart, C.byref(nout)), "dspsr_amd_filterbank_perform_search")
+        return int(nout.value), int(cc.value)
+
+    def search_is_fused(self) -> bool:
+        """perform_search runs detection and the time scrunch inside the inverse pass (else: separate launches, same numbers)."""
+        return bool(lib.dspsr_amd_filterbank_search_is_fused(self.handle))
+
     def npass(self, raw_input: bool = True) -> int:
         """Transform passes of a call: 2 (short responses on the 8-bit block), 3, or 4 (two-pass inverse)."""
         return int(lib.dspsr_amd_filterbank_npass(self.handle, 1 if raw_input else 0))
@@ -299,6 +331,39 @@ def tfp_filterbank(ctx: Context, raw, nchan, npart, out, pscrunch=False, tscrunc
     cfg = _lib.TfpConfig(nchan, 2, int(bool(pscrunch)), int(tscrunch))
     _check(ctx.handle, lib.dspsr_amd_tfp_filterbank(ctx.handle, C.byref(cfg), raw.data_ptr(), layout, scale,
                                                     out.data_ptr(), npart), "dspsr_amd_tfp_filterbank")
+
+
+def sigproc_digitize_fpt(ctx: Context, inp, out, nbit=8, use_digi_scales=True, input_scale=1.0, scale_fac=1.0, flip_band=False,
+                         swap_band=False):
+    """dsp::SigProcDigitizer::pack on FPT rows [nchan][npol][ndat] (float32, device) -> packed n-bit device bytes in TPF order."""
+    nchan, npol, ndat = inp.shape
+    ics, ips = _strides3(inp)
+    _check(ctx.handle, lib.dspsr_amd_sigproc_digitize_fpt(ctx.handle, inp.data_ptr(), ics, ips, ndat, nchan, npol, nbit, int(use_digi_scales),
+                                                          input_scale, scale_fac, int(flip_band), int(swap_band), out.data_ptr()),
+           "dspsr_amd_sigproc_digitize_fpt")
+    return out
+
+
+def tscrunch_fpt(ctx: Context, inp, out, sfactor, carry, carry_count=0):
+    """dsp::TScrunch::fpt_tscrunch on device rows [nchan][npol][ndat] as a stream (carry: device [nchan][npol] floats).
+    Returns (nout, carry_count_after)."""
+    nchan, npol, ndat = inp.shape
+    ics, ips = _strides3(inp)
+    ocs, ops = _strides3(out)
+    cc, nout = C.c_uint32(carry_count), C.c_uint64(0)
+    _check(ctx.handle, lib.dspsr_amd_tscrunch_fpt(ctx.handle, inp.data_ptr(), ics, ips, out.data_ptr(), ocs, ops, nchan, npol, ndat, sfactor,
+                                                  carry.data_ptr(), C.byref(cc), C.byref(nout)), "dspsr_amd_tscrunch_fpt")
+    return int(nout.value), int(cc.value)
+
+
+def fscrunch_fpt(ctx: Context, inp, out, sfactor):
+    """dsp::FScrunch::fpt_fscrunch on device rows [nchan][npol][nfloat] -> [nchan / sfactor][npol][nfloat]."""
+    nchan, npol, nfloat = inp.shape
+    ics, ips = _strides3(inp)
+    ocs, ops = _strides3(out)
+    _check(ctx.handle, lib.dspsr_amd_fscrunch_fpt(ctx.handle, inp.data_ptr(), ics, ips, out.data_ptr(), ocs, ops, nchan, npol, nfloat, sfactor),
+           "dspsr_amd_fscrunch_fpt")
+    return out
 
 
 def copy_data_fpt(ctx: Context, to, frm):
@@ -375,6 +440,28 @@ class Rescale:
         ndat = inp.numel() // (self.nchan * self.npol)
         _check(self.ctx.handle, lib.dspsr_amd_rescale_transform(self.handle, inp.data_ptr(), out.data_ptr(), ndat),
                "dspsr_amd_rescale_transform")
+        return out
+
+    def transform_fpt(self, inp, out=None):
+        """FPT rows: inp/out float32 device tensors [nchan][npol][ndat] (strided views allowed; out defaults to in place)."""
+        out = inp if out is None else out
+        ics, ips = _strides3(inp)
+        ocs, ops = _strides3(out)
+        _check(self.ctx.handle, lib.dspsr_amd_rescale_transform_fpt(self.handle, inp.data_ptr(), ics, ips, out.data_ptr(), ocs, ops,
+                                                                    inp.shape[2]), "dspsr_amd_rescale_transform_fpt")
+        return out
+
+    def digitize_fpt(self, inp, out, nbit=8, scale_fac=1.0, flip_band=False, swap_band=False):
+        """Rescale -> SigProcDigitizer of FPT rows [nchan][npol][ndat] in one pass (the bytes of transform_fpt() +
+        sigproc_digitize_fpt(), without the rescaled block)."""
+        ics, ips = _strides3(inp)
+        ndat = inp.shape[2]
+        need = ndat * self.nchan * self.npol * nbit // 8
+        if out.numel() * out.element_size() < need:
+            raise DspsrAmdError("dspsr_amd.Rescale.digitize_fpt: out holds %d bytes, %d needed" % (out.numel() * out.element_size(), need))
+        _check(self.ctx.handle, lib.dspsr_amd_rescale_digitize_fpt(self.handle, inp.data_ptr(), ics, ips, ndat, nbit, scale_fac,
+                                                                   int(flip_band), int(swap_band), out.data_ptr()),
+               "dspsr_amd_rescale_digitize_fpt")
         return out
 
     def pscrunch_digitize(self, inp, out, nbit=8, scale_fac=1.0, flip_band=False, swap_band=False):

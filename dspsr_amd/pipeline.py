@@ -19,7 +19,8 @@ import numpy as np
 
 from . import _lib
 from .engine import (Context, Dedispersion, DspsrAmdError, FilterbankEngine, FoldEngine, Rescale, SampleDelay, add_fpt, copy_data_fpt,
-                     dedispersion_sample_delays, eight_bit_scale, pscrunch_tfp, sigproc_digitize, tfp_filterbank)
+                     dedispersion_sample_delays, eight_bit_scale, fscrunch_fpt, pscrunch_tfp, sigproc_digitize, sigproc_digitize_fpt,
+                     tfp_filterbank, tscrunch_fpt)
 
 
 @dataclass
@@ -1096,6 +1097,13 @@ class SearchConfig:
     rescale_constant: bool = False    # -c
     scale_fac: float = 1.0            # -s
     parts_per_block: int = 4096       # FFT blocks (2*nchan samples each) per call; a multiple of tscrunch
+    # the convolving branch, `-F nchan:D` (LoadToFil.C:176-222): LoadToFilCoherent
+    dispersion_measure: float = 0.0   # -D  (with -F N:D: coherent dedispersion inside the filterbank)
+    freq_res: int = 0                 # -x  (0 => optimal, as dsp::Dedispersion chooses)
+    fscrunch: int = 0                 # -f
+    npol: int = 1                     # -d  output polarisations: 1 Intensity, 2 PPQQ (LoadToFil.C:262-269)
+    max_parts: int = 32               # parts per launch group
+    fused: bool = True                # detection + time scrunch inside the inverse pass where the geometry allows it
 
 
 def write_sigproc_header(f, *, source_name="unknown", rawdatafile="unknown", machine_id=0, telescope_id=0, src_raj=0.0, src_dej=0.0,
@@ -1222,4 +1230,136 @@ class LoadToFil:
     def close(self):
         if self.rescale is not None:
             self.rescale.close()
+        self.ctx.close()
+
+
+class LoadToFilCoherent:
+    """digifil with the convolving filterbank, `digifil -F N:D [-x M] [-f F] -t T -b nbit` (Signal/General/LoadToFil.C:176-222,250-362):
+    dsp::Filterbank with the Dedispersion response -> Detection::square_law (Intensity / PPQQ: no PScrunch behind it, :281) ->
+    [FScrunch] -> TScrunch -> Rescale -> SigProcDigitizer, FPT order throughout, every stage on the device.  One launch group runs
+    filterbank, detection and time scrunch (FilterbankEngine.perform_search): the detected rows never exist at the filterbank's
+    output rate.  process_block(raw) takes the 8-bit block of LoadToFold (npart * nsamp_step + nsamp_overlap samples, the overlap
+    re-presented by the caller) and returns the packed bytes [time][pol][chan] of the output samples completed by it."""
+
+    def __init__(self, cfg: SearchConfig, info: InputInfo, device: int = 0, stream: int | None = None):
+        import torch
+        self.torch = torch
+        self.cfg, self.info = cfg, info
+        if cfg.npol not in (1, 2):
+            raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: npol=%d (Intensity 1 / PPQQ 2 are built)" % cfg.npol)
+        if cfg.npol == 2 and info.npol != 2:
+            raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: PPQQ needs two input polarisations")
+        if cfg.nchan % info.nchan:
+            raise DspsrAmdError("dsp::Filterbank::make_preparations output nchan=%d not a multiple of input nchan=%d" % (cfg.nchan, info.nchan))
+        if cfg.dispersion_measure == 0.0:
+            raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: -F N:D with a dispersion measure (without one digifil takes the "
+                                "TFPFilterbank: dspsr_amd.LoadToFil)")
+        self.ctx = Context(device, stream)
+        r = Dedispersion(info.centre_frequency, info.bandwidth, cfg.dispersion_measure, input_nchan=info.nchan, ndim=info.ndim)
+        if cfg.freq_res:
+            r.set_frequency_resolution(cfg.freq_res)                                   # LoadToFil.C:190-191
+        r.match(cfg.nchan)
+        self.response = r
+        nsub = cfg.nchan // info.nchan
+        self.fb = FilterbankEngine(self.ctx).setup(nsub, r.ndat, r.impulse_pos, r.impulse_neg, info.nchan, info.npol, info.ndim == 1,
+                                                   r.kernel, max_parts=cfg.max_parts)
+        self.nkeep, self.nsamp_step, self.nsamp_overlap = self.fb.nkeep, self.fb.nsamp_step, self.fb.nsamp_overlap
+        n_fft = nsub * r.ndat
+        nsamp_fft = 2 * n_fft if info.ndim == 1 else n_fft
+        self.fb_rate = info.rate * (float(r.ndat) / float(nsamp_fft))
+        ts = max(1, cfg.tscrunch)
+        self.out_rate = self.fb_rate / ts
+        self.out_start = info.start_seconds + r.impulse_pos / self.fb_rate
+        self.scale8 = eight_bit_scale()
+        self.layout = _lib.RAW_CASPSR if info.machine == "CASPSR" else _lib.RAW_GENERIC
+        self.state = _lib.PPQQ if cfg.npol == 2 else _lib.INTENSITY
+        self.nchan_out = cfg.nchan // cfg.fscrunch if cfg.fscrunch else cfg.nchan
+        if cfg.fscrunch and cfg.nchan % cfg.fscrunch:
+            raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: nchan=%d is not a multiple of fscrunch=%d" % (cfg.nchan, cfg.fscrunch))
+        dev = "cuda:%d" % device
+        nmax = (ts - 1 + cfg.parts_per_block * self.nkeep) // ts
+        # FScrunch sits between Detection and TScrunch (LoadToFil.C:286-304): the fused launch group cannot hold it, so with -f the
+        # three operations run one after the other (perform_search at tscrunch 1 = filterbank + detection)
+        self.fused = cfg.fused and not cfg.fscrunch
+        self.scrunched = torch.empty((self.nchan_out, cfg.npol, max(1, nmax)), dtype=torch.float32, device=dev)
+        self.carry = torch.zeros((self.nchan_out, cfg.npol), dtype=torch.float32, device=dev)
+        self.carry_count = 0
+        self.detected = None
+        if not self.fused:
+            nd = cfg.parts_per_block * self.nkeep
+            self.detected = torch.empty((cfg.nchan, cfg.npol, nd), dtype=torch.float32, device=dev)
+            self.det_carry = torch.zeros((cfg.nchan, cfg.npol), dtype=torch.float32, device=dev)
+            self.fscr = torch.empty((self.nchan_out, cfg.npol, nd), dtype=torch.float32, device=dev) if cfg.fscrunch else None
+        self.rescale = None
+        if cfg.rescale_seconds:
+            interval = int(cfg.rescale_seconds * self.out_rate)                          # Rescale::init, Rescale.C:102-103
+            if not interval:
+                raise DspsrAmdError("dsp::Rescale::init nsample == 0")
+            self.rescale = Rescale(self.ctx, self.nchan_out, cfg.npol, interval, cfg.rescale_constant)
+        nbits = 32 if cfg.nbit == -32 else cfg.nbit
+        self.bytes_per_sample = self.nchan_out * cfg.npol * nbits // 8
+        self.packed = torch.empty(max(1, nmax) * self.bytes_per_sample, dtype=torch.uint8, device=dev)
+        self.ndat_out = 0
+        # Filterbank.C:124-128 leaves scale = n_fft * freq_res on its output; FScrunch / TScrunch multiply it by their factors
+        # (TimeSeries::rescale, TScrunch.C:126, FScrunch.C:103); without Rescale the digitiser divides by it (SigProcDigitizer.C:158)
+        self.input_scale = float(n_fft) * float(r.ndat) * ts * (cfg.fscrunch or 1)
+
+    def block_bytes(self, npart=None):
+        npart = npart or self.cfg.parts_per_block
+        nsamp = npart * self.nsamp_step + self.nsamp_overlap
+        if self.layout == _lib.RAW_CASPSR:
+            return ((nsamp + 3) // 4) * 8
+        return nsamp * self.info.nchan * self.info.npol * self.info.ndim
+
+    def detect_scrunch(self, raw, npart=None):
+        """Filterbank -> Detection -> [FScrunch] -> TScrunch of one block: the scrunched rows [nchan_out][npol][nout] (a view)."""
+        cfg = self.cfg
+        npart = npart or cfg.parts_per_block
+        if raw.numel() < self.block_bytes(npart):
+            raise DspsrAmdError("dspsr_amd.LoadToFilCoherent.process_block: block holds %d bytes, %d needed" % (raw.numel(), self.block_bytes(npart)))
+        ts = max(1, cfg.tscrunch)
+        if self.fused:
+            nout, self.carry_count = self.fb.perform_search(self.scrunched, self.carry, self.carry_count, npart, ts, self.state, raw=raw,
+                                                            layout=self.layout, scale=self.scale8)
+            return self.scrunched[:, :, :nout]
+        nd = npart * self.nkeep
+        det = self.detected[:, :, :nd]
+        self.fb.perform_search(det, self.det_carry, 0, npart, 1, self.state, raw=raw, layout=self.layout, scale=self.scale8)
+        if cfg.fscrunch:
+            det = fscrunch_fpt(self.ctx, det, self.fscr[:, :, :nd], cfg.fscrunch)
+        nout, self.carry_count = tscrunch_fpt(self.ctx, det, self.scrunched, ts, self.carry, self.carry_count)
+        return self.scrunched[:, :, :nout]
+
+    def process_block(self, raw, npart=None):
+        cfg = self.cfg
+        scr = self.detect_scrunch(raw, npart)
+        nout = scr.shape[2]
+        packed = self.packed[:nout * self.bytes_per_sample]
+        flip = self.info.bandwidth > 0
+        if nout:
+            if self.rescale is not None and cfg.nbit != -32:
+                self.rescale.digitize_fpt(scr, packed, cfg.nbit, cfg.scale_fac, flip_band=flip)        # Rescale + digitiser, one pass
+            else:
+                if self.rescale is not None:
+                    self.rescale.transform_fpt(scr)                                                     # in place, LoadToFil.C:312-313
+                sigproc_digitize_fpt(self.ctx, scr, packed, cfg.nbit, use_digi_scales=self.rescale is not None,
+                                     input_scale=1.0 if self.rescale is not None else self.input_scale, scale_fac=cfg.scale_fac,
+                                     flip_band=flip)
+        self.ndat_out += nout
+        return packed
+
+    def header_values(self):
+        nchan, bw = self.nchan_out, -abs(self.info.bandwidth)
+        fch1 = self.info.centre_frequency - 0.5 * bw + 0.5 * bw / nchan
+        nbits = 32 if self.cfg.nbit == -32 else self.cfg.nbit
+        return dict(fch1=fch1, foff=bw / nchan, nchans=nchan, nbits=nbits, tsamp=1.0 / self.out_rate,
+                    tstart_mjd=self.info.mjd_day + (self.info.mjd_sec + self.out_start) / 86400.0, nifs=self.cfg.npol)
+
+    def synchronize(self):
+        self.ctx.synchronize()
+
+    def close(self):
+        if self.rescale is not None:
+            self.rescale.close()
+        self.fb.close()
         self.ctx.close()

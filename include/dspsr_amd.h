@@ -190,6 +190,40 @@ int dspsr_amd_filterbank_perform_fold(dspsr_amd_filterbank* fb, const float* in_
                                       uint64_t in_pol_stride, uint64_t in_step, const int8_t* raw_dev, int raw_layout,
                                       float scale, int state, dspsr_amd_fold* fold, uint64_t npart);
 
+/* ---- digifil with a convolving filterbank, `digifil -F N:D [-x M] -t T` (Signal/General/LoadToFil.C:185-222,250-304) ---------
+ * One launch group for dsp::Filterbank (+ Dedispersion response) -> dsp::Detection::square_law (Detection.C:218-320: Intensity
+ * = (Re0^2 + Im0^2) + (Re1^2 + Im1^2), or PPQQ) -> dsp::TScrunch, FPT branch (TScrunch.C:128-178): the detected rows are never
+ * written at the filterbank's output rate.  The npart * nkeep detected samples of every channel continue a STREAM: TScrunch's
+ * input buffering re-presents the ndat % tscrunch left-over samples in front of the next block (TScrunch.C:110-111); here the
+ * partial sum of those samples stays in carry_dev -- the same sequential sum, out = in[0]; out += in[1]; ... , bit for bit.
+ *   out_state       DSPSR_AMD_INTENSITY (npol_out 1) | DSPSR_AMD_PPQQ (npol_out 2)
+ *   out_dev         rows [chan][npol_out] of *nout floats, FPT order like the reference's TimeSeries
+ *   carry_dev       [nchan][npol_out] floats owned by the caller (any content when *carry_count == 0)
+ *   carry_count     in: samples already summed into carry_dev (< tscrunch); out: samples left over by this call
+ *   nout            out: complete output samples written per row = (carry_in + npart * nkeep) / tscrunch
+ * tscrunch = 1 writes the detected samples themselves.  Three-pass and two-pass geometries run it inside the inverse pass; the
+ * others (freq_res > 8192, odd factors) through an internal detected block + dspsr_amd_tscrunch_fpt -- the same numbers. */
+#define DSPSR_AMD_INTENSITY 2
+#define DSPSR_AMD_PPQQ 3
+int dspsr_amd_filterbank_perform_search(dspsr_amd_filterbank* fb, const float* in_f32_dev, uint64_t in_chan_stride,
+                                        uint64_t in_pol_stride, uint64_t in_step, const int8_t* raw_dev, int raw_layout,
+                                        float scale, int out_state, uint32_t tscrunch, float* out_dev, uint64_t out_chan_stride,
+                                        uint64_t out_pol_stride, float* carry_dev, uint32_t* carry_count, uint64_t npart,
+                                        uint64_t* nout);
+/* 1: dspsr_amd_filterbank_perform_search runs inside the inverse pass for this object; 0: through the internal detected block */
+int dspsr_amd_filterbank_search_is_fused(const dspsr_amd_filterbank* fb);
+/* dsp::TScrunch::fpt_tscrunch (TScrunch.C:148-178) on device rows [nchan][npol] of ndat_in floats (ndim 1), as a stream:
+ * carry / carry_count / nout as above.  Out of place only (digifil scrunches in place on the host, LoadToFil.C:296-304: here every
+ * output sample has its own thread). */
+int dspsr_amd_tscrunch_fpt(dspsr_amd_ctx* ctx, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
+                           float* out_dev, uint64_t out_chan_stride, uint64_t out_pol_stride, uint32_t nchan, uint32_t npol,
+                           uint64_t ndat_in, uint32_t sfactor, float* carry_dev, uint32_t* carry_count, uint64_t* nout);
+/* dsp::FScrunch::fpt_fscrunch (FScrunch.C:117-145): out row (c, p) = in row (c*sfactor, p); += rows c*sfactor + 1 ... in order.
+ * nchan_in must be a multiple of sfactor; out of place only. */
+int dspsr_amd_fscrunch_fpt(dspsr_amd_ctx* ctx, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
+                           float* out_dev, uint64_t out_chan_stride, uint64_t out_pol_stride, uint32_t nchan_in, uint32_t npol,
+                           uint64_t nfloat, uint32_t sfactor);
+
 /* ---- dsp::Detection::Engine (Detection.h:98-106) ------------------------------------------
  * polarimetry(ndim, in, out): in = complex rows [nchan][2][ndat]; in-place allowed for ndim 2
  * (LoadToFold1.C:545-546 uses input==output).  Layouts as above. */
@@ -340,6 +374,19 @@ int dspsr_amd_rescale_pscrunch_digitize(dspsr_amd_rescale* r, const float* in_tf
 int dspsr_amd_sigproc_digitize(dspsr_amd_ctx* ctx, const float* in_tfp_dev, uint64_t ndat, uint32_t nchan, uint32_t npol,
                                int nbit, int use_digi_scales, double input_scale, float scale_fac, int flip_band,
                                int swap_band, void* out_dev);
+/* The same two operations on FPT-ordered rows [nchan][npol] of ndat floats -- what digifil's convolving branch hands them (the
+ * Filterbank keeps the reference's FPT order): Rescale.C:232-262,330-347 (FPT branches; the statistics, intervals and offset /
+ * scale arrays are those of the TFP form: one dspsr_amd_rescale object serves either order, index ichan*npol + ipol) and
+ * SigProcDigitizer.C:238-290 (FPT branch: the bytes leave in the same TPF order as from TFP input, outidx = idat*nchan*npol +
+ * ipol*nchan + ichan; pack_float :346-358 for nbit -32).
+ * dspsr_amd_rescale_digitize_fpt: both in one pass over the rows (the rescaled block is not written), identical bytes. */
+int dspsr_amd_rescale_transform_fpt(dspsr_amd_rescale* r, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
+                                    float* out_dev, uint64_t out_chan_stride, uint64_t out_pol_stride, uint64_t ndat);
+int dspsr_amd_sigproc_digitize_fpt(dspsr_amd_ctx* ctx, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
+                                   uint64_t ndat, uint32_t nchan, uint32_t npol, int nbit, int use_digi_scales, double input_scale,
+                                   float scale_fac, int flip_band, int swap_band, void* out_dev);
+int dspsr_amd_rescale_digitize_fpt(dspsr_amd_rescale* r, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
+                                   uint64_t ndat, int nbit, float scale_fac, int flip_band, int swap_band, void* out_dev);
 
 /* ---- host-side preparation (stays on the host in the reference as well) --------------------- */
 typedef struct {

@@ -639,6 +639,71 @@ def tscrunch_tfp(x: np.ndarray, sfactor: int) -> np.ndarray:
     return out
 
 
+def tscrunch_fpt(x: np.ndarray, sfactor: int) -> np.ndarray:
+    """dsp::TScrunch::fpt_tscrunch (Signal/General/TScrunch.C:148-178), ndim 1: x [nchan][npol][ndat] ->
+    [nchan][npol][ndat // sfactor]; out = in[0]; out += in[1]; ... sequentially in float.  (The ndat % sfactor samples left over
+    stay with the caller: TScrunch's input buffering re-presents them in front of the next block, :110-111.)"""
+    x = np.asarray(x, np.float32)
+    nout = x.shape[2] // sfactor
+    acc = x[:, :, 0:nout * sfactor:sfactor].copy()
+    for j in range(1, sfactor):
+        acc = acc + x[:, :, j:nout * sfactor:sfactor]
+    return acc
+
+
+def fscrunch_fpt(x: np.ndarray, sfactor: int) -> np.ndarray:
+    """dsp::FScrunch::fpt_fscrunch (Signal/General/FScrunch.C:117-145): x [nchan][npol][nfloat] -> [nchan // sfactor][npol][nfloat];
+    out row = in row c*sfactor, += rows c*sfactor + 1 ... in order."""
+    x = np.asarray(x, np.float32)
+    nout = x.shape[0] // sfactor
+    acc = x[0:nout * sfactor:sfactor].copy()
+    for j in range(1, sfactor):
+        acc = acc + x[j:nout * sfactor:sfactor]
+    return acc
+
+
+def sigproc_digitize_fpt(x: np.ndarray, nbit: int, **kw) -> np.ndarray:
+    """dsp::SigProcDigitizer::pack, FPT branch (SigProcDigitizer.C:238-290; pack_float :346-358): x [nchan][npol][ndat].  The same
+    expression per sample as the TFP branch and the same TPF byte order (outidx = idat*nchan*npol + ipol*nchan + ichan)."""
+    return sigproc_digitize(np.ascontiguousarray(np.asarray(x, np.float32).transpose(2, 0, 1)), nbit, **kw)
+
+
+class DigifilCoherent:
+    """digifil with a convolving filterbank, `digifil -F N:D [-x M] -t T -b nbit` (Signal/General/LoadToFil.C:185-222,250-362),
+    on the OUTPUT of the filterbank: Detection::square_law (Intensity, npol 1; PPQQ, npol 2) -> [FScrunch] -> TScrunch (FPT,
+    left-over samples buffered) -> Rescale (FPT: the same statistics per (chan, pol) as TFP) -> SigProcDigitizer (FPT branch).
+    Feed it the complex filterbank rows [nchan][npol][ndat] block by block; it returns the packed bytes of each block."""
+
+    def __init__(self, tscrunch: int = 1, fscrunch: int = 0, nbit: int = 8, npol_out: int = 1, rescale_interval: int = 0,
+                 rescale_constant: bool = False, rescale: bool = True, scale_fac: float = 1.0, flip_band: bool = False):
+        self.tscrunch, self.fscrunch, self.nbit, self.npol_out = tscrunch, fscrunch, nbit, npol_out
+        self.scale_fac, self.flip_band = scale_fac, flip_band
+        self.rescale = Rescale(rescale_interval, rescale_constant) if rescale else None
+        self.left = None                                          # TScrunch input buffering: samples not yet scrunched
+        self.input_scale = 1.0                                    # (Filterbank scale; Rescale resets it to 1, Rescale.C:204)
+
+    def detect_scrunch(self, fb: np.ndarray) -> np.ndarray:
+        det = square_law(fb, "Intensity" if self.npol_out == 1 else "PPQQ")           # LoadToFil.C:250-279
+        if self.fscrunch:                                                               # :286-294
+            det = fscrunch_fpt(det, self.fscrunch)
+        if self.tscrunch and self.tscrunch > 1:                                         # :296-304
+            if self.left is not None:
+                det = np.concatenate([self.left, det], axis=2)
+            nout = det.shape[2] // self.tscrunch
+            self.left = det[:, :, nout * self.tscrunch:].copy()
+            det = tscrunch_fpt(det, self.tscrunch)
+        return det
+
+    def process(self, fb: np.ndarray) -> np.ndarray:
+        det = self.detect_scrunch(fb)
+        tfp = np.ascontiguousarray(det.transpose(2, 0, 1))                             # same per-(chan, pol) arithmetic in either order
+        if self.rescale is not None:                                                    # :306-316
+            tfp = self.rescale.transform(tfp)
+        return sigproc_digitize(tfp, self.nbit, use_digi_scales=self.rescale is not None,
+                                input_scale=1.0 if self.rescale is not None else self.input_scale, scale_fac=self.scale_fac,
+                                flip_band=self.flip_band)
+
+
 # --------------------------------------------------------------------------------------
 # Integer-sample inter-channel delay, -K (f-4)
 # --------------------------------------------------------------------------------------

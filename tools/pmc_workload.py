@@ -41,6 +41,17 @@ def main():
         rec.update(parts_per_block=wl["nparts"], parts_per_launch_group=wl["nparts"],
                    algorithmic_bytes_per_block=nbytes + lf.detected.numel() * 4, roofline_kernel="k_tfp")
         lf.close()
+    elif name == "cfg5c":
+        lf, raw, cfg = bench.make_search_coherent(wl, torch)
+        torch.cuda.synchronize()
+        for _ in range(K):
+            lf.detect_scrunch(raw)                 # the roofline group alone (Rescale + digitiser run on the 16x smaller rows)
+        torch.cuda.synchronize()
+        N = cfg.nchan * lf.response.ndat
+        b_alg = 2 * (2 * N) + 8 * N + cfg.nchan * cfg.npol * 4 * lf.nkeep / cfg.tscrunch
+        rec.update(parts_per_block=cfg.parts_per_block, parts_per_launch_group=cfg.max_parts, algorithmic_bytes_per_part=int(b_alg),
+                   algorithmic_bytes_per_block=int(b_alg * cfg.parts_per_block))
+        lf.close()
     elif name == "fold":
         import dspsr_amd
         from dspsr_amd import pipeline
