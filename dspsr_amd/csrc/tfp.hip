@@ -305,11 +305,15 @@ __global__ __launch_bounds__(512) void k_tfp4k(const TfpParams p, const cf* __re
   ltw_fill<LOGC>(lds, ltw_off, tw, tid, nt);
   const uint32_t col = threadIdx.x & 3u, jp = threadIdx.x >> 2, pa = jp, pb = jp ? 256u - jp : 128u;
   const bool j0 = jp == 0;
-  // w^pa, w^pb, w = exp(-i pi / C) = (c, -s): argument p / 2C revolutions, exact in float.  The twiddle of bin 256 k + p is
-  // w^p times exp(-i pi k / 16), a compile-time constant: 4 packed operations per k and tile instead of 32 registers held
-  // across the transform (which spilled)
-  const v2f wpc = {__builtin_amdgcn_cosf((float)pa * (1.0f / 8192.0f)), __builtin_amdgcn_cosf((float)pb * (1.0f / 8192.0f))};
-  const v2f wps = {__builtin_amdgcn_sinf((float)pa * (1.0f / 8192.0f)), __builtin_amdgcn_sinf((float)pb * (1.0f / 8192.0f))};
+  // w^(256 k + pa), w^(256 k + pb), w = exp(-i pi / C) = (c, -s): argument bin / 2C revolutions, exact in float -- the values the
+  // generic kernel uses for the same bins, so the two kernels agree bit for bit (32 registers held across the tile loop)
+  v2f wc[8], ws[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const float xa = (float)(256u * k + pa) * (1.0f / 8192.0f), xb = (float)(256u * k + pb) * (1.0f / 8192.0f);
+    wc[k] = (v2f){__builtin_amdgcn_cosf(xa), __builtin_amdgcn_cosf(xb)};
+    ws[k] = (v2f){__builtin_amdgcn_sinf(xa), __builtin_amdgcn_sinf(xb)};
+  }
   // samples decoded at HALF scale: A = (Z[k] + conj Z[C-k]) / 2, B = (Z[k] - conj Z[C-k]) / 2i then need no factor 1/2, and a
   // power-of-two scale commutes with every rounding -- the same bits as k_tfp's 0.5f * (...)
   const float sc2 = 0.5f * p.scale, hs2 = 0.5f * sc2;
@@ -371,18 +375,13 @@ __global__ __launch_bounds__(512) void k_tfp4k(const TfpParams p, const cf* __re
         __syncthreads();                         // every wave has read the last exchange: the next tile's image may land
         if (more) fetch_image(next);
         FB_ST(8, 3);                             // transform
-        v2f wpc_t = wpc, wps_t = wps;            // opaque copies: the per-bin twiddles below are loop invariant and would
-        asm volatile("" : "+v"(wpc_t), "+v"(wps_t));   // otherwise be hoisted out of the tile loop (32 registers, spilled)
         // one packed evaluation: (Z[k], mirror operands) of bins 256 k + (pa | pb) -> their powers and those of the mirror bins, added
         // to the running sums.  The accumulators start an output sample at zero (0 + x == x: the sums of TScrunch.C:193-200 bit for bit)
         auto eval = [&](const int k, const v2f mr, const v2f mi) {
           const v2f zr = v[k].x, zi = v[k].y;
           const v2f ar = zr + mr, ai = zi - mi;                       // A = Z[k] + conj Z[C-k]           (halved by the input scale)
           const v2f br = zi + mi, bi = mr - zr;                       // B = (Z[k] - conj Z[C-k]) / i
-          // cos / sin(pi k / 16), k < 8
-          constexpr float C16[8] = {1.0f, 0.98078528040323043f, C16_1, 0.83146961230254524f, C16_2, 0.55557023301960218f, S16_1, 0.19509032201612825f};
-          constexpr float S16[8] = {0.0f, 0.19509032201612825f, S16_1, 0.55557023301960218f, C16_2, 0.83146961230254524f, C16_1, 0.98078528040323043f};
-          const v2f wck = k ? C16[k] * wpc_t - S16[k] * wps_t : wpc_t, wsk = k ? S16[k] * wpc_t + C16[k] * wps_t : wps_t;
+          const v2f wck = wc[k], wsk = ws[k];
           const v2f wr = wck * br + wsk * bi, wi = wck * bi - wsk * br;           // w^bin B,  w^bin = (c, -s)
           const v2f xr = ar + wr, xi = ai + wi, yr = ar - wr, yi = ai - wi;       // X[k] = A + w^k B,  X[C-k] = conj(A - w^k B)
           v2f pk = xr * xr; pk += xi * xi;                            // TFPFilterbank.C:56-59: Re^2 then += Im^2

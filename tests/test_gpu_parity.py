@@ -764,9 +764,10 @@ def test_tfp_filterbank_search_mode(oracle, gpu, nchan, tscrunch, pscrunch, npar
 def test_tfp_4096_register_split_equals_generic_kernel(gpu, pscrunch, layout_name, tscrunch, npart):
     """nchan = 4096 with an even tscrunch takes k_tfp4k (Hermitian split, powers, pol and time sums on the last stage's registers,
     DPP adds inside the quad); tscrunch = 1 takes the generic k_tfp (staged transform).  Summing the generic kernel's per-part
-    powers in time order (float32, sequentially: TScrunch.C:193-200) must reproduce k_tfp4k up to the two kernels' twiddle
-    rounding (1e-6 of the rms), for both raw layouts, with and without pscrunch, and with a ragged last output sample dropped.
-    An unaligned block (generic kernel for any tscrunch) gives the same answer."""
+    powers in time order (float32, sequentially: TScrunch.C:193-200) must reproduce k_tfp4k BIT FOR BIT (the same twiddles, the same
+    operations on samples decoded at half scale -- a power of two commutes with every rounding), for both raw layouts, with and
+    without pscrunch, and with a ragged last output sample dropped.  An unaligned block (generic kernel for any tscrunch) gives
+    the same bits."""
     dspsr_amd, ctx = gpu
     from dspsr_amd import _lib
     rng = np.random.default_rng(77)
@@ -782,14 +783,13 @@ def test_tfp_4096_register_split_equals_generic_kernel(gpu, pscrunch, layout_nam
         want = want + one[i:nout * tscrunch:tscrunch]
     got = torch.full((nout, nchan, npol), -1.0, dtype=torch.float32, device="cuda")
     dspsr_amd.tfp_filterbank(ctx, raw, nchan, npart, got, pscrunch, tscrunch, layout=layout, scale=0.0123)
-    rms = float(want.double().pow(2).mean().sqrt())
-    assert float((got - want).abs().max()) <= 1e-6 * rms * 8 and float(got.min()) >= 0.0
+    assert torch.equal(got, want) and float(got.min()) >= 0.0 and float(got.max()) > 0.0
     if layout_name == "generic":
         shifted = torch.zeros(raw.numel() + 2, dtype=torch.int8, device="cuda")
         shifted[2:] = raw                                               # 2-byte aligned only: no 16-byte pieces, generic kernel
         got2 = torch.zeros_like(got)
         dspsr_amd.tfp_filterbank(ctx, shifted[2:], nchan, npart, got2, pscrunch, tscrunch, layout=layout, scale=0.0123)
-        assert float((got2 - want).abs().max()) <= 1e-6 * rms * 8
+        assert torch.equal(got2, want)
 
 
 @pytest.mark.parametrize("nchan,npol,ndat,interval,constant,blocks", [
