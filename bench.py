@@ -66,6 +66,17 @@ WORKLOADS = {
     "cfg5": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=4096, dm=0.0, freq_res=1,
                  nbin=0, machine="DADA", tscrunch=16, nparts=32768,
                  cmd="digifil -F 4096 -t 16 -b 8 (TFP filterbank + square law + tscrunch, Rescale, PScrunch, 8-bit digitizer; no fold)"),
+    # transform lengths with an odd factor (Filterbank.C:107-155 plans whatever FFTW plans; here 2^k * {3, 5, 7, 9, 15}): nchan_subband
+    # = 96 = 3 * 32 (three interleaved sub-sequences forward + one radix-3 pass) and freq_res = 12288 = 3 * 4096 (three pseudo-channels
+    # per channel + one radix-3 pass in time, Detection and Fold as launches of their own), with their power-of-two neighbours
+    "odd_nchan": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=96, dm=8.0, freq_res=4096, nbin=1024,
+                      machine="CASPSR", cmd="dspsr -F 96:D -x 4096 -D 8 -b 1024 (nchan_subband = 3 * 32)"),
+    "odd_nchan_nb": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=128, dm=8.0, freq_res=4096, nbin=1024,
+                         machine="CASPSR", cmd="dspsr -F 128:D -x 4096 -D 8 -b 1024 (power-of-two neighbour of -F 96:D)"),
+    "odd_fres": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=1024, dm=1000.0, freq_res=12288, nbin=1024,
+                     machine="CASPSR", cmd="dspsr -F 1024:D -x 12288 -D 1000 -b 1024 (freq_res = 3 * 4096)"),
+    "odd_fres_nb": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=1024, dm=1000.0, freq_res=8192, nbin=1024,
+                        machine="CASPSR", cmd="dspsr -F 1024:D -x 8192 -D 1000 -b 1024 (power-of-two neighbour of -x 12288)"),
     # the other branch of digifil (LoadToFil.C:185-222): convolving filterbank with coherent dedispersion in search mode -- the headline
     # geometry, detected (Intensity), time scrunched, rescaled and digitised instead of folded
     "cfg5c": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=1024, dm=1000.0, freq_res=4096, nbin=0,
@@ -1126,7 +1137,7 @@ def main():
                                                 "replicas so that N = 1 agrees with the single-GPU record" % world)
         if world == 1:
             others = []
-            for w in ("cfg1", "cfg1opt", "cfg2", "cfg3"):
+            for w in ("cfg1", "cfg1opt", "cfg2", "cfg3", "odd_nchan", "odd_fres"):
                 others.append(brief(run_fold_workload(w, short, *ctx, steps=2 * ssteps, warmup=swarm, full=False)))
             sm = argparse.Namespace(**vars(args))
             sm.steps, sm.warmup, sm.no_cpu_baseline = 2 * ssteps, swarm, True

@@ -174,9 +174,13 @@ struct SubSplit {
   uint64_t pol_stride;        // float: floats between polarisation rows
   uint32_t nchan, ichan, npol, ndim;
   uint64_t t_first;           // first sample of the group
-  uint64_t nper;              // samples per sub-sequence
+  uint64_t nper;              // samples per sub-sequence (all windows)
   uint32_t R;
   uint64_t sub_stride;        // bytes from one sub-block to the next
+  // windows: the group's parts as nwin separate windows of wlen samples per sub-sequence, win_step input samples apart (parts that
+  // do not follow each other: the sub-groups of a misaligned part step); nwin = 1, wlen = nper: one contiguous range
+  uint32_t nwin;
+  uint64_t wlen, win_step;
 };
 // Twiddles of the radix-R steps outside the tiles (R = 3, 5, 7, 9, 15): exp(-2 pi i t / (R 2^logP)), t < R 2^logP.  With
 // t = a 2^logP + b the twiddle is W_R^a -- R values, built in double on the host and handed over in this table -- times
@@ -205,8 +209,8 @@ struct TimeCombine {
   const cf* Y;
   uint64_t y_chan_stride, y_pol_stride;     // complex elements; parts M' apart
   uint32_t logMi, mo, nfilt_pos, nkeep, C, npol;
-  uint64_t part0;
-  uint32_t nparts;
+  uint64_t part0;                           // part of the call that local part lp is: part0 + lp * part_stride
+  uint32_t nparts, part_stride;
   OddTw tw;                                 // W_R^a of the radix-R step in time
 };
 

@@ -460,28 +460,113 @@ __global__ __launch_bounds__(512) void k_fwd_cols_dual(const FbGeom g, const FbI
 //   k_sub_split   : the launch group's samples de-interleaved into R contiguous single-channel blocks (generic byte order /
 //                   float rows), so that passes 0-2 see ordinary inputs
 //   k_sub_combine : the radix-R step in place on the R sub-spectra of every (part, sequence)
+// Element j of sub-sequence c of window lp is input sample t_first + lp*win_step + R*j + c.
+// KIND / EB: source form and bytes per element -- 1: generic 8-bit order, one element = the EB = npol*ndim bytes of a sample;
+// 2: CASPSR (4 B pol0 | 4 B pol1), EB = 2; 0: float32 rows, one element = the ndim floats of one polarisation (EB = 4 ndim).
+// Fast form (FAST): a thread takes n*R consecutive input samples (n = 16 / EB) and writes, for every c, the n elements they hold
+// as ONE 16-byte store -- a ninth of the memory instructions of the element-wise form (one load and one store per BYTE), which
+// moved the input at 2.3 TB/s (profiles/r05_experiments.txt item 3).  The element-wise form keeps the tails and odd shapes.
+template <int KIND, int EB> struct SplitElem { typedef uint32_t type; };
+template <> struct SplitElem<0, 8> { typedef uint2 type; };
+template <int KIND, int EB>
+DEV typename SplitElem<KIND, EB>::type sub_split_load(const SubSplit& p, const uint32_t q, const uint64_t t)
+{
+  if constexpr (KIND == 0) {
+    const float* __restrict__ x = (const float*)p.base + p.chan_off + q * p.pol_stride;
+    if constexpr (EB == 8) return *(const uint2*)(x + 2 * t);
+    else return __float_as_uint(x[t]);
+  } else if constexpr (KIND == 2) {
+    const uint8_t* __restrict__ b = (const uint8_t*)p.base + (t >> 2) * 8 + (t & 3);
+    return (uint32_t)b[0] | ((uint32_t)b[4] << 8);
+  } else {
+    const uint8_t* __restrict__ b = (const uint8_t*)p.base + (t * p.nchan + p.ichan) * EB;
+    if constexpr (EB == 4) return ((uintptr_t)b & 3) ? ((uint32_t)*(const uint16_t*)b | ((uint32_t)*(const uint16_t*)(b + 2) << 16)) : *(const uint32_t*)b;
+    else if constexpr (EB == 2) return *(const uint16_t*)b;
+    else return *b;
+  }
+}
+template <int KIND, int EB, int RT>
 __global__ __launch_bounds__(256) void k_sub_split(const SubSplit p, uint8_t* __restrict__ out)
 {
-  const uint64_t n = p.nper * p.R;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t j = i / p.R;
-    const uint32_t c = (uint32_t)(i - j * p.R);
-    const uint64_t t = p.t_first + i;                                       // = t_first + R*j + c
-    uint8_t* __restrict__ o = out + (uint64_t)c * p.sub_stride;
-    if (p.kind == 0) {                                                      // float rows -> [pol][j][ndim] floats
-      const float* __restrict__ x = (const float*)p.base + p.chan_off;
-      float* __restrict__ of = (float*)o;
-      for (uint32_t q = 0; q < p.npol; q++)
-        for (uint32_t d = 0; d < p.ndim; d++) of[(q * p.nper + j) * p.ndim + d] = x[q * p.pol_stride + t * p.ndim + d];
-    } else if (p.kind == 2) {                                               // CASPSR 4 B pol0 | 4 B pol1 -> (p0, p1) pairs
-      const uint8_t* __restrict__ b = (const uint8_t*)p.base + (t >> 2) * 8 + (t & 3);
-      o[2 * j] = b[0];
-      o[2 * j + 1] = b[4];
-    } else {                                                                // generic: byte ((t*nchan + c)*npol + p)*ndim + d
-      const uint32_t es = p.npol * p.ndim;
-      const uint8_t* __restrict__ b = (const uint8_t*)p.base + (t * p.nchan + p.ichan) * es;
-      for (uint32_t q = 0; q < es; q++) o[j * es + q] = b[q];
+  constexpr uint32_t N = 16 / EB;                                   // elements per 16-byte store
+  constexpr uint32_t R = RT;
+  const uint32_t nrow = KIND == 0 ? p.npol : 1u;                    // float: one row of elements per polarisation
+  const uint64_t groups = p.wlen / N;                               // whole 16-byte groups per window and sub-sequence
+  const uint64_t nunit = (uint64_t)p.nwin * nrow * groups;
+  for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < nunit; u += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t gq = u % groups, rest = u / groups;
+    const uint32_t q = (uint32_t)(rest % nrow), lp = (uint32_t)(rest / nrow);
+    const uint64_t m0 = gq * N, t0 = p.t_first + lp * p.win_step + R * m0;
+    const uint64_t oj = (uint64_t)lp * p.wlen + m0;                  // element index inside the sub-sequence
+    {
+      typename SplitElem<KIND, EB>::type e[N * RT];
+      // 8-bit sources: the thread's 16 R input bytes as whole dwords where the alignment allows (a load per BYTE otherwise)
+      bool have = false;
+      if constexpr (KIND == 2) {
+        if ((t0 & 3) == 0) {                                        // whole 4-sample groups: 4 B pol0 | 4 B pol1
+          const uint2* __restrict__ gp = (const uint2*)((const uint8_t*)p.base + (t0 >> 2) * 8);
+          uint2 grp[2 * RT];
+#pragma unroll
+          for (uint32_t i = 0; i < 2 * RT; i++) grp[i] = gp[i];
+#pragma unroll
+          for (uint32_t i = 0; i < N * RT; i++)
+            e[i] = ((grp[i >> 2].x >> (8 * (i & 3))) & 0xffu) | (((grp[i >> 2].y >> (8 * (i & 3))) & 0xffu) << 8);
+          have = true;
+        }
+      } else if constexpr (KIND == 1) {
+        const uint8_t* __restrict__ b = (const uint8_t*)p.base + t0 * EB;
+        if (p.nchan == 1 && ((uintptr_t)b & 3) == 0) {
+          uint32_t w[4 * RT];
+#pragma unroll
+          for (uint32_t i = 0; i < 4 * RT; i++) w[i] = ((const uint32_t*)b)[i];
+#pragma unroll
+          for (uint32_t i = 0; i < N * RT; i++) {
+            if constexpr (EB == 4) e[i] = w[i];
+            else if constexpr (EB == 2) e[i] = (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+            else e[i] = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+          }
+          have = true;
+        }
+      }
+      if (!have) {
+#pragma unroll
+        for (uint32_t i = 0; i < N * RT; i++) e[i] = sub_split_load<KIND, EB>(p, q, t0 + i);
+      }
+#pragma unroll
+      for (uint32_t c = 0; c < (uint32_t)RT; c++) {
+        uint4 v;
+        if constexpr (EB == 8) v = make_uint4(e[c].x, e[c].y, e[RT + c].x, e[RT + c].y);
+        else if constexpr (EB == 4) v = make_uint4(e[c], e[RT + c], e[2 * RT + c], e[3 * RT + c]);
+        else if constexpr (EB == 2) v = make_uint4(e[c] | (e[RT + c] << 16), e[2 * RT + c] | (e[3 * RT + c] << 16),
+                                                   e[4 * RT + c] | (e[5 * RT + c] << 16), e[6 * RT + c] | (e[7 * RT + c] << 16));
+        else {
+          uint32_t w[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) w[k] = e[(4 * k) * RT + c] | (e[(4 * k + 1) * RT + c] << 8) | (e[(4 * k + 2) * RT + c] << 16) | (e[(4 * k + 3) * RT + c] << 24);
+          v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        *(uint4*)(out + (uint64_t)c * p.sub_stride + ((uint64_t)q * p.nper + oj) * EB) = v;
+      }
     }
+  }
+}
+// element-wise form: elements [m_lo, wlen) of every window and sub-sequence (everything when the fast form does not apply)
+template <int KIND, int EB>
+__global__ __launch_bounds__(256) void k_sub_split_tail(const SubSplit p, uint8_t* __restrict__ out, const uint64_t m_lo)
+{
+  const uint32_t nrow = KIND == 0 ? p.npol : 1u;
+  const uint64_t per = (p.wlen - m_lo) * p.R, n = (uint64_t)p.nwin * nrow * per;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t w = i % per, rest = i / per;
+    const uint32_t q = (uint32_t)(rest % nrow), lp = (uint32_t)(rest / nrow);
+    const uint64_t m = m_lo + w / p.R;
+    const uint32_t c = (uint32_t)(w % p.R);
+    const auto e = sub_split_load<KIND, EB>(p, q, p.t_first + lp * p.win_step + p.R * m + c);
+    uint8_t* __restrict__ o = out + (uint64_t)c * p.sub_stride + ((uint64_t)q * p.nper + (uint64_t)lp * p.wlen + m) * EB;
+    if constexpr (EB == 8) *(uint2*)o = e;
+    else if constexpr (EB == 4) *(uint32_t*)o = e;
+    else if constexpr (EB == 2) *(uint16_t*)o = (uint16_t)e;
+    else *o = (uint8_t)e;
   }
 }
 
@@ -557,9 +642,34 @@ void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, c
 {
   hipLaunchKernelGGL(k_float_transpose, grid, dim3(256), 0, stream, g, in, Rt, part0);
 }
+template <int KIND, int EB>
+static void sub_split_launch(hipStream_t stream, const SubSplit& p, uint8_t* out, uint32_t ncu)
+{
+  constexpr uint32_t N = 16 / EB;
+  // the fast form needs 16-byte aligned stores: sub-blocks, polarisation rows and windows a multiple of 16 bytes apart
+  const bool fast = (p.sub_stride % 16) == 0 && ((p.nper * EB) % 16) == 0 && ((p.wlen * EB) % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  uint64_t m_lo = 0;
+  if (fast && p.wlen >= N) {
+    m_lo = (p.wlen / N) * N;
+    switch (p.R) {
+      case 3: hipLaunchKernelGGL((k_sub_split<KIND, EB, 3>), dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+      case 5: hipLaunchKernelGGL((k_sub_split<KIND, EB, 5>), dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+      case 7: hipLaunchKernelGGL((k_sub_split<KIND, EB, 7>), dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+      case 9: hipLaunchKernelGGL((k_sub_split<KIND, EB, 9>), dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+      case 15: hipLaunchKernelGGL((k_sub_split<KIND, EB, 15>), dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
+      default: m_lo = 0; break;
+    }
+  }
+  if (m_lo < p.wlen) hipLaunchKernelGGL((k_sub_split_tail<KIND, EB>), dim3(8 * ncu), dim3(256), 0, stream, p, out, m_lo);
+}
 void fb_launch_sub_split(hipStream_t stream, const SubSplit& p, uint8_t* out, uint32_t ncu)
 {
-  hipLaunchKernelGGL(k_sub_split, dim3(8 * ncu), dim3(256), 0, stream, p, out);
+  const uint32_t es = p.npol * p.ndim;
+  if (p.kind == 0) { if (p.ndim == 2) sub_split_launch<0, 8>(stream, p, out, ncu); else sub_split_launch<0, 4>(stream, p, out, ncu); }
+  else if (p.kind == 2) sub_split_launch<2, 2>(stream, p, out, ncu);
+  else if (es == 4) sub_split_launch<1, 4>(stream, p, out, ncu);
+  else if (es == 2) sub_split_launch<1, 2>(stream, p, out, ncu);
+  else sub_split_launch<1, 1>(stream, p, out, ncu);
 }
 void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu, cf* Xout, uint32_t mo, uint32_t rm)
 {

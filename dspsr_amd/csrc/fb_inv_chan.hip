@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_time_combine(const TimeCombine p, const
       a.x += v0.x; a.y += v0.y;
       if (p.npol == 2) { const cf v1 = cmul(y[p.y_pol_stride], w); b.x += v1.x; b.y += v1.y; }
     }
-    const uint64_t part = p.part0 + lp;
+    const uint64_t part = p.part0 + (uint64_t)lp * p.part_stride;
     const uint32_t chan = out.chan0 + c;
     float* __restrict__ row = out.base + chan * out.chan_stride;
     if (out.kind == 1) {

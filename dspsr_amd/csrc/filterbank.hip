@@ -588,9 +588,6 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         if (i3a > per_part_items) per_part_items = i3a;
         if (i3b > per_part_items) per_part_items = i3b;
         while (nb > 1 && per_part_items * nb >= (1ull << 31)) nb /= 2;
-        // (the sub-sequences of a launch group share one de-interleaved block: the parts must start a multiple of nsub samples
-        //  apart -- always so for nchan_subband = nsub * 2^k, for freq_res = nsub * 2^k only when the kept length allows it)
-        if (g.nsub > 1 && in.part_step % g.nsub) nb = 1;
         nb_step = nb;
       }
       if (g.nsub > 1) {
@@ -601,7 +598,21 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
           return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: 16-bit UWB blocks need power-of-two nchan_subband and "
                          "freq_res (k_sub_split de-interleaves 8-bit and float32 input)");
         const uint32_t ndim = g.real_input ? 1u : 2u;
-        const uint64_t step = in.part_step, nper = ((uint64_t)(nb - 1) * step + fb->L) / R;       // (step and L are multiples of nsub)
+        // The sub-sequences of a launch share ONE de-interleaved block, so its parts must start a multiple of R samples apart.  The
+        // part step is a multiple of the odd factor of nchan_subband always, of the factor of freq_res only when the kept length
+        // allows it: otherwise the group runs as rp interleaved sub-groups -- parts q, q + rp, q + 2 rp, ... start rp steps apart,
+        // a multiple of R -- each with its own de-interleave (round 4 fell back to ONE part per launch here: a cliff for persistent
+        // kernels that amortise ramp-up and tail over 32-256 parts).
+        auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
+        const uint32_t rp = (in.part_step % R) ? R / gcd((uint32_t)(in.part_step % R), R) : 1u;
+        const uint32_t nb_all = nb;
+        for (uint32_t q = 0; q < rp && q < nb_all; q++) {
+        const uint32_t nb = (nb_all - q + rp - 1) / rp;                                  // parts of this sub-group
+        const uint64_t part0q = part0 + q;
+        // (sub-groups: the parts do not follow each other -- every part is a window of its own in the de-interleaved block, L / R
+        //  samples per sub-sequence, instead of one contiguous range that would cover the other sub-groups' samples as well)
+        const uint64_t step = in.part_step * rp;                                         // (a multiple of R, like L)
+        const uint64_t wlen = rp > 1 ? fb->L / R : ((uint64_t)(nb - 1) * step + fb->L) / R, nper = rp > 1 ? (uint64_t)nb * wlen : wlen;
         const size_t es = in.kind == 0 ? (size_t)g.npol * ndim * sizeof(float) : (size_t)g.npol * ndim;   // bytes per sample, all pols
         const size_t sub_stride = (nper * es + 15) & ~(size_t)15;
         if (sub_stride * R > fb->dsub_bytes) {
@@ -613,7 +624,8 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
           fb->dsub_bytes = sub_stride * R;
         }
         SubSplit sp = {in.kind, in.base, in.kind == 0 ? (uint64_t)ichan * in_chan_stride_bytes_or_floats : 0, in.pol_stride,
-                       fb->cfg.input_nchan, ichan, (uint32_t)g.npol, ndim, part0 * step, nper, R, sub_stride};
+                       fb->cfg.input_nchan, ichan, (uint32_t)g.npol, ndim, part0q * in.part_step, nper, R, sub_stride,
+                       rp > 1 ? nb : 1u, wlen, step};
         fb_launch_sub_split(ctx->stream, sp, fb->dsub, fb->ncu);
         const uint64_t Ls = fb->L / R;
         for (uint32_t c = 0; c < R; c++) {
@@ -621,7 +633,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
           cs.kind = in.kind == 0 ? 0 : 1;                           // (the split writes the generic byte order)
           cs.base = fb->dsub + (size_t)c * sub_stride;
           cs.pol_stride = in.kind == 0 ? nper * ndim : 0;
-          cs.part_step = step / R;
+          cs.part_step = rp > 1 ? wlen : step / R;
           cs.nchan = 1; cs.ichan = 0;
           const bool f8 = cs.kind == 1 && g.real_input && g.npol == 2;
           const bool fc = cs.kind == 1 && !g.real_input && g.npol == 2 && (cs.part_step % 4) == 0 && g.logR >= 3;
@@ -666,12 +678,14 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
           hipLaunchKernelGGL(fb->k3, dim3(grid_for(n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->Xp, kern, yo, ctx->tw,
                              0ull, nb, nb);
           TimeCombine tc = {fb->Y, (uint64_t)g.npol * fb->max_parts * Mi, (uint64_t)fb->max_parts * Mi, (uint32_t)g.logM, fb->out_M,
-                            fb->out_nfilt_pos, fb->out_nkeep, fb->out_C, (uint32_t)g.npol, part0, nb, make_odd_tw(fb->msub)};
+                            fb->out_nfilt_pos, fb->out_nkeep, fb->out_C, (uint32_t)g.npol, part0q, nb, rp, make_odd_tw(fb->msub)};
           FbOut cu = co;
           cu.chan0 = ichan * fb->out_C;
           if (cu.kind == 1 || cu.kind == 2) fb_launch_time_combine(ctx->stream, tc, cu, fb->msub, fb->ncu);
-          continue;
+          continue;                                                                    // (next sub-group)
         }
+        if (rp != 1) return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: part step %llu is not a multiple of %u",
+                                    (unsigned long long)in.part_step, R);            // (cannot happen: see above)
         fb_launch_sub_combine(ctx->stream, g, fb->X, nb * fb->nseq, fb->ncu);
         if (co.kind == 3) {
           const int rc = fb_launch_fused(fb, k3, fb->X, kern, co, part0, nb, fused_segmented);
@@ -680,6 +694,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
           // (search mode: one workgroup per tile of channels, walking the group's parts in order)
           hipLaunchKernelGGL(k3, dim3(grid_for(co.kind == 5 ? n3s / nb : n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X,
                              kern, co, ctx->tw, part0, nb, nb);
+        }
         }
         continue;
       }

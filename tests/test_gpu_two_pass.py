@@ -236,6 +236,12 @@ def test_rejected_channel_counts(gpu):
     (60, 128, (9, 10), 3, dict(layout="caspsr", max_parts=2)),
     (96, 3 * 256, (50, 41), 2, dict()),                                 # both lengths at once: -F 96:D -x 768 (9 sub-sequences)
     (80, 3 * 128, (20, 21), 2, dict(real=False)),                       # 5 x 3
+    # part steps that are not a multiple of the factor: the launch group runs as 3 / 5 interleaved sub-groups of several parts
+    # (round 4: one part per launch), every part a window of its own in the de-interleaved block
+    (16, 3 * 256, (50, 41), 9, dict(max_parts=7)),
+    (16, 5 * 256, (60, 61), 11, dict(use_raw=False, max_parts=8)),
+    (8, 3 * 512, (60, 61), 7, dict(layout="caspsr", max_parts=7)),
+    (32, 9 * 64, (30, 21), 8, dict(real=False, max_parts=8)),
 ])
 def test_filterbank_freq_res_three_five_times_power_of_two(oracle, gpu, C, M, nfilt, npart, kw):
     _fb_case(oracle, gpu, C, M, nfilt, npart, **kw)
