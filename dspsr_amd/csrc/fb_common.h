@@ -188,17 +188,26 @@ struct SubSplit {
 // an argument error below 2e-8 revolutions, so the product is as accurate as the hi / lo split of twiddles_big (2.4e-7; the
 // single-argument form it replaces, (a + b / 2^logP) / R, rounded the whole angle: up to 4e-7, and the time-domain step's
 // t * (1 / freq_res) up to 7.5e-7).
-struct OddTw { float2 w[16]; };                       // w[a] = exp(-2 pi i a / R), a < R
+constexpr uint32_t ODD_MAX = 63;                      // largest odd factor of a transform length
+struct OddTw { float2 w[ODD_MAX + 1]; uint32_t R; };   // w[a] = exp(-2 pi i a / R), a < R
 template <int R> DEV cf twiddle_odd(const uint32_t t, const int logP, const OddTw& tab)
 {
   const uint32_t a = (t >> logP) % (uint32_t)R, b = t & ((1u << logP) - 1);
   const float x = (float)b * __uint_as_float((uint32_t)(127 - logP) << 23) / (float)R;
   return cmul(tab.w[a], make_float2(__builtin_amdgcn_cosf(x), -__builtin_amdgcn_sinf(x)));
 }
+// the same for a factor known only at run time (R any odd number <= ODD_MAX; t may need 64 bits)
+DEV cf twiddle_odd_rt(const uint64_t t, const int logP, const OddTw& tab)
+{
+  const uint32_t a = (uint32_t)((t >> logP) % tab.R), b = (uint32_t)(t & ((1ull << logP) - 1));
+  const float x = (float)b * __uint_as_float((uint32_t)(127 - logP) << 23) / (float)tab.R;
+  return cmul(tab.w[a], make_float2(__builtin_amdgcn_cosf(x), -__builtin_amdgcn_sinf(x)));
+}
 inline OddTw make_odd_tw(const uint32_t R)
 {
   OddTw t;
-  for (uint32_t a = 0; a < 16; a++) {
+  t.R = R;
+  for (uint32_t a = 0; a <= ODD_MAX; a++) {
     const double ang = -2.0 * M_PI * (double)(a % R) / (double)R;
     t.w[a] = make_float2((float)cos(ang), (float)sin(ang));
   }
@@ -529,8 +538,11 @@ k1c_t fb_pick_col1();
 k3_t fb_pick_rinv(int logm, int epi);      // epilogue: 0 output written, 1 fused fold, 2 search mode
 void fb_launch_raw_cols(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_sub_split(hipStream_t stream, const SubSplit& p, uint8_t* out, uint32_t ncu);
-void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu, cf* Xout = nullptr, uint32_t mo = 0,
-                           uint32_t rm = 1);
+// radix-nsub step on the sub-spectra in X.  Xout == nullptr: in place where a kernel is instantiated for the factor (3, 5, 7, 9,
+// 15), else into Xalt; returns the buffer that holds the combined spectrum.  Xout != nullptr (freq_res with an odd factor): the
+// spectrum in pseudo-channel order into Xout.
+cf* fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu, cf* Xalt, cf* Xout = nullptr, uint32_t mo = 0,
+                          uint32_t rm = 1);
 void fb_launch_time_combine(hipStream_t stream, const TimeCombine& p, const FbOut& out, uint32_t R, uint32_t ncu);
 void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, cf* Rt, uint64_t part0);

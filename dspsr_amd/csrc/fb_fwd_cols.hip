@@ -642,6 +642,48 @@ void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, c
 {
   hipLaunchKernelGGL(k_float_transpose, grid, dim3(256), 0, stream, g, in, Rt, part0);
 }
+// Any odd factor (run-time R <= ODD_MAX: 11, 13, 21, 25 ... -- dspsr -F 400:D, -F 25:D): one thread per OUTPUT bin kk = k + q L',
+// X[kk] = sum_c W_L^(c kk) F_c[k], out of place (the R outputs of a position need the R inputs other threads are still reading).  R
+// loads (the threads of the R bands share them in L2) and R twiddles per output instead of R per R outputs: a few times the cost of
+// the instantiated kernels, for lengths they do not cover.
+template <bool MSUB>
+__global__ __launch_bounds__(256) void k_sub_combine_any(const FbGeom g, const cf* __restrict__ X, const uint32_t nseqs,
+                                                         cf* __restrict__ Xout, const uint32_t mo, const uint32_t rm, const OddTw wr)
+{
+  const int logLs = g.logM + g.logR;
+  const uint32_t R = wr.R, Ls = 1u << logLs, L = Ls * R;
+  const uint32_t X3m = (1u << g.logX3) - 1, Mm = (1u << g.logM) - 1;
+  const uint64_t n = (uint64_t)nseqs * L;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t o = (uint32_t)(i & (Ls - 1));
+    const uint64_t rest = i >> logLs;
+    const uint32_t q = (uint32_t)(rest % R);
+    const uint64_t seq = rest / R;
+    const cf* __restrict__ base = X + seq * (uint64_t)L + o;
+    const uint32_t t = o >> g.logX3, m = t & Mm, sp = ((t >> g.logM) << g.logX3) | (o & X3m);
+    const uint32_t k = (sp << g.logM) + m, kk = k + (q << logLs);
+    cf acc = base[0];
+    for (uint32_t c = 1; c < R; c++) {
+      const cf v = cmul(base[(uint64_t)c << logLs], twiddle_odd_rt((uint64_t)c * kk, logLs, wr));
+      acc.x += v.x; acc.y += v.y;
+    }
+    if constexpr (!MSUB) {
+      Xout[seq * (uint64_t)L + ((uint64_t)q << logLs) + o] = acc;
+    } else {
+      const uint32_t Rr = R << g.logR, N = g.real_input ? L >> 1 : L;
+      const bool up = kk > N;
+      const uint32_t kq = up ? L - kk : kk;
+      const uint32_t cc = kq / mo, mm = kq - cc * mo, mi = mm / rm, r = mm - mi * rm, s = cc * rm + r;
+      uint32_t row, bin;
+      if (kk == N && g.real_input) { row = Rr >> 1; bin = 0; }
+      else if (!up) { row = s; bin = mi; }
+      else if (mi) { row = Rr - 1 - s; bin = (1u << g.logM) - mi; }
+      else { row = Rr - s; bin = 0; }
+      Xout[seq * (uint64_t)L + (((((uint64_t)(row >> g.logX3) << g.logM) + bin) << g.logX3) | (row & X3m))] = acc;
+    }
+  }
+}
+
 template <int KIND, int EB>
 static void sub_split_launch(hipStream_t stream, const SubSplit& p, uint8_t* out, uint32_t ncu)
 {
@@ -671,15 +713,18 @@ void fb_launch_sub_split(hipStream_t stream, const SubSplit& p, uint8_t* out, ui
   else if (es == 2) sub_split_launch<1, 2>(stream, p, out, ncu);
   else sub_split_launch<1, 1>(stream, p, out, ncu);
 }
-void fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu, cf* Xout, uint32_t mo, uint32_t rm)
+cf* fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t nseqs, uint32_t ncu, cf* Xalt, cf* Xout, uint32_t mo, uint32_t rm)
 {
-#define FB_SUBC(R)                                                                                                              \
-  case R:                                                                                                                       \
-    if (!Xout) hipLaunchKernelGGL((k_sub_combine<R, false>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, X, 0u, 1u, make_odd_tw(R)); \
-    else hipLaunchKernelGGL((k_sub_combine<R, true>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, Xout, mo, rm, make_odd_tw(R));   \
-    break;
+#define FB_SUBC(R)                                                                                                                          \
+  case R:                                                                                                                                   \
+    if (!Xout) hipLaunchKernelGGL((k_sub_combine<R, false>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, X, 0u, 1u, make_odd_tw(R));   \
+    else hipLaunchKernelGGL((k_sub_combine<R, true>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, Xout, mo, rm, make_odd_tw(R));     \
+    return Xout ? Xout : X;
   switch (g.nsub) { FB_SUBC(3) FB_SUBC(5) FB_SUBC(7) FB_SUBC(9) FB_SUBC(15) default: break; }
 #undef FB_SUBC
+  if (!Xout) hipLaunchKernelGGL((k_sub_combine_any<false>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, Xalt, 0u, 1u, make_odd_tw(g.nsub));
+  else hipLaunchKernelGGL((k_sub_combine_any<true>), dim3(8 * ncu), dim3(256), 0, stream, g, X, nseqs, Xout, mo, rm, make_odd_tw(g.nsub));
+  return Xout ? Xout : Xalt;
 }
 
 }  // namespace dspsr_amd

@@ -6,9 +6,12 @@ namespace dspsr_amd {
 // freq_res = R * 2^k, last step: y[n] = sum_r exp(+2 pi i r n / freq_res) y_r[n mod M'] for the kept samples n of every channel and
 // part, from the pseudo-channels' whole transforms Y[c*R + r][pol][part][M'] (written by the inverse pass as complex rows), into
 // the caller's output: complex rows (kind 1) or detected samples (kind 2; Detection.C:423-474 layouts as in k_inv_chan).
-template <int R>
+// RT = 0: the factor at run time (p.tw.R: any odd number <= ODD_MAX)
+template <int RT>
 __global__ __launch_bounds__(256) void k_time_combine(const TimeCombine p, const FbOut out)
 {
+  const uint32_t R = RT ? (uint32_t)RT : p.tw.R;
+  constexpr int UNR = RT ? RT : 1;
   const uint32_t Mi = 1u << p.logMi;
   const uint64_t n = (uint64_t)p.nparts * p.C * p.nkeep;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -17,12 +20,13 @@ __global__ __launch_bounds__(256) void k_time_combine(const TimeCombine p, const
     const uint32_t c = (uint32_t)(pc % p.C), lp = (uint32_t)(pc / p.C);
     const uint32_t nn = p.nfilt_pos + t, ni = nn & (Mi - 1);
     cf a = make_float2(0.f, 0.f), b = a;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
+#pragma unroll UNR
+    for (uint32_t r = 0; r < R; r++) {
       const cf* __restrict__ y = p.Y + (uint64_t)(c * R + r) * p.y_chan_stride + ((uint64_t)lp << p.logMi) + ni;
       cf w = make_float2(1.f, 0.f);
-      if (r) {                                                   // exp(+2 pi i r n / freq_res), freq_res = R M' (r n < 15 * 2^26)
-        w = twiddle_odd<R>((uint32_t)r * nn, p.logMi, p.tw);
+      if (r) {                                                   // exp(+2 pi i r n / freq_res), freq_res = R M' (r n < 63 * 63 * 2^13)
+        if constexpr (RT != 0) w = twiddle_odd<RT ? RT : 3>(r * nn, p.logMi, p.tw);
+        else w = twiddle_odd_rt((uint64_t)r * nn, p.logMi, p.tw);
         w.y = -w.y;
       }
       const cf v0 = cmul(y[0], w);
@@ -69,7 +73,7 @@ void fb_launch_time_combine(hipStream_t stream, const TimeCombine& p, const FbOu
     case 7: hipLaunchKernelGGL(k_time_combine<7>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
     case 9: hipLaunchKernelGGL(k_time_combine<9>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
     case 15: hipLaunchKernelGGL(k_time_combine<15>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
-    default: break;
+    default: hipLaunchKernelGGL(k_time_combine<0>, dim3(8 * ncu), dim3(256), 0, stream, p, out); break;
   }
 }
 

@@ -90,17 +90,19 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   // tile stay powers of two: bins m = R m' + r of a channel are R pseudo-channels of freq_res / R bins (the inner filterbank of
   // nchan_subband * R channels below, whole transforms kept), whose time series k_time_combine adds with the twiddles
   // exp(+2 pi i r n / freq_res) -- the decimation-in-frequency form of the freq_res-point backward transform.
-  // (odd factors 3, 5, 7, 9, 15 of either length; both lengths at once as long as the product of the two factors is one of those)
+  // (odd factors up to ODD_MAX = 63 of either length; both lengths at once as long as the product of the two factors stays within it)
   auto odd_part = [](uint32_t v) { while (v && !(v & 1)) v >>= 1; return v; };
-  auto radix_ok = [](uint32_t r) { return r == 3 || r == 5 || r == 7 || r == 9 || r == 15; };
+  // (any odd factor up to ODD_MAX: 3, 5, 7, 9, 15 have radix kernels of their own, the others -- 11, 13, 21, 25, ... -- the
+  //  run-time-radix forms k_sub_combine_any / k_time_combine<0>)
+  auto radix_ok = [](uint32_t r) { return (r & 1u) && r >= 3 && r <= ODD_MAX; };
   uint32_t msub = 0;
   if (!ispow2(cfg->freq_res)) {
     msub = odd_part(cfg->freq_res);
     if (!radix_ok(msub) || cfg->nchan_subband == 0 || !(ispow2(cfg->nchan_subband) || radix_ok(odd_part(cfg->nchan_subband) * msub)) ||
         cfg->freq_res / msub < 2 || cfg->force_four_pass == 1)
       return fb_fail(ctx, DSPSR_AMD_EINVAL,
-                     "dspsr_amd_filterbank_create: freq_res=%u must be 2^k >= 2, or 2^k (k >= 1) times 3, 5, 7, 9 or 15 (times the odd "
-                     "factor of nchan_subband=%u: again one of those; freq_res=1 is the non-convolving filterbank, not built yet)",
+                     "dspsr_amd_filterbank_create: freq_res=%u must be 2^k >= 2, or 2^k (k >= 1) times an odd number <= 63 (times the odd "
+                     "factor of nchan_subband=%u: again <= 63; freq_res=1 is the non-convolving filterbank, not built yet)",
                      cfg->freq_res, cfg->nchan_subband);
   } else if (cfg->freq_res < 2)
     return fb_fail(ctx, DSPSR_AMD_EINVAL,
@@ -118,7 +120,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   if (!ispow2(nchan_sb)) {
     nsub = nchan_sb ? odd_part(nchan_sb) : 0;
     if (!radix_ok(nsub))
-      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u must be 2^k or 2^k times 3, 5, 7, 9 or 15",
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u must be 2^k or 2^k times an odd number <= 63",
                      cfg->nchan_subband);
     if (cfg->force_four_pass == 1)
       return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u (not a power of two) has no four-pass form",
@@ -672,7 +674,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
             return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of the pseudo-channel spectrum failed");
           if (!fb->Y && hipMalloc((void**)&fb->Y, ye * sizeof(cf)) != hipSuccess)
             return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of the pseudo-channel time series failed");
-          fb_launch_sub_combine(ctx->stream, g, fb->X, nb * fb->nseq, fb->ncu, fb->Xp, fb->out_M, fb->msub);
+          (void)fb_launch_sub_combine(ctx->stream, g, fb->X, nb * fb->nseq, fb->ncu, nullptr, fb->Xp, fb->out_M, fb->msub);
           // Y[pseudo-channel][pol][part of the group][Mi] complex: rows (pseudo-channel, pol), parts 2*Mi floats apart
           FbOut yo = {1, (float*)fb->Y, (uint64_t)g.npol * fb->max_parts * Mi * 2, (uint64_t)fb->max_parts * Mi * 2, Mi * 2, 0, 2, 0};
           hipLaunchKernelGGL(fb->k3, dim3(grid_for(n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->Xp, kern, yo, ctx->tw,
@@ -686,13 +688,14 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
         }
         if (rp != 1) return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: part step %llu is not a multiple of %u",
                                     (unsigned long long)in.part_step, R);            // (cannot happen: see above)
-        fb_launch_sub_combine(ctx->stream, g, fb->X, nb * fb->nseq, fb->ncu);
+        // (factors without a radix kernel of their own combine out of place, into the A scratch -- idle behind pass 2)
+        const cf* Xc = fb_launch_sub_combine(ctx->stream, g, fb->X, nb * fb->nseq, fb->ncu, fb->A);
         if (co.kind == 3) {
-          const int rc = fb_launch_fused(fb, k3, fb->X, kern, co, part0, nb, fused_segmented);
+          const int rc = fb_launch_fused(fb, k3, Xc, kern, co, part0, nb, fused_segmented);
           if (rc != DSPSR_AMD_OK) return rc;
         } else {
           // (search mode: one workgroup per tile of channels, walking the group's parts in order)
-          hipLaunchKernelGGL(k3, dim3(grid_for(co.kind == 5 ? n3s / nb : n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, fb->X,
+          hipLaunchKernelGGL(k3, dim3(grid_for(co.kind == 5 ? n3s / nb : n3s, fb->ncu * fb->wg3)), dim3(fb->nt3), fb->lds3, ctx->stream, g, Xc,
                              kern, co, ctx->tw, part0, nb, nb);
         }
         }
