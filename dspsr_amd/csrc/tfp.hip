@@ -470,8 +470,8 @@ extern "C" int dspsr_amd_tfp_filterbank(dspsr_amd_ctx* ctx, const dspsr_amd_tfp_
 {
   if (!ctx || !cfg || !raw_dev || !out_dev) return DSPSR_AMD_EINVAL;
   const uint32_t nchan = cfg->nchan;
-  if (nchan < 16 || (nchan & (nchan - 1)) || nchan > 4096)
-    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_tfp_filterbank: nchan=%u must be a power of two in [16, 4096]", nchan);
+  if (nchan < 16 || (nchan & (nchan - 1)) || nchan > 8192)
+    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_tfp_filterbank: nchan=%u must be a power of two in [16, 8192]", nchan);
   if (cfg->npol != 2)
     return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_tfp_filterbank: only real dual-polarisation 8-bit input is built (npol=%u)", cfg->npol);
   const uint32_t sf = cfg->tscrunch ? cfg->tscrunch : 1;

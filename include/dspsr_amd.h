@@ -241,7 +241,7 @@ int dspsr_amd_detect_square_law(dspsr_amd_ctx* ctx, int intensity, const float* 
  * (TScrunch.C:180-206) fused in one launch.  Real dual-pol 8-bit input, raw_dev = first byte of the block.
  *   out_dev: [npart/tscrunch][nchan][pscrunch ? 1 : 2] floats (PPQQ or Intensity, TimeSeries::OrderTFP) */
 typedef struct {
-  uint32_t nchan;      /* -F nchan (power of two, 16..4096) */
+  uint32_t nchan;      /* -F nchan (power of two, 16..8192: both polarisations of one part fill a 2^14-point tile at 8192) */
   uint32_t npol;       /* input polarisations (2) */
   uint32_t pscrunch;   /* 1: Intensity (p0+p1), 0: PPQQ */
   uint32_t tscrunch;   /* -t factor, 0/1 = none */

@@ -738,7 +738,8 @@ def test_pipeline_turns_mode_subintegrations(oracle, gpu, turns):
 
 
 @pytest.mark.parametrize("nchan,tscrunch,pscrunch,npart", [(4096, 16, True, 64), (4096, 16, False, 35), (256, 4, True, 130),
-                                                           (64, 1, False, 300), (1024, 32, True, 96), (16, 2, False, 1024)])
+                                                           (64, 1, False, 300), (1024, 32, True, 96), (16, 2, False, 1024),
+                                                           (8192, 4, True, 24), (8192, 1, False, 5)])
 def test_tfp_filterbank_search_mode(oracle, gpu, nchan, tscrunch, pscrunch, npart):
     """digifil front end: TFPFilterbank + pscrunch + TScrunch fused, against the float32 oracle
     (same operation order); tolerance 2e-5 of the rms power (FFT rounding differs from pocketfft)."""
