@@ -74,7 +74,7 @@ SYMBOLS = {
     "dspsr_amd_filterbank_perform_search": (_i, [_vp, _vp, _u64, _u64, _u64, _vp, _i, _f, _i, _u32, _vp, _u64, _u64, _vp,
                                                  C.POINTER(_u32), _u64, C.POINTER(_u64)]),
     "dspsr_amd_filterbank_search_is_fused": (_i, [_vp]),
-    "dspsr_amd_tscrunch_fpt": (_i, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u32, _u64, _u32, _vp, C.POINTER(_u32),
+    "dspsr_amd_tscrunch_fpt": (_i, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u32, _u32, _u64, _u32, _vp, C.POINTER(_u32),
                                     C.POINTER(_u64)]),
     "dspsr_amd_fscrunch_fpt": (_i, [_vp, _vp, _u64, _u64, _vp, _u64, _u64, _u32, _u32, _u64, _u32]),
     "dspsr_amd_sample_delay_create": (_i, [_vp, _u32, _u32, _vp, _i, _pp]),

@@ -1022,7 +1022,7 @@ extern "C" int dspsr_amd_filterbank_perform_search(dspsr_amd_filterbank* fb, con
   rc = dspsr_amd_detect_square_law(ctx, out_state == DSPSR_AMD_INTENSITY, cplx, fb->cfg.npol * crow, crow, det, npo * drow, drow,
                                    (uint32_t)nchan_out, fb->cfg.npol, ndat);
   if (rc != DSPSR_AMD_OK) return rc;
-  return dspsr_amd_tscrunch_fpt(ctx, det, npo * drow, drow, out_dev, out_chan_stride, out_pol_stride, (uint32_t)nchan_out, npo, ndat,
+  return dspsr_amd_tscrunch_fpt(ctx, det, npo * drow, drow, out_dev, out_chan_stride, out_pol_stride, (uint32_t)nchan_out, npo, 1, ndat,
                                 tscrunch, carry_dev, carry_count, nout);
 }
 

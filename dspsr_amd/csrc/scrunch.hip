@@ -11,24 +11,27 @@ namespace dspsr_amd {
 // the samples behind the last complete output go to `carry`.  blockIdx.y = row (chan * npol + pol).
 __global__ __launch_bounds__(256) void k_tscrunch_fpt(const float* __restrict__ in, const uint64_t ics, const uint64_t ips,
                                                       float* __restrict__ out, const uint64_t ocs, const uint64_t ops, const uint32_t npol,
-                                                      const uint64_t ndat_in, const uint32_t sf, const uint32_t c0, float* __restrict__ carry,
-                                                      const uint64_t nout, const uint32_t rem)
+                                                      const uint32_t ndim, const uint64_t ndat_in, const uint32_t sf, const uint32_t c0,
+                                                      float* __restrict__ carry, const uint64_t nout, const uint32_t rem)
 {
   const uint32_t chan = blockIdx.y / npol, pol = blockIdx.y % npol;
   const float* __restrict__ x = in + chan * ics + pol * ips;
   float* __restrict__ y = out + chan * ocs + pol * ops;
   const uint64_t ngroup = nout + (rem ? 1 : 0);
-  for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < ngroup; o += (uint64_t)gridDim.x * blockDim.x) {
+  // one thread per (output sample, dimension): consecutive threads = the dimensions of a sample, then the next sample
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < ngroup * ndim; w += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t o = w / ndim;
+    const uint32_t d = (uint32_t)(w - o * ndim);
     // stream samples [o*sf, (o+1)*sf) = input samples [o*sf - c0, ...) ; the last group holds `rem` samples only
     const uint64_t s0 = o * sf, s1 = o < nout ? s0 + sf : s0 + rem;
     uint64_t i = s0 < c0 ? 0 : s0 - c0;
     const uint64_t i1 = s1 - c0;
     float acc;
-    if (o == 0 && c0) acc = carry[blockIdx.y];
-    else { acc = x[i]; i++; }
-    for (; i < i1; i++) acc = __fadd_rn(acc, x[i]);
-    if (o < nout) y[o] = acc;
-    else carry[blockIdx.y] = acc;
+    if (o == 0 && c0) acc = carry[blockIdx.y * ndim + d];
+    else { acc = x[i * ndim + d]; i++; }
+    for (; i < i1; i++) acc = __fadd_rn(acc, x[i * ndim + d]);
+    if (o < nout) y[o * ndim + d] = acc;
+    else carry[blockIdx.y * ndim + d] = acc;
   }
 }
 
@@ -52,9 +55,9 @@ using namespace dspsr_amd;
 
 extern "C" int dspsr_amd_tscrunch_fpt(dspsr_amd_ctx* ctx, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
                                       float* out_dev, uint64_t out_chan_stride, uint64_t out_pol_stride, uint32_t nchan, uint32_t npol,
-                                      uint64_t ndat_in, uint32_t sfactor, float* carry_dev, uint32_t* carry_count, uint64_t* nout)
+                                      uint32_t ndim, uint64_t ndat_in, uint32_t sfactor, float* carry_dev, uint32_t* carry_count, uint64_t* nout)
 {
-  if (!ctx || !carry_count || !nout) return DSPSR_AMD_EINVAL;
+  if (!ctx || !carry_count || !nout || !ndim) return DSPSR_AMD_EINVAL;
   if (!sfactor) return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dsp::TScrunch::get_factor scrunch factor not set");        // TScrunch.C:88-90
   if (*carry_count >= sfactor)
     return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_tscrunch_fpt: carry_count=%u must be < sfactor=%u", *carry_count, sfactor);
@@ -68,11 +71,11 @@ extern "C" int dspsr_amd_tscrunch_fpt(dspsr_amd_ctx* ctx, const float* in_dev, u
   const uint64_t rows = (uint64_t)nchan * npol;
   if (rows > 65535) return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_tscrunch_fpt: nchan*npol=%llu exceeds the grid limit", (unsigned long long)rows);
   const uint64_t ngroup = *nout + (rem ? 1 : 0);
-  uint64_t bx = (ngroup + 255) / 256;
+  uint64_t bx = (ngroup * ndim + 255) / 256;
   if (bx > 1024) bx = 1024;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(k_tscrunch_fpt, dim3((uint32_t)bx, (uint32_t)rows), dim3(256), 0, ctx->stream, in_dev, in_chan_stride, in_pol_stride,
-                     out_dev, out_chan_stride, out_pol_stride, npol, ndat_in, sfactor, *carry_count, carry_dev, *nout, rem);
+                     out_dev, out_chan_stride, out_pol_stride, npol, ndim, ndat_in, sfactor, *carry_count, carry_dev, *nout, rem);
   *carry_count = rem;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_tscrunch_fpt: %s", hipGetErrorString(e));

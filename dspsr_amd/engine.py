@@ -344,15 +344,16 @@ def sigproc_digitize_fpt(ctx: Context, inp, out, nbit=8, use_digi_scales=True, i
     return out
 
 
-def tscrunch_fpt(ctx: Context, inp, out, sfactor, carry, carry_count=0):
-    """dsp::TScrunch::fpt_tscrunch on device rows [nchan][npol][ndat] as a stream (carry: device [nchan][npol] floats).
-    Returns (nout, carry_count_after)."""
-    nchan, npol, ndat = inp.shape
+def tscrunch_fpt(ctx: Context, inp, out, sfactor, carry, carry_count=0, ndim=1):
+    """dsp::TScrunch::fpt_tscrunch on device rows [nchan][npol][ndat * ndim] as a stream (carry: device [nchan][npol][ndim]
+    floats).  Returns (nout, carry_count_after)."""
+    nchan, npol, nfloat = inp.shape
     ics, ips = _strides3(inp)
     ocs, ops = _strides3(out)
     cc, nout = C.c_uint32(carry_count), C.c_uint64(0)
-    _check(ctx.handle, lib.dspsr_amd_tscrunch_fpt(ctx.handle, inp.data_ptr(), ics, ips, out.data_ptr(), ocs, ops, nchan, npol, ndat, sfactor,
-                                                  carry.data_ptr(), C.byref(cc), C.byref(nout)), "dspsr_amd_tscrunch_fpt")
+    _check(ctx.handle, lib.dspsr_amd_tscrunch_fpt(ctx.handle, inp.data_ptr(), ics, ips, out.data_ptr(), ocs, ops, nchan, npol, ndim,
+                                                  nfloat // ndim, sfactor, carry.data_ptr(), C.byref(cc), C.byref(nout)),
+           "dspsr_amd_tscrunch_fpt")
     return int(nout.value), int(cc.value)
 
 

@@ -52,6 +52,8 @@
 #include "dsp/Convolution.h"        // dsp::Convolution, dsp::Convolution::Engine
 #include "dsp/Detection.h"          // dsp::Detection::Engine
 #include "dsp/Fold.h"               // dsp::Fold::Engine, dsp::PhaseSeries
+#include "dsp/TScrunch.h"           // dsp::TScrunch::Engine
+#include "dsp/FScrunch.h"           // dsp::FScrunch::Engine
 #include "Error.h"
 
 #include "dspsr_amd.h"
@@ -618,6 +620,79 @@ namespace HIP
     uint64_t plan_ndat, plan_idat_start;
     uint32_t* d_hits;                            // zeroed samples: [nchan][nbin] counts on the device
     uint64_t d_hits_size;
+  };
+
+  //! dsp::TScrunch::Engine (Signal/General/dsp/TScrunch.h:61-69; the reference's twin: CUDA::TScrunchEngine, TScrunchCUDA.cu:204-300,
+  //! wired by LoadToFITS.C:435): out[o] = in[o*sfactor] + in[o*sfactor + 1] + ..., added in that order, FPT rows of ndim 1 or 2.
+  //! Out of place like the CUDA engine.  The ndat % sfactor samples the block leaves over are the buffering policy's
+  //! (TScrunch.C:110-111 re-presents them); the engine call covers ndat / sfactor whole output samples.
+  class TScrunchEngine : public dsp::TScrunch::Engine
+  {
+  public:
+    TScrunchEngine (dspsr_amd_ctx* _ctx) : ctx (_ctx), carry (0), carry_floats (0) { }
+    ~TScrunchEngine () { if (carry) dspsr_amd_free (ctx, carry); }
+
+    void fpt_tscrunch (const dsp::TimeSeries* in, dsp::TimeSeries* out, unsigned sfactor)
+    {
+      if (in->get_ndim () != out->get_ndim ())
+        throw Error (InvalidParam, "HIP::TScrunchEngine::fpt_tscrunch", "cannot handle input ndim=%u != output ndim=%u",
+                     in->get_ndim (), out->get_ndim ());
+      if (out == in)
+        throw Error (InvalidParam, "HIP::TScrunchEngine::fpt_tscrunch", "only out-of-place transformation implemented");
+      if (in->get_ndat () == 0)
+        return;
+      const unsigned nchan = in->get_nchan (), npol = in->get_npol (), ndim = in->get_ndim ();
+      // (the C-ABI treats the rows as a stream; here every call starts a fresh one: nothing carried in, the left-over partial sums
+      //  land in a scratch of [nchan][npol][ndim] floats and are dropped)
+      const uint64_t need = uint64_t (nchan) * npol * ndim;
+      if (need > carry_floats)
+      {
+        if (carry) dspsr_amd_free (ctx, carry);
+        void* p = 0;
+        check (ctx, dspsr_amd_malloc (ctx, need * sizeof (float), &p), "HIP::TScrunchEngine::fpt_tscrunch");
+        carry = (float*) p; carry_floats = need;
+      }
+      const float* ibase = in->get_datptr (0, 0);
+      float* obase = out->get_datptr (0, 0);
+      uint32_t count = 0;
+      uint64_t nout = 0;
+      check (ctx, dspsr_amd_tscrunch_fpt (ctx, ibase, nchan > 1 ? in->get_datptr (1, 0) - ibase : 0, npol > 1 ? in->get_datptr (0, 1) - ibase : 0,
+                                          obase, nchan > 1 ? out->get_datptr (1, 0) - obase : 0, npol > 1 ? out->get_datptr (0, 1) - obase : 0,
+                                          nchan, npol, ndim, in->get_ndat (), sfactor, carry, &count, &nout),
+             "HIP::TScrunchEngine::fpt_tscrunch");
+    }
+
+  protected:
+    dspsr_amd_ctx* ctx;
+    float* carry;
+    uint64_t carry_floats;
+  };
+
+  //! dsp::FScrunch::Engine (Signal/General/dsp/FScrunch.h:56-64; CUDA::FScrunchEngine, FScrunchCUDA.cu:50-90): output channel c =
+  //! input channels c*sfactor ... (c+1)*sfactor - 1 added in order, any ndim (the CUDA engine takes ndim 2 only), out of place
+  class FScrunchEngine : public dsp::FScrunch::Engine
+  {
+  public:
+    FScrunchEngine (dspsr_amd_ctx* _ctx) : ctx (_ctx) { }
+
+    void fpt_fscrunch (const dsp::TimeSeries* in, dsp::TimeSeries* out, unsigned sfactor)
+    {
+      if (out == in)
+        throw Error (InvalidParam, "HIP::FScrunchEngine::fpt_fscrunch", "only out-of-place transformation implemented");
+      if (in->get_ndat () == 0)
+        return;
+      const unsigned nchan = in->get_nchan (), npol = in->get_npol ();
+      const float* ibase = in->get_datptr (0, 0);
+      float* obase = out->get_datptr (0, 0);
+      check (ctx, dspsr_amd_fscrunch_fpt (ctx, ibase, nchan > 1 ? in->get_datptr (1, 0) - ibase : 0, npol > 1 ? in->get_datptr (0, 1) - ibase : 0,
+                                          obase, nchan / sfactor > 1 ? out->get_datptr (1, 0) - obase : 0,
+                                          npol > 1 ? out->get_datptr (0, 1) - obase : 0, nchan, npol,
+                                          in->get_ndat () * uint64_t (in->get_ndim ()), sfactor),
+             "HIP::FScrunchEngine::fpt_fscrunch");
+    }
+
+  protected:
+    dspsr_amd_ctx* ctx;
   };
 }
 

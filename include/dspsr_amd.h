@@ -213,13 +213,16 @@ int dspsr_amd_filterbank_perform_search(dspsr_amd_filterbank* fb, const float* i
                                         uint64_t* nout);
 /* 1: dspsr_amd_filterbank_perform_search runs inside the inverse pass for this object; 0: through the internal detected block */
 int dspsr_amd_filterbank_search_is_fused(const dspsr_amd_filterbank* fb);
-/* dsp::TScrunch::fpt_tscrunch (TScrunch.C:148-178) on device rows [nchan][npol] of ndat_in floats (ndim 1), as a stream:
+/* dsp::TScrunch::fpt_tscrunch (TScrunch.C:148-178; TScrunch::Engine::fpt_tscrunch, dsp/TScrunch.h:61-69, CUDA twin TScrunchCUDA.cu:
+ * 204-300: ndim 1 or 2) on device rows [nchan][npol] of ndat_in samples of ndim floats each, every dimension on its own, as a stream:
  * carry / carry_count / nout as above.  Out of place only (digifil scrunches in place on the host, LoadToFil.C:296-304: here every
  * output sample has its own thread). */
 int dspsr_amd_tscrunch_fpt(dspsr_amd_ctx* ctx, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
                            float* out_dev, uint64_t out_chan_stride, uint64_t out_pol_stride, uint32_t nchan, uint32_t npol,
-                           uint64_t ndat_in, uint32_t sfactor, float* carry_dev, uint32_t* carry_count, uint64_t* nout);
-/* dsp::FScrunch::fpt_fscrunch (FScrunch.C:117-145): out row (c, p) = in row (c*sfactor, p); += rows c*sfactor + 1 ... in order.
+                           uint32_t ndim, uint64_t ndat_in, uint32_t sfactor, float* carry_dev /* [nchan][npol][ndim] */,
+                           uint32_t* carry_count, uint64_t* nout);
+/* dsp::FScrunch::fpt_fscrunch (FScrunch.C:117-145; FScrunch::Engine::fpt_fscrunch, dsp/FScrunch.h:56-64, CUDA twin FScrunchCUDA.cu:
+ * 50-90): out row (c, p) = in row (c*sfactor, p); += rows c*sfactor + 1 ... in order.
  * nchan_in must be a multiple of sfactor; out of place only. */
 int dspsr_amd_fscrunch_fpt(dspsr_amd_ctx* ctx, const float* in_dev, uint64_t in_chan_stride, uint64_t in_pol_stride,
                            float* out_dev, uint64_t out_chan_stride, uint64_t out_pol_stride, uint32_t nchan_in, uint32_t npol,

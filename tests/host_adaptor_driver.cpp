@@ -431,6 +431,45 @@ int main ()
     d2h (ctx, out2_h, out2_d);
     for (unsigned c = 0; c < C; c++) for (unsigned p = 0; p < 2; p++) for (unsigned k = 0; k < 40; k++)
       REQUIRE (out2_h.get_datptr (c, p)[k] == det_h.get_datptr (c, p)[10 + k], "copy_data_fpt %u %u %u", c, p, k);
+
+    // ---------------------------------------------------------------- TScrunch::Engine / FScrunch::Engine (digifil, LoadToFITS.C:435)
+    {
+      const unsigned nch = 12, npl = 2, nd = 1003, sf = 7, fsf = 3;
+      for (unsigned ndim = 1; ndim <= 2; ndim++)
+      {
+        dsp::TimeSeries x_h, x_d, t_h, t_d, f_h, f_d;
+        x_h.set_nchan (nch); x_h.set_npol (npl); x_h.set_ndim (ndim); x_h.resize (nd);
+        for (unsigned c = 0; c < nch; c++) for (unsigned p = 0; p < npl; p++) for (unsigned k = 0; k < nd * ndim; k++)
+          x_h.get_datptr (c, p)[k] = rnd () * rnd ();
+        x_d.set_memory (dmem); x_d.internal_match (&x_h); h2d (ctx, x_d, x_h);
+        t_h.set_nchan (nch); t_h.set_npol (npl); t_h.set_ndim (ndim); t_h.resize (nd / sf);
+        t_d.set_memory (dmem); t_d.internal_match (&t_h);
+        HIP::TScrunchEngine tsc (ctx);
+        tsc.fpt_tscrunch (&x_d, &t_d, sf);
+        d2h (ctx, t_h, t_d);
+        for (unsigned c = 0; c < nch; c++) for (unsigned p = 0; p < npl; p++) for (unsigned o = 0; o < nd / sf; o++) for (unsigned d = 0; d < ndim; d++)
+        {
+          float acc = x_h.get_datptr (c, p)[(o * sf) * ndim + d];                 // TScrunch.C:165-172
+          for (unsigned j = 1; j < sf; j++) acc += x_h.get_datptr (c, p)[(o * sf + j) * ndim + d];
+          REQUIRE (t_h.get_datptr (c, p)[o * ndim + d] == acc, "fpt_tscrunch ndim %u [%u][%u][%u]", ndim, c, p, o);
+        }
+        f_h.set_nchan (nch / fsf); f_h.set_npol (npl); f_h.set_ndim (ndim); f_h.resize (nd);
+        f_d.set_memory (dmem); f_d.internal_match (&f_h);
+        HIP::FScrunchEngine fsc (ctx);
+        fsc.fpt_fscrunch (&x_d, &f_d, fsf);
+        d2h (ctx, f_h, f_d);
+        for (unsigned c = 0; c < nch / fsf; c++) for (unsigned p = 0; p < npl; p++) for (unsigned k = 0; k < nd * ndim; k++)
+        {
+          float acc = x_h.get_datptr (c * fsf, p)[k];                              // FScrunch.C:128-141
+          for (unsigned j = 1; j < fsf; j++) acc += x_h.get_datptr (c * fsf + j, p)[k];
+          REQUIRE (f_h.get_datptr (c, p)[k] == acc, "fpt_fscrunch ndim %u [%u][%u][%u]", ndim, c, p, k);
+        }
+        bool threw = false;
+        try { tsc.fpt_tscrunch (&x_d, &x_d, sf); } catch (Error& e) { threw = true; }
+        REQUIRE (threw, "fpt_tscrunch in place must be refused (as CUDA::TScrunchEngine does)");
+      }
+      printf ("TScrunch / FScrunch engines == CPU loops (ndim 1, 2)\n");
+    }
   }
   catch (Error& error)
   {

@@ -27,6 +27,8 @@ dsp::Filterbank::Engine* d (dspsr_amd_ctx* c) { return new HIP::FilterbankEngine
 dsp::Convolution::Engine* e (dspsr_amd_ctx* c) { return new HIP::ConvolutionEngine (c); }
 dsp::Detection::Engine* f (dspsr_amd_ctx* c) { return new HIP::DetectionEngine (c); }
 dsp::Fold::Engine* g (dspsr_amd_ctx* c) { return new HIP::FoldEngine (c); }
+dsp::TScrunch::Engine* ts (dspsr_amd_ctx* c) { return new HIP::TScrunchEngine (c); }
+dsp::FScrunch::Engine* fs (dspsr_amd_ctx* c) { return new HIP::FScrunchEngine (c); }
 // deferred mode: the adaptors of one pipeline thread share a HIP::Chain; the raw-input hand-over against the REAL dsp::BitSeries
 #include "dsp/BitSeries.h"
 void h (dspsr_amd_ctx* c, const dsp::BitSeries* host, dsp::BitSeries* device)
