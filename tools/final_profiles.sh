@@ -6,7 +6,7 @@ T=$1
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp && cd $R
-for w in target cfg1 cfg1opt cfg2 cfg3 cfg4 cfg5 cfg5c fold; do
+for w in target cfg1 cfg1opt cfg2 cfg3 cfg4 cfg5 cfg5c odd_nchan odd_fres fold; do
   a="--workload $w"; [ $w = target ] && a="--no-companions --no-h2d"
   rm -rf gpurun_out/$T/prof_$w
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/prof_$w -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline $a > gpurun_out/$T/${w}_bench.json 2> gpurun_out/$T/${w}.err || { echo "$w failed"; tail -3 gpurun_out/$T/${w}.err; exit 1; }
@@ -16,7 +16,7 @@ for w in target cfg1 cfg1opt cfg2 cfg3 cfg4 cfg5 cfg5c fold; do
   echo "== $w: $(grep -o '"value": [0-9.]*' gpurun_out/$T/${w}_bench.json | head -1) $(grep -o '"frac": [0-9.]*' gpurun_out/$T/${w}_bench.json | head -1)"
   head -6 gpurun_out/$T/${w}_kernel_stats.txt
 done
-for w in target cfg1 cfg1opt cfg2 cfg3 cfg4 cfg5 cfg5c fold; do
+for w in target cfg1 cfg1opt cfg2 cfg3 cfg4 cfg5 cfg5c odd_nchan odd_fres fold; do
   bash tools/pmc_traffic.sh $T $w > gpurun_out/$T/pmc_$w.txt 2>&1 || { echo "pmc $w failed"; tail -3 gpurun_out/$T/pmc_$w.txt; exit 1; }
   head -1 gpurun_out/$T/pmc_$w.txt | cut -c1-400
   rm -rf gpurun_out/$T/pmc_${w}_*_SIZE
