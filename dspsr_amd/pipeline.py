@@ -1101,7 +1101,8 @@ class SearchConfig:
     dispersion_measure: float = 0.0   # -D  (with -F N:D: coherent dedispersion inside the filterbank)
     freq_res: int = 0                 # -x  (0 => optimal, as dsp::Dedispersion chooses)
     fscrunch: int = 0                 # -f
-    npol: int = 1                     # -d  output polarisations: 1 Intensity, 2 PPQQ (LoadToFil.C:262-269)
+    npol: int = 1                     # -d  output polarisations: 1 Intensity, 2 PPQQ, 4 Coherence (LoadToFil.C:262-277)
+    dedisperse: bool = False          # -K  remove the inter-channel dispersion delays (dsp::SampleDelay, LoadToFil.C:236-247)
     max_parts: int = 32               # parts per launch group
     fused: bool = True                # detection + time scrunch inside the inverse pass where the geometry allows it
 
@@ -1245,24 +1246,31 @@ class LoadToFilCoherent:
         import torch
         self.torch = torch
         self.cfg, self.info = cfg, info
-        if cfg.npol not in (1, 2):
-            raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: npol=%d (Intensity 1 / PPQQ 2 are built)" % cfg.npol)
-        if cfg.npol == 2 and info.npol != 2:
-            raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: PPQQ needs two input polarisations")
+        if cfg.npol not in (1, 2, 4):
+            raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: npol=%d (Intensity 1 / PPQQ 2 / Coherence 4 are built; NthPower 3 is not)" % cfg.npol)
+        if cfg.npol >= 2 and info.npol != 2:
+            raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: PPQQ / Coherence need two input polarisations")
         if cfg.nchan % info.nchan:
             raise DspsrAmdError("dsp::Filterbank::make_preparations output nchan=%d not a multiple of input nchan=%d" % (cfg.nchan, info.nchan))
-        if cfg.dispersion_measure == 0.0:
-            raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: -F N:D with a dispersion measure (without one digifil takes the "
-                                "TFPFilterbank: dspsr_amd.LoadToFil)")
+        if cfg.dispersion_measure == 0.0 and not cfg.freq_res:
+            raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: -F N:D with a dispersion measure, or -F N -x M (with neither digifil "
+                                "takes the TFPFilterbank: dspsr_amd.LoadToFil)")
         self.ctx = Context(device, stream)
-        r = Dedispersion(info.centre_frequency, info.bandwidth, cfg.dispersion_measure, input_nchan=info.nchan, ndim=info.ndim)
-        if cfg.freq_res:
-            r.set_frequency_resolution(cfg.freq_res)                                   # LoadToFil.C:190-191
-        r.match(cfg.nchan)
-        self.response = r
         nsub = cfg.nchan // info.nchan
+        if cfg.dispersion_measure != 0.0:
+            r = Dedispersion(info.centre_frequency, info.bandwidth, cfg.dispersion_measure, input_nchan=info.nchan, ndim=info.ndim)
+            if cfg.freq_res:
+                r.set_frequency_resolution(cfg.freq_res)                               # LoadToFil.C:190-191
+            r.match(cfg.nchan)
+            kernel = r.kernel
+        else:
+            # -F N -x M without :D (LoadToFil.C:199-216): the convolving filterbank with no response -- nothing is discarded
+            # (Filterbank.C:139-155: freq_res as set, nfilt 0)
+            from types import SimpleNamespace
+            r, kernel = SimpleNamespace(ndat=cfg.freq_res, impulse_pos=0, impulse_neg=0, kernel=None), None
+        self.response = r
         self.fb = FilterbankEngine(self.ctx).setup(nsub, r.ndat, r.impulse_pos, r.impulse_neg, info.nchan, info.npol, info.ndim == 1,
-                                                   r.kernel, max_parts=cfg.max_parts)
+                                                   kernel, max_parts=cfg.max_parts)
         self.nkeep, self.nsamp_step, self.nsamp_overlap = self.fb.nkeep, self.fb.nsamp_step, self.fb.nsamp_overlap
         n_fft = nsub * r.ndat
         nsamp_fft = 2 * n_fft if info.ndim == 1 else n_fft
@@ -1272,21 +1280,39 @@ class LoadToFilCoherent:
         self.out_start = info.start_seconds + r.impulse_pos / self.fb_rate
         self.scale8 = eight_bit_scale()
         self.layout = _lib.RAW_CASPSR if info.machine == "CASPSR" else _lib.RAW_GENERIC
-        self.state = _lib.PPQQ if cfg.npol == 2 else _lib.INTENSITY
+        self.state = {1: _lib.INTENSITY, 2: _lib.PPQQ, 4: _lib.COHERENCE}[cfg.npol]
         self.nchan_out = cfg.nchan // cfg.fscrunch if cfg.fscrunch else cfg.nchan
         if cfg.fscrunch and cfg.nchan % cfg.fscrunch:
             raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: nchan=%d is not a multiple of fscrunch=%d" % (cfg.nchan, cfg.fscrunch))
         dev = "cuda:%d" % device
         nmax = (ts - 1 + cfg.parts_per_block * self.nkeep) // ts
-        # FScrunch sits between Detection and TScrunch (LoadToFil.C:286-304): the fused launch group cannot hold it, so with -f the
-        # three operations run one after the other (perform_search at tscrunch 1 = filterbank + detection)
-        self.fused = cfg.fused and not cfg.fscrunch
+        # -K: dsp::SampleDelay sits between the filterbank and Detection (LoadToFil.C:236-247).  Detection acts sample by sample,
+        # so delaying the detected rows gives the reference's numbers; the last total_delay samples of a block are re-presented in
+        # front of the next one (InputBuffering, SampleDelay.C:117,146): they live in the head room in front of `detected`.
+        self.sample_delay, self.sd_carried, head = None, 0, 0
+        if cfg.dedisperse:
+            dual = info.ndim == 2                              # Observation.C:80-87; Filterbank.C:358-364
+            delays = dedispersion_sample_delays(info.centre_frequency, info.bandwidth, cfg.dispersion_measure, cfg.nchan,
+                                                self.fb_rate, swap=dual and info.nchan == 1,
+                                                nsub_swap=info.nchan if dual and info.nchan > 1 else 0)
+            self.sample_delay = SampleDelay(self.ctx, delays, cfg.npol)
+            head = self.sample_delay.total_delay
+            if head > cfg.parts_per_block * self.nkeep:
+                raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: inter-channel delay of %d samples exceeds the block of %d"
+                                    % (head, cfg.parts_per_block * self.nkeep))
+            self.out_start += self.sample_delay.zero_delay / self.fb_rate               # SampleDelay.C:159
+        self.sd_head = head
+        # FScrunch sits between Detection and TScrunch (LoadToFil.C:286-304) and SampleDelay in front of Detection: the fused launch
+        # group holds neither, nor the four Coherence products, so with -f, -K or -d 4 the operations run one after the other
+        # (perform_search at tscrunch 1 = filterbank + detection; Coherence: perform_detect with ndim 1)
+        self.fused = cfg.fused and not cfg.fscrunch and not cfg.dedisperse and cfg.npol != 4
+        nmax = (ts - 1 + head + cfg.parts_per_block * self.nkeep) // ts
         self.scrunched = torch.empty((self.nchan_out, cfg.npol, max(1, nmax)), dtype=torch.float32, device=dev)
         self.carry = torch.zeros((self.nchan_out, cfg.npol), dtype=torch.float32, device=dev)
         self.carry_count = 0
         self.detected = None
         if not self.fused:
-            nd = cfg.parts_per_block * self.nkeep
+            nd = head + cfg.parts_per_block * self.nkeep
             self.detected = torch.empty((cfg.nchan, cfg.npol, nd), dtype=torch.float32, device=dev)
             self.det_carry = torch.zeros((cfg.nchan, cfg.npol), dtype=torch.float32, device=dev)
             self.fscr = torch.empty((self.nchan_out, cfg.npol, nd), dtype=torch.float32, device=dev) if cfg.fscrunch else None
@@ -1322,12 +1348,28 @@ class LoadToFilCoherent:
             nout, self.carry_count = self.fb.perform_search(self.scrunched, self.carry, self.carry_count, npart, ts, self.state, raw=raw,
                                                             layout=self.layout, scale=self.scale8)
             return self.scrunched[:, :, :nout]
-        nd = npart * self.nkeep
-        det = self.detected[:, :, :nd]
-        self.fb.perform_search(det, self.det_carry, 0, npart, 1, self.state, raw=raw, layout=self.layout, scale=self.scale8)
-        if cfg.fscrunch:
-            det = fscrunch_fpt(self.ctx, det, self.fscr[:, :, :nd], cfg.fscrunch)
-        nout, self.carry_count = tscrunch_fpt(self.ctx, det, self.scrunched, ts, self.carry, self.carry_count)
+        nd, head = npart * self.nkeep, self.sd_head
+        det = self.detected[:, :, head:head + nd]
+        if cfg.npol == 4:
+            self.fb.perform_detect(det, npart, self.state, 1, raw=raw, layout=self.layout, scale=self.scale8)
+        else:
+            self.fb.perform_search(det, self.det_carry, 0, npart, 1, self.state, raw=raw, layout=self.layout, scale=self.scale8)
+        rows = carry = None
+        if self.sample_delay is not None:
+            off, nin = head - self.sd_carried, self.sd_carried + nd
+            rows = self.detected[:, :, off:off + nin]
+            nd = self.sample_delay.transform(rows)                                   # in place (LoadToFil.C:240-241)
+            carry = nin - nd                 # InputBuffering::set_next_start: the unshifted tail goes in front of the next block
+            det = rows[:, :, :nd]
+        nout = 0
+        if nd:
+            if cfg.fscrunch:
+                det = fscrunch_fpt(self.ctx, det, self.fscr[:, :, :nd], cfg.fscrunch)
+            nout, self.carry_count = tscrunch_fpt(self.ctx, det, self.scrunched, ts, self.carry, self.carry_count)
+        if rows is not None:
+            if carry:
+                copy_data_fpt(self.ctx, self.detected[:, :, head - carry:head], rows[:, :, nd:])
+            self.sd_carried = carry
         return self.scrunched[:, :, :nout]
 
     def process_block(self, raw, npart=None):

@@ -669,21 +669,34 @@ def sigproc_digitize_fpt(x: np.ndarray, nbit: int, **kw) -> np.ndarray:
 
 
 class DigifilCoherent:
-    """digifil with a convolving filterbank, `digifil -F N:D [-x M] -t T -b nbit` (Signal/General/LoadToFil.C:185-222,250-362),
-    on the OUTPUT of the filterbank: Detection::square_law (Intensity, npol 1; PPQQ, npol 2) -> [FScrunch] -> TScrunch (FPT,
-    left-over samples buffered) -> Rescale (FPT: the same statistics per (chan, pol) as TFP) -> SigProcDigitizer (FPT branch).
+    """digifil with a convolving filterbank, `digifil -F N:D [-x M] [-K] -t T -b nbit` (Signal/General/LoadToFil.C:185-222,234-362),
+    on the OUTPUT of the filterbank: [SampleDelay, -K, :236-247: in place on the complex rows, the unshifted tail buffered for the
+    next block] -> Detection (:250-279: Intensity, npol 1; PPQQ, npol 2; Coherence with ndim 1, npol 4) -> [FScrunch] -> TScrunch
+    (FPT, left-over samples buffered) -> Rescale (FPT: the same statistics per (chan, pol) as TFP) -> SigProcDigitizer (FPT branch).
     Feed it the complex filterbank rows [nchan][npol][ndat] block by block; it returns the packed bytes of each block."""
 
     def __init__(self, tscrunch: int = 1, fscrunch: int = 0, nbit: int = 8, npol_out: int = 1, rescale_interval: int = 0,
-                 rescale_constant: bool = False, rescale: bool = True, scale_fac: float = 1.0, flip_band: bool = False):
+                 rescale_constant: bool = False, rescale: bool = True, scale_fac: float = 1.0, flip_band: bool = False,
+                 delays=None, input_scale: float = 1.0):
         self.tscrunch, self.fscrunch, self.nbit, self.npol_out = tscrunch, fscrunch, nbit, npol_out
         self.scale_fac, self.flip_band = scale_fac, flip_band
         self.rescale = Rescale(rescale_interval, rescale_constant) if rescale else None
         self.left = None                                          # TScrunch input buffering: samples not yet scrunched
-        self.input_scale = 1.0                                    # (Filterbank scale; Rescale resets it to 1, Rescale.C:204)
+        self.input_scale = input_scale                            # (Filterbank scale x scrunch factors; Rescale resets it to 1, Rescale.C:204)
+        self.delays = None if delays is None else np.asarray(delays, np.int64)
+        self.sd_left = None                                       # SampleDelay input buffering: the last total_delay samples
 
     def detect_scrunch(self, fb: np.ndarray) -> np.ndarray:
-        det = square_law(fb, "Intensity" if self.npol_out == 1 else "PPQQ")           # LoadToFil.C:250-279
+        if self.delays is not None:                                                     # LoadToFil.C:236-247
+            if self.sd_left is not None:
+                fb = np.concatenate([self.sd_left, fb], axis=2)
+            out, _zero, total = sample_delay(fb, self.delays)
+            self.sd_left = fb[:, :, out.shape[2]:].copy() if total else None            # InputBuffering: SampleDelay.C:117,146
+            fb = out
+        if self.npol_out == 4:                                                          # :273-277 (ndim stays 1)
+            det = np.ascontiguousarray(detect_layout(detect_products(fb, "Coherence"), 1))
+        else:
+            det = square_law(fb, "Intensity" if self.npol_out == 1 else "PPQQ")       # :262-269
         if self.fscrunch:                                                               # :286-294
             det = fscrunch_fpt(det, self.fscrunch)
         if self.tscrunch and self.tscrunch > 1:                                         # :296-304
