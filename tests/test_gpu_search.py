@@ -152,6 +152,45 @@ def test_perform_search_equals_detection_and_tscrunch_of_the_filterbank_output(o
     fb.close()
 
 
+@pytest.mark.parametrize("npol,input_nchan,nchan,freq_res,dm", [
+    (1, 1, 64, 512, 20.0),            # one polarisation: Intensity = Re^2 + Im^2 of it (Detection.C:218-320 with npol 1)
+    (2, 4, 64, 512, 20.0),            # four input channels (a filterbank of 16 channels on each)
+    (1, 2, 32, 1024, 20.0),
+])
+def test_perform_search_single_pol_and_multi_channel_input(oracle, gpu, npol, input_nchan, nchan, freq_res, dm):
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(49)
+    r = dspsr_amd.Dedispersion(1382.0, -50.0, dm, input_nchan=input_nchan, ndim=2)
+    r.set_frequency_resolution(freq_res)
+    r.match(nchan)
+    fb = dspsr_amd.FilterbankEngine(ctx).setup(nchan // input_nchan, r.ndat, r.impulse_pos, r.impulse_neg, input_nchan, npol, False, r.kernel,
+                                               max_parts=4)
+    sf = 16
+    for state_name in (["Intensity", "PPQQ"] if npol == 2 else ["Intensity"]):
+        npo = 1 if state_name == "Intensity" else 2
+        state = dspsr_amd.INTENSITY if npo == 1 else dspsr_amd.PPQQ
+        carry = torch.zeros((nchan, npo), dtype=torch.float32, device="cuda")
+        cc, got, dets = 0, [], []
+        for npart in (5, 3):
+            nsamp = npart * fb.nsamp_step + fb.nsamp_overlap
+            raw = torch.from_numpy(np.clip(np.rint(rng.standard_normal(nsamp * input_nchan * npol * 2) * 24.0), -128, 127).astype(np.int8)).cuda()
+            cplx = torch.zeros((nchan, npol, 2 * npart * fb.nkeep), dtype=torch.float32, device="cuda")
+            fb.perform_raw(raw, dspsr_amd.RAW_GENERIC, 0.0123, cplx, npart)
+            c = cplx.cpu().numpy().view(np.complex64)
+            if npol == 1:
+                dets.append((c.real * c.real + c.imag * c.imag).astype(np.float32))
+            else:
+                dets.append(oracle.square_law(c, state_name))
+            out = torch.full((nchan, npo, (cc + npart * fb.nkeep) // sf + 1), -1.0, dtype=torch.float32, device="cuda")
+            nout, cc = fb.perform_search(out, carry, cc, npart, sf, state, raw=raw, layout=dspsr_amd.RAW_GENERIC, scale=0.0123)
+            got.append(out[:, :, :nout].cpu().numpy())
+        want = oracle.tscrunch_fpt(np.concatenate(dets, axis=2), sf)
+        got = np.concatenate(got, axis=2)
+        assert got.shape == want.shape and want.shape[2] > 0
+        assert np.array_equal(got, want), (state_name, np.abs(got - want).max())
+    fb.close()
+
+
 def test_perform_search_two_pass_geometry(oracle, gpu):
     """The two-pass path of short responses (complex dual-pol 8-bit input, -F 512:D -x 512 on a 50 MHz band: k_rows_inv with the search
     epilogue) == the three-pass kernels' complex output, detected and scrunched by the oracle."""
