@@ -212,8 +212,9 @@ __global__ __launch_bounds__(256) void k_digitize_fpt(const float* __restrict__ 
 {
   __shared__ float tile[64][65];
   const uint32_t k0 = blockIdx.x * 64, ipol = blockIdx.z;
-  const uint64_t t0 = (uint64_t)blockIdx.y * 64;
   const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // read: tx = time, ty + 4 j = channel of the tile
+  // (time tiles beyond the grid's y limit: the block walks on; the trip count is the same for every thread of a block)
+  for (uint64_t t0 = (uint64_t)blockIdx.y * 64; t0 < ndat; t0 += (uint64_t)gridDim.y * 64) {
   for (uint32_t j = 0; j < 16; j++) {
     const uint32_t k = k0 + ty + 4 * j;
     float v = 0.f;
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(256) void k_digitize_fpt(const float* __restrict__ 
       const uint32_t tt = ty + 4 * j, k = k0 + tx;
       if (k < nchan && t0 + tt < ndat) ((float*)out)[(t0 + tt) * nchan * npol + (uint64_t)ipol * nchan + k] = __fdiv_rn(tile[tx][tt], fscale);
     }
-    return;
+    __syncthreads();
+    continue;
   }
   const uint32_t spb = nbit >= 8 ? 1 : 8 / nbit, units = 64 / spb;  // bytes (16-bit: samples) of the tile per time sample
   for (uint32_t u = threadIdx.x; u < 64 * units; u += 256) {
@@ -252,6 +254,8 @@ __global__ __launch_bounds__(256) void k_digitize_fpt(const float* __restrict__ 
     const uint64_t oidx = ((t0 + tt) * nchan * npol + (uint64_t)ipol * nchan + k) / spb;
     if (nbit == 16) ((uint16_t*)out)[oidx] = (uint16_t)byte;
     else out[oidx] = (uint8_t)byte;
+  }
+  __syncthreads();                                                   // the tile is free for the next time slice
   }
 }
 
@@ -537,7 +541,8 @@ static hipError_t launch_digitize_fpt(dspsr_amd_ctx* ctx, bool resc, const float
                                       uint32_t nchan, uint32_t npol, int nbit, const float* offset, const float* scale, const DigiParams& d,
                                       float fscale, int flip_band, int swap_band)
 {
-  const dim3 grid((nchan + 63) / 64, (uint32_t)((ndat + 63) / 64), npol);
+  const uint64_t ty = (ndat + 63) / 64;
+  const dim3 grid((nchan + 63) / 64, (uint32_t)(ty > 65535 ? 65535 : ty), npol);
   if (resc) hipLaunchKernelGGL(k_digitize_fpt<true>, grid, dim3(256), 0, ctx->stream, in, ics, ips, out, ndat, nchan, npol, nbit, offset, scale,
                                d.scale, d.mean, d.xpol_offset, d.max, fscale, flip_band, swap_band);
   else hipLaunchKernelGGL(k_digitize_fpt<false>, grid, dim3(256), 0, ctx->stream, in, ics, ips, out, ndat, nchan, npol, nbit, offset, scale,
@@ -566,9 +571,7 @@ static int digitize_fpt_check(dspsr_amd_ctx* ctx, const char* who, uint32_t ncha
     return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dsp::SigProcDigitizer::set_nbit nbit=%i not understood", nbit);
   if (nbit > 0 && nbit < 8 && nchan % (8 / nbit))
     return ctx_fail(ctx, DSPSR_AMD_EINVAL, "%s: nchan=%u not a multiple of %d samples per byte", who, nchan, 8 / nbit);
-  if ((ndat + 63) / 64 > 65535 || npol > 65535)
-    return ctx_fail(ctx, DSPSR_AMD_EINVAL, "%s: ndat=%llu / npol=%u exceed the grid limits (digitise the block in pieces)", who,
-                    (unsigned long long)ndat, npol);
+  if (npol > 65535) return ctx_fail(ctx, DSPSR_AMD_EINVAL, "%s: npol=%u exceeds the grid limit", who, npol);
   return DSPSR_AMD_OK;
 }
 

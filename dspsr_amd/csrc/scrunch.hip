@@ -8,16 +8,17 @@
 namespace dspsr_amd {
 
 // One thread per output sample; the rows are a STREAM (see dspsr_amd.h): the first c0 samples of output 0 are already in `carry`,
-// the samples behind the last complete output go to `carry`.  blockIdx.y = row (chan * npol + pol).
+// the samples behind the last complete output go to `carry`.  blockIdx.y (+ k gridDim.y) = row (chan * npol + pol).
 __global__ __launch_bounds__(256) void k_tscrunch_fpt(const float* __restrict__ in, const uint64_t ics, const uint64_t ips,
                                                       float* __restrict__ out, const uint64_t ocs, const uint64_t ops, const uint32_t npol,
                                                       const uint32_t ndim, const uint64_t ndat_in, const uint32_t sf, const uint32_t c0,
-                                                      float* __restrict__ carry, const uint64_t nout, const uint32_t rem)
+                                                      float* __restrict__ carry, const uint64_t nout, const uint32_t rem, const uint32_t nrow)
 {
-  const uint32_t chan = blockIdx.y / npol, pol = blockIdx.y % npol;
+  const uint64_t ngroup = nout + (rem ? 1 : 0);
+  for (uint32_t row = blockIdx.y; row < nrow; row += gridDim.y) {
+  const uint32_t chan = row / npol, pol = row % npol;
   const float* __restrict__ x = in + chan * ics + pol * ips;
   float* __restrict__ y = out + chan * ocs + pol * ops;
-  const uint64_t ngroup = nout + (rem ? 1 : 0);
   // one thread per (output sample, dimension): consecutive threads = the dimensions of a sample, then the next sample
   for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < ngroup * ndim; w += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t o = w / ndim;
@@ -27,25 +28,28 @@ __global__ __launch_bounds__(256) void k_tscrunch_fpt(const float* __restrict__ 
     uint64_t i = s0 < c0 ? 0 : s0 - c0;
     const uint64_t i1 = s1 - c0;
     float acc;
-    if (o == 0 && c0) acc = carry[blockIdx.y * ndim + d];
+    if (o == 0 && c0) acc = carry[(uint64_t)row * ndim + d];
     else { acc = x[i * ndim + d]; i++; }
     for (; i < i1; i++) acc = __fadd_rn(acc, x[i * ndim + d]);
     if (o < nout) y[o * ndim + d] = acc;
-    else carry[blockIdx.y * ndim + d] = acc;
+    else carry[(uint64_t)row * ndim + d] = acc;
+  }
   }
 }
 
 __global__ __launch_bounds__(256) void k_fscrunch_fpt(const float* __restrict__ in, const uint64_t ics, const uint64_t ips,
                                                       float* __restrict__ out, const uint64_t ocs, const uint64_t ops, const uint32_t npol,
-                                                      const uint64_t nfloat, const uint32_t sf)
+                                                      const uint64_t nfloat, const uint32_t sf, const uint32_t nrow)
 {
-  const uint32_t chan = blockIdx.y / npol, pol = blockIdx.y % npol;
-  const float* __restrict__ x = in + (uint64_t)chan * sf * ics + pol * ips;
-  float* __restrict__ y = out + chan * ocs + pol * ops;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nfloat; i += (uint64_t)gridDim.x * blockDim.x) {
-    float acc = x[i];
-    for (uint32_t f = 1; f < sf; f++) acc = __fadd_rn(acc, x[f * ics + i]);
-    y[i] = acc;
+  for (uint32_t row = blockIdx.y; row < nrow; row += gridDim.y) {
+    const uint32_t chan = row / npol, pol = row % npol;
+    const float* __restrict__ x = in + (uint64_t)chan * sf * ics + pol * ips;
+    float* __restrict__ y = out + chan * ocs + pol * ops;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nfloat; i += (uint64_t)gridDim.x * blockDim.x) {
+      float acc = x[i];
+      for (uint32_t f = 1; f < sf; f++) acc = __fadd_rn(acc, x[f * ics + i]);
+      y[i] = acc;
+    }
   }
 }
 
@@ -69,13 +73,13 @@ extern "C" int dspsr_amd_tscrunch_fpt(dspsr_amd_ctx* ctx, const float* in_dev, u
   if (in_dev == out_dev)
     return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_tscrunch_fpt: in place is not supported on the device (use a second block)");
   const uint64_t rows = (uint64_t)nchan * npol;
-  if (rows > 65535) return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_tscrunch_fpt: nchan*npol=%llu exceeds the grid limit", (unsigned long long)rows);
+  if (rows > 0xffffffffull) return DSPSR_AMD_EINVAL;
   const uint64_t ngroup = *nout + (rem ? 1 : 0);
   uint64_t bx = (ngroup * ndim + 255) / 256;
   if (bx > 1024) bx = 1024;
   if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(k_tscrunch_fpt, dim3((uint32_t)bx, (uint32_t)rows), dim3(256), 0, ctx->stream, in_dev, in_chan_stride, in_pol_stride,
-                     out_dev, out_chan_stride, out_pol_stride, npol, ndim, ndat_in, sfactor, *carry_count, carry_dev, *nout, rem);
+  hipLaunchKernelGGL(k_tscrunch_fpt, dim3((uint32_t)bx, (uint32_t)(rows > 65535 ? 65535 : rows)), dim3(256), 0, ctx->stream, in_dev, in_chan_stride,
+                     in_pol_stride, out_dev, out_chan_stride, out_pol_stride, npol, ndim, ndat_in, sfactor, *carry_count, carry_dev, *nout, rem, (uint32_t)rows);
   *carry_count = rem;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_tscrunch_fpt: %s", hipGetErrorString(e));
@@ -95,11 +99,11 @@ extern "C" int dspsr_amd_fscrunch_fpt(dspsr_amd_ctx* ctx, const float* in_dev, u
   if (in_dev == out_dev)
     return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_fscrunch_fpt: in place is not supported on the device (use a second block)");
   const uint64_t rows = (uint64_t)(nchan_in / sfactor) * npol;
-  if (rows > 65535) return ctx_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_fscrunch_fpt: output rows=%llu exceed the grid limit", (unsigned long long)rows);
+  if (rows > 0xffffffffull) return DSPSR_AMD_EINVAL;
   uint64_t bx = (nfloat + 255) / 256;
   if (bx > 1024) bx = 1024;
-  hipLaunchKernelGGL(k_fscrunch_fpt, dim3((uint32_t)bx, (uint32_t)rows), dim3(256), 0, ctx->stream, in_dev, in_chan_stride, in_pol_stride,
-                     out_dev, out_chan_stride, out_pol_stride, npol, nfloat, sfactor);
+  hipLaunchKernelGGL(k_fscrunch_fpt, dim3((uint32_t)bx, (uint32_t)(rows > 65535 ? 65535 : rows)), dim3(256), 0, ctx->stream, in_dev, in_chan_stride,
+                     in_pol_stride, out_dev, out_chan_stride, out_pol_stride, npol, nfloat, sfactor, (uint32_t)rows);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_fscrunch_fpt: %s", hipGetErrorString(e));
   return DSPSR_AMD_OK;

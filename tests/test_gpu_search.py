@@ -104,6 +104,28 @@ def test_output_stage_fpt_equals_tfp_kernels_and_oracle(oracle, gpu, nbit, nchan
         r.close()
 
 
+def test_fpt_kernels_beyond_the_grid_limits(oracle, gpu):
+    """More rows than gridDim.y holds (70 000 channels through TScrunch / FScrunch) and more time tiles than gridDim.y holds
+    (4.3 M samples through the FPT digitiser): the blocks walk on."""
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(50)
+    x = rng.standard_normal((70000, 1, 40)).astype(np.float32)
+    d_x = torch.from_numpy(x).cuda()
+    out = torch.zeros((70000, 1, 5), dtype=torch.float32, device="cuda")
+    carry = torch.zeros((70000, 1), dtype=torch.float32, device="cuda")
+    nout, cc = dspsr_amd.tscrunch_fpt(ctx, d_x, out, 7, carry, 0)
+    assert (nout, cc) == (5, 5) and np.array_equal(out.cpu().numpy(), oracle.tscrunch_fpt(x, 7))
+    fo = torch.zeros((35000, 1, 40), dtype=torch.float32, device="cuda")
+    dspsr_amd.fscrunch_fpt(ctx, d_x, fo, 2)
+    assert np.array_equal(fo.cpu().numpy(), oracle.fscrunch_fpt(x, 2))
+    nd = 65535 * 64 + 1000
+    y = (rng.standard_normal((2, 1, nd)) * 3.0).astype(np.float32)
+    packed = torch.zeros(nd * 2, dtype=torch.uint8, device="cuda")
+    dspsr_amd.sigproc_digitize_fpt(ctx, torch.from_numpy(y).cuda(), packed, 8, use_digi_scales=True, input_scale=1.0, scale_fac=1.0)
+    want = oracle.sigproc_digitize_fpt(y, 8, use_digi_scales=True, input_scale=1.0, scale_fac=1.0)
+    assert np.array_equal(packed.cpu().numpy().reshape(want.shape), want)
+
+
 def _fb_case(dspsr_amd, ctx, oracle, nchan, freq_res, dm, real, max_parts, input_nchan=1):
     """A filterbank object with the oracle's dedispersion kernel and its block geometry."""
     ndim = 1 if real else 2
