@@ -44,15 +44,19 @@ for i in range(ncases):
     npart = int(rng.integers(1, 4)) if logN <= 19 else int(rng.integers(1, 3))
     if rng.integers(0, 6) == 0 and logN - logM >= 3 and logM <= 13:
         # nchan_subband = 3 * 2^k / 5 * 2^k: interleaved sub-sequences + one radix-3 / radix-5 step (three-pass geometries)
-        R = int(rng.choice([3, 5, 7, 9, 15]))
-        C = R * (C >> (2 if R < 7 else 3 if R < 15 else 4)) if C >= 16 else C
+        R = int(rng.choice([3, 5, 7, 9, 15, 11, 13, 21, 25, 27, 33, 45, 63]))
+        sh = int(np.ceil(np.log2(R)))
+        C = R * (C >> sh) if (C >> sh) >= 1 else C
         kw["four_pass"] = 0
     elif rng.integers(0, 6) == 0 and 3 <= logM <= 15 and logN - logM <= 12:
         # freq_res = 3 * 2^k / 5 * 2^k: pseudo-channels of freq_res / R bins + one radix-R step in time (k_time_combine)
-        R = int(rng.choice([3, 5, 7, 9, 15]))
-        M = R * (M >> (2 if R < 7 else 3))
+        R = int(rng.choice([3, 5, 7, 9, 15, 11, 13, 21, 25, 27, 33, 45, 63]))
+        sh = int(np.ceil(np.log2(R)))
+        M = R * (M >> sh) if (M >> sh) >= 2 else M
         pos, neg = int(rng.integers(0, max(1, M // 3))), int(rng.integers(0, max(1, M // 3)))
         kw["four_pass"] = 0
+        kw["max_parts"] = int(rng.integers(1, 8))                          # (sub-groups of parts q, q + rp, ...)
+        npart = int(rng.integers(1, 8)) if logN <= 17 else npart
     if rng.integers(0, 6) == 0:
         # the two-pass family of short responses (complex dual-pol, nchan_subband * freq_res^2 == 2^27): 8-bit blocks take the
         # two-pass kernels (or, four_pass = 2, the three-pass ones), float32 rows always the three-pass ones
