@@ -188,7 +188,7 @@ struct SubSplit {
 // an argument error below 2e-8 revolutions, so the product is as accurate as the hi / lo split of twiddles_big (2.4e-7; the
 // single-argument form it replaces, (a + b / 2^logP) / R, rounded the whole angle: up to 4e-7, and the time-domain step's
 // t * (1 / freq_res) up to 7.5e-7).
-constexpr uint32_t ODD_MAX = 63;                      // largest odd factor of a transform length
+constexpr uint32_t ODD_MAX = 127;                     // largest odd factor of a transform length
 struct OddTw { float2 w[ODD_MAX + 1]; uint32_t R; };   // w[a] = exp(-2 pi i a / R), a < R
 template <int R> DEV cf twiddle_odd(const uint32_t t, const int logP, const OddTw& tab)
 {

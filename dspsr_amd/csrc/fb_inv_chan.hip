@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_time_combine(const TimeCombine p, const
     for (uint32_t r = 0; r < R; r++) {
       const cf* __restrict__ y = p.Y + (uint64_t)(c * R + r) * p.y_chan_stride + ((uint64_t)lp << p.logMi) + ni;
       cf w = make_float2(1.f, 0.f);
-      if (r) {                                                   // exp(+2 pi i r n / freq_res), freq_res = R M' (r n < 63 * 63 * 2^13)
+      if (r) {                                                   // exp(+2 pi i r n / freq_res), freq_res = R M' (r n < 127 * 127 * 2^13 < 2^32: the run-time form takes 64 bits anyway)
         if constexpr (RT != 0) w = twiddle_odd<RT ? RT : 3>(r * nn, p.logMi, p.tw);
         else w = twiddle_odd_rt((uint64_t)r * nn, p.logMi, p.tw);
         w.y = -w.y;

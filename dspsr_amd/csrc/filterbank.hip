@@ -90,7 +90,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   // tile stay powers of two: bins m = R m' + r of a channel are R pseudo-channels of freq_res / R bins (the inner filterbank of
   // nchan_subband * R channels below, whole transforms kept), whose time series k_time_combine adds with the twiddles
   // exp(+2 pi i r n / freq_res) -- the decimation-in-frequency form of the freq_res-point backward transform.
-  // (odd factors up to ODD_MAX = 63 of either length; both lengths at once as long as the product of the two factors stays within it)
+  // (odd factors up to ODD_MAX = 127 of either length; both lengths at once as long as the product of the two factors stays within it)
   auto odd_part = [](uint32_t v) { while (v && !(v & 1)) v >>= 1; return v; };
   // (any odd factor up to ODD_MAX: 3, 5, 7, 9, 15 have radix kernels of their own, the others -- 11, 13, 21, 25, ... -- the
   //  run-time-radix forms k_sub_combine_any / k_time_combine<0>)
@@ -101,8 +101,8 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     if (!radix_ok(msub) || cfg->nchan_subband == 0 || !(ispow2(cfg->nchan_subband) || radix_ok(odd_part(cfg->nchan_subband) * msub)) ||
         cfg->freq_res / msub < 2 || cfg->force_four_pass == 1)
       return fb_fail(ctx, DSPSR_AMD_EINVAL,
-                     "dspsr_amd_filterbank_create: freq_res=%u must be 2^k >= 2, or 2^k (k >= 1) times an odd number <= 63 (times the odd "
-                     "factor of nchan_subband=%u: again <= 63; freq_res=1 is the non-convolving filterbank, not built yet)",
+                     "dspsr_amd_filterbank_create: freq_res=%u must be 2^k >= 2, or 2^k (k >= 1) times an odd number <= 127 (times the odd "
+                     "factor of nchan_subband=%u: again <= 127; freq_res=1 is the non-convolving filterbank, not built yet)",
                      cfg->freq_res, cfg->nchan_subband);
   } else if (cfg->freq_res < 2)
     return fb_fail(ctx, DSPSR_AMD_EINVAL,
@@ -120,7 +120,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   if (!ispow2(nchan_sb)) {
     nsub = nchan_sb ? odd_part(nchan_sb) : 0;
     if (!radix_ok(nsub))
-      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u must be 2^k or 2^k times an odd number <= 63",
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u must be 2^k or 2^k times an odd number <= 127",
                      cfg->nchan_subband);
     if (cfg->force_four_pass == 1)
       return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nchan_subband=%u (not a power of two) has no four-pass form",

@@ -80,15 +80,15 @@ int dspsr_amd_add_fpt(dspsr_amd_ctx* ctx, float* to_dev, uint64_t to_chan_stride
  *    impulse_pos/neg and copies the host-built, already swapped kernel to the device) */
 typedef struct {
   uint32_t nchan_subband;   /* output channels per input channel          Filterbank.C:68
-                               2^k, or 2^k times an odd R <= 63 (dspsr -F 96:D, -F 400:D, -F 25:D, -F 44:D: the reference plans any
+                               2^k, or 2^k times an odd R <= 127 (dspsr -F 96:D, -F 400:D, -F 1000:D, -F 25:D: the reference plans any
                                length, Filterbank.C:107-155; here the forward transform of R interleaved power-of-two
                                sub-sequences + one radix-R step -- kernels of their own for R = 3, 5, 7, 9, 15, a run-time-radix
                                form for the others; freq_res <= 8192 then) */
   uint32_t freq_res;        /* response ndat = backward FFT length                            Filterbank.C:93
-                               2^k >= 2, or 2^k times an odd R <= 63 (dspsr -x 12288, -x 11264): bins R m' + r of a channel are R
+                               2^k >= 2, or 2^k times an odd R <= 127 (dspsr -x 12288, -x 11264): bins R m' + r of a channel are R
                                pseudo-channels of freq_res / R bins through the power-of-two passes, one radix-R step in time adds
                                their transforms (a pass of its own: fold_is_fused() == 0; freq_res / R <= 8192).  Both lengths may
-                               carry an odd factor when the product of the two stays <= 63 (-F 96:D -x 768) */
+                               carry an odd factor when the product of the two stays <= 127 (-F 96:D -x 768) */
   uint32_t nfilt_pos;       /* response impulse_pos                       Filterbank.C:90  */
   uint32_t nfilt_neg;       /* response impulse_neg                       Filterbank.C:91  */
   uint32_t input_nchan;     /* input channels (kernel has input_nchan*nchan_subband*freq_res bins) */

@@ -44,13 +44,13 @@ for i in range(ncases):
     npart = int(rng.integers(1, 4)) if logN <= 19 else int(rng.integers(1, 3))
     if rng.integers(0, 6) == 0 and logN - logM >= 3 and logM <= 13:
         # nchan_subband = 3 * 2^k / 5 * 2^k: interleaved sub-sequences + one radix-3 / radix-5 step (three-pass geometries)
-        R = int(rng.choice([3, 5, 7, 9, 15, 11, 13, 21, 25, 27, 33, 45, 63]))
+        R = int(rng.choice([3, 5, 7, 9, 15, 11, 13, 21, 25, 27, 33, 45, 63, 75, 99, 125, 127]))
         sh = int(np.ceil(np.log2(R)))
         C = R * (C >> sh) if (C >> sh) >= 1 else C
         kw["four_pass"] = 0
     elif rng.integers(0, 6) == 0 and 3 <= logM <= 15 and logN - logM <= 12:
         # freq_res = 3 * 2^k / 5 * 2^k: pseudo-channels of freq_res / R bins + one radix-R step in time (k_time_combine)
-        R = int(rng.choice([3, 5, 7, 9, 15, 11, 13, 21, 25, 27, 33, 45, 63]))
+        R = int(rng.choice([3, 5, 7, 9, 15, 11, 13, 21, 25, 27, 33, 45, 63, 75, 99, 125, 127]))
         sh = int(np.ceil(np.log2(R)))
         M = R * (M >> sh) if (M >> sh) >= 2 else M
         pos, neg = int(rng.integers(0, max(1, M // 3))), int(rng.integers(0, max(1, M // 3)))

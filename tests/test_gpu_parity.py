@@ -365,7 +365,7 @@ def test_pipeline_folds_with_tempo2_predictor(oracle, gpu):
 def test_filterbank_errors(gpu):
     dspsr_amd, ctx = gpu
     with pytest.raises(dspsr_amd.DspsrAmdError):
-        dspsr_amd.FilterbankEngine(ctx).setup(8, 8 * 67, 1, 1)        # freq_res is not 2^k times an odd factor <= 63
+        dspsr_amd.FilterbankEngine(ctx).setup(8, 8 * 131, 1, 1)       # freq_res is not 2^k times an odd factor <= 127
     with pytest.raises(dspsr_amd.DspsrAmdError):
         dspsr_amd.FilterbankEngine(ctx).setup(8, 64, 40, 30)          # nfilt_tot >= freq_res
     with pytest.raises(dspsr_amd.DspsrAmdError):

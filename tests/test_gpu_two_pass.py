@@ -171,13 +171,15 @@ def test_two_pass_segmented_fused_fold_and_pipeline(oracle, gpu):
     (192, 64, (5, 7), dict(real=False, use_raw=False)),            # complex float rows
     (24, 128, (9, 10), dict(real=False, input_nchan=2)),           # two input channels
     (320, 128, (9, 10), dict(npol=1)),                             # single polarisation, 5 * 64
-    # any odd factor up to 63 (round 5: run-time-radix combine, k_sub_combine_any): dspsr -F 400:D, -F 25:D -x 2048, primes too
+    # any odd factor up to 127 (round 5) (round 5: run-time-radix combine, k_sub_combine_any): dspsr -F 400:D, -F 25:D -x 2048, primes too
     (400, 256, (20, 21), dict()),                                  # 25 * 16
     (25, 2048, (300, 211), dict(max_parts=3)),                     # one channel per sub-sequence
     (44, 512, (40, 30), dict(real=False)),                         # 11 * 4, complex dual-pol
     (52, 128, (9, 10), dict(layout="caspsr")),                     # 13 * 4
     (63, 256, (20, 21), dict(use_raw=False)),                      # 63 sub-sequences of one channel, float32 rows
     (42, 1024, (100, 101), dict(real=False, input_nchan=2)),       # 21 * 2, two input channels
+    (1000, 64, (5, 7), dict()),                                    # -F 1000:D: 125 * 8
+    (254, 256, (20, 21), dict(real=False)),                        # the largest factor, a prime: 127 * 2
 ])
 def test_filterbank_three_and_five_times_power_of_two_channels(oracle, gpu, C, M, nfilt, kw):
     _fb_case(oracle, gpu, C, M, nfilt, 3, max_parts=kw.pop("max_parts", 2), seed=9, **kw)
@@ -216,7 +218,7 @@ def test_non_power_of_two_channels_fused_fold_bit_identical(oracle, gpu):
 
 def test_rejected_channel_counts(gpu):
     dspsr_amd, ctx = gpu
-    for C in (65, 67, 2 * 65, 127, 4 * 81):                 # odd factor above 63
+    for C in (129, 131, 2 * 129, 255, 4 * 243):              # odd factor above 127
         with pytest.raises(dspsr_amd.DspsrAmdError):
             dspsr_amd.FilterbankEngine(ctx).setup(C, 256, 5, 5, 1, 2, True, None)
 
@@ -249,7 +251,7 @@ def test_rejected_channel_counts(gpu):
     (16, 5 * 256, (60, 61), 11, dict(use_raw=False, max_parts=8)),
     (8, 3 * 512, (60, 61), 7, dict(layout="caspsr", max_parts=7)),
     (32, 9 * 64, (30, 21), 8, dict(real=False, max_parts=8)),
-    # any odd factor up to 63 of freq_res (k_sub_combine_any<true>, k_time_combine<0>): dspsr -x 11264, -x 6400
+    # any odd factor up to 127 (round 5) of freq_res (k_sub_combine_any<true>, k_time_combine<0>): dspsr -x 11264, -x 6400
     (16, 11 * 1024, (700, 600), 2, dict()),                             # -x 11264
     (8, 25 * 256, (301, 300), 5, dict(max_parts=5)),                    # -x 6400, part step not a multiple of 25: five sub-groups
     (32, 13 * 64, (30, 21), 3, dict(real=False)),
@@ -257,6 +259,8 @@ def test_rejected_channel_counts(gpu):
     (16, 63 * 16, (20, 21), 2, dict(use_raw=False)),
     (24, 15 * 64, (40, 41), 2, dict()),                                 # 3 (channels) x 15 = 45
     (80, 5 * 64, (9, 10), 2, dict(real=False)),                         # 5 x 5 = 25
+    (8, 125 * 64, (500, 411), 3, dict(max_parts=3)),                    # -x 8000
+    (24, 7 * 64 * 5, (40, 41), 2, dict()),                              # 3 x 35 = 105
 ])
 def test_filterbank_freq_res_three_five_times_power_of_two(oracle, gpu, C, M, nfilt, npart, kw):
     _fb_case(oracle, gpu, C, M, nfilt, npart, **kw)
@@ -313,7 +317,7 @@ def test_freq_res_not_power_of_two_detected_and_folded(oracle, gpu):
 
 def test_freq_res_other_lengths_are_refused(gpu):
     dspsr_amd, ctx = gpu
-    for C, M in ((16, 65 * 64), (16, 127 * 64), (24, 7 * 64 * 3 * 5), (80, 13 * 64), (16, 3)):    # odd factors above 63 (together)
+    for C, M in ((16, 129 * 64), (16, 255 * 64), (24, 7 * 64 * 3 * 5 * 3), (80, 27 * 64), (16, 3)):    # odd factors above 127 (together)
         with pytest.raises(dspsr_amd.DspsrAmdError):
             dspsr_amd.FilterbankEngine(ctx).setup(C, M, 1, 1, 1, 2, True, None)
 
