@@ -185,6 +185,17 @@ def test_filterbank_three_and_five_times_power_of_two_channels(oracle, gpu, C, M
     _fb_case(oracle, gpu, C, M, nfilt, 3, max_parts=kw.pop("max_parts", 2), seed=9, **kw)
 
 
+@pytest.mark.parametrize("C,M,nfilt,kw", [
+    (3 * 4096, 4096, (422, 400), dict()),                          # L = 3 * 2^25, 8192 rows per sub-spectrum: the largest three-pass rows
+    (25 * 256, 4096, (422, 400), dict(layout="caspsr")),           # run-time-radix combine at L = 25 * 2^21
+    (16, 45 * 2048, (9000, 8000), dict()),                         # freq_res = 45 * 2^11 = 92160: long pseudo-channel responses
+])
+def test_odd_factor_twiddles_at_large_lengths(oracle, gpu, C, M, nfilt, kw):
+    """the radix-R twiddles come from v_sin / v_cos on a split argument (fb_common.h twiddle_odd): the float64 oracle at
+    lengths near the largest the three-pass form accepts, same tolerance as every other geometry (2e-6 sqrt(log2 2N) rms)."""
+    _fb_case(oracle, gpu, C, M, nfilt, 1, seed=10, **kw)
+
+
 def test_non_power_of_two_channels_fused_fold_bit_identical(oracle, gpu):
     """perform_fold == perform_detect + fold, bit for bit, with 96 channels (fused kernel, one workgroup per tile)."""
     dspsr_amd, ctx = gpu
