@@ -371,7 +371,8 @@ __global__ __launch_bounds__(512) void k_tfp4k(const TfpParams p, const cf* __re
       const bool more = gi + 1 < groups_per_out || item + gridDim.x < nitem;
       const uint64_t next = gi + 1 < groups_per_out ? group + 1 : (item + gridDim.x) * groups_per_out;
       FB_ST(8, 2);
-      auto post = [&](const uint32_t, const uint32_t, const uint32_t, cx2 (&v)[16]) {
+      auto post = [&](cx2 (&vv)[1][16]) {
+        cx2 (&v)[16] = vv[0];
         __syncthreads();                         // every wave has read the last exchange: the next tile's image may land
         if (more) fetch_image(next);
         FB_ST(8, 3);                             // transform
@@ -446,6 +447,233 @@ __global__ __launch_bounds__(512) void k_tfp4k(const TfpParams p, const cf* __re
   FB_ST_END(8);
 }
 
+// The same post-processing on the last stage's registers for nchan = 512, 1024, 2048 and 8192 (digifil -F 512 ... 8192).  The last
+// stage has radix RL = 2 / 4 / 8 / 2 and a thread holds H = 16 / RL butterfly pairs v[h][k]: pair q = H tid + h is column q % T,
+// position pair (j, P - j) with j = q / T.  The tile's columns are (part, pol) = (c / 2, c % 2):
+//   nchan 2048 (T = 8):  h = pol; the four lanes of a quad are the tile's four parts, all at position j = tid / 4
+//   nchan 1024 (T = 16): h = 2 ph + pol; lane l of a quad holds parts 2 l + ph, position j = tid / 4
+//   nchan 512  (T = 32): h = 2 ph + pol; lane l of a quad holds parts 4 l + ph
+//   nchan 8192 (T = 2):  h = 2 jh + pol; one part per tile, four position pairs j = 4 tid + jh per thread
+// so the polarisation sum is an add inside the thread and the time sum over the tile's parts a chain of quad broadcasts in time
+// order (every lane of the quad ends up with the same sums; lane 0 of it stores).  Everything else -- pairing of the bins, twiddle
+// arguments, half-scale decode, order of every rounding -- is k_tfp4k's, i.e. the generic kernel's: bit-identical outputs.
+template <int LOGC, bool CASPSR, bool PSC>
+__global__ __launch_bounds__(512) void k_tfpm(const TfpParams p, const cf* __restrict__ tw)
+{
+  typedef FftPlan<LOGC> P;
+  static_assert(LOGC == 9 || LOGC == 10 || LOGC == 11 || LOGC == 13, "k_tfpm: 16 x 16 x {2, 4, 8} and 16 x 16 x 16 x 2");
+  constexpr int logT = 14 - LOGC, logTp = logT - 1;
+  constexpr int LOGRL = P::REM, RL = 1 << LOGRL, H = (PTS / RL) / 2, NK = RL / 2;
+  constexpr int logP = LOGC - LOGRL;
+  constexpr uint32_t nt = 512, C = 1u << LOGC, Pn = 1u << logP, T = 1u << logT, NPT = 1u << logTp;
+  constexpr int JH = H > (int)T ? H / (int)T : 1;              // position pairs per thread
+  constexpr int PH = (H / 2) / JH;                             // parts per thread
+  constexpr uint32_t LP = NPT / PH;                            // lanes of a quad that hold different parts (1 or 4)
+  static_assert(LP == 1 || LP == 4, "k_tfpm: the parts of a tile are one lane or the four lanes of a quad");
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  uint32_t tid = threadIdx.x;
+  constexpr uint32_t npol_out = PSC ? 1 : 2;
+  const uint64_t nout = p.npart / p.sfactor;
+  const uint32_t ltw_off = lds_pad(PTS * nt) + 8;
+  ltw_fill<LOGC>(lds, ltw_off, tw, tid, nt);
+  // position pair jh of this thread: (pa, pb) = (j, P - j); j = 0 goes with P / 2
+  auto jof = [&](const int jh) -> uint32_t { return JH == 1 ? threadIdx.x >> 2 : (uint32_t)JH * threadIdx.x + jh; };
+  // w^(P k + pa), w^(P k + pb), w = exp(-i pi / C): argument bin / 2C revolutions, exact in float (the generic kernel's values)
+  v2f wc[JH][NK], ws[JH][NK];
+#pragma unroll
+  for (int jh = 0; jh < JH; jh++) {
+    const uint32_t j = jof(jh), pa = j, pb = j ? Pn - j : Pn / 2;
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+      const float xa = (float)(Pn * k + pa) * (0.5f / (float)C), xb = (float)(Pn * k + pb) * (0.5f / (float)C);
+      wc[jh][k] = (v2f){__builtin_amdgcn_cosf(xa), __builtin_amdgcn_cosf(xb)};
+      ws[jh][k] = (v2f){__builtin_amdgcn_sinf(xa), __builtin_amdgcn_sinf(xb)};
+    }
+  }
+  const float sc2 = 0.5f * p.scale, hs2 = 0.5f * sc2;           // half scale: see k_tfp4k
+  const uint32_t groups_per_out = p.sfactor >> logTp;            // sfactor is a multiple of the tile's parts (host)
+  const uint64_t nitem = nout;
+  auto elem = [&](const int g2, const int i, uint32_t& pl, uint32_t& n) {
+    const uint32_t e = first_stage_elem<LOGC>(tid, logT, g2, i);
+    pl = (e & ((1u << logT) - 1)) >> 1;
+    n = e >> logT;
+  };
+  // image by LDS-DMA as in k_tfp4k; part q of the tile lies q * IMG_SKEW bytes further on, so that the lanes of a first-stage
+  // read -- consecutive lanes = consecutive parts at the same offset -- fall on different banks
+  constexpr uint32_t NCH = (PTS * 2) / 16, IMG_SKEW = NPT > 1 ? 256u / NPT : 0u;
+  auto fetch_image = [&](const uint64_t group) {
+    const uint8_t* src = p.raw + (group << logTp) * (uint64_t)C * 4 + 16u * threadIdx.x;
+#pragma unroll
+    for (uint32_t r = 0; r < NCH; r++) {
+      const uint32_t off = 16u * ((threadIdx.x & ~63u) + r * nt);                    // this wave's 1 KB of the tile
+      lds_dma_b128(src + 16u * nt * r, lds_byte_addr((const uint8_t*)lds + off + (off >> (LOGC + 2)) * IMG_SKEW));
+    }
+  };
+  auto bc0 = [](const float a) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x00, 0xf, 0xf, false)); };
+  auto bc1 = [](const float a) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x55, 0xf, 0xf, false)); };
+  auto bc2 = [](const float a) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xAA, 0xf, 0xf, false)); };
+  auto bc3 = [](const float a) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xFF, 0xf, 0xf, false)); };
+  if (blockIdx.x < nitem) fetch_image((uint64_t)blockIdx.x * groups_per_out);
+  FB_ST_BEGIN(8);
+  for (uint64_t item = blockIdx.x; item < nitem; item += gridDim.x) {
+    // running sums of an output sample: [jh][pol][k] bins P k + (pa | pb) and their mirrors P (RL - 1 - k) + (pb | pa); bin C / 2
+    v2f accK[JH][npol_out][NK], accM[JH][npol_out][NK];
+    float accH[npol_out];
+#pragma unroll
+    for (int jh = 0; jh < JH; jh++)
+#pragma unroll
+      for (uint32_t q = 0; q < npol_out; q++)
+#pragma unroll
+        for (int k = 0; k < NK; k++) accK[jh][q][k] = accM[jh][q][k] = (v2f){0.f, 0.f};
+#pragma unroll
+    for (uint32_t q = 0; q < npol_out; q++) accH[q] = 0.f;
+    for (uint32_t gi = 0; gi < groups_per_out; gi++) {
+      const uint64_t group = item * groups_per_out + gi;
+      asm volatile("" : "+v"(tid));
+      cx2 x[NPAIR];
+      FB_ST(8, 0);
+      {
+        const uint8_t* img = (const uint8_t*)lds;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < P::R1; i++) {
+          uint32_t pl, n;
+          elem(0, i, pl, n);
+          const uint32_t w = tfp_word_aligned<CASPSR>(img + (pl << (LOGC + 2)) + pl * IMG_SKEW, 2 * n);
+          x[i].x = (v2f){__builtin_fmaf((float)(int8_t)(w & 0xff), sc2, hs2), __builtin_fmaf((float)(int8_t)((w >> 8) & 0xff), sc2, hs2)};
+          x[i].y = (v2f){__builtin_fmaf((float)(int8_t)((w >> 16) & 0xff), sc2, hs2), __builtin_fmaf((float)(int8_t)(w >> 24), sc2, hs2)};
+        }
+      }
+      FB_ST(8, 1);
+      const bool more = gi + 1 < groups_per_out || item + gridDim.x < nitem;
+      const uint64_t next = gi + 1 < groups_per_out ? group + 1 : (item + gridDim.x) * groups_per_out;
+      FB_ST(8, 2);
+      auto post = [&](cx2 (&v)[H][RL]) {
+        __syncthreads();                         // every wave has read the last exchange: the next tile's image may land
+        if (more) fetch_image(next);
+        FB_ST(8, 3);
+        const bool wave0 = threadIdx.x < 64;     // (wave uniform) only wave 0 holds position pairs with j = 0
+#pragma unroll
+        for (int jh = 0; jh < JH; jh++) {
+          const bool j0 = wave0 && jof(jh) == 0;
+          // powers of this thread's parts (ph) and polarisations for the bins of position pair jh
+          v2f pk[PH][2][NK], pm[PH][2][NK];
+          float ph2[PH][2];
+#pragma unroll
+          for (int ph = 0; ph < PH; ph++)
+#pragma unroll
+            for (int pol = 0; pol < 2; pol++) {
+              cx2 (&u)[RL] = v[(jh * PH + ph) * 2 + pol];
+#pragma unroll
+              for (int k = 0; k < NK; k++) {
+                const cx2 g = u[RL - 1 - k], sp = u[(RL - k) & (RL - 1)];
+                v2f mr, mi;
+                if (wave0) {                     // lanes j = 0: low half Z[P (RL - k)] (k = 0: Z[0] itself), high half Z[P (RL-1-k) + P/2]
+                  mr = (v2f){j0 ? sp.x[0] : g.x[1], j0 ? g.x[1] : g.x[0]};
+                  mi = (v2f){j0 ? sp.y[0] : g.y[1], j0 ? g.y[1] : g.y[0]};
+                } else {
+                  mr = __builtin_shufflevector(g.x, g.x, 1, 0);
+                  mi = __builtin_shufflevector(g.y, g.y, 1, 0);
+                }
+                const v2f zr = u[k].x, zi = u[k].y;
+                const v2f ar = zr + mr, ai = zi - mi;
+                const v2f br = zi + mi, bi = mr - zr;
+                const v2f wck = wc[jh][k], wsk = ws[jh][k];
+                const v2f wr = wck * br + wsk * bi, wi = wck * bi - wsk * br;
+                const v2f xr = ar + wr, xi = ai + wi, yr = ar - wr, yi = ai - wi;
+                v2f a = xr * xr; a += xi * xi;                    // TFPFilterbank.C:56-59: Re^2 then += Im^2
+                v2f b = yr * yr; b += yi * yi;
+                pk[ph][pol][k] = a; pm[ph][pol][k] = b;
+              }
+              // bin C / 2 = P (RL / 2) + 0: its own mirror, w = -i  (meaningful in the lane j = 0 only)
+              const float hr = u[RL / 2].x[0] + u[RL / 2].x[0], hi = -(u[RL / 2].y[0] + u[RL / 2].y[0]);
+              float hh = hr * hr; hh += hi * hi;
+              ph2[ph][pol] = hh;
+            }
+          if constexpr (PSC) {                   // :79-80 pol sum BEFORE the time sum
+#pragma unroll
+            for (int ph = 0; ph < PH; ph++) {
+#pragma unroll
+              for (int k = 0; k < NK; k++) { pk[ph][0][k] += pk[ph][1][k]; pm[ph][0][k] += pm[ph][1][k]; }
+              ph2[ph][0] += ph2[ph][1];
+            }
+          }
+          // time sum, parts in time order: part = PH * lane + ph
+          auto tsum = [&](float& acc, const float (&val)[PH]) {
+            if constexpr (LP == 1) {
+#pragma unroll
+              for (int ph = 0; ph < PH; ph++) acc += val[ph];
+            } else {
+#pragma unroll
+              for (int ph = 0; ph < PH; ph++) acc += bc0(val[ph]);
+#pragma unroll
+              for (int ph = 0; ph < PH; ph++) acc += bc1(val[ph]);
+#pragma unroll
+              for (int ph = 0; ph < PH; ph++) acc += bc2(val[ph]);
+#pragma unroll
+              for (int ph = 0; ph < PH; ph++) acc += bc3(val[ph]);
+            }
+          };
+#pragma unroll
+          for (uint32_t q = 0; q < npol_out; q++) {
+#pragma unroll
+            for (int k = 0; k < NK; k++)
+#pragma unroll
+              for (int e = 0; e < 2; e++) {
+                float vk[PH], vm[PH];
+#pragma unroll
+                for (int ph = 0; ph < PH; ph++) { vk[ph] = pk[ph][q][k][e]; vm[ph] = pm[ph][q][k][e]; }
+                float ak = accK[jh][q][k][e], am = accM[jh][q][k][e];
+                tsum(ak, vk); tsum(am, vm);
+                accK[jh][q][k][e] = ak; accM[jh][q][k][e] = am;
+              }
+            if (jh == 0) {
+              float vh[PH];
+#pragma unroll
+              for (int ph = 0; ph < PH; ph++) vh[ph] = ph2[ph][q];
+              tsum(accH[q], vh);
+            }
+          }
+        }
+      };
+      wgfft<LOGC, -1, false, false, true>(lds, ltw_off, tid, logT, x, post);
+      if (gi + 1 == groups_per_out && (LP == 1 || (threadIdx.x & 3u) == 0)) {
+        // every lane of a quad holds the same sums: lane 0 stores (TFP order: out[sample][bin][pol])
+        float* const o = p.out + item * (uint64_t)C * npol_out;
+#pragma unroll
+        for (int jh = 0; jh < JH; jh++) {
+          uint32_t j = jof(jh);
+          asm volatile("" : "+v"(j));            // (loop-invariant addresses: keep them out of the tile loop's registers)
+          const bool j0 = j == 0;
+          const uint32_t pa = j, pb = j ? Pn - j : Pn / 2;
+#pragma unroll
+          for (uint32_t q = 0; q < npol_out; q++)
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+              o[(Pn * k + pa) * npol_out + q] = accK[jh][q][k][0];
+              o[(Pn * k + pb) * npol_out + q] = accK[jh][q][k][1];
+              if (!j0) {
+                o[(Pn * (RL - 1 - k) + pb) * npol_out + q] = accM[jh][q][k][0];
+                o[(Pn * (RL - 1 - k) + pa) * npol_out + q] = accM[jh][q][k][1];
+              } else {
+                if (k) o[(Pn * (RL - k)) * npol_out + q] = accM[jh][q][k][0];
+                o[(Pn * (RL - 1 - k) + pb) * npol_out + q] = accM[jh][q][k][1];            // (pb = P / 2)
+              }
+            }
+          if (jh == 0 && j0) {
+#pragma unroll
+            for (uint32_t q = 0; q < npol_out; q++) o[(C / 2) * npol_out + q] = accH[q];
+          }
+        }
+      }
+      FB_ST(8, 4);
+      FB_ST_TILE(8, 5);
+    }
+  }
+  FB_ST_END(8);
+}
+
 typedef void (*ktfp_t)(TfpParams, const cf*);
 template <int... I> struct iseq_t {};
 template <int N, int... I> struct mkseq_t : mkseq_t<N - 1, N - 1, I...> {};
@@ -497,6 +725,15 @@ extern "C" int dspsr_amd_tfp_filterbank(dspsr_amd_ctx* ctx, const dspsr_amd_tfp_
   // digifil's own geometry (-F 4096 with an even -t): post-processing on the last stage's registers, see k_tfp4k
   if (nchan == 4096 && coal && (sf % 2) == 0)
     k = p.caspsr ? (p.pscrunch ? k_tfp4k<true, true> : k_tfp4k<true, false>) : (p.pscrunch ? k_tfp4k<false, true> : k_tfp4k<false, false>);
+  // its generalisation to -F 512 / 1024 / 2048 / 8192 (tscrunch a multiple of the tile's 16 / 8 / 4 / 1 parts), see k_tfpm
+#define TFPM(L) (p.caspsr ? (p.pscrunch ? k_tfpm<L, true, true> : k_tfpm<L, true, false>) : (p.pscrunch ? k_tfpm<L, false, true> : k_tfpm<L, false, false>))
+  if (coal && (sf % T) == 0) {
+    if (nchan == 512) k = TFPM(9);
+    else if (nchan == 1024) k = TFPM(10);
+    else if (nchan == 2048) k = TFPM(11);
+    else if (nchan == 8192) k = TFPM(13);
+  }
+#undef TFPM
   const size_t lds = lds_total_words_host(16384, logC) * sizeof(cf);
   hipError_t e = dspsr_amd_allow_lds((const void*)k, lds);      // raised once per kernel, not per call
   if (e != hipSuccess) return ctx_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_tfp_filterbank: %s", hipGetErrorString(e));

@@ -258,7 +258,8 @@ template <class O> DEV void out_set_h(O&, const int, long) {}
 // positions (p, P - p) of ONE column -- p = 0 goes with P/2 --, read as two 8-byte elements.  Its outputs are then bins k*P + p in
 // the low halves and k*P + (P - p) in the high halves of v[k]: the Hermitian mirror C - (k*P + p) = (R-1-k)*P + (P - p) of every
 // bin lies in the SAME thread (high half of v[R-1-k]), so the real-transform post-processing (X[k] from Z[k], Z[C-k]) needs no
-// further exchange.  Pair q = H*tid + h is column q % T, position pair q / T; out(col, p, pstride, v) gets that column and p.
+// further exchange.  Pair q = H*tid + h is column q % T, position pair q / T; `out(v)` is called ONCE with the thread's whole
+// image cx2 v[H][R].
 // ILV (the stage in FRONT of a MIRROR stage): its exchange writes the pair as (re, im) of column c, (re, im) of column c + 1 --
 // whole 8-byte elements per column -- instead of the split form (re c, re c+1, im c, im c+1) every other stage reads back.
 template <int LOGR, int SIGN, bool FIRST, bool LAST, bool STAGED, bool MIRROR = false, bool ILV = false, class Out, class Mid>
@@ -328,9 +329,7 @@ DEV void wgfft_stage(cf* lds, const uint32_t ltw_off, const uint32_t tid, const 
     const uint32_t p = rest & ((1u << logP) - 1);
     const uint32_t s = rest >> logP;
     if constexpr (LAST && MIRROR) {
-      const uint32_t q = H * tid + h;
-      out_set_h(out, h, 0);
-      out(q & ((1u << logT) - 1), q >> logT, 1u << logP, v[h]);
+      if (h == 0) out(v);                // the whole register image at once: pair h is column (H tid + h) % T, positions ((H tid + h) / T, P - that)
     } else if constexpr (LAST) {
       out_set_h(out, h, 0);
       out(col, p, 1u << logP, v[h]);     // Q == 1, s == 0

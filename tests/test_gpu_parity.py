@@ -793,6 +793,38 @@ def test_tfp_4096_register_split_equals_generic_kernel(gpu, pscrunch, layout_nam
         assert torch.equal(got2, want)
 
 
+@pytest.mark.parametrize("pscrunch", [True, False])
+@pytest.mark.parametrize("nchan,layout_name,tscrunch,npart", [
+    (2048, "generic", 16, 100), (2048, "caspsr", 4, 30), (2048, "generic", 12, 50),
+    (1024, "generic", 16, 200), (1024, "caspsr", 8, 70), (1024, "generic", 24, 100),
+    (8192, "generic", 16, 40), (8192, "caspsr", 1, 5), (8192, "generic", 3, 11),
+    (512, "generic", 16, 300), (512, "caspsr", 32, 100)])
+def test_tfp_register_split_other_channel_counts_equal_the_generic_kernel(gpu, nchan, pscrunch, layout_name, tscrunch, npart):
+    """k_tfpm (nchan = 512 / 1024 / 2048 / 8192, tscrunch a multiple of the 16 / 8 / 4 / 1 parts of a tile): the last stage's registers hold
+    several (part, polarisation) columns per thread, the time sum runs over quad broadcasts.  Reference: the generic kernel (taken
+    for a block that is only 2-byte aligned) at tscrunch 1, its per-part powers summed in time order -- BIT FOR BIT."""
+    dspsr_amd, ctx = gpu
+    from dspsr_amd import _lib
+    rng = np.random.default_rng(78)
+    layout = _lib.RAW_CASPSR if layout_name == "caspsr" else _lib.RAW_GENERIC
+    host = np.clip(np.rint(rng.standard_normal(npart * 2 * nchan * 2) * 24.0), -128, 127).astype(np.int8)
+    raw = torch.from_numpy(host).cuda()
+    shifted = torch.zeros(raw.numel() + 18, dtype=torch.int8, device="cuda")
+    off = 2 if layout_name == "generic" else 8           # (CASPSR groups of 8 bytes: still no 16-byte alignment)
+    shifted[off:off + raw.numel()] = raw
+    npol = 1 if pscrunch else 2
+    nout = npart // tscrunch
+    one = torch.zeros((npart, nchan, npol), dtype=torch.float32, device="cuda")
+    dspsr_amd.tfp_filterbank(ctx, shifted[off:off + raw.numel()], nchan, npart, one, pscrunch, 1, layout=layout, scale=0.0123)
+    want = one[0:nout * tscrunch:tscrunch].clone()
+    for i in range(1, tscrunch):
+        want = want + one[i:nout * tscrunch:tscrunch]
+    got = torch.full((nout, nchan, npol), -1.0, dtype=torch.float32, device="cuda")
+    dspsr_amd.tfp_filterbank(ctx, raw, nchan, npart, got, pscrunch, tscrunch, layout=layout, scale=0.0123)
+    assert torch.equal(got, want), (int((got != want).sum()), float((got - want).abs().max()))
+    assert float(got.min()) >= 0.0 and float(got.max()) > 0.0
+
+
 @pytest.mark.parametrize("nchan,npol,ndat,interval,constant,blocks", [
     (1024, 1, 4096, 0, False, 1), (256, 2, 3000, 1000, False, 3), (64, 4, 2500, 700, True, 2), (4096, 1, 1024, 512, False, 2),
     (16, 1, 100000, 0, False, 1), (33, 2, 777, 100, False, 2)])
