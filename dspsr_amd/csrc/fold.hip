@@ -780,42 +780,55 @@ static int fold_fold_impl(dspsr_amd_fold* f, const float* in_dev, uint64_t in_ch
   }
   if (!slot_reserve(sl, nbin + 1, niv))
     return ctx_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_fold_fold: plan allocation failed");
-  for (uint32_t b = 0; b <= nbin; b++) sl.h_bin_start[b] = 0;
-  for (const RunBin& r : f->binplan) sl.h_bin_start[r.ibin + 1]++;
-  for (uint32_t b = 0; b < nbin; b++) sl.h_bin_start[b + 1] += sl.h_bin_start[b];
-  f->cursor.assign(sl.h_bin_start, sl.h_bin_start + nbin);
-  for (const RunBin& r : f->binplan) {
-    Interval v; v.offset = r.offset; v.hits = r.hits; v.pad = 0;
-    sl.h_iv[f->cursor[r.ibin]++] = v;
-  }
   // sample span covered by the plan (intervals are time ordered)
   uint64_t first = f->binplan.front().offset, last = f->binplan.back().offset + f->binplan.back().hits;
   first -= first % 4;                                  // keeps 16-byte alignment of the chunk loads for any ndim
   const bool aligned = ((uintptr_t)in_dev % 16 == 0) && (in_chan_stride % 4 == 0) && (in_pol_stride % 4 == 0);
+  // One walk over the runs decides which kernel folds them: the longest run (re-associated sums, see FOLD_LONG_RUN) and whether
+  // the plan fits the dense per-chunk table of k_fold_dense -- at most one run per (chunk, phase bin), runs cut at the chunk ends;
+  // a plan with two runs of a bin inside a chunk (a folding period shorter than the chunk) does not.  The table is also refused
+  // when it would be more than a quarter of the bytes it helps to fold (few channels, many bins).  (This host code runs once per
+  // block next to a kernel of a few hundred microseconds: at Benchmark/fold.csh's shape the three separate walks and the bucket
+  // sort below, which the dense kernel does not read, made the host as slow as the device -- profiles/r05_experiments.txt item 6.)
   uint32_t max_run = 0;
-  for (const RunBin& r : f->binplan) if (r.hits > max_run) max_run = r.hits;
-  const bool lng = aligned && nbin <= (uint32_t)FOLD_BPT * 1024 && max_run >= FOLD_LONG_RUN;   // re-associated sums (see FOLD_LONG_RUN)
-  // Dense per-chunk table (k_fold_dense): at most one run per (chunk, phase bin), runs cut at the chunk ends.
-  // Whether the plan qualifies is decided BEFORE the table is touched, in one walk over the runs with a scratch of nbin words
-  // (the chunk in which each bin last had a piece): a plan with two runs of a bin inside a chunk -- a folding period shorter than
-  // the chunk -- used to be discovered half way through filling up to 64 MB of pinned table.  The table is also refused when it
-  // would be more than a quarter of the bytes it helps to fold (few channels, many bins).
-  bool dense = false;
+  bool one_per_chunk = aligned && nbin <= (uint32_t)FOLD_BPT * 1024;
   size_t ntab = 0;
-  if (aligned && !lng && nbin <= (uint32_t)FOLD_BPT * 1024) {
+  if (one_per_chunk) {
     const uint64_t nchunk = (last - first + FOLD_CHUNK - 1) / FOLD_CHUNK;
     ntab = (size_t)nchunk * nbin;
     const uint64_t data_words = (last - first) * (uint64_t)f->nchan * f->npol * f->ndim;
-    if (ntab <= ((size_t)1 << 24) && 4 * (uint64_t)ntab <= data_words) {
-      dense = true;
-      f->cursor.assign(nbin, ~0u);                          // (scratch: chunk of the bin's previous piece)
-      for (const RunBin& r : f->binplan) {
-        if (r.hits == 0) continue;
-        const uint64_t c0 = (r.offset - first) / FOLD_CHUNK, c1 = (r.offset - first + r.hits - 1) / FOLD_CHUNK;
-        if (f->cursor[r.ibin] == (uint32_t)c0) { dense = false; break; }     // a second run of this bin in the chunk
-        f->cursor[r.ibin] = (uint32_t)c1;
-      }
+    one_per_chunk = ntab <= ((size_t)1 << 24) && 4 * (uint64_t)ntab <= data_words;
+  }
+  if (one_per_chunk) {
+    f->cursor.assign(nbin, ~0u);                            // (scratch: chunk of the bin's previous piece)
+    uint32_t* const lastc = f->cursor.data();
+    for (const RunBin& r : f->binplan) {
+      if (r.hits > max_run) max_run = r.hits;
+      if (r.hits == 0 || !one_per_chunk) continue;
+      const uint64_t c0 = (r.offset - first) / FOLD_CHUNK, c1 = (r.offset - first + r.hits - 1) / FOLD_CHUNK;
+      if (lastc[r.ibin] == (uint32_t)c0) one_per_chunk = false;             // a second run of this bin in the chunk
+      lastc[r.ibin] = (uint32_t)c1;
     }
+  } else {
+    for (const RunBin& r : f->binplan) if (r.hits > max_run) max_run = r.hits;
+  }
+  const bool lng = aligned && nbin <= (uint32_t)FOLD_BPT * 1024 && max_run >= FOLD_LONG_RUN;   // re-associated sums (see FOLD_LONG_RUN)
+  const bool will_dense = one_per_chunk && !lng;
+  // the intervals bucketed by phase bin (stable => time order kept inside a bin): what the walk kernels and the per-channel hit
+  // count of a zeroed input read -- not the dense kernel
+  const bool need_iv = !will_dense || hits_dev;
+  if (need_iv) {
+    for (uint32_t b = 0; b <= nbin; b++) sl.h_bin_start[b] = 0;
+    for (const RunBin& r : f->binplan) sl.h_bin_start[r.ibin + 1]++;
+    for (uint32_t b = 0; b < nbin; b++) sl.h_bin_start[b + 1] += sl.h_bin_start[b];
+    f->cursor.assign(sl.h_bin_start, sl.h_bin_start + nbin);
+    for (const RunBin& r : f->binplan) {
+      Interval v; v.offset = r.offset; v.hits = r.hits; v.pad = 0;
+      sl.h_iv[f->cursor[r.ibin]++] = v;
+    }
+  }
+  bool dense = will_dense;
+  {
     if (dense) {
       if (ntab > sl.aux_cap) {
         if (sl.h_aux) (void)hipHostFree(sl.h_aux);
@@ -841,8 +854,6 @@ static int fold_fold_impl(dspsr_amd_fold* f, const float* in_dev, uint64_t in_ch
     }
   }
   {
-    // (the interval lists are still needed by the walk kernels and by the per-channel hit count of a zeroed input)
-    const bool need_iv = !dense || hits_dev;
     const PlanCopy pc[3] = {{sl.d_bin_start, sl.h_bin_start, need_iv ? (nbin + 1) * sizeof(uint32_t) : 0},
                             {sl.d_iv, sl.h_iv, need_iv ? niv * sizeof(Interval) : 0},
                             {sl.d_aux, sl.h_aux, dense ? ntab * sizeof(uint32_t) : 0}};
@@ -884,6 +895,7 @@ static int fold_fold_impl(dspsr_amd_fold* f, const float* in_dev, uint64_t in_ch
       }
     }
     // planes of one channel folded together (ndim < 4): 4 or 2 rows per workgroup when the channels alone fill the chip
+    // (one row per workgroup at Benchmark/fold.csh's shape, four times the workgroups: 311-313 against 321-331 Msamples/s, same box)
     const uint32_t nrw = (f->ndim * f->npol == 4 && f->ndim < 4 && (uint64_t)f->nchan * (lng ? nseg : nsplit) >= 2 * ctx->ncu)
                              ? f->npol : 1u;
     dim3 grid(f->npol / nrw, f->nchan, lng ? nseg : nsplit);

@@ -6,13 +6,13 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dspsr_amd
 from dspsr_amd import pipeline
-nchan, npol, ndat, rate = 1024, 4, 1 << 17, 1e6 / 32.0
+nchan, npol, rate = 1024, 4, 1e6 / 32.0
 text = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "vela_polyco.json")))["text"]
 polyco = pipeline.Polyco(text)
 day, sec0 = 55299, 7545.0
 nbin = pipeline.choose_nbin(1.0 / polyco.frequency(day, sec0), rate)
 ctx = dspsr_amd.Context(0, torch.cuda.current_stream().cuda_stream)
-for pad in (0, 64, 512, 2048 + 64, 4096 + 192, 0):
+for pad, ndat in ((0, 1 << 17), (2112, 1 << 17), (0, 1 << 15), (0, 1 << 16), (0, 1 << 18), (0, 1 << 19), (0, 1 << 17)):
     fold = dspsr_amd.FoldEngine(ctx)
     fold.set_shape(nchan, npol, 1, nbin)
     buf = torch.rand((nchan, npol, ndat + pad), dtype=torch.float32, device="cuda")
@@ -31,7 +31,7 @@ for pad in (0, 64, 512, 2048 + 64, 4096 + 192, 0):
         a.record(); fold.fold(det); b.record()
     torch.cuda.synchronize()
     ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-    print("pad %5d floats: %.4f ms per block, %.2f TB/s" % (pad, ms, nchan * npol * ndat * 4 / ms / 1e9), flush=True)
+    print("ndat 2^%d pad %5d floats: %.4f ms per block, %.2f TB/s" % (int(np.log2(ndat)), pad, ms, nchan * npol * ndat * 4 / ms / 1e9), flush=True)
     fold.close()
     del buf, det
 ctx.close()
