@@ -370,6 +370,22 @@ DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx
   if constexpr (P::NS <= 1) {
     wgfft_stage<P::LOGR1, SIGN, !FROM_LDS, true, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out, mid, 1);
   } else {
+    if constexpr (!MIRROR) {
+      // (this form -- the middle stages as an unrolled loop -- is kept for every pass that does not use MIRROR: written as the
+      //  constexpr chain below, the fused inverse pass k_inv_chan<12, 1, 2> came out with 28 bytes of scratch per lane and ran 15 %
+      //  slower, profiles/r05_experiments.txt item 7)
+      wgfft_stage<4, SIGN, !FROM_LDS, false, STAGED>(lds, ltw_off, tid, logT, LOGF, 0, x, out, mid, 1);
+      int logP = 4;
+      uint32_t toff = ltw_off + (4u << (LOGF - 4));
+#pragma unroll
+      for (int j = 1; j < P::NQ - (P::REM ? 0 : 1); j++) {
+        wgfft_stage<4, SIGN, false, false, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out, mid, j + 1);
+        logP += 4;
+        toff += 4u << (LOGF - logP);
+      }
+      if constexpr (P::REM != 0) wgfft_stage<P::REM, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out, mid, P::NS);
+      else wgfft_stage<4, SIGN, false, true, STAGED>(lds, toff, tid, logT, LOGF, logP, x, out, mid, P::NS);
+    } else {
     // radix-16 stages between the first and the last: at most two (LOGF <= 13); the one in front of a MIRROR stage writes ILV
     constexpr int NMID = P::NQ - (P::REM ? 0 : 1) - 1;
     static_assert(NMID >= 0 && NMID <= 2, "wgfft: at most four stages");
@@ -388,6 +404,7 @@ DEV void wgfft(cf* lds, const uint32_t ltw_off, uint32_t tid, const int logT, cx
     }
     if constexpr (P::REM != 0) wgfft_stage<P::REM, SIGN, false, true, STAGED, MIRROR>(lds, toff, tid, logT, LOGF, logP, x, out, mid, P::NS);
     else wgfft_stage<4, SIGN, false, true, STAGED, MIRROR>(lds, toff, tid, logT, LOGF, logP, x, out, mid, P::NS);
+    }
   }
 }
 template <int LOGF, int SIGN, bool STAGED = false, bool FROM_LDS = false, bool MIRROR = false, class Out>
