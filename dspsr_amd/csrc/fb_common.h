@@ -546,5 +546,9 @@ cf* fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t n
 void fb_launch_time_combine(hipStream_t stream, const TimeCombine& p, const FbOut& out, uint32_t R, uint32_t ncu);
 void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, cf* Rt, uint64_t part0);
+// non-convolving filterbank, freq_res = 1 (fb_plain.hip): kernel choice + dynamic-LDS limit at create time, one launch per call
+int fb_plain_check(dspsr_amd_ctx* ctx, int logC, bool real_input, uint32_t npol, size_t* lds_bytes);
+int fb_plain_launch(dspsr_amd_ctx* ctx, int logC, bool real_input, uint32_t npol, uint32_t input_nchan, const cf* kern,
+                    const FbIn& in, const FbOut& out, uint64_t in_chan_stride, uint64_t npart);
 
 }  // namespace dspsr_amd

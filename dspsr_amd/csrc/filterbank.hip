@@ -57,6 +57,7 @@ struct dspsr_amd_filterbank_impl {
   // freq_res = 3 * 2^k / 5 * 2^k (msub = 3, 5; see k_time_combine): g and everything above describe the INNER filterbank of
   // nchan_subband * msub pseudo-channels with freq_res / msub bins and the whole transform kept; cfg and these the caller's
   uint32_t msub = 0, out_C = 0, out_M = 0, out_nfilt_pos = 0, out_nkeep = 0;
+  int plain_logC = -1;       // >= 0: freq_res = 1, the non-convolving filterbank (fb_plain.hip): no scratch, one launch per call
   cf* Xp = nullptr;          // the combined spectrum in pseudo-channel order (k_sub_combine writes it there)
   cf* Y = nullptr;           // the pseudo-channels' time series of one launch group [pseudo-channel][pol][part][freq_res / msub]
   size_t Xp_elems = 0, Y_elems = 0;
@@ -92,6 +93,41 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   // exp(+2 pi i r n / freq_res) -- the decimation-in-frequency form of the freq_res-point backward transform.
   // (odd factors up to ODD_MAX = 127 of either length; both lengths at once as long as the product of the two factors stays within it)
   auto odd_part = [](uint32_t v) { while (v && !(v & 1)) v >>= 1; return v; };
+  if (cfg->freq_res == 1) {
+    // the non-convolving filterbank (Filterbank.C:614-623, `dspsr -F N`): nchan_subband-point forward transforms, bin k of a part
+    // is the part's one output sample of channel k
+    if (cfg->nfilt_pos || cfg->nfilt_neg)
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nfilt_pos+nfilt_neg=%u >= freq_res=1",
+                     cfg->nfilt_pos + cfg->nfilt_neg);
+    if (!ispow2(cfg->nchan_subband) || cfg->nchan_subband < 2 || cfg->nchan_subband > (1u << MAX_LOGF))
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: freq_res=1 (non-convolving filterbank) needs nchan_subband=%u "
+                     "to be a power of two in [2, %u]", cfg->nchan_subband, 1u << MAX_LOGF);
+    if (cfg->input_nchan == 0) return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: input_nchan=0");
+    const int logC = ilog2(cfg->nchan_subband);
+    const int rc = fb_plain_check(ctx, logC, cfg->real_input != 0, cfg->npol, nullptr);
+    if (rc != DSPSR_AMD_OK)
+      return fb_fail(ctx, rc, "dspsr_amd_filterbank_create: no kernel for the %u-channel non-convolving filterbank", cfg->nchan_subband);
+    dspsr_amd_filterbank* fb = new dspsr_amd_filterbank;
+    fb->ctx = ctx;
+    fb->cfg = *cfg;
+    fb->plain_logC = logC;
+    fb->N = cfg->nchan_subband;
+    fb->L = cfg->real_input ? 2 * fb->N : fb->N;
+    fb->nseq = cfg->real_input ? 1 : cfg->npol;
+    fb->ncu = ctx->ncu;
+    fb->max_parts = cfg->max_parts ? cfg->max_parts : 1;
+    FbGeom& g = fb->g;
+    g = FbGeom();
+    g.real_input = cfg->real_input ? 1 : 0;
+    g.npol = cfg->npol;
+    g.C = cfg->nchan_subband;
+    g.nsub = 1;
+    g.nfilt_pos = 0;
+    g.nkeep = 1;
+    g.xstride = fb->L;
+    *out = fb;
+    return DSPSR_AMD_OK;
+  }
   // (any odd factor up to ODD_MAX: 3, 5, 7, 9, 15 have radix kernels of their own, the others -- 11, 13, 21, 25, ... -- the
   //  run-time-radix forms k_sub_combine_any / k_time_combine<0>)
   auto radix_ok = [](uint32_t r) { return (r & 1u) && r >= 3 && r <= ODD_MAX; };
@@ -102,12 +138,11 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
         cfg->freq_res / msub < 2 || cfg->force_four_pass == 1)
       return fb_fail(ctx, DSPSR_AMD_EINVAL,
                      "dspsr_amd_filterbank_create: freq_res=%u must be 2^k >= 2, or 2^k (k >= 1) times an odd number <= 127 (times the odd "
-                     "factor of nchan_subband=%u: again <= 127; freq_res=1 is the non-convolving filterbank, not built yet)",
+                     "factor of nchan_subband=%u: again <= 127)",
                      cfg->freq_res, cfg->nchan_subband);
   } else if (cfg->freq_res < 2)
     return fb_fail(ctx, DSPSR_AMD_EINVAL,
-                   "dspsr_amd_filterbank_create: freq_res=%u must be >= 2 "
-                   "(freq_res=1 is the non-convolving filterbank, not built yet)", cfg->freq_res);
+                   "dsp::Filterbank::make_preparations Response.ndat = 0 (freq_res=%u)", cfg->freq_res);
   if (cfg->nfilt_pos + cfg->nfilt_neg >= cfg->freq_res)
     return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_create: nfilt_pos+nfilt_neg=%u >= freq_res=%u",
                    cfg->nfilt_pos + cfg->nfilt_neg, cfg->freq_res);
@@ -533,6 +568,14 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
     return fb_fail(ctx, DSPSR_AMD_ESTATE, "dspsr_amd_filterbank_perform: set_kernel (Engine::setup) not called");
   if (npart == 0) return DSPSR_AMD_OK;
   const FbGeom& g = fb->g;
+  if (fb->plain_logC >= 0) {
+    if (out.kind != 0 && out.kind != 1 && out.kind != 2)
+      return fb_fail(ctx, DSPSR_AMD_EINVAL, "dspsr_amd_filterbank_perform: output kind %d has no non-convolving form", out.kind);
+    const int rc = fb_plain_launch(ctx, fb->plain_logC, g.real_input != 0, (uint32_t)g.npol, fb->cfg.input_nchan, fb->kernel, in, out,
+                                   in_chan_stride_bytes_or_floats, npart);
+    if (rc != DSPSR_AMD_OK) return fb_fail(ctx, rc, "dspsr_amd_filterbank_perform: launch of the non-convolving filterbank failed");
+    return DSPSR_AMD_OK;
+  }
   // 8-bit real dual-pol single-channel input: one 32-bit word per sample pair; regroup it per tile first
   // (k_raw_transpose) unless the rows are already long enough or the layout preconditions fail
   const bool fast8 = (in.kind == 1 || in.kind == 2) && g.real_input && g.npol == 2 && fb->cfg.input_nchan == 1 &&
@@ -1029,13 +1072,14 @@ extern "C" int dspsr_amd_filterbank_perform_search(dspsr_amd_filterbank* fb, con
 extern "C" int dspsr_amd_filterbank_npass(const dspsr_amd_filterbank* fb, int raw_input)
 {
   if (!fb) return 0;
+  if (fb->plain_logC >= 0) return 1;
   if (fb->g.four_pass) return 4;
   return fb->two_pass && raw_input ? 2 : 3;
 }
 
 extern "C" int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb)
 {
-  if (!fb || fb->msub) return 0;            // (freq_res = 3 * 2^k / 5 * 2^k: the last step is a pass of its own, k_time_combine)
+  if (!fb || fb->msub || fb->plain_logC >= 0) return 0;            // (freq_res = 3 * 2^k / 5 * 2^k: the last step is a pass of its own, k_time_combine)
   // (segment sums pay when most of the transform is kept: at -F 64:D -x 16384 only 1817 of 16384 samples are, the unfused pass
   //  writes just those, and the fused one measured 541 against 458 us per 8 parts)
   if (fb->g.four_pass)
