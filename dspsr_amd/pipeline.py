@@ -18,7 +18,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from .engine import (Context, Dedispersion, DspsrAmdError, FilterbankEngine, FoldEngine, Rescale, SampleDelay, add_fpt, copy_data_fpt,
+from .engine import (Context, ConvolutionEngine, Dedispersion, DspsrAmdError, FilterbankEngine, FoldEngine, Rescale, SampleDelay, add_fpt, copy_data_fpt,
                      dedispersion_sample_delays, eight_bit_scale, fscrunch_fpt, pscrunch_tfp, sigproc_digitize, sigproc_digitize_fpt,
                      tfp_filterbank, tscrunch_fpt)
 
@@ -44,6 +44,10 @@ class Config:
     two_pass: bool = True             # short responses (complex dual-pol input, nchan_subband * freq_res^2 == 2^27): forward and
                                       # inverse transforms in two workgroup tiles; False = the three-pass kernels (A/B runs)
     interchan_dedispersion: bool = False   # -K: remove the inter-channel dispersion delay (LoadToFold1.C:605-624)
+    convolve_when: str = "during"          # -F N:D = "during" (the response inside the filterbank, LoadToFold1.C:318-323); -F N = "after":
+                                           # non-convolving filterbank (freq_res 1), then dsp::Convolution on its channels
+                                           # (Filterbank::Config::After, FilterbankConfig.C:56, LoadToFold1.C:337-380); "never": the
+                                           # filterbank alone (no coherent dedispersion)
     record_time: bool = False              # -r: time every operation (Operation.C:90-113); each one then ends with a stream
                                            # synchronisation so that the wall times are honest (FilterbankCUDA.cu:302-303)
 
@@ -605,6 +609,81 @@ def reduce_replicas(prof, hits, integration_length, ndat_total, dist=None, rank=
     return prof, cnt[:-1].astype(np.uint32), float(length.item()), int(cnt[-1])
 
 
+class FilterbankThenConvolution:
+    """`dspsr -F N` (Filterbank::Config::After, the default of FilterbankConfig.C:56): dsp::Filterbank with freq_res = 1 -- one
+    nsub-point forward transform per output sample, no response (LoadToFold1.C:318-323 sets it only for Config::During) -- then
+    dsp::Convolution with the dedispersion response on the filterbank's channels (LoadToFold1.C:337-380, Convolution.C:338-461),
+    here the filterbank object with nchan_subband = 1 per channel.  `response` None: the filterbank alone (Config::Never /
+    no coherent dedispersion).
+
+    Presents the interface LoadToFold uses of a FilterbankEngine (perform_raw / perform_detect / perform_fold on the 8-bit block,
+    nkeep / nsamp_step / nsamp_overlap in INPUT samples), so one part here = one part of the convolution = nsamp_step filterbank
+    output samples.  The reference carries the convolution's overlap from block to block (InputBuffering); the blocks this
+    pipeline is handed overlap in the raw samples instead (block_bytes), and the filterbank recomputes those few samples."""
+
+    def __init__(self, ctx, nsub, input_nchan, npol, real_input, response, max_parts=1, parts_per_block=1,
+                 fused_fold=_lib.FUSED_AUTO):
+        import torch
+        self.torch, self.ctx = torch, ctx
+        self.front = FilterbankEngine(ctx).setup(nsub, 1, 0, 0, input_nchan, npol, real_input, None)
+        self.nchan, self.npol = nsub * input_nchan, npol
+        self.nsamp_fft_front = self.front.nsamp_fft                      # input samples per filterbank output sample
+        self.conv = None
+        if response is not None:
+            self.conv = ConvolutionEngine(ctx).setup(1, response.ndat, response.impulse_pos, response.impulse_neg, self.nchan, npol,
+                                                     False, response.kernel, max_parts=max_parts, fused_fold=fused_fold)
+            self.nkeep, self.part_out, self.ovl_out = self.conv.nkeep, self.conv.nsamp_step, self.conv.nsamp_overlap
+        else:
+            self.nkeep, self.part_out, self.ovl_out = 1, 1, 0
+        self.nsamp_step = self.part_out * self.nsamp_fft_front
+        self.nsamp_overlap = self.ovl_out * self.nsamp_fft_front
+        self.nsamp_fft = self.nsamp_step + self.nsamp_overlap
+        self.channelised = None                                           # the filterbank's output block [chan][pol][2 * ndat]
+        self._cap = parts_per_block
+
+    def _front(self, raw, layout, scale, npart):
+        ndat = npart * self.part_out + self.ovl_out
+        if self.channelised is None or self.channelised.shape[2] < 2 * ndat:
+            n = max(ndat, self._cap * self.part_out + self.ovl_out)
+            self.channelised = self.torch.empty((self.nchan, self.npol, 2 * n), dtype=self.torch.float32,
+                                                device="cuda:%d" % self.ctx.device)
+        self.front.perform_raw(raw, layout, scale, self.channelised, ndat)
+        return self.channelised
+
+    def perform_raw(self, raw, layout, scale, out, npart, out_step=None):
+        if self.conv is None:
+            return self.front.perform_raw(raw, layout, scale, out, npart, out_step)
+        x = self._front(raw, layout, scale, npart)
+        self.conv.perform(x, out, npart, 2 * self.part_out, out_step or 2 * self.nkeep)
+
+    def perform_detect(self, det, npart, state=_lib.COHERENCE, ndim=4, raw=None, layout=_lib.RAW_GENERIC, scale=1.0):
+        if self.conv is None:
+            return self.front.perform_detect(det, npart, state, ndim, raw=raw, layout=layout, scale=scale)
+        x = self._front(raw, layout, scale, npart)
+        self.conv.perform_detect(det, npart, state, ndim, inp=x, in_step=2 * self.part_out)
+
+    def perform_fold(self, fold, npart, state=_lib.COHERENCE, raw=None, layout=_lib.RAW_GENERIC, scale=1.0):
+        if self.conv is None:
+            return self.front.perform_fold(fold, npart, state, raw=raw, layout=layout, scale=scale)
+        x = self._front(raw, layout, scale, npart)
+        self.conv.perform_fold(fold, npart, state, inp=x, in_step=2 * self.part_out)
+
+    def fold_is_fused(self):
+        return (self.conv or self.front).fold_is_fused()
+
+    def npass(self, raw_input=True):
+        return 1 + (self.conv.npass(False) if self.conv is not None else 0)
+
+    def finish(self):
+        self.ctx.synchronize()
+
+    def close(self):
+        self.front.close()
+        if self.conv is not None:
+            self.conv.close()
+        self.channelised = None
+
+
 class LoadToFold:
     """One pipeline instance = one GPU = one stream (SingleThread).  `raw` blocks are int8 torch
     tensors already resident on the device (the PCIe copy is the caller's, as TransferCUDA is a
@@ -629,6 +708,13 @@ class LoadToFold:
             raise DspsrAmdError("dsp::Fold::fold no polynomial and no period specified")   # Fold.C:638-640
         if info.npol != 2:
             raise DspsrAmdError("dsp::Detection::polarimetry Cannot detect polarization when npol != 2")
+        if cfg.convolve_when not in ("during", "after", "never"):
+            raise DspsrAmdError("dspsr_amd.LoadToFold: convolve_when=%r is not one of during / after / never" % (cfg.convolve_when,))
+        if cfg.nchan % info.nchan:
+            raise DspsrAmdError("dsp::Filterbank::make_preparations output nchan=%d not a multiple of input nchan=%d"
+                                % (cfg.nchan, info.nchan))
+        if cfg.convolve_when != "during":
+            return self._init_after(device, stream, subband, dump_before)
         self.ctx = Context(device, stream)
         # kernel (host) --------------------------------------------------------------------
         self.response = Dedispersion(info.centre_frequency, info.bandwidth, cfg.dispersion_measure,
@@ -638,9 +724,6 @@ class LoadToFold:
             self.response.set_frequency_resolution(cfg.freq_res)
         self.response.match(cfg.nchan)
         r = self.response
-        if cfg.nchan % info.nchan:
-            raise DspsrAmdError("dsp::Filterbank::make_preparations output nchan=%d not a multiple of input nchan=%d"
-                                % (cfg.nchan, info.nchan))
         # engines --------------------------------------------------------------------------
         nsub = cfg.nchan // info.nchan
         kernel = r.kernel
@@ -733,6 +816,52 @@ class LoadToFold:
         self.nsamples_in = 0            # unique input samples consumed (per pol)
         self.ndat_out = 0               # output samples produced so far
         self.subints = []               # completed sub-integrations (host copies) on the writer rank
+
+    def _init_after(self, device, stream, subband, dump_before):
+        """`dspsr -F N` (Filterbank::Config::After) and the filterbank without coherent dedispersion (Config::Never): the non-convolving
+        filterbank (freq_res = 1) followed by dsp::Convolution on its output channels (LoadToFold1.C:296-380).  The response is matched
+        to the FILTERBANK'S OUTPUT observation (Convolution.C:105-130 -> Dedispersion::match(input)): cfg.nchan channels, complex,
+        dual sideband and DC centred (Filterbank.C:341-348: freq_res = 1), band swapped when the input was single-channel dual
+        sideband (:358-364; a multi-channel dual-sideband input sets nsub_swap, which Response::match does not read, Response.C:132-181)."""
+        torch, cfg, info = self.torch, self.cfg, self.info
+        if subband is not None:
+            raise DspsrAmdError("dspsr_amd.LoadToFold: sub-band sharded runs are built for -F N:D (convolve_when = during)")
+        if cfg.interchan_dedispersion or dump_before:
+            raise DspsrAmdError("dspsr_amd.LoadToFold: -K and the dump taps are built for -F N:D (convolve_when = during)")
+        self.ctx = Context(device, stream)
+        r = None
+        if cfg.convolve_when == "after":
+            r = Dedispersion(info.centre_frequency, info.bandwidth, cfg.dispersion_measure, input_nchan=cfg.nchan, ndim=2,
+                             dual_sideband=1, dc_centred=True, swap=(info.ndim == 2 and info.nchan == 1))
+            if cfg.freq_res:
+                r.set_frequency_resolution(cfg.freq_res)
+            r.match(cfg.nchan)
+        self.response = r
+        nsub = cfg.nchan // info.nchan
+        self.in_nchan, self.nchan_out = info.nchan, cfg.nchan
+        self.fb = FilterbankThenConvolution(self.ctx, nsub, info.nchan, info.npol, info.ndim == 1, r, max_parts=cfg.max_parts,
+                                            parts_per_block=cfg.parts_per_block,
+                                            fused_fold=(_lib.FUSED_NEVER if not cfg.fused_fold else
+                                                        _lib.FUSED_ALWAYS if cfg.force_fused else _lib.FUSED_AUTO))
+        self.nkeep, self.nsamp_step, self.nsamp_overlap = self.fb.nkeep, self.fb.nsamp_step, self.fb.nsamp_overlap
+        self.npol_out = 4 // cfg.ndim
+        self.fold = FoldEngine(self.ctx)
+        self.fold.set_shape(self.nchan_out, self.npol_out, cfg.ndim, cfg.nbin)
+        self.scale8 = eight_bit_scale()
+        self.layout = _lib.RAW_CASPSR if info.machine == "CASPSR" else _lib.RAW_GENERIC
+        self.out_rate = info.rate / float(self.fb.nsamp_fft_front)                       # Filterbank.C:338-339: freq_res / nsamp_fft
+        ndat = r.ndat if r is not None else 1
+        self.out_start = info.start_seconds + (r.impulse_pos if r is not None else 0) / self.out_rate   # Convolution.C:300
+        self.scalefac = float(nsub) * (float(ndat) * float(ndat) if r is not None else 1.0)            # Filterbank.C:124-125, Convolution.C:305
+        self.sample_delay, self.sd_carried, self.sd_head, self.sd_short = None, 0, 0, 0
+        self.detected = torch.empty((self.nchan_out, self.npol_out, cfg.parts_per_block * self.nkeep * cfg.ndim),
+                                    dtype=torch.float32, device="cuda:%d" % device)
+        self.fused_mode = self.fb.fold_is_fused() if (cfg.fused_fold and cfg.ndim == 4) else 0
+        self.fused_fold = self.fused_mode != 0
+        self.optime, self.dumps, self._dump_cplx = {}, {}, None
+        self.hits = np.zeros(cfg.nbin, dtype=np.uint32)
+        self.integration_length, self.ndat_total = 0.0, 0
+        self.nsamples_in, self.ndat_out, self.subints = 0, 0, []
 
     def _op(self, name, fn):
         """Operation::operate with record_time (Operation.C:90-113): wall time of the operation including its stream

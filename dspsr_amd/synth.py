@@ -48,8 +48,11 @@ def voltages(ndat, freq, bw, tsamp_us, dm, period, npol=2, ndim=1, nchan=1, sigm
             if ndim == 1:
                 x = rng.standard_normal(ndat) * env
                 X = np.fft.rfft(x)
-                # real-sampled band: baseband bin k <-> sky freq (fc - bw/2) + k*bw/ndat  (lower edge at DC)
-                f = (np.arange(X.size) / ndat) * chbw - 0.5 * chbw
+                # real-sampled band (sampling rate 2 |bw|): rfft bin k of ndat samples lies k * 2 bw / ndat from the band edge at DC,
+                # i.e. at sky frequency fc - bw/2 + 2 k bw / ndat  (round 5: the factor 2 was missing -- the band was dispersed as
+                # if it were half as wide, a quarter of the delay per MHz; parity tests compare product and oracle on the same
+                # input and did not notice, the physical test tests/test_dedispersion_physics.py does)
+                f = (np.arange(X.size) / ndat) * (2.0 * chbw) - 0.5 * chbw
             else:
                 x = (rng.standard_normal(ndat) + 1j * rng.standard_normal(ndat)) * env * np.sqrt(0.5)
                 X = np.fft.fft(x)

@@ -200,3 +200,60 @@ def test_plain_filterbank_refusals(gpu):
             dspsr_amd.FilterbankEngine(ctx).setup(kw["nchan_subband"], 1, kw["nfilt_pos"], 0)
     with pytest.raises(dspsr_amd.DspsrAmdError):
         dspsr_amd.FilterbankEngine(ctx).setup(64, 0, 0, 0)                       # Response.ndat = 0 (Filterbank.C:101-103)
+
+
+def _after_oracle(o, raw, obs, nchan, nbin, period, when, kernel=None):
+    """Oracle chain of `dspsr -F N` (Config::After): Filterbank with freq_res = 1, Dedispersion matched to ITS OUTPUT, Convolution,
+    Detection, Fold -- in float64."""
+    plan1 = o.filterbank_plan(obs, nchan, None, 1)
+    fb1 = o.filterbank(o.unpack_8bit(raw, obs), plan1, None, dtype=np.float64)
+    obs1 = o.filterbank_output_observation(obs, plan1)
+    fobs = o.Observation(**obs1.__dict__)
+    resp = None
+    if when == "after":
+        resp = o.Dedispersion().match(obs1)
+        if kernel is not None:
+            # the product's host-built chirp (std::polar(float)) == the oracle's (float64 cos / sin, rounded) to one ulp
+            assert np.abs(resp.buffer - kernel).max() <= 1.2e-7
+        fb1 = o.convolution(np.ascontiguousarray(fb1).view(np.float64), resp.ndat, resp.impulse_pos, resp.impulse_neg, resp.buffer, False,
+                            dtype=np.float64)
+        fobs.start_seconds += resp.impulse_pos / fobs.rate         # Convolution.C:300
+    det = o.detect_layout(o.detect_products(fb1, "Coherence"), 4)
+    return det, fobs, resp
+
+
+@pytest.mark.parametrize("when", ["after", "never"])
+@pytest.mark.parametrize("machine", ["DADA", "CASPSR"])
+def test_pipeline_filterbank_then_convolution(oracle, gpu, when, machine):
+    """`dspsr -F 16` on a dispersed pulsed signal: non-convolving filterbank, then dsp::Convolution per channel with the response matched
+    to the filterbank's output (DC-centred dual-sideband channels), Detection, Fold -- several blocks, against the float64 oracle."""
+    dspsr_amd, _ = gpu
+    from dspsr_amd import pipeline, synth
+    o = oracle
+    freq, bw, tsamp, dm, period, nchan, nbin = 1382.0, -16.0, 1.0 / 32.0, 30.0, 0.004, 16, 64
+    cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=4, parts_per_block=3,
+                          max_parts=2, convolve_when=when)
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, machine=machine)
+    lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    nblocks = 3
+    step = cfg.parts_per_block * lt.nsamp_step
+    ndat = nblocks * step + lt.nsamp_overlap
+    ndat += (-ndat) % 4                                           # (CASPSR blocks hold whole groups of four samples)
+    raw = synth.voltages(ndat, freq, bw, tsamp, dm, period, layout="caspsr" if machine == "CASPSR" else "generic")
+    d_raw = torch.from_numpy(raw).cuda()
+    for b in range(nblocks):
+        lt.process_block(d_raw[2 * b * step: 2 * (b * step + step + lt.nsamp_overlap)])
+    lt.finish_subint()
+    lt.synchronize()
+    got = lt.subints[0]["profile_dev"].cpu().numpy().reshape(nchan, 1, nbin, 4)
+    obs = o.Observation(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, dispersion_measure=dm, machine=machine)
+    det, fobs, resp = _after_oracle(o, raw, obs, nchan, nbin, period, when, lt.response.kernel if when == "after" else None)
+    ps = o.PhaseSeries(nchan, 1, 4, nbin, data=np.zeros((nchan, 1, nbin, 4), np.float64))
+    fcfg = o.FoldConfig(nbin=nbin, folding_period=period)
+    per_block = cfg.parts_per_block * lt.nkeep
+    for b in range(nblocks):
+        o.fold(det, fobs, fcfg, ps, idat_start=b * per_block, ndat_fold=per_block)
+    assert np.array_equal(lt.subints[0]["hits"], ps.hits)
+    assert np.abs(got - ps.data).max() <= 1e-5 * np.abs(ps.data).max()
+    assert abs(lt.out_rate - fobs.rate) <= 1e-9 * fobs.rate and abs(lt.out_start - fobs.start_seconds) <= 1e-12
+    lt.close()
