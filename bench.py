@@ -83,6 +83,12 @@ WORKLOADS = {
                   machine="DADA", tscrunch=16, nparts=64, max_parts=32,
                   cmd="digifil -F 1024:D -x 4096 -D 1000 -t 16 -b 8 (convolving filterbank + square law + tscrunch in one launch group, "
                       "Rescale + 8-bit digitizer; no fold)"),
+    # `dspsr -F 128` without `:D` (Filterbank::Config::After, the default of FilterbankConfig.C:56): the non-convolving filterbank
+    # (freq_res = 1, csrc/fb_plain.hip), then dsp::Convolution with the dedispersion response on its 128 channels (the filterbank
+    # object with nchan_subband = 1: four tile passes at this response length), Detection, Fold
+    "after": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=128, dm=67.99, freq_res=65536, nbin=512,
+                  machine="CASPSR", when="after", parts_per_block=32, max_parts=32,
+                  cmd="dspsr -F 128 -x 65536 -D 67.99 -b 512 (filterbank, THEN convolution: Config::After; header.dada band, vela.par DM)"),
     # the reference's fold benchmark (Benchmark/fold.csh on Benchmark/fold_header.dada): already-detected input, 1024
     # channels x 4 polarisation products at 32 us, folded with vela.polyco -- dsp::Fold alone
     "fold": dict(freq=1382.0, bw=-400.0, in_nchan=1024, ndim=1, tsamp_us=32.0, nchan=1024, dm=0.0, freq_res=1, nbin=0,
@@ -791,7 +797,7 @@ def make_fold_pipeline(name, args, torch, rank, world, local_rank):
         sys.exit("bench.py: workload %s has %d sub-bands, --gpus %d is more" % (name, wl["in_nchan"], world))
     info = pipeline.InputInfo(centre_frequency=wl["freq"], bandwidth=wl["bw"], nchan=wl["in_nchan"], npol=2,
                               ndim=wl["ndim"], tsamp_us=wl["tsamp_us"], machine=wl["machine"])
-    parts_per_block, max_parts = args.parts_per_block, args.max_parts
+    parts_per_block, max_parts = args.parts_per_block or wl.get("parts_per_block", 0), args.max_parts or wl.get("max_parts", 0)
     n_fft = (wl["nchan"] // wl["in_nchan"]) * wl["freq_res"]
     if not parts_per_block:
         nsamp_fft = 2 * n_fft if wl["ndim"] == 1 else n_fft
@@ -805,7 +811,8 @@ def make_fold_pipeline(name, args, torch, rank, world, local_rank):
     cfg = pipeline.Config(nchan=wl["nchan"], dispersion_measure=wl["dm"], nbin=wl["nbin"],
                           folding_period=0.0893, freq_res=wl["freq_res"], ndim=args.ndim,
                           parts_per_block=parts_per_block, max_parts=max_parts,
-                          fused_fold=not args.no_fused_fold, two_pass=not getattr(args, "no_two_pass", False))
+                          fused_fold=not args.no_fused_fold, two_pass=not getattr(args, "no_two_pass", False),
+                          convolve_when=wl.get("when", "during"))
     lt = pipeline.LoadToFold(cfg, info, device=local_rank, stream=torch.cuda.current_stream().cuda_stream,
                              subband=rank if sharded else None)
 
@@ -942,7 +949,10 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
         npass = lt.fb.npass(True)
         group = {2: ("k_raw_cols+k_fwd_col1+k_rows_inv<.,.,false>", "k_raw_cols+k_fwd_col1+k_rows_inv<.,.,true>"),
                  3: ("k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,false>", "k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,true>"),
-                 4: ("k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b", "k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b<.,true>+k_fold_segsum")}[npass]
+                 4: ("k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b", "k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b<.,true>+k_fold_segsum"),
+                 # Config::After: the non-convolving filterbank, then the convolution's passes on float rows
+                 5: ("k_fb_plain+k_float_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b", "k_fb_plain+k_float_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b<.,true>+k_fold_segsum"),
+                 }.get(npass, ("%d tile passes" % npass,) * 2)
         exch = ("dspsr_amd_reduce_profiles_* (RCCL behind the C-ABI, csrc/comm.hip), snapshot on the compute stream, collective "
                 "on its own stream" if rccl is not None else
                 "torch.distributed (gloo rehearsal on one device)" if world > 1 and single else
@@ -1020,7 +1030,7 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
                 "note": "the same blocks copied from pinned host memory (%.1f MB each) on a second stream, double buffered, "
                         "overlapped with the kernels; `value` above is for blocks already resident in HBM" % (raw.numel() / 1e6)}
             del host
-        if full and world == 1 and not args.no_cpu_baseline:
+        if full and world == 1 and not args.no_cpu_baseline and "when" not in wl:
             geom = {"freq_res": r.ndat, "nkeep": lt.nkeep, "nsamp_step": lt.nsamp_step, "nsamp_overlap": lt.nsamp_overlap,
                     "nfilt_pos": r.impulse_pos, "kernel": r.kernel, "scale8": lt.scale8, "out_rate": lt.out_rate}
             try:
@@ -1137,7 +1147,7 @@ def main():
                                                 "replicas so that N = 1 agrees with the single-GPU record" % world)
         if world == 1:
             others = []
-            for w in ("cfg1", "cfg1opt", "cfg2", "cfg3", "odd_nchan", "odd_fres"):
+            for w in ("cfg1", "cfg1opt", "cfg2", "cfg3", "odd_nchan", "odd_fres", "after"):
                 others.append(brief(run_fold_workload(w, short, *ctx, steps=2 * ssteps, warmup=swarm, full=False)))
             sm = argparse.Namespace(**vars(args))
             sm.steps, sm.warmup, sm.no_cpu_baseline = 2 * ssteps, swarm, True

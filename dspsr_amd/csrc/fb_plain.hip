@@ -28,39 +28,22 @@ struct PlainParams {
   int logT;                 // columns per tile
 };
 
-// one complex sample of polarisation `seq` at time t (complex input): up to two raw words
-DEV void plain_fetch1(const FbGeom& g, const FbIn& in, const uint32_t seq, const uint64_t t, uint32_t& w0, uint32_t& w1)
-{
-  w0 = w1 = 0u;
-  if (in.kind == 0) {
-    const float* x = (const float*)in.base + seq * in.pol_stride + 2 * t;
-    w0 = __float_as_uint(x[0]); w1 = __float_as_uint(x[1]);
-  } else if (in.kind == 4) {                              // UWB: word (block*npol + pol)*2048 + t%2048 = (re, im) int16
-    w0 = ((const uint32_t*)in.base)[((t >> 11) * g.npol + seq) * 2048 + (t & 2047)];
-  } else {                                                // generic 8-bit complex: ((t*nchan+c)*npol+p)*2+d
-    const uint8_t* b = (const uint8_t*)in.base + ((t * in.nchan + in.ichan) * g.npol + seq) * 2;
-    if ((((uintptr_t)in.base) & 1) == 0) w0 = *(const uint16_t*)b;
-    else w0 = (uint32_t)b[0] | ((uint32_t)b[1] << 8);
-  }
-}
-DEV cf plain_decode1(const FbIn& in, const uint32_t w0, const uint32_t w1)
-{
-  if (in.kind == 0) return make_float2(__uint_as_float(w0), __uint_as_float(w1));
-  if (in.kind == 4) return make_float2((float)(int16_t)((w0 & 0xffff) ^ 0x8000) * in.scale, (float)(int16_t)((w0 >> 16) ^ 0x8000) * in.scale);
-  return make_float2(cvt8((int8_t)(w0 & 0xff), in.scale), cvt8((int8_t)((w0 >> 8) & 0xff), in.scale));
-}
-// real single-polarisation input: samples t, t + 1 as two raw words
-DEV void plain_fetch_r1(const FbGeom& g, const FbIn& in, const uint64_t t, uint32_t& w0, uint32_t& w1)
-{
-  if (in.kind == 0) {
-    const float* x = (const float*)in.base + t;
-    w0 = __float_as_uint(x[0]); w1 = __float_as_uint(x[1]);
-  } else {                                                // generic 8-bit real, one polarisation: byte t*nchan + c
-    const uint8_t* b = (const uint8_t*)in.base + t * in.nchan + in.ichan;
-    w0 = b[0]; w1 = b[in.nchan];
-  }
-}
-DEV float plain_decode_r1(const FbIn& in, const uint32_t w) { return in.kind == 0 ? __uint_as_float(w) : cvt8((int8_t)(w & 0xff), in.scale); }
+// Input forms, decided ONCE per kernel (uniform) so that the loads of a tile are one straight-line burst: with the form looked up
+// per element (fetch_pair's chain of tests) every load sat behind a branch and a `s_waitcnt vmcnt(0)` -- sixteen dependent
+// round trips per tile, 13 us per tile where the transform needs 3 (profiles/r05_experiments.txt item 8).
+//   real, two polarisations (MODE 0):  F_WORD   generic 8-bit, one input channel, 4-byte aligned block: (p0, p1)[t], (p0, p1)[t+1] = one word
+//                                      F_CASPSR 4 B pol0 | 4 B pol1: two half words
+//                                      F_FLOAT  float32 rows
+//                                      F_BYTES  generic 8-bit, any channel count / alignment: four bytes
+//   real, one polarisation (MODE 1):   F_FLOAT, F_BYTES
+//   complex (MODE 2):                  F_FLOAT (re, im) pairs, F_UWB 16-bit offset binary, F_HALF generic 8-bit (re, im) as one half word
+//                                      (2-byte aligned block), F_BYTES
+enum { F_WORD = 0, F_CASPSR, F_FLOAT, F_BYTES, F_UWB, F_HALF };
+
+// points per workgroup tile: 2^13 (256 threads, two workgroups per compute unit) up to 256 channels, 2^14 above (runs of 128 bytes
+// per channel row at 512 channels, 64 at 1024: measured 2.26 -> see profiles/r05_experiments.txt item 8); at most 512 columns (the staged image must fit the exchange buffer).  A function of the channel
+// count alone, so the column count is a compile-time constant of every instantiation (LDS addresses fold into immediates).
+constexpr int plain_log_points(int logC) { return (logC <= 8 ? 13 : 14) < logC + 9 ? (logC <= 8 ? 13 : 14) : logC + 9; }
 
 // MODE 0: real input, two polarisations (column pair = the two polarisations of one part)
 //      1: real input, one polarisation  (column pair = two consecutive parts)
@@ -71,10 +54,10 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
   typedef FftPlan<LOGF> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
-  const uint32_t nt = blockDim.x;
-  const int logT = p.logT, loghT = logT - 1;
+  constexpr int logT = plain_log_points(LOGF) - LOGF, loghT = logT - 1;
+  constexpr uint32_t nt = 1u << (plain_log_points(LOGF) - LOG_PTS);
   constexpr uint32_t C = 1u << LOGF;
-  const uint32_t T = 1u << logT, hT = T >> 1;
+  constexpr uint32_t T = 1u << logT, hT = T >> 1;
   const bool two_pol = p.g.npol == 2;                                     // uniform
   const uint32_t tile_parts = two_pol ? hT : T;
   const uint32_t ntile = (uint32_t)((p.npart + tile_parts - 1) / tile_parts);
@@ -84,42 +67,184 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
   // time samples (real: of the 2C-sample part; complex: of the C-sample part) between parts
   const uint64_t step = p.in.part_step;
 
-  auto in_of = [&](const uint32_t ichan) {
-    FbIn ci = p.in;
-    ci.ichan = ichan;
-    if (ci.kind == 0) ci.base = (const float*)p.in.base + (uint64_t)ichan * p.in_chan_stride;
-    return ci;
-  };
+  // the input form (uniform)
+  int form;
+  if (MODE == 0) form = p.in.kind == 0 ? F_FLOAT : p.in.kind == 2 ? F_CASPSR : (p.in.nchan == 1 && (((uintptr_t)p.in.base) & 3) == 0) ? F_WORD : F_BYTES;
+  else if (MODE == 1) form = p.in.kind == 0 ? F_FLOAT : F_BYTES;
+  else form = p.in.kind == 0 ? F_FLOAT : p.in.kind == 4 ? F_UWB : (((uintptr_t)p.in.base) & 1) == 0 ? F_HALF : F_BYTES;
+  const uint64_t last_part = p.npart - 1;
+  // columns of element (g2, i) of this thread: pair index, position; the parts of a ragged last tile are clamped to the last part
+  // (loaded again, never stored), so no load is conditional
   auto fetch = [&](const uint32_t item, Raw4 (&raw)[NPAIR]) {
     const uint32_t tile = item % ntile, ichan = item / ntile;
-    const FbIn ci = in_of(ichan);
+    uint64_t pa[NPAIR], pb[NPAIR];                                        // first sample of the pair's two columns (in input samples)
 #pragma unroll
     for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
       for (int i = 0; i < P::R1; i++) {
         const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
         const uint32_t col = e & (T - 1), n = e >> logT;
-        Raw4& r = raw[(g2 / 2) * P::R1 + i];
-        r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0u;
+        const int h = (g2 / 2) * P::R1 + i;
+        const uint32_t nn = MODE == 2 ? n : 2 * n;
         if (two_pol) {
-          const uint64_t part = (uint64_t)tile * hT + (col >> 1);
-          if (part >= p.npart) continue;
-          if constexpr (MODE == 0) r = fetch_pair<4>(p.g, ci, 0, part * step + 2ull * n);
-          else if constexpr (MODE == 2) {
-            plain_fetch1(p.g, ci, 0, part * step + n, r.w[0], r.w[1]);
-            plain_fetch1(p.g, ci, 1, part * step + n, r.w[2], r.w[3]);
+          uint64_t part = (uint64_t)tile * hT + (col >> 1);
+          part = part < last_part ? part : last_part;
+          pa[h] = pb[h] = part * step + nn;
+        } else {
+          uint64_t part = (uint64_t)tile * T + col;
+          const uint64_t p0 = part < last_part ? part : last_part, p1 = part + 1 < last_part ? part + 1 : last_part;
+          pa[h] = p0 * step + nn;
+          pb[h] = p1 * step + nn;
+        }
+      }
+    if constexpr (MODE == 0) {
+      if (form == F_WORD) {
+        const uint8_t* b = (const uint8_t*)p.in.base;
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) raw[h].w[0] = *(const uint32_t*)(b + 2 * pa[h]);
+      } else if (form == F_CASPSR) {
+        const uint8_t* b = (const uint8_t*)p.in.base;
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) {
+          const uint8_t* q = b + (pa[h] >> 2) * 8 + (pa[h] & 3);
+          raw[h].w[0] = *(const uint16_t*)q;
+          raw[h].w[1] = *(const uint16_t*)(q + 4);
+        }
+      } else if (form == F_FLOAT) {
+        const float* x = (const float*)p.in.base + (uint64_t)ichan * p.in_chan_stride;
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) {
+          const float* q = x + pa[h];
+          raw[h].w[0] = __float_as_uint(q[0]); raw[h].w[1] = __float_as_uint(q[1]);
+          raw[h].w[2] = __float_as_uint(q[p.in.pol_stride]); raw[h].w[3] = __float_as_uint(q[p.in.pol_stride + 1]);
+        }
+      } else {
+        const uint64_t skip = (uint64_t)p.in.nchan * 2;
+        const uint8_t* b = (const uint8_t*)p.in.base + (uint64_t)ichan * 2;
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) {
+          const uint8_t* q = b + pa[h] * skip;
+          raw[h].w[0] = q[0]; raw[h].w[1] = q[1]; raw[h].w[2] = q[skip]; raw[h].w[3] = q[skip + 1];
+        }
+      }
+    } else if constexpr (MODE == 1) {
+      if (form == F_FLOAT) {
+        const float* x = (const float*)p.in.base + (uint64_t)ichan * p.in_chan_stride;
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) {
+          raw[h].w[0] = __float_as_uint(x[pa[h]]); raw[h].w[1] = __float_as_uint(x[pa[h] + 1]);
+          raw[h].w[2] = __float_as_uint(x[pb[h]]); raw[h].w[3] = __float_as_uint(x[pb[h] + 1]);
+        }
+      } else {
+        const uint64_t skip = p.in.nchan;
+        const uint8_t* b = (const uint8_t*)p.in.base + ichan;
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) {
+          raw[h].w[0] = b[pa[h] * skip]; raw[h].w[1] = b[(pa[h] + 1) * skip];
+          raw[h].w[2] = b[pb[h] * skip]; raw[h].w[3] = b[(pb[h] + 1) * skip];
+        }
+      }
+    } else {
+      // complex input: the pair's columns are (pol 0, pol 1) of one part, or pol 0 of two parts
+      const uint32_t sb = two_pol ? 1u : 0u;
+      if (form == F_FLOAT) {
+        const float* x = (const float*)p.in.base + (uint64_t)ichan * p.in_chan_stride;
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) {
+          const float* qa = x + 2 * pa[h];
+          const float* qb = x + sb * p.in.pol_stride + 2 * pb[h];
+          raw[h].w[0] = __float_as_uint(qa[0]); raw[h].w[1] = __float_as_uint(qa[1]);
+          raw[h].w[2] = __float_as_uint(qb[0]); raw[h].w[3] = __float_as_uint(qb[1]);
+        }
+      } else if (form == F_UWB) {                          // word (block * npol + pol) * 2048 + t % 2048 = (re, im) int16
+        const uint32_t* b = (const uint32_t*)p.in.base;
+        const uint32_t np = (uint32_t)p.g.npol;
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) {
+          raw[h].w[0] = b[((pa[h] >> 11) * np) * 2048 + (pa[h] & 2047)];
+          raw[h].w[2] = b[((pb[h] >> 11) * np + sb) * 2048 + (pb[h] & 2047)];
+        }
+      } else {                                              // generic 8-bit complex: ((t * nchan + c) * npol + p) * 2 + d
+        const uint64_t skip = (uint64_t)p.in.nchan * p.g.npol * 2;
+        const uint8_t* b = (const uint8_t*)p.in.base + (uint64_t)ichan * p.g.npol * 2;
+        if (form == F_HALF) {
+#pragma unroll
+          for (int h = 0; h < NPAIR; h++) {
+            raw[h].w[0] = *(const uint16_t*)(b + pa[h] * skip);
+            raw[h].w[2] = *(const uint16_t*)(b + pb[h] * skip + 2 * sb);
           }
         } else {
-          const uint64_t pa = (uint64_t)tile * T + col;
-          if constexpr (MODE == 1) {
-            if (pa < p.npart) plain_fetch_r1(p.g, ci, pa * step + 2ull * n, r.w[0], r.w[1]);
-            if (pa + 1 < p.npart) plain_fetch_r1(p.g, ci, (pa + 1) * step + 2ull * n, r.w[2], r.w[3]);
-          } else if constexpr (MODE == 2) {
-            if (pa < p.npart) plain_fetch1(p.g, ci, 0, pa * step + n, r.w[0], r.w[1]);
-            if (pa + 1 < p.npart) plain_fetch1(p.g, ci, 0, (pa + 1) * step + n, r.w[2], r.w[3]);
+#pragma unroll
+          for (int h = 0; h < NPAIR; h++) {
+            const uint8_t* qa = b + pa[h] * skip;
+            const uint8_t* qb = b + pb[h] * skip + 2 * sb;
+            raw[h].w[0] = (uint32_t)qa[0] | ((uint32_t)qa[1] << 8);
+            raw[h].w[2] = (uint32_t)qb[0] | ((uint32_t)qb[1] << 8);
           }
         }
       }
+    }
+  };
+  const float scale = p.in.scale;
+  auto decode = [&](const Raw4 (&raw)[NPAIR], cx2 (&x)[NPAIR]) {
+    if constexpr (MODE == 0) {
+      if (form == F_WORD) {
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) {
+          const uint32_t w = raw[h].w[0];                     // (p0[2n], p1[2n], p0[2n+1], p1[2n+1]) = (Re z0, Re z1, Im z0, Im z1)
+          x[h].x = (v2f){cvt8((int8_t)(w & 0xff), scale), cvt8((int8_t)((w >> 8) & 0xff), scale)};
+          x[h].y = (v2f){cvt8((int8_t)((w >> 16) & 0xff), scale), cvt8((int8_t)(w >> 24), scale)};
+        }
+      } else if (form == F_CASPSR) {
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) {
+          const uint32_t w0 = raw[h].w[0], w1 = raw[h].w[1];  // (p0[2n], p0[2n+1]), (p1[2n], p1[2n+1])
+          x[h].x = (v2f){cvt8((int8_t)(w0 & 0xff), scale), cvt8((int8_t)(w1 & 0xff), scale)};
+          x[h].y = (v2f){cvt8((int8_t)((w0 >> 8) & 0xff), scale), cvt8((int8_t)((w1 >> 8) & 0xff), scale)};
+        }
+      } else if (form == F_FLOAT) {
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) {
+          x[h].x = (v2f){__uint_as_float(raw[h].w[0]), __uint_as_float(raw[h].w[2])};
+          x[h].y = (v2f){__uint_as_float(raw[h].w[1]), __uint_as_float(raw[h].w[3])};
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) {                     // bytes (p0[2n], p1[2n], p0[2n+1], p1[2n+1])
+          x[h].x = (v2f){cvt8((int8_t)raw[h].w[0], scale), cvt8((int8_t)raw[h].w[1], scale)};
+          x[h].y = (v2f){cvt8((int8_t)raw[h].w[2], scale), cvt8((int8_t)raw[h].w[3], scale)};
+        }
+      }
+    } else if constexpr (MODE == 1) {
+#pragma unroll
+      for (int h = 0; h < NPAIR; h++) {                       // (xa[2n], xa[2n+1], xb[2n], xb[2n+1]) of parts a, b
+        if (form == F_FLOAT) {
+          x[h].x = (v2f){__uint_as_float(raw[h].w[0]), __uint_as_float(raw[h].w[2])};
+          x[h].y = (v2f){__uint_as_float(raw[h].w[1]), __uint_as_float(raw[h].w[3])};
+        } else {
+          x[h].x = (v2f){cvt8((int8_t)raw[h].w[0], scale), cvt8((int8_t)raw[h].w[2], scale)};
+          x[h].y = (v2f){cvt8((int8_t)raw[h].w[1], scale), cvt8((int8_t)raw[h].w[3], scale)};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < NPAIR; h++) {
+        cf a, b;
+        if (form == F_FLOAT) {
+          a = make_float2(__uint_as_float(raw[h].w[0]), __uint_as_float(raw[h].w[1]));
+          b = make_float2(__uint_as_float(raw[h].w[2]), __uint_as_float(raw[h].w[3]));
+        } else if (form == F_UWB) {                           // convert_offset_binary, UWBUnpackerCUDA.cu:24
+          const uint32_t wa = raw[h].w[0], wb = raw[h].w[2];
+          a = make_float2((float)(int16_t)((wa & 0xffff) ^ 0x8000) * scale, (float)(int16_t)((wa >> 16) ^ 0x8000) * scale);
+          b = make_float2((float)(int16_t)((wb & 0xffff) ^ 0x8000) * scale, (float)(int16_t)((wb >> 16) ^ 0x8000) * scale);
+        } else {
+          const uint32_t wa = raw[h].w[0], wb = raw[h].w[2];
+          a = make_float2(cvt8((int8_t)(wa & 0xff), scale), cvt8((int8_t)((wa >> 8) & 0xff), scale));
+          b = make_float2(cvt8((int8_t)(wb & 0xff), scale), cvt8((int8_t)((wb >> 8) & 0xff), scale));
+        }
+        x[h] = make_cx2(a, b);
+      }
+    }
   };
 
   uint32_t item, next;
@@ -134,26 +259,9 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
   for (;;) {
     asm volatile("" : "+v"(tid));
     cx2 x[NPAIR];
-    {
-      const FbIn ci = in_of(item / ntile);
-#pragma unroll
-      for (int h = 0; h < NPAIR; h++) {
-        if constexpr (MODE == 0) {
-          cf a, b;
-          decode_pair<4>(p.g, ci, raw[h], a, b, 0);             // a = (x0[2n], x1[2n]), b = (x0[2n+1], x1[2n+1])
-          x[h].x = (v2f){a.x, a.y};
-          x[h].y = (v2f){b.x, b.y};
-        } else if constexpr (MODE == 1) {
-          x[h].x = (v2f){plain_decode_r1(ci, raw[h].w[0]), plain_decode_r1(ci, raw[h].w[2])};
-          x[h].y = (v2f){plain_decode_r1(ci, raw[h].w[1]), plain_decode_r1(ci, raw[h].w[3])};
-        } else {
-          const cf a = plain_decode1(ci, raw[h].w[0], raw[h].w[1]), b = plain_decode1(ci, raw[h].w[2], raw[h].w[3]);
-          x[h] = make_cx2(a, b);
-        }
-      }
-    }
+    decode(raw, x);
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++jrun, 8u, total, next);
-    if (more) fetch(next, raw);
+    fetch(more ? next : item, raw);      // unconditional: a conditional prefetch is waited for where it is issued (fb_inv_chan.h)
 
     auto store = [&](const uint32_t col, const uint32_t pp, const uint32_t pstride, auto& v) {
       constexpr int R = sizeof(v) / sizeof(v[0]);
@@ -203,11 +311,17 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
       }
     };
     if constexpr (MODE == 2) {
-      const uint32_t nitem = C << loghT;
-      for (uint32_t idx = tid; idx < nitem; idx += nt) {
-        const uint32_t j = idx & (hT - 1), k = idx >> loghT;
-        const float4 z = stg[j * plane + k];
-        emit(k, j, make_float2(z.x, z.z), make_float2(z.y, z.w));
+      constexpr int NIT = (int)((C << loghT) / nt);                       // 16 bins of a pair per thread
+      float4 z[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const uint32_t idx = tid + it * nt;
+        z[it] = stg[(idx & (hT - 1)) * plane + (idx >> loghT)];
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const uint32_t idx = tid + it * nt;
+        emit(idx >> loghT, idx & (hT - 1), make_float2(z[it].x, z[it].z), make_float2(z[it].y, z[it].w));
       }
     } else {
       // X[k] = A + w^k B, X[C-k] = conj(A - w^k B);  A = (Z[k] + conj Z[C-k]) / 2, B = (Z[k] - conj Z[C-k]) / 2i, w = exp(-i pi / C)
@@ -219,20 +333,28 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
         const v2f wr = c * br + sn * bi, wi = c * bi - sn * br;            // w^k = (c, -sn)
         xr = ar + wr; xi = ai + wi; yr = ar - wr; yi = wi - ai;
       };
-      const uint32_t nitem = (C / 2) << loghT;
-      for (uint32_t idx = tid; idx < nitem; idx += nt) {
-        const uint32_t j = idx & (hT - 1), kp = idx >> loghT;
+      // (C/2 * hT bin pairs on nt = C * T / 32 threads: eight per thread -- all sixteen LDS reads first, then the arithmetic)
+      constexpr int NIT = (int)(((C / 2) << loghT) / nt);
+      float4 zk[NIT], zm[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const uint32_t idx = tid + it * nt, j = idx & (hT - 1), kp = idx >> loghT;
+        zk[it] = stg[j * plane + kp];
+        zm[it] = stg[j * plane + (kp ? C - kp : C / 2)];
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const uint32_t idx = tid + it * nt, j = idx & (hT - 1), kp = idx >> loghT;
         v2f xr, xi, yr, yi;
         if (kp == 0) {               // bins 0 and C/2 are their own mirrors: X[0] from Z[0] (w = 1), X[C/2] from Z[C/2] (w = -i)
-          const float4 z0 = stg[j * plane], zh = stg[j * plane + C / 2];
           v2f ur, ui;
-          split(z0, z0, 1.0f, 0.0f, xr, xi, ur, ui);
+          split(zk[it], zk[it], 1.0f, 0.0f, xr, xi, ur, ui);
           emit(0, j, make_float2(xr[0], xi[0]), make_float2(xr[1], xi[1]));
-          split(zh, zh, 0.0f, 1.0f, yr, yi, ur, ui);
+          split(zm[it], zm[it], 0.0f, 1.0f, yr, yi, ur, ui);
           emit(C / 2, j, make_float2(yr[0], yi[0]), make_float2(yr[1], yi[1]));
         } else {
           const float xa = (float)kp * __uint_as_float((uint32_t)(127 - (LOGF + 1)) << 23);       // k / 2C revolutions, exact
-          split(stg[j * plane + kp], stg[j * plane + (C - kp)], __builtin_amdgcn_cosf(xa), __builtin_amdgcn_sinf(xa), xr, xi, yr, yi);
+          split(zk[it], zm[it], __builtin_amdgcn_cosf(xa), __builtin_amdgcn_sinf(xa), xr, xi, yr, yi);
           emit(kp, j, make_float2(xr[0], xi[0]), make_float2(xr[1], xi[1]));
           emit(C - kp, j, make_float2(yr[0], yi[0]), make_float2(yr[1], yi[1]));
         }
@@ -253,10 +375,6 @@ template <int... I> static kplain_t pick_plain(int logf, int mode, iseq<I...>)
   if (logf < 1 || logf > (int)sizeof...(I)) return nullptr;
   return mode == 0 ? m0[logf - 1] : mode == 1 ? m1[logf - 1] : m2[logf - 1];
 }
-
-// points per workgroup tile: 2^13 (256 threads, two workgroups per compute unit) up to 1024 channels, 2^14 above (longer runs of
-// output samples per channel row); at most 512 columns (the staged image must fit the exchange buffer)
-static int plain_log_points(int logC) { const int lp = logC <= 10 ? 13 : 14; return lp < logC + 9 ? lp : logC + 9; }
 
 int fb_plain_check(dspsr_amd_ctx* ctx, int logC, bool real_input, uint32_t npol, size_t* lds_bytes)
 {

@@ -85,6 +85,12 @@ typedef struct {
                                sub-sequences + one radix-R step -- kernels of their own for R = 3, 5, 7, 9, 15, a run-time-radix
                                form for the others; freq_res <= 8192 then) */
   uint32_t freq_res;        /* response ndat = backward FFT length                            Filterbank.C:93
+                               1: the NON-CONVOLVING filterbank of `dspsr -F N` (Filterbank::Config::After / Never; Filterbank.C:614-623,
+                               FilterbankCUDA.cu:92-116 with plan_bwd == NULL): one nchan_subband-point forward transform per output
+                               sample, no backward transform, nkeep = 1, no overlap (nfilt_pos = nfilt_neg = 0); nchan_subband 2^k in
+                               [2, 8192]; a kernel of input_nchan * nchan_subband factors is applied if set (Response::operate); one
+                               launch, no scratch (csrc/fb_plain.hip).  dsp::Convolution then runs on its output as a second object
+                               with nchan_subband = 1.
                                2^k >= 2, or 2^k times an odd R <= 127 (dspsr -x 12288, -x 11264): bins R m' + r of a channel are R
                                pseudo-channels of freq_res / R bins through the power-of-two passes, one radix-R step in time adds
                                their transforms (a pass of its own: fold_is_fused() == 0; freq_res / R <= 8192).  Both lengths may
@@ -177,6 +183,7 @@ int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb);
 /* How many transform passes (trips of the part through HBM scratch + 1) a call makes -- the role of the plan choice inside
  * CUDA::FilterbankEngine::setup (FilterbankCUDA.cu:92-116: one forward and one batched backward cuFFT plan).  raw_input != 0:
  * the answer for dspsr_amd_filterbank_perform_raw / _detect / _fold on a generic 8-bit block, else for float32 rows.
+ *   1  freq_res = 1: the non-convolving filterbank, one tile pass from the input to the output rows;
  *   2  short responses: complex dual-pol 8-bit input with 512 <= freq_res <= 4096 and 2^13 / freq_res <= nchan_subband <=
  *      2^27 / freq_res^2 (upper end: one 50 MHz sub-band with -F 512:D -x 512): column forward pass, then rows + chirp + inverse
  *      transforms in ONE tile -- the spectrum stays on chip;
