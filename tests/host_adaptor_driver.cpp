@@ -470,6 +470,91 @@ int main ()
       }
       printf ("TScrunch / FScrunch engines == CPU loops (ndim 1, 2)\n");
     }
+
+    // ---------------------------------------------------------------- `dspsr -F N` (Filterbank::Config::After, LoadToFold1.C:296-380):
+    // the NON-CONVOLVING filterbank (freq_res = 1, no response: Filterbank.C:614-623) through HIP::FilterbankEngine, then
+    // dsp::Convolution on its channels through HIP::ConvolutionEngine, in the reference's call order -- against direct DFTs in double
+    {
+      const unsigned Cp = 8, nfb = 330;                                   // 8 channels: 16 real samples per output sample
+      const unsigned Mc = 64, cpos = 5, cneg = 7, cstep = Mc - cpos - cneg, ncv = (nfb - (cpos + cneg)) / cstep;
+      dsp::TimeSeries x_h, x_d;
+      x_h.set_nchan (1); x_h.set_npol (2); x_h.set_ndim (1); x_h.set_state (Signal::Nyquist); x_h.set_rate (16e6);
+      x_h.resize (uint64_t (nfb) * 2 * Cp);
+      x_d.set_memory (dmem); x_d.internal_match (&x_h);
+      for (unsigned p = 0; p < 2; p++) for (uint64_t i = 0; i < x_h.get_ndat (); i++) x_h.get_datptr (0, p)[i] = rnd ();
+      h2d (ctx, x_d, x_h);
+      dsp::Filterbank plain;
+      plain.nchan_subband = Cp; plain.freq_res = 1; plain.input = &x_d; plain.response = 0;
+      HIP::FilterbankEngine pfe (ctx);
+      pfe.setup (&plain);
+      uint64_t pfft = 0, povl = 0, pstep = 0; unsigned pkeep = 0;
+      dsp::TimeSeries c_d, c_h, y_d, y_h;
+      c_d.set_nchan (Cp); c_d.set_npol (2); c_d.set_ndim (2); c_d.set_state (Signal::Analytic); c_d.set_rate (1e6);
+      c_d.set_memory (dmem); c_d.resize (nfb);
+      c_h.internal_match (&c_d);
+      pfe.perform (&x_d, &c_d, nfb, 2 * Cp, 2);                           // in_step = nsamp_step, out_step = 2 * nkeep = 2 (Filterbank.C:517-519)
+      pfe.finish ();
+      (void) pfft; (void) povl; (void) pstep; (void) pkeep;
+      d2h (ctx, c_h, c_d);
+      double worst = 0, scale_fb = 0;
+      for (unsigned p = 0; p < 2; p++) for (unsigned t = 0; t < nfb; t += 37) for (unsigned k = 0; k < Cp; k++) {
+        double re = 0, im = 0;                                            // frc1d: X[k] = sum_n x[n] exp(-2 pi i n k / 2C), k < C
+        for (unsigned n = 0; n < 2 * Cp; n++) {
+          const double a = -2.0 * M_PI * double (n) * k / double (2 * Cp), v = x_h.get_datptr (0, p)[uint64_t (t) * 2 * Cp + n];
+          re += v * cos (a); im += v * sin (a);
+        }
+        const double dr = c_h.get_datptr (k, p)[2 * t] - re, di = c_h.get_datptr (k, p)[2 * t + 1] - im;
+        if (fabs (dr) > worst) worst = fabs (dr);
+        if (fabs (di) > worst) worst = fabs (di);
+        if (fabs (re) > scale_fb) scale_fb = fabs (re);
+      }
+      REQUIRE (worst <= 2e-6 * scale_fb && scale_fb > 0, "non-convolving filterbank differs from the direct transform by %g (scale %g)", worst, scale_fb);
+      // Convolution on the filterbank's channels: nchan responses of Mc bins each (Convolution.C:338-461)
+      dsp::Response cresp;
+      cresp.impulse_pos = cpos; cresp.impulse_neg = cneg; cresp.nchan = Cp; cresp.ndat = Mc;
+      cresp.kernel.resize (2 * size_t (Cp) * Mc);
+      for (size_t k = 0; k < size_t (Cp) * Mc; k++) { const float a = 3.0f * rnd (); cresp.kernel[2 * k] = cosf (a); cresp.kernel[2 * k + 1] = sinf (a); }
+      dsp::Convolution conv;
+      conv.response = &cresp; conv.input = &c_d; conv.nsamp_fft = Mc; conv.nsamp_overlap = cpos + cneg;
+      HIP::ConvolutionEngine cve (ctx);
+      cve.prepare (&conv);
+      y_d.set_nchan (Cp); y_d.set_npol (2); y_d.set_ndim (2); y_d.set_state (Signal::Analytic); y_d.set_rate (1e6);
+      y_d.set_memory (dmem); y_d.resize (uint64_t (ncv) * cstep);
+      y_h.internal_match (&y_d);
+      cve.perform (&c_d, &y_d, ncv);
+      HIP::check (ctx, dspsr_amd_stream_sync (ctx), "sync");
+      d2h (ctx, y_h, y_d);
+      double cworst = 0, cscale = 0;
+      std::vector<double> sr (Mc), si (Mc);
+      for (unsigned c = 0; c < Cp; c += 3) for (unsigned p = 0; p < 2; p++) for (unsigned part = 0; part < ncv; part += 2) {
+        const float* xin = c_h.get_datptr (c, p) + 2 * size_t (part) * cstep;
+        for (unsigned k = 0; k < Mc; k++) {                                // fcc1d, times the channel's response
+          double re = 0, im = 0;
+          for (unsigned n = 0; n < Mc; n++) {
+            const double a = -2.0 * M_PI * double (n) * k / double (Mc);
+            re += xin[2 * n] * cos (a) - xin[2 * n + 1] * sin (a);
+            im += xin[2 * n] * sin (a) + xin[2 * n + 1] * cos (a);
+          }
+          const double kr = cresp.kernel[2 * (size_t (c) * Mc + k)], ki = cresp.kernel[2 * (size_t (c) * Mc + k) + 1];
+          sr[k] = re * kr - im * ki; si[k] = re * ki + im * kr;
+        }
+        for (unsigned t = 0; t < cstep; t += 5) {                           // bcc1d (unnormalised), samples [nfilt_pos, nfilt_pos + step)
+          double re = 0, im = 0;
+          for (unsigned k = 0; k < Mc; k++) {
+            const double a = 2.0 * M_PI * double (k) * (cpos + t) / double (Mc);
+            re += sr[k] * cos (a) - si[k] * sin (a);
+            im += sr[k] * sin (a) + si[k] * cos (a);
+          }
+          const float* got = y_h.get_datptr (c, p) + 2 * (size_t (part) * cstep + t);
+          if (fabs (got[0] - re) > cworst) cworst = fabs (got[0] - re);
+          if (fabs (got[1] - im) > cworst) cworst = fabs (got[1] - im);
+          if (fabs (re) > cscale) cscale = fabs (re);
+        }
+      }
+      REQUIRE (cworst <= 4e-6 * cscale && cscale > 0, "Filterbank + Convolution differs from the direct transforms by %g (scale %g)", cworst, cscale);
+      printf ("dspsr -F N: non-convolving FilterbankEngine (freq_res 1) + ConvolutionEngine == direct transforms (%.1e, %.1e of the scale)\n",
+              worst / scale_fb, cworst / cscale);
+    }
   }
   catch (Error& error)
   {
