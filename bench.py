@@ -87,7 +87,7 @@ WORKLOADS = {
     # (freq_res = 1, csrc/fb_plain.hip), then dsp::Convolution with the dedispersion response on its 128 channels (the filterbank
     # object with nchan_subband = 1: four tile passes at this response length), Detection, Fold
     "after": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=128, dm=67.99, freq_res=65536, nbin=512,
-                  machine="CASPSR", when="after", parts_per_block=128, max_parts=128,
+                  machine="CASPSR", when="after", parts_per_block=32, max_parts=32,
                   cmd="dspsr -F 128 -x 65536 -D 67.99 -b 512 (filterbank, THEN convolution: Config::After; header.dada band, vela.par DM)"),
     # the reference's fold benchmark (Benchmark/fold.csh on Benchmark/fold_header.dada): already-detected input, 1024
     # channels x 4 polarisation products at 32 us, folded with vela.polyco -- dsp::Fold alone

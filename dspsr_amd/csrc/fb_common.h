@@ -59,6 +59,11 @@ struct FbIn {
   uint64_t part_step;   // time samples between parts
   uint32_t nchan, ichan;
   float scale;
+  // channel-batched convolution (float32 complex rows of several input channels in ONE launch group, filterbank.hip fb_run_batched):
+  // the "parts" of pass 1 are then virtual sequences vp = (part * npol + pol) * batch + c -- channel c of the group lies
+  // chan_stride_c complex samples behind `base`; 0: off
+  uint32_t batch;
+  uint64_t chan_stride_c;
 };
 
 struct FbOut {

@@ -181,10 +181,18 @@ __global__ __launch_bounds__(512) void k_fwd_cols(const FbGeom g, const FbIn in,
   auto fetch = [&](const uint32_t item, RawW<RAWW> (&raw)[PTS / 2]) {
     const uint32_t tile = item & (ntile - 1);
     const uint32_t rest = item >> logNt;
-    const uint32_t seq = seq_of(rest);
+    uint32_t seq = seq_of(rest);
     const bool pret = in.kind == 3 || in.kind == 5;   // pre-transposed: [part][tile][na][T] pairs, contiguous per tile
-    const uint64_t t0 = pret ? ((uint64_t)rest * ntile + tile) * ((uint64_t)T << LOGF)       // rest = part*nseq + seq
-                             : (part0 + part_of(rest)) * in.part_step + tile * T;
+    uint64_t t0 = pret ? ((uint64_t)rest * ntile + tile) * ((uint64_t)T << LOGF)       // rest = part*nseq + seq
+                       : (part0 + part_of(rest)) * in.part_step + tile * T;
+    if constexpr (RAWW == 4) {
+      // channel-batched convolution (FbIn::batch, float32 complex rows): `rest` = (part * npol + pol) * batch + channel
+      if (in.batch) {                                  // uniform
+        const uint32_t c = rest % in.batch, ps = rest / in.batch;
+        seq = ps % (uint32_t)g.npol;
+        t0 = (part0 + ps / (uint32_t)g.npol) * in.part_step + c * in.chan_stride_c + tile * T;
+      }
+    }
     // element i of a thread's first-stage butterfly is row na = nab + i*MS of one column pair: sample index =
     // base + i*step with a wave-uniform step (no per-element index arithmetic or branches between the loads)
     constexpr uint32_t MS = 1u << (LOGF - P::LOGR1);

@@ -57,6 +57,8 @@ struct dspsr_amd_filterbank_impl {
   // freq_res = 3 * 2^k / 5 * 2^k (msub = 3, 5; see k_time_combine): g and everything above describe the INNER filterbank of
   // nchan_subband * msub pseudo-channels with freq_res / msub bins and the whole transform kept; cfg and these the caller's
   uint32_t msub = 0, out_C = 0, out_M = 0, out_nfilt_pos = 0, out_nkeep = 0;
+  dspsr_amd_filterbank* batch = nullptr;   // dsp::Convolution on many channels (nchan_subband = 1, complex float rows): the inverse passes of a
+                             // filterbank of `batch->cfg.nchan_subband` channels per group, see fb_run_batched
   int plain_logC = -1;       // >= 0: freq_res = 1, the non-convolving filterbank (fb_plain.hip): no scratch, one launch per call
   cf* Xp = nullptr;          // the combined spectrum in pseudo-channel order (k_sub_combine writes it there)
   cf* Y = nullptr;           // the pseudo-channels' time series of one launch group [pseudo-channel][pol][part][freq_res / msub]
@@ -414,6 +416,33 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     }
     g.tw_lo = fb->tw_lo;
   }
+  // dsp::Convolution behind a filterbank (nchan_subband = 1 on many input channels, `dspsr -F N`): one launch group per input channel
+  // holds parts x 2 x freq_res points -- a tile or two per compute unit and four launches per channel.  The channels of a GROUP run
+  // as one launch group instead (fb_run_batched): forward passes on the group's (part, pol, channel) sequences with this object's
+  // per-channel geometry, inverse passes of a `group`-channel filterbank object (natural spectrum order) on the spectra laid side
+  // by side.  Complex float32 rows read in place by pass 1; other inputs keep the loop over the channels.
+  if (cfg->nchan_subband == 1 && !cfg->real_input && cfg->npol == 2 && cfg->input_nchan >= 4 && cfg->force_four_pass != 2 &&
+      g.four_pass && !g.xblocked && !msub && nsub == 1 && !(g.logR >= 6 && g.logT1 <= 4) && fb->k1_w4) {
+    uint32_t ch = 1;
+    while (ch < 64 && cfg->input_nchan % (2 * ch) == 0) ch *= 2;
+    // (scratch of the group object: max_parts x 2 x ch x freq_res elements per buffer; keep it near 2 GB)
+    while (ch > 2 && (uint64_t)fb->max_parts * 2 * ch * fb->N * sizeof(cf) > (2ull << 30)) ch /= 2;
+    // (the group object must keep its spectrum in natural order: ch * freq_res <= 2^21, see `blocked` above)
+    while (ch > 1 && ilog2(ch) + g.logMf > 21) ch /= 2;
+    if (ch >= 2) {
+      dspsr_amd_filterbank_config c2 = *cfg;
+      c2.nchan_subband = ch;
+      c2.input_nchan = cfg->input_nchan / ch;
+      c2.force_four_pass = 1;
+      c2.max_parts = fb->max_parts;
+      dspsr_amd_filterbank* inv = nullptr;
+      if (dspsr_amd_filterbank_create(ctx, &c2, &inv) == DSPSR_AMD_OK && inv) {
+        if (inv->g.four_pass && !inv->g.xblocked && inv->k3a && inv->k3b && inv->g.logMf == g.logMf) fb->batch = inv;
+        else dspsr_amd_filterbank_destroy(inv);
+      }
+      ctx->error[0] = 0;                       // (a refusal of the group object is not an error of this call)
+    }
+  }
   *out = fb;
   return DSPSR_AMD_OK;
 }
@@ -421,6 +450,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
 extern "C" void dspsr_amd_filterbank_destroy(dspsr_amd_filterbank* fb)
 {
   if (!fb) return;
+  if (fb->batch) dspsr_amd_filterbank_destroy(fb->batch);
   (void)hipStreamSynchronize(fb->ctx->stream);
   if (fb->A) (void)hipFree(fb->A);
   if (fb->X) (void)hipFree(fb->X);
@@ -561,6 +591,58 @@ static int fb_launch_fused(dspsr_amd_filterbank* fb, k3_t k3, const cf* X, const
 static inline uint32_t fb_out_C(const dspsr_amd_filterbank* fb) { return fb->msub ? fb->out_C : fb->g.C; }
 static inline uint32_t fb_out_nkeep(const dspsr_amd_filterbank* fb) { return fb->msub ? fb->out_nkeep : fb->g.nkeep; }
 
+// dsp::Convolution on the channels of a filterbank, one launch group per GROUP of channels (see dspsr_amd_filterbank_create):
+//   pass 1 / pass 2   this object's kernels and per-channel geometry on the virtual sequences vp = (part * 2 + pol) * CH + c of the
+//                     group (FbIn::batch): spectra X[vp][freq_res] = X[part][pol][c][m], natural order
+//   inverse passes    those of the group object (CH channels per "input channel", four-pass, natural order): its X layout is exactly
+//                     that, its chirp slice [CH][freq_res] the group's rows of this object's kernel, its output channels chan0 + c
+// Same kernels, same arithmetic per channel as the loop over the channels.
+static int fb_run_batched(dspsr_amd_filterbank* fb, const FbIn& in, const FbOut& out, uint64_t npart, uint64_t chan_stride)
+{
+  dspsr_amd_ctx* ctx = fb->ctx;
+  dspsr_amd_filterbank* inv = fb->batch;
+  const FbGeom& gf = fb->g;
+  const FbGeom& gi = inv->g;
+  const uint32_t CH = inv->cfg.nchan_subband, ngroup = fb->cfg.input_nchan / CH;
+  const uint32_t Rr = 1u << gf.logR, M = 1u << gf.logM;
+  const float* in_f32 = (const float*)in.base;
+  for (uint32_t grp = 0; grp < ngroup; grp++) {
+    const cf* kern = fb->kernel ? fb->kernel + (uint64_t)grp * CH * fb->N : nullptr;
+    FbOut co = out;
+    co.chan0 = grp * CH;
+    uint32_t nb_step = 0;
+    for (uint64_t part0 = 0; part0 < npart; part0 += nb_step) {
+      uint32_t nb = (uint32_t)((npart - part0) < inv->max_parts ? (npart - part0) : inv->max_parts);
+      {
+        uint64_t per_part = (uint64_t)(Rr >> gf.logT1) * 2 * CH;
+        const uint64_t i2 = (uint64_t)(M >> gf.logT2) * 2 * CH, i3a = (uint64_t)gi.C << (gi.logMb - gi.logTm),
+                       i3b = (uint64_t)gi.C << (gi.logMa - gi.logTt);
+        if (i2 > per_part) per_part = i2;
+        if (i3a > per_part) per_part = i3a;
+        if (i3b > per_part) per_part = i3b;
+        while (nb > 1 && per_part * nb >= (1ull << 31)) nb /= 2;
+        nb_step = nb;
+      }
+      const uint32_t nvp = nb * 2 * CH;
+      FbIn ci = in;
+      ci.base = in_f32 + (uint64_t)grp * CH * chan_stride;
+      ci.batch = CH;
+      ci.chan_stride_c = chan_stride / 2;
+      ci.nchan = 1; ci.ichan = 0;
+      const uint64_t n1 = (uint64_t)(Rr >> gf.logT1) * nvp, n2 = (uint64_t)(M >> gf.logT2) * nvp;
+      hipLaunchKernelGGL(fb->k1_w4, dim3(grid_for(n1, fb->ncu * fb->wg1)), dim3(fb->nt1), fb->lds1, ctx->stream, gf, ci, inv->A, ctx->tw, part0,
+                         nvp, 1u, 32u);
+      hipLaunchKernelGGL(fb->k2, dim3(grid_for(n2, fb->ncu)), dim3(fb->nt2), fb->lds2, ctx->stream, gf, inv->A, inv->X, ctx->tw, nvp, 1u, 4u);
+      const uint64_t n3a = ((uint64_t)gi.C << (gi.logMb - gi.logTm)) * nb, n3b = ((uint64_t)gi.C << (gi.logMa - gi.logTt)) * nb;
+      hipLaunchKernelGGL(inv->k3a, dim3(grid_for(n3a, fb->ncu)), dim3(inv->nt3), inv->lds3, ctx->stream, gi, inv->X, kern, inv->A, ctx->tw, nb, 8u);
+      hipLaunchKernelGGL(inv->k3b, dim3(grid_for(n3b, fb->ncu)), dim3(inv->nt4), inv->lds4, ctx->stream, gi, inv->A, co, ctx->tw, part0, nb, 8u);
+    }
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fb_fail(ctx, DSPSR_AMD_EHIP, "dspsr_amd_filterbank_perform: launch failed: %s", hipGetErrorString(e));
+  return DSPSR_AMD_OK;
+}
+
 static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, uint64_t in_chan_stride_bytes_or_floats)
 {
   dspsr_amd_ctx* ctx = fb->ctx;
@@ -576,6 +658,8 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
     if (rc != DSPSR_AMD_OK) return fb_fail(ctx, rc, "dspsr_amd_filterbank_perform: launch of the non-convolving filterbank failed");
     return DSPSR_AMD_OK;
   }
+  if (fb->batch && in.kind == 0 && (out.kind == 0 || out.kind == 1 || out.kind == 2) && (in_chan_stride_bytes_or_floats % 2) == 0)
+    return fb_run_batched(fb, in, out, npart, in_chan_stride_bytes_or_floats);
   // 8-bit real dual-pol single-channel input: one 32-bit word per sample pair; regroup it per tile first
   // (k_raw_transpose) unless the rows are already long enough or the layout preconditions fail
   const bool fast8 = (in.kind == 1 || in.kind == 2) && g.real_input && g.npol == 2 && fb->cfg.input_nchan == 1 &&

@@ -257,3 +257,40 @@ def test_pipeline_filterbank_then_convolution(oracle, gpu, when, machine):
     assert np.abs(got - ps.data).max() <= 1e-5 * np.abs(ps.data).max()
     assert abs(lt.out_rate - fobs.rate) <= 1e-9 * fobs.rate and abs(lt.out_start - fobs.start_seconds) <= 1e-12
     lt.close()
+
+
+@pytest.mark.parametrize("nchan,M,nfilt,npart", [(16, 2048, (200, 150), 5), (128, 1024, (100, 90), 3), (12, 512, (40, 30), 7),
+                                                 (8, 65536, (3000, 2000), 2), (4, 256, (20, 13), 40)])
+def test_convolution_of_many_channels_as_one_launch_group(oracle, gpu, nchan, M, nfilt, npart):
+    """dsp::Convolution behind a filterbank (`dspsr -F N`: nchan_subband = 1 on many complex channels, float32 rows): the channels of a
+    group run as ONE launch group -- forward passes per channel, inverse passes of a group-wide filterbank (filterbank.hip
+    fb_run_batched).  Against the float64 oracle, and bit for bit against the loop over the channels (force_four_pass = 2 turns the
+    grouping off); complex rows and detected output; parts in several launch groups."""
+    dspsr_amd, ctx = gpu
+    o = oracle
+    rng = np.random.default_rng(31)
+    kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, nchan * M)).astype(np.complex64)
+    step = M - sum(nfilt)
+    x = rng.standard_normal((nchan, 2, 2 * (npart * step + sum(nfilt)))).astype(np.float32)
+    ref = o.convolution(x, M, nfilt[0], nfilt[1], kernel, False, npart=npart, dtype=np.float64)
+    d_x = torch.from_numpy(x).cuda()
+    outs, dets = [], []
+    for grouped in (True, False):
+        eng = dspsr_amd.FilterbankEngine(ctx).setup(1, M, nfilt[0], nfilt[1], nchan, 2, False, kernel, max_parts=3,
+                                                    force_four_pass=0 if grouped else 2)
+        out = torch.zeros((nchan, 2, 2 * npart * step), dtype=torch.float32, device="cuda")
+        eng.perform(d_x, out, npart, 2 * step, 2 * step)
+        det = torch.zeros((nchan, 1, 4 * npart * step), dtype=torch.float32, device="cuda")
+        eng.perform_detect(det, npart, dspsr_amd.STOKES, 4, inp=d_x, in_step=2 * step)
+        eng.finish()
+        outs.append(out.cpu().numpy())
+        dets.append(det.cpu().numpy())
+        eng.close()
+    got = outs[0].view(np.complex64).astype(np.complex128)
+    rms = math.sqrt(np.mean(np.abs(ref) ** 2))
+    tol = 2e-6 * math.sqrt(math.log2(2 * M))
+    assert math.sqrt(np.mean(np.abs(got - ref) ** 2)) / rms <= tol
+    assert np.abs(got - ref).max() <= 8 * tol * rms
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(dets[0], dets[1])
+    want = oracle.detect_layout(oracle.detect_products(ref, "Stokes"), 4).reshape(nchan, 1, -1)
+    assert np.abs(dets[0] - want).max() <= 1e-5 * np.abs(want).max()
