@@ -69,6 +69,26 @@ for i in range(ncases):
         if rng.integers(0, 4) == 0 and logM <= 10 and logC + logM <= 17:
             kw["input_nchan"] = 2
         npart = int(rng.integers(1, 5))
+    fam = rng.integers(0, 8)
+    if fam == 0:
+        # the non-convolving filterbank (freq_res = 1, csrc/fb_plain.hip): any power-of-two channel count, every input form, part
+        # counts from a fraction of a tile to several tiles per workgroup
+        C, M, pos, neg = 1 << int(rng.integers(1, 14)), 1, 0, 0
+        real = bool(rng.integers(0, 3) != 0)
+        kw = dict(npol=2 if rng.integers(0, 4) else 1, real=real, use_raw=bool(rng.integers(0, 3) != 0), seed=int(rng.integers(1, 1000)))
+        if real and kw["npol"] == 2 and kw["use_raw"] and rng.integers(0, 3) == 0:
+            kw["layout"] = "caspsr"
+        elif rng.integers(0, 3) == 0:
+            kw["input_nchan"] = int(rng.integers(2, 6))
+        npart = int(rng.integers(1, max(2, min(6000, (1 << 19) // (C * kw.get("input_nchan", 1))))))
+    elif fam == 1:
+        # dsp::Convolution on many channels (nchan_subband = 1, complex float rows): groups of channels as one launch group
+        logM = int(rng.integers(4, 15))
+        C, M = 1, 1 << logM
+        pos, neg = int(rng.integers(0, max(1, M // 3))), int(rng.integers(0, max(1, M // 3)))
+        kw = dict(npol=2, real=False, use_raw=False, max_parts=int(rng.integers(1, 5)), seed=int(rng.integers(1, 1000)),
+                  input_nchan=int(rng.choice([4, 6, 8, 12, 16, 20, 32, 64])), four_pass=int(rng.choice([0, 0, 0, 2])))
+        npart = int(rng.integers(1, 7)) if logM + int(np.log2(kw["input_nchan"])) <= 17 else int(rng.integers(1, 3))
     desc = "C=%d M=%d nfilt=(%d,%d) npart=%d %s" % (C, M, pos, neg, npart, kw)
     try:
         _fb_case(oracle, (dspsr_amd, ctx), C, M, (pos, neg), npart, **kw)

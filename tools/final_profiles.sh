@@ -6,7 +6,10 @@ T=$1
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp && cd $R
-for w in target cfg1 cfg1opt cfg2 cfg3 cfg4 cfg5 cfg5c odd_nchan odd_fres fold; do
+WL=${WL:-target cfg1 cfg1opt cfg2 cfg3 cfg4 cfg5 cfg5c odd_nchan odd_fres after fold}
+PHASE=${PHASE:-all}      # stats | pmc | all (a call on the GPU box is limited to 20 minutes: run the two phases as two calls if need be)
+if [ $PHASE != pmc ]; then
+for w in $WL; do
   a="--workload $w"; [ $w = target ] && a="--no-companions --no-h2d"
   rm -rf gpurun_out/$T/prof_$w
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$T/prof_$w -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline $a > gpurun_out/$T/${w}_bench.json 2> gpurun_out/$T/${w}.err || { echo "$w failed"; tail -3 gpurun_out/$T/${w}.err; exit 1; }
@@ -16,8 +19,11 @@ for w in target cfg1 cfg1opt cfg2 cfg3 cfg4 cfg5 cfg5c odd_nchan odd_fres fold; 
   echo "== $w: $(grep -o '"value": [0-9.]*' gpurun_out/$T/${w}_bench.json | head -1) $(grep -o '"frac": [0-9.]*' gpurun_out/$T/${w}_bench.json | head -1)"
   head -6 gpurun_out/$T/${w}_kernel_stats.txt
 done
-for w in target cfg1 cfg1opt cfg2 cfg3 cfg4 cfg5 cfg5c odd_nchan odd_fres fold; do
+fi
+if [ $PHASE != stats ]; then
+for w in $WL; do
   bash tools/pmc_traffic.sh $T $w > gpurun_out/$T/pmc_$w.txt 2>&1 || { echo "pmc $w failed"; tail -3 gpurun_out/$T/pmc_$w.txt; exit 1; }
   head -1 gpurun_out/$T/pmc_$w.txt | cut -c1-400
   rm -rf gpurun_out/$T/pmc_${w}_*_SIZE
 done
+fi
