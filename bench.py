@@ -89,6 +89,11 @@ WORKLOADS = {
     "after": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=128, dm=67.99, freq_res=65536, nbin=512,
                   machine="CASPSR", when="after", parts_per_block=32, max_parts=32,
                   cmd="dspsr -F 128 -x 65536 -D 67.99 -b 512 (filterbank, THEN convolution: Config::After; header.dada band, vela.par DM)"),
+    # the filterbank alone (Filterbank::Config::Never: `dspsr -F 128` with coherent dedispersion switched off, or any DM-0 source):
+    # k_fb_plain writing the detected rows, then Fold -- the roofline of the non-convolving filterbank kernel itself
+    "plain": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=128, dm=0.0, freq_res=1, nbin=512,
+                  machine="DADA", when="never", parts_per_block=1 << 21, max_parts=1 << 21,
+                  cmd="dspsr -F 128 without coherent dedispersion (Config::Never: non-convolving filterbank, Detection, Fold)"),
     # the reference's fold benchmark (Benchmark/fold.csh on Benchmark/fold_header.dada): already-detected input, 1024
     # channels x 4 polarisation products at 32 us, folded with vela.polyco -- dsp::Fold alone
     "fold": dict(freq=1382.0, bw=-400.0, in_nchan=1024, ndim=1, tsamp_us=32.0, nchan=1024, dm=0.0, freq_res=1, nbin=0,
@@ -941,17 +946,23 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
     out = None
     if rank == 0:
         r = lt.response
+        if r is None:                                   # Config::Never: the filterbank alone (freq_res = 1, nothing dropped)
+            import types
+            r = types.SimpleNamespace(ndat=1, impulse_pos=0, impulse_neg=0, kernel=None)
         nchan_subband = cfg.nchan // info.nchan
         N = nchan_subband * r.ndat
         nsamp_fft = 2 * N if info.ndim == 1 else N
         b_alg = algorithmic_bytes_per_part(2, nsamp_fft * info.ndim, 8, N, nchan_subband, lt.nkeep)
+        if lt.response is None:
+            b_alg -= 8 * N                              # no response: no chirp to read
         achieved = b_alg * cfg.parts_per_block * lt.in_nchan / (fb_ms * 1e-3) / 1e9
         npass = lt.fb.npass(True)
         group = {2: ("k_raw_cols+k_fwd_col1+k_rows_inv<.,.,false>", "k_raw_cols+k_fwd_col1+k_rows_inv<.,.,true>"),
                  3: ("k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,false>", "k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,true>"),
                  4: ("k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b", "k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b<.,true>+k_fold_segsum"),
                  # Config::After: the non-convolving filterbank, then the convolution's passes on float rows
-                 5: ("k_fb_plain+k_float_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b", "k_fb_plain+k_float_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b<.,true>+k_fold_segsum"),
+                 5: ("k_fb_plain+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b", "k_fb_plain+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b<.,true>+k_fold_segsum"),
+                 1: ("k_fb_plain", "k_fb_plain"),
                  }.get(npass, ("%d tile passes" % npass,) * 2)
         exch = ("dspsr_amd_reduce_profiles_* (RCCL behind the C-ABI, csrc/comm.hip), snapshot on the compute stream, collective "
                 "on its own stream" if rccl is not None else
@@ -1147,7 +1158,7 @@ def main():
                                                 "replicas so that N = 1 agrees with the single-GPU record" % world)
         if world == 1:
             others = []
-            for w in ("cfg1", "cfg1opt", "cfg2", "cfg3", "odd_nchan", "odd_fres", "after"):
+            for w in ("cfg1", "cfg1opt", "cfg2", "cfg3", "odd_nchan", "odd_fres", "after", "plain"):
                 others.append(brief(run_fold_workload(w, short, *ctx, steps=2 * ssteps, warmup=swarm, full=False)))
             sm = argparse.Namespace(**vars(args))
             sm.steps, sm.warmup, sm.no_cpu_baseline = 2 * ssteps, swarm, True
