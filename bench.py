@@ -89,6 +89,12 @@ WORKLOADS = {
     "after": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=128, dm=67.99, freq_res=65536, nbin=512,
                   machine="CASPSR", when="after", parts_per_block=32, max_parts=32,
                   cmd="dspsr -F 128 -x 65536 -D 67.99 -b 512 (filterbank, THEN convolution: Config::After; header.dada band, vela.par DM)"),
+    # the same with the shortest response the smearing allows a power of two above (3657 of 8192 points dropped): the convolution of a
+    # (channel, part) sequence then fits ONE workgroup tile -- forward transform, response, backward transform, Detection in one pass
+    # over the rows (csrc/fb_conv1.hip) instead of four
+    "after8k": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=128, dm=67.99, freq_res=8192, nbin=512,
+                    machine="CASPSR", when="after", parts_per_block=256, max_parts=256,
+                    cmd="dspsr -F 128 -x 8192 -D 67.99 -b 512 (filterbank, THEN convolution in one tile pass: Config::After)"),
     # the filterbank alone (Filterbank::Config::Never: `dspsr -F 128` with coherent dedispersion switched off, or any DM-0 source):
     # k_fb_plain writing the detected rows, then Fold -- the roofline of the non-convolving filterbank kernel itself
     "plain": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=128, dm=0.0, freq_res=1, nbin=512,
@@ -963,6 +969,7 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
                  # Config::After: the non-convolving filterbank, then the convolution's passes on float rows
                  5: ("k_fb_plain+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b", "k_fb_plain+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b<.,true>+k_fold_segsum"),
                  1: ("k_fb_plain", "k_fb_plain"),
+                 2: ("k_fb_plain+k_conv1", "k_fb_plain+k_conv1"),
                  }.get(npass, ("%d tile passes" % npass,) * 2)
         exch = ("dspsr_amd_reduce_profiles_* (RCCL behind the C-ABI, csrc/comm.hip), snapshot on the compute stream, collective "
                 "on its own stream" if rccl is not None else

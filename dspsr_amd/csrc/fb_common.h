@@ -551,6 +551,10 @@ cf* fb_launch_sub_combine(hipStream_t stream, const FbGeom& g, cf* X, uint32_t n
 void fb_launch_time_combine(hipStream_t stream, const TimeCombine& p, const FbOut& out, uint32_t R, uint32_t ncu);
 void fb_launch_raw_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, uint16_t* Rt, uint64_t part0);
 void fb_launch_float_transpose(dim3 grid, hipStream_t stream, const FbGeom& g, const FbIn& in, cf* Rt, uint64_t part0);
+// dsp::Convolution with n_fft <= 8192 in one tile pass (fb_conv1.hip): complex float32 rows, two polarisations
+int fb_conv1_check(int logM, size_t* lds_bytes);
+int fb_conv1_launch(dspsr_amd_ctx* ctx, int logM, const float* in, uint64_t chan_stride, uint64_t pol_stride, uint64_t in_step,
+                    const cf* kern, const FbOut& out, uint32_t nchan, uint32_t nfilt_pos, uint32_t nkeep, uint64_t npart);
 // non-convolving filterbank, freq_res = 1 (fb_plain.hip): kernel choice + dynamic-LDS limit at create time, one launch per call
 int fb_plain_check(dspsr_amd_ctx* ctx, int logC, bool real_input, uint32_t npol, size_t* lds_bytes);
 int fb_plain_launch(dspsr_amd_ctx* ctx, int logC, bool real_input, uint32_t npol, uint32_t input_nchan, const cf* kern,

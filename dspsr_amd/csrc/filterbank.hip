@@ -59,6 +59,8 @@ struct dspsr_amd_filterbank_impl {
   uint32_t msub = 0, out_C = 0, out_M = 0, out_nfilt_pos = 0, out_nkeep = 0;
   dspsr_amd_filterbank* batch = nullptr;   // dsp::Convolution on many channels (nchan_subband = 1, complex float rows): the inverse passes of a
                              // filterbank of `batch->cfg.nchan_subband` channels per group, see fb_run_batched
+  int conv1_logM = -1;       // >= 0: dsp::Convolution shapes with n_fft <= 8192 on complex float rows run in ONE tile pass (fb_conv1.hip)
+  cf* kernel_nat = nullptr;  // ... its response in natural order when `kernel` is stored in the blocked order of the four-pass kernels
   int plain_logC = -1;       // >= 0: freq_res = 1, the non-convolving filterbank (fb_plain.hip): no scratch, one launch per call
   cf* Xp = nullptr;          // the combined spectrum in pseudo-channel order (k_sub_combine writes it there)
   cf* Y = nullptr;           // the pseudo-channels' time series of one launch group [pseudo-channel][pol][part][freq_res / msub]
@@ -416,6 +418,12 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     }
     g.tw_lo = fb->tw_lo;
   }
+  // dsp::Convolution with a short response (n_fft <= 8192) on complex float rows: the whole transform of a (channel, part) sequence,
+  // both polarisations, fits one workgroup tile -- forward transform, response, backward transform, keep window and Detection in ONE
+  // pass over the rows (fb_conv1.hip) instead of four.  force_four_pass != 0 keeps the four-pass kernels (tests, comparison runs).
+  if (cfg->nchan_subband == 1 && !cfg->real_input && cfg->npol == 2 && cfg->force_four_pass == 0 && !msub && nsub == 1 &&
+      g.logMf >= 6 && g.logMf <= 13 && fb_conv1_check(g.logMf, nullptr) == DSPSR_AMD_OK)
+    fb->conv1_logM = g.logMf;
   // dsp::Convolution behind a filterbank (nchan_subband = 1 on many input channels, `dspsr -F N`): one launch group per input channel
   // holds parts x 2 x freq_res points -- a tile or two per compute unit and four launches per channel.  The channels of a GROUP run
   // as one launch group instead (fb_run_batched): forward passes on the group's (part, pol, channel) sequences with this object's
@@ -455,6 +463,7 @@ extern "C" void dspsr_amd_filterbank_destroy(dspsr_amd_filterbank* fb)
   if (fb->A) (void)hipFree(fb->A);
   if (fb->X) (void)hipFree(fb->X);
   if (fb->kernel) (void)hipFree(fb->kernel);
+  if (fb->kernel_nat) (void)hipFree(fb->kernel_nat);
   if (fb->Rt) (void)hipFree(fb->Rt);
   if (fb->det) (void)hipFree(fb->det);
   if (fb->fpart) (void)hipFree(fb->fpart);
@@ -484,6 +493,13 @@ extern "C" int dspsr_amd_filterbank_set_kernel(dspsr_amd_filterbank* fb, const f
     return fb_fail(fb->ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_set_kernel: hipMalloc failed");
   const cf* src = (const cf*)kernel_host;
   std::vector<cf> perm;
+  if (fb->conv1_logM >= 0 && fb->g.xblocked) {
+    // (the one-pass convolution reads the response in natural order; the four-pass kernels of this geometry take it blocked)
+    if (!fb->kernel_nat && hipMalloc((void**)&fb->kernel_nat, expect * sizeof(cf)) != hipSuccess)
+      return fb_fail(fb->ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_set_kernel: hipMalloc failed");
+    if (hipMemcpy(fb->kernel_nat, src, expect * sizeof(cf), hipMemcpyHostToDevice) != hipSuccess)
+      return fb_fail(fb->ctx, DSPSR_AMD_EHIP, "dspsr_amd_filterbank_set_kernel: copy of the response failed");
+  }
   if (fb->g.xblocked) {
     // four-pass geometries: the chirp lies on the device in the order of the blocked spectrum (k_inv_a loads both alike)
     const FbGeom& g = fb->g;
@@ -656,6 +672,14 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
     const int rc = fb_plain_launch(ctx, fb->plain_logC, g.real_input != 0, (uint32_t)g.npol, fb->cfg.input_nchan, fb->kernel, in, out,
                                    in_chan_stride_bytes_or_floats, npart);
     if (rc != DSPSR_AMD_OK) return fb_fail(ctx, rc, "dspsr_amd_filterbank_perform: launch of the non-convolving filterbank failed");
+    return DSPSR_AMD_OK;
+  }
+  if (fb->conv1_logM >= 0 && in.kind == 0 && (out.kind == 0 || out.kind == 1 || out.kind == 2) && (in_chan_stride_bytes_or_floats % 2) == 0 &&
+      (in.pol_stride % 2) == 0 && ((uintptr_t)in.base % 8) == 0) {
+    const cf* kern = fb->kernel ? (fb->g.xblocked ? fb->kernel_nat : fb->kernel) : nullptr;
+    const int rc = fb_conv1_launch(ctx, fb->conv1_logM, (const float*)in.base, in_chan_stride_bytes_or_floats, in.pol_stride, 2 * in.part_step, kern, out,
+                                   fb->cfg.input_nchan, g.nfilt_pos, g.nkeep, npart);
+    if (rc != DSPSR_AMD_OK) return fb_fail(ctx, rc, "dspsr_amd_filterbank_perform: launch of the one-pass convolution failed");
     return DSPSR_AMD_OK;
   }
   if (fb->batch && in.kind == 0 && (out.kind == 0 || out.kind == 1 || out.kind == 2) && (in_chan_stride_bytes_or_floats % 2) == 0)
@@ -1157,12 +1181,16 @@ extern "C" int dspsr_amd_filterbank_npass(const dspsr_amd_filterbank* fb, int ra
 {
   if (!fb) return 0;
   if (fb->plain_logC >= 0) return 1;
+  if (fb->conv1_logM >= 0 && !raw_input) return 1;
   if (fb->g.four_pass) return 4;
   return fb->two_pass && raw_input ? 2 : 3;
 }
 
 extern "C" int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb)
 {
+  // (short responses of dsp::Convolution shapes: Detection inside the one-pass kernel, Fold as a launch of its own -- the segment-sum
+  //  fold belongs to the four-pass kernels)
+  if (fb && fb->conv1_logM >= 0) return 0;
   if (!fb || fb->msub || fb->plain_logC >= 0) return 0;            // (freq_res = 3 * 2^k / 5 * 2^k: the last step is a pass of its own, k_time_combine)
   // (segment sums pay when most of the transform is kept: at -F 64:D -x 16384 only 1817 of 16384 samples are, the unfused pass
   //  writes just those, and the fused one measured 541 against 458 us per 8 parts)

@@ -260,7 +260,8 @@ def test_pipeline_filterbank_then_convolution(oracle, gpu, when, machine):
 
 
 @pytest.mark.parametrize("nchan,M,nfilt,npart", [(16, 2048, (200, 150), 5), (128, 1024, (100, 90), 3), (12, 512, (40, 30), 7),
-                                                 (8, 65536, (3000, 2000), 2), (4, 256, (20, 13), 40)])
+                                                 (8, 65536, (3000, 2000), 2), (4, 256, (20, 13), 40), (3, 8192, (700, 650), 5),
+                                                 (5, 4096, (0, 0), 3), (2, 64, (5, 7), 300), (1, 128, (9, 0), 130)])
 def test_convolution_of_many_channels_as_one_launch_group(oracle, gpu, nchan, M, nfilt, npart):
     """dsp::Convolution behind a filterbank (`dspsr -F N`: nchan_subband = 1 on many complex channels, float32 rows): the channels of a
     group run as ONE launch group -- forward passes per channel, inverse passes of a group-wide filterbank (filterbank.hip
@@ -275,9 +276,11 @@ def test_convolution_of_many_channels_as_one_launch_group(oracle, gpu, nchan, M,
     ref = o.convolution(x, M, nfilt[0], nfilt[1], kernel, False, npart=npart, dtype=np.float64)
     d_x = torch.from_numpy(x).cuda()
     outs, dets = [], []
-    for grouped in (True, False):
-        eng = dspsr_amd.FilterbankEngine(ctx).setup(1, M, nfilt[0], nfilt[1], nchan, 2, False, kernel, max_parts=3,
-                                                    force_four_pass=0 if grouped else 2)
+    # force_four_pass 1: four tile passes, channels grouped; 2: four tile passes, loop over the channels; 0: the library's choice
+    # (one tile pass for n_fft <= 8192, csrc/fb_conv1.hip; grouped four-pass above)
+    for ffp in (1, 2, 0):
+        eng = dspsr_amd.FilterbankEngine(ctx).setup(1, M, nfilt[0], nfilt[1], nchan, 2, False, kernel, max_parts=3, force_four_pass=ffp)
+        assert eng.npass(False) == (1 if ffp == 0 and M <= 8192 else 4)
         out = torch.zeros((nchan, 2, 2 * npart * step), dtype=torch.float32, device="cuda")
         eng.perform(d_x, out, npart, 2 * step, 2 * step)
         det = torch.zeros((nchan, 1, 4 * npart * step), dtype=torch.float32, device="cuda")
@@ -286,11 +289,12 @@ def test_convolution_of_many_channels_as_one_launch_group(oracle, gpu, nchan, M,
         outs.append(out.cpu().numpy())
         dets.append(det.cpu().numpy())
         eng.close()
-    got = outs[0].view(np.complex64).astype(np.complex128)
     rms = math.sqrt(np.mean(np.abs(ref) ** 2))
     tol = 2e-6 * math.sqrt(math.log2(2 * M))
-    assert math.sqrt(np.mean(np.abs(got - ref) ** 2)) / rms <= tol
-    assert np.abs(got - ref).max() <= 8 * tol * rms
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(dets[0], dets[1])
     want = oracle.detect_layout(oracle.detect_products(ref, "Stokes"), 4).reshape(nchan, 1, -1)
-    assert np.abs(dets[0] - want).max() <= 1e-5 * np.abs(want).max()
+    for o_, d_ in zip(outs, dets):
+        got = o_.view(np.complex64).astype(np.complex128)
+        assert math.sqrt(np.mean(np.abs(got - ref) ** 2)) / rms <= tol
+        assert np.abs(got - ref).max() <= 8 * tol * rms
+        assert np.abs(d_ - want).max() <= 1e-5 * np.abs(want).max()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(dets[0], dets[1])         # grouped == loop, bit for bit
