@@ -1165,7 +1165,7 @@ def main():
                                                 "replicas so that N = 1 agrees with the single-GPU record" % world)
         if world == 1:
             others = []
-            for w in ("cfg1", "cfg1opt", "cfg2", "cfg3", "odd_nchan", "odd_fres", "after", "plain"):
+            for w in ("cfg1", "cfg1opt", "cfg2", "cfg3", "odd_nchan", "odd_fres", "after", "after8k", "plain"):
                 others.append(brief(run_fold_workload(w, short, *ctx, steps=2 * ssteps, warmup=swarm, full=False)))
             sm = argparse.Namespace(**vars(args))
             sm.steps, sm.warmup, sm.no_cpu_baseline = 2 * ssteps, swarm, True
