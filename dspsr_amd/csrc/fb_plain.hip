@@ -77,36 +77,34 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
   // (loaded again, never stored), so no load is conditional
   auto fetch = [&](const uint32_t item, Raw4 (&raw)[NPAIR]) {
     const uint32_t tile = item % ntile, ichan = item / ntile;
-    uint64_t pa[NPAIR], pb[NPAIR];                                        // first sample of the pair's two columns (in input samples)
-#pragma unroll
-    for (int g2 = 0; g2 < P::G1; g2 += 2)
-#pragma unroll
-      for (int i = 0; i < P::R1; i++) {
-        const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
-        const uint32_t col = e & (T - 1), n = e >> logT;
-        const int h = (g2 / 2) * P::R1 + i;
-        const uint32_t nn = MODE == 2 ? n : 2 * n;
-        if (two_pol) {
-          uint64_t part = (uint64_t)tile * hT + (col >> 1);
-          part = part < last_part ? part : last_part;
-          pa[h] = pb[h] = part * step + nn;
-        } else {
-          uint64_t part = (uint64_t)tile * T + col;
-          const uint64_t p0 = part < last_part ? part : last_part, p1 = part + 1 < last_part ? part + 1 : last_part;
-          pa[h] = p0 * step + nn;
-          pb[h] = p1 * step + nn;
-        }
+    // first input sample of the two columns of pair h (computed where it is used: kept in arrays, the sixteen 64-bit pairs spilled)
+    auto samp = [&](const int h, uint64_t& sa, uint64_t& sb) {
+      const int g2 = 2 * (h / P::R1), i = h % P::R1;
+      const uint32_t e = first_stage_elem<LOGF>(tid, logT, g2, i);
+      const uint32_t col = e & (T - 1), n = e >> logT;
+      const uint32_t nn = MODE == 2 ? n : 2 * n;
+      if (two_pol) {
+        uint64_t part = (uint64_t)tile * hT + (col >> 1);
+        part = part < last_part ? part : last_part;
+        sa = sb = part * step + nn;
+      } else {
+        const uint64_t part = (uint64_t)tile * T + col;
+        const uint64_t p0 = part < last_part ? part : last_part, p1 = part + 1 < last_part ? part + 1 : last_part;
+        sa = p0 * step + nn;
+        sb = p1 * step + nn;
       }
+    };
     if constexpr (MODE == 0) {
       if (form == F_WORD) {
         const uint8_t* b = (const uint8_t*)p.in.base;
 #pragma unroll
-        for (int h = 0; h < NPAIR; h++) raw[h].w[0] = *(const uint32_t*)(b + 2 * pa[h]);
+        for (int h = 0; h < NPAIR; h++) { uint64_t sa, sb; samp(h, sa, sb); (void)sb; raw[h].w[0] = *(const uint32_t*)(b + 2 * sa); }
       } else if (form == F_CASPSR) {
         const uint8_t* b = (const uint8_t*)p.in.base;
 #pragma unroll
         for (int h = 0; h < NPAIR; h++) {
-          const uint8_t* q = b + (pa[h] >> 2) * 8 + (pa[h] & 3);
+          uint64_t sa, sb; samp(h, sa, sb);
+          const uint8_t* q = b + (sa >> 2) * 8 + (sa & 3);
           raw[h].w[0] = *(const uint16_t*)q;
           raw[h].w[1] = *(const uint16_t*)(q + 4);
         }
@@ -114,7 +112,8 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
         const float* x = (const float*)p.in.base + (uint64_t)ichan * p.in_chan_stride;
 #pragma unroll
         for (int h = 0; h < NPAIR; h++) {
-          const float* q = x + pa[h];
+          uint64_t sa, sb; samp(h, sa, sb);
+          const float* q = x + sa;
           raw[h].w[0] = __float_as_uint(q[0]); raw[h].w[1] = __float_as_uint(q[1]);
           raw[h].w[2] = __float_as_uint(q[p.in.pol_stride]); raw[h].w[3] = __float_as_uint(q[p.in.pol_stride + 1]);
         }
@@ -123,7 +122,8 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
         const uint8_t* b = (const uint8_t*)p.in.base + (uint64_t)ichan * 2;
 #pragma unroll
         for (int h = 0; h < NPAIR; h++) {
-          const uint8_t* q = b + pa[h] * skip;
+          uint64_t sa, sb; samp(h, sa, sb);
+          const uint8_t* q = b + sa * skip;
           raw[h].w[0] = q[0]; raw[h].w[1] = q[1]; raw[h].w[2] = q[skip]; raw[h].w[3] = q[skip + 1];
         }
       }
@@ -132,27 +132,30 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
         const float* x = (const float*)p.in.base + (uint64_t)ichan * p.in_chan_stride;
 #pragma unroll
         for (int h = 0; h < NPAIR; h++) {
-          raw[h].w[0] = __float_as_uint(x[pa[h]]); raw[h].w[1] = __float_as_uint(x[pa[h] + 1]);
-          raw[h].w[2] = __float_as_uint(x[pb[h]]); raw[h].w[3] = __float_as_uint(x[pb[h] + 1]);
+          uint64_t sa, sb; samp(h, sa, sb);
+          raw[h].w[0] = __float_as_uint(x[sa]); raw[h].w[1] = __float_as_uint(x[sa + 1]);
+          raw[h].w[2] = __float_as_uint(x[sb]); raw[h].w[3] = __float_as_uint(x[sb + 1]);
         }
       } else {
         const uint64_t skip = p.in.nchan;
         const uint8_t* b = (const uint8_t*)p.in.base + ichan;
 #pragma unroll
         for (int h = 0; h < NPAIR; h++) {
-          raw[h].w[0] = b[pa[h] * skip]; raw[h].w[1] = b[(pa[h] + 1) * skip];
-          raw[h].w[2] = b[pb[h] * skip]; raw[h].w[3] = b[(pb[h] + 1) * skip];
+          uint64_t sa, sb; samp(h, sa, sb);
+          raw[h].w[0] = b[sa * skip]; raw[h].w[1] = b[(sa + 1) * skip];
+          raw[h].w[2] = b[sb * skip]; raw[h].w[3] = b[(sb + 1) * skip];
         }
       }
     } else {
       // complex input: the pair's columns are (pol 0, pol 1) of one part, or pol 0 of two parts
-      const uint32_t sb = two_pol ? 1u : 0u;
+      const uint32_t spol = two_pol ? 1u : 0u;
       if (form == F_FLOAT) {
         const float* x = (const float*)p.in.base + (uint64_t)ichan * p.in_chan_stride;
 #pragma unroll
         for (int h = 0; h < NPAIR; h++) {
-          const float* qa = x + 2 * pa[h];
-          const float* qb = x + sb * p.in.pol_stride + 2 * pb[h];
+          uint64_t sa, sb; samp(h, sa, sb);
+          const float* qa = x + 2 * sa;
+          const float* qb = x + spol * p.in.pol_stride + 2 * sb;
           raw[h].w[0] = __float_as_uint(qa[0]); raw[h].w[1] = __float_as_uint(qa[1]);
           raw[h].w[2] = __float_as_uint(qb[0]); raw[h].w[3] = __float_as_uint(qb[1]);
         }
@@ -161,8 +164,9 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
         const uint32_t np = (uint32_t)p.g.npol;
 #pragma unroll
         for (int h = 0; h < NPAIR; h++) {
-          raw[h].w[0] = b[((pa[h] >> 11) * np) * 2048 + (pa[h] & 2047)];
-          raw[h].w[2] = b[((pb[h] >> 11) * np + sb) * 2048 + (pb[h] & 2047)];
+          uint64_t sa, sb; samp(h, sa, sb);
+          raw[h].w[0] = b[((sa >> 11) * np) * 2048 + (sa & 2047)];
+          raw[h].w[2] = b[((sb >> 11) * np + spol) * 2048 + (sb & 2047)];
         }
       } else {                                              // generic 8-bit complex: ((t * nchan + c) * npol + p) * 2 + d
         const uint64_t skip = (uint64_t)p.in.nchan * p.g.npol * 2;
@@ -170,14 +174,16 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
         if (form == F_HALF) {
 #pragma unroll
           for (int h = 0; h < NPAIR; h++) {
-            raw[h].w[0] = *(const uint16_t*)(b + pa[h] * skip);
-            raw[h].w[2] = *(const uint16_t*)(b + pb[h] * skip + 2 * sb);
+          uint64_t sa, sb; samp(h, sa, sb);
+            raw[h].w[0] = *(const uint16_t*)(b + sa * skip);
+            raw[h].w[2] = *(const uint16_t*)(b + sb * skip + 2 * spol);
           }
         } else {
 #pragma unroll
           for (int h = 0; h < NPAIR; h++) {
-            const uint8_t* qa = b + pa[h] * skip;
-            const uint8_t* qb = b + pb[h] * skip + 2 * sb;
+          uint64_t sa, sb; samp(h, sa, sb);
+            const uint8_t* qa = b + sa * skip;
+            const uint8_t* qb = b + sb * skip + 2 * spol;
             raw[h].w[0] = (uint32_t)qa[0] | ((uint32_t)qa[1] << 8);
             raw[h].w[2] = (uint32_t)qb[0] | ((uint32_t)qb[1] << 8);
           }
@@ -311,17 +317,20 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
       }
     };
     if constexpr (MODE == 2) {
-      constexpr int NIT = (int)((C << loghT) / nt);                       // 16 bins of a pair per thread
-      float4 z[NIT];
+      constexpr int NIT = (int)((C << loghT) / nt);                       // 16 bins of a pair per thread, eight LDS reads at a time
 #pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const uint32_t idx = tid + it * nt;
-        z[it] = stg[(idx & (hT - 1)) * plane + (idx >> loghT)];
-      }
+      for (int i0 = 0; i0 < NIT; i0 += 8) {
+        float4 z[8];
 #pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const uint32_t idx = tid + it * nt;
-        emit(idx >> loghT, idx & (hT - 1), make_float2(z[it].x, z[it].z), make_float2(z[it].y, z[it].w));
+        for (int it = 0; it < 8; it++) {
+          const uint32_t idx = tid + (i0 + it) * nt;
+          z[it] = stg[(idx & (hT - 1)) * plane + (idx >> loghT)];
+        }
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+          const uint32_t idx = tid + (i0 + it) * nt;
+          emit(idx >> loghT, idx & (hT - 1), make_float2(z[it].x, z[it].z), make_float2(z[it].y, z[it].w));
+        }
       }
     } else {
       // X[k] = A + w^k B, X[C-k] = conj(A - w^k B);  A = (Z[k] + conj Z[C-k]) / 2, B = (Z[k] - conj Z[C-k]) / 2i, w = exp(-i pi / C)
@@ -333,18 +342,23 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
         const v2f wr = c * br + sn * bi, wi = c * bi - sn * br;            // w^k = (c, -sn)
         xr = ar + wr; xi = ai + wi; yr = ar - wr; yi = wi - ai;
       };
-      // (C/2 * hT bin pairs on nt = C * T / 32 threads: eight per thread -- all sixteen LDS reads first, then the arithmetic)
+      // (C/2 * hT bin pairs on nt = C * T / 32 threads: eight per thread -- eight LDS reads, then the arithmetic of four pairs, twice:
+      //  all sixteen reads at once spilled 64 bytes per lane)
       constexpr int NIT = (int)(((C / 2) << loghT) / nt);
-      float4 zk[NIT], zm[NIT];
+      static_assert(NIT == 8, "eight bin pairs per thread");
 #pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const uint32_t idx = tid + it * nt, j = idx & (hT - 1), kp = idx >> loghT;
-        zk[it] = stg[j * plane + kp];
-        zm[it] = stg[j * plane + (kp ? C - kp : C / 2)];
+      for (int i0 = 0; i0 < NIT; i0 += 4) {
+      float4 zk[4], zm[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t idx = tid + (i0 + q) * nt, j = idx & (hT - 1), kp = idx >> loghT;
+        zk[q] = stg[j * plane + kp];
+        zm[q] = stg[j * plane + (kp ? C - kp : C / 2)];
       }
 #pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const uint32_t idx = tid + it * nt, j = idx & (hT - 1), kp = idx >> loghT;
+      for (int q = 0; q < 4; q++) {
+        const int it = q;
+        const uint32_t idx = tid + (i0 + q) * nt, j = idx & (hT - 1), kp = idx >> loghT;
         v2f xr, xi, yr, yi;
         if (kp == 0) {               // bins 0 and C/2 are their own mirrors: X[0] from Z[0] (w = 1), X[C/2] from Z[C/2] (w = -i)
           v2f ur, ui;
@@ -358,6 +372,7 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
           emit(kp, j, make_float2(xr[0], xi[0]), make_float2(xr[1], xi[1]));
           emit(C - kp, j, make_float2(yr[0], yi[0]), make_float2(yr[1], yi[1]));
         }
+      }
       }
     }
     if (!more) break;
