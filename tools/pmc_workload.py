@@ -85,9 +85,11 @@ def main():
         torch.cuda.synchronize()
         r = lt.response
         nchan_subband = cfg.nchan // info.nchan
-        N = nchan_subband * r.ndat
+        N = nchan_subband * (r.ndat if r is not None else 1)
         nsamp_fft = 2 * N if info.ndim == 1 else N
         b_alg = bench.algorithmic_bytes_per_part(2, nsamp_fft * info.ndim, 8, N, nchan_subband, lt.nkeep)
+        if r is None:
+            b_alg -= 8 * N                          # Config::Never: no response to read
         if mode == "fused":
             b_alg -= 2 * nchan_subband * lt.nkeep * 8
         rec.update(parts_per_block=cfg.parts_per_block, parts_per_launch_group=cfg.max_parts, fused_fold=bool(lt.fused_fold),
