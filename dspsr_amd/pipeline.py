@@ -886,6 +886,9 @@ class LoadToFold:
         """The lines `dspsr` prints while it prepares (report_vitals, LoadToFold1.C:773-792,874-879): dedispersion filter
         length, what the filterbank requires, the block size."""
         r, cfg = self.response, self.cfg
+        if r is None:                                     # Config::Never: no response
+            from types import SimpleNamespace
+            r = SimpleNamespace(ndat=1, minimum_ndat=0)
         nsamp_fft = self.nsamp_step + self.nsamp_overlap
         nblock = cfg.parts_per_block * self.nsamp_step + self.nsamp_overlap
         return ["dspsr: dedispersion filter length=%d (minimum=%d) complex samples" % (r.ndat, r.minimum_ndat),

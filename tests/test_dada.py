@@ -271,3 +271,31 @@ def test_dspsr_spelled_driver(tmp_path):
         assert prof.shape == (16, 1, 64, 4) and int(hits.sum()) == int(hdr["NDAT_TOTAL"])
         total += int(hdr["NDAT_TOTAL"])
     assert total > 0 and float(np.abs(prof).max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fb,dm", [("16", 30.0), ("16", 0.0)])
+def test_dspsr_spelled_driver_filterbank_then_convolution(tmp_path, fb, dm):
+    """`-F 16` without `:D` (Filterbank::Config::After; -D 0: the filterbank alone) through the same tool: the non-convolving filterbank
+    and dsp::Convolution on its channels, fed from the file block by block."""
+    import subprocess
+    import sys
+    from dspsr_amd import pipeline
+    freq, bw, tsamp, period = 1382.0, -16.0, 1.0 / 32.0, 0.004
+    raw = synth.voltages(400000, freq, bw, tsamp, max(dm, 1.0), period)
+    path = tmp_path / "synthetic.dada"
+    path.write_bytes(synth.dada_header(freq, bw, 1, 2, 1, tsamp) + raw.tobytes())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "dspsr_amd_fold.py"), "-F", fb, "-D", str(dm), "-b", "64", "-c", str(period),
+           "-L", "0.002", "-O", str(tmp_path / "out"), str(path)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    files = sorted(f for f in os.listdir(tmp_path) if f.startswith("out_") and f.endswith(".ps"))
+    assert len(files) >= 5
+    total = 0
+    for f in files:
+        hdr, hits, prof = pipeline.read_phase_series(str(tmp_path / f))
+        assert prof.shape == (16, 1, 64, 4) and int(hits.sum()) == int(hdr["NDAT_TOTAL"])
+        total += int(hdr["NDAT_TOTAL"])
+    # one output sample per 32 input samples, less the convolution's overlap at the end of the file
+    assert 0 < total <= 400000 // 32 and total >= 400000 // 32 - 2200 and float(np.abs(prof).max()) > 0

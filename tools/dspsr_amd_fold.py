@@ -3,6 +3,7 @@
 dspsr_amd.dada.fold_file for trying the engine on a DADA file; not a re-implementation of the dspsr application.
 
   dspsr_amd_fold.py -F 1024:D -D 1000 -b 1024 -c 0.0893 [-x 4096] [-L 10 | -s | -turns N] [-P polyco] [-K] [-d 4] [-r]
+  dspsr_amd_fold.py -F 128 ...   (no `:D`: filterbank, THEN coherent dedispersion per channel -- Filterbank::Config::After; -D 0: none)
                     [--dump Detection] [--dump Fold] [-O out_prefix] file.dada
 
 Every completed sub-integration is written as <prefix>_<n>.ps (the PhaseSeries hand-off file of INTEGRATION.md:
@@ -17,7 +18,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("file")
-    ap.add_argument("-F", dest="fb", required=True, help="nchan:D  (convolving filterbank with coherent dedispersion)")
+    ap.add_argument("-F", dest="fb", required=True, help="nchan:D (convolving filterbank, coherent dedispersion During) or nchan (filterbank, then dsp::Convolution: After)")
     ap.add_argument("-D", dest="dm", type=float, default=None, help="dispersion measure (default: DM of the header)")
     ap.add_argument("-b", dest="nbin", type=int, default=0, help="phase bins (default: dsp::Fold::choose_nbin)")
     ap.add_argument("-c", dest="period", type=float, default=0.0, help="constant folding period in seconds")
@@ -33,8 +34,9 @@ def main():
     ap.add_argument("-O", dest="prefix", default="dspsr_amd", help="output file name prefix")
     ap.add_argument("--cuda", dest="device", type=int, default=0, help="device id (the reference's spelling)")
     a = ap.parse_args()
-    if not a.fb.endswith(":D"):
-        sys.exit("only -F nchan:D (filterbank with coherent dedispersion During) is on this path")
+    when = "during" if a.fb.endswith(":D") else "after"
+    if ":" in a.fb and not a.fb.endswith(":D"):
+        sys.exit("-F nchan:D (coherent dedispersion During the filterbank) or -F nchan (After it) are on this path; not %s" % a.fb)
     import torch
     from dspsr_amd import dada, pipeline
     hdr, _ = dada.read_header(a.file)
@@ -51,7 +53,8 @@ def main():
     nbin = a.nbin or pipeline.choose_nbin(pfold, out_rate)
     cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=a.period, freq_res=a.nfft,
                           subint_seconds=a.subint, subint_turns=1.0 if a.single else a.turns, ndim=a.ndim,
-                          interchan_dedispersion=a.interchan, record_time=a.record)
+                          interchan_dedispersion=a.interchan, record_time=a.record,
+                          convolve_when="never" if when == "after" and dm == 0.0 else when)
     torch.cuda.set_device(a.device)
     lt = dada.fold_file(a.file, cfg, polyco=polyco, device=a.device, stream=torch.cuda.current_stream().cuda_stream,
                         dump_before=tuple(a.dump))
