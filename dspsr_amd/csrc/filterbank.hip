@@ -429,7 +429,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   // as one launch group instead (fb_run_batched): forward passes on the group's (part, pol, channel) sequences with this object's
   // per-channel geometry, inverse passes of a `group`-channel filterbank object (natural spectrum order) on the spectra laid side
   // by side.  Complex float32 rows read in place by pass 1; other inputs keep the loop over the channels.
-  if (cfg->nchan_subband == 1 && !cfg->real_input && cfg->npol == 2 && cfg->input_nchan >= 4 && cfg->force_four_pass != 2 &&
+  if (fb->conv1_logM < 0 && cfg->nchan_subband == 1 && !cfg->real_input && cfg->npol == 2 && cfg->input_nchan >= 4 && cfg->force_four_pass != 2 &&
       g.four_pass && !g.xblocked && !msub && nsub == 1 && !(g.logR >= 6 && g.logT1 <= 4) && fb->k1_w4) {
     uint32_t ch = 1;
     while (ch < 64 && cfg->input_nchan % (2 * ch) == 0) ch *= 2;

@@ -102,9 +102,10 @@ typedef struct {
   uint32_t real_input;      /* 1: Signal::Nyquist (ndim 1), 0: Signal::Analytic (ndim 2) */
   uint32_t max_parts;       /* parts processed per launch group (scratch is sized for this); 0 => default */
   uint32_t force_four_pass; /* 0 => passes chosen from the geometry; 1: two-pass inverse (the path of freq_res > 8192 and of
-                               dsp::Convolution) also where the single-pass inverse would do; 2: never the two-pass path of
-                               short responses (complex dual-pol input, nchan_subband * freq_res^2 <= 2^27: forward and
-                               inverse transforms in two tiles); same results to rounding in every case */
+                               dsp::Convolution) also where the single-pass inverse would do -- and instead of the one-pass
+                               convolution of short responses; 2: never the two-pass path of short responses (complex dual-pol input,
+                               nchan_subband * freq_res^2 <= 2^27: forward and inverse transforms in two tiles), the one-pass
+                               convolution or the grouping of a convolution's channels; same results to rounding in every case */
   uint32_t fused_fold;      /* dspsr_amd_filterbank_perform_fold: DSPSR_AMD_FUSED_AUTO (fold inside the last filterbank
                                pass when the channel tiles fill the chip), _ALWAYS, _NEVER -- same sums bit for bit */
 } dspsr_amd_filterbank_config;
@@ -183,12 +184,17 @@ int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb);
 /* How many transform passes (trips of the part through HBM scratch + 1) a call makes -- the role of the plan choice inside
  * CUDA::FilterbankEngine::setup (FilterbankCUDA.cu:92-116: one forward and one batched backward cuFFT plan).  raw_input != 0:
  * the answer for dspsr_amd_filterbank_perform_raw / _detect / _fold on a generic 8-bit block, else for float32 rows.
- *   1  freq_res = 1: the non-convolving filterbank, one tile pass from the input to the output rows;
+ *   1  freq_res = 1: the non-convolving filterbank, one tile pass from the input to the output rows; and (raw_input == 0)
+ *      dsp::Convolution shapes -- nchan_subband = 1, complex input with two polarisations -- with 64 <= freq_res <= 8192 on float32
+ *      rows: forward transform, response, backward transform, keep window and Detection of a (channel, part) sequence in ONE tile
+ *      (csrc/fb_conv1.hip; force_four_pass != 0 keeps the four passes);
  *   2  short responses: complex dual-pol 8-bit input with 512 <= freq_res <= 4096 and 2^13 / freq_res <= nchan_subband <=
  *      2^27 / freq_res^2 (upper end: one 50 MHz sub-band with -F 512:D -x 512): column forward pass, then rows + chirp + inverse
  *      transforms in ONE tile -- the spectrum stays on chip;
  *   3  forward columns, forward rows, inverse per channel (freq_res <= 8192);
- *   4  two-pass inverse (freq_res > 8192, dsp::Convolution shapes, force_four_pass = 1).
+ *   4  two-pass inverse (freq_res > 8192, dsp::Convolution shapes, force_four_pass = 1).  dsp::Convolution on >= 4 complex channels
+ *      of float32 rows runs GROUPS of channels as one launch group (forward passes per channel, inverse passes of a group-wide
+ *      filterbank: the same numbers bit for bit; force_four_pass = 2 keeps the loop over the channels).
  * The count is that of the TILE passes.  Lengths with an odd factor run the three tile passes per power-of-two sub-sequence and
  * add trips through HBM outside the tiles: nchan_subband = R * 2^k a de-interleave of the input (k_sub_split) and one radix-R pass
  * over the spectrum (k_sub_combine); freq_res = R * 2^k a radix-R pass over the pseudo-channels' time series as well
