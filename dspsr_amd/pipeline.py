@@ -46,8 +46,10 @@ class Config:
     interchan_dedispersion: bool = False   # -K: remove the inter-channel dispersion delay (LoadToFold1.C:605-624)
     convolve_when: str = "during"          # -F N:D = "during" (the response inside the filterbank, LoadToFold1.C:318-323); -F N = "after":
                                            # non-convolving filterbank (freq_res 1), then dsp::Convolution on its channels
-                                           # (Filterbank::Config::After, FilterbankConfig.C:56, LoadToFold1.C:337-380); "never": the
-                                           # filterbank alone (no coherent dedispersion)
+                                           # (Filterbank::Config::After, FilterbankConfig.C:56, LoadToFold1.C:337-380); -F N:B = "before":
+                                           # dsp::Convolution of the whole input channel, then the non-convolving filterbank
+                                           # (Config::Before, FilterbankConfig.C:76-78, LoadToFold1.C:326-385); "never": the filterbank
+                                           # alone (no coherent dedispersion)
     record_time: bool = False              # -r: time every operation (Operation.C:90-113); each one then ends with a stream
                                            # synchronisation so that the wall times are honest (FilterbankCUDA.cu:302-303)
 
@@ -688,6 +690,68 @@ class FilterbankThenConvolution:
         self.channelised = None
 
 
+class ConvolutionThenFilterbank:
+    """`dspsr -F N:B` (Filterbank::Config::Before, FilterbankConfig.C:76-78; LoadToFold1.C:326-385): dsp::Convolution with the dedispersion
+    response of the WHOLE input channel first (the filterbank object with nchan_subband = 1 on the 8-bit block: Convolution.C:338-461),
+    then the non-convolving filterbank (freq_res = 1, Filterbank.C:614-623) on the dedispersed complex rows.  Every channel then
+    refers to the input channel's centre frequency: no dispersion delay is left between the output channels.
+    The convolution keeps `ck` complex samples per part and the filterbank consumes `nsub` per output sample; the reference carries
+    the remainder from block to block (InputBuffering).  Here one part of the interface LoadToFold uses is P = nsub / gcd(ck, nsub)
+    parts of the convolution, which hold a whole number of filterbank transforms -- no remainder, same samples."""
+
+    def __init__(self, ctx, nsub, input_nchan, npol, real_input, response, max_parts=1, parts_per_block=1):
+        import torch
+        self.torch, self.ctx = torch, ctx
+        self.conv = ConvolutionEngine(ctx).setup(1, response.ndat, response.impulse_pos, response.impulse_neg, input_nchan, npol, real_input,
+                                                 response.kernel, max_parts=max_parts)
+        self.back = FilterbankEngine(ctx).setup(nsub, 1, 0, 0, input_nchan, npol, False, None)
+        ck = self.conv.nkeep
+        self.P = nsub // math.gcd(ck, nsub)
+        self.nsub, self.in_nchan, self.npol = nsub, input_nchan, npol
+        self.nkeep = self.P * ck // nsub                         # filterbank output samples per (super) part
+        self.nsamp_step = self.P * self.conv.nsamp_step
+        self.nsamp_overlap = self.conv.nsamp_overlap
+        self.nsamp_fft = self.nsamp_step + self.nsamp_overlap
+        self.dedispersed = None                                   # the convolution's output block [input chan][pol][2 * ndat]
+        self._cap = parts_per_block
+
+    def _front(self, raw, layout, scale, npart):
+        ncv = npart * self.P
+        ndat = ncv * self.conv.nkeep
+        if self.dedispersed is None or self.dedispersed.shape[2] < 2 * ndat:
+            n = max(ndat, self._cap * self.P * self.conv.nkeep)
+            self.dedispersed = self.torch.empty((self.in_nchan, self.npol, 2 * n), dtype=self.torch.float32,
+                                                device="cuda:%d" % self.ctx.device)
+        self.conv.perform_raw(raw, layout, scale, self.dedispersed, ncv)
+        return self.dedispersed, ndat // self.nsub
+
+    def perform_raw(self, raw, layout, scale, out, npart, out_step=None):
+        x, nfb = self._front(raw, layout, scale, npart)
+        self.back.perform(x, out, nfb, 2 * self.nsub, out_step or 2)
+
+    def perform_detect(self, det, npart, state=_lib.COHERENCE, ndim=4, raw=None, layout=_lib.RAW_GENERIC, scale=1.0):
+        x, nfb = self._front(raw, layout, scale, npart)
+        self.back.perform_detect(det, nfb, state, ndim, inp=x, in_step=2 * self.nsub)
+
+    def perform_fold(self, fold, npart, state=_lib.COHERENCE, raw=None, layout=_lib.RAW_GENERIC, scale=1.0):
+        x, nfb = self._front(raw, layout, scale, npart)
+        self.back.perform_fold(fold, nfb, state, inp=x, in_step=2 * self.nsub)
+
+    def fold_is_fused(self):
+        return 0
+
+    def npass(self, raw_input=True):
+        return self.conv.npass(raw_input) + 1
+
+    def finish(self):
+        self.ctx.synchronize()
+
+    def close(self):
+        self.conv.close()
+        self.back.close()
+        self.dedispersed = None
+
+
 class LoadToFold:
     """One pipeline instance = one GPU = one stream (SingleThread).  `raw` blocks are int8 torch
     tensors already resident on the device (the PCIe copy is the caller's, as TransferCUDA is a
@@ -712,8 +776,8 @@ class LoadToFold:
             raise DspsrAmdError("dsp::Fold::fold no polynomial and no period specified")   # Fold.C:638-640
         if info.npol != 2:
             raise DspsrAmdError("dsp::Detection::polarimetry Cannot detect polarization when npol != 2")
-        if cfg.convolve_when not in ("during", "after", "never"):
-            raise DspsrAmdError("dspsr_amd.LoadToFold: convolve_when=%r is not one of during / after / never" % (cfg.convolve_when,))
+        if cfg.convolve_when not in ("during", "after", "before", "never"):
+            raise DspsrAmdError("dspsr_amd.LoadToFold: convolve_when=%r is not one of during / after / before / never" % (cfg.convolve_when,))
         if cfg.nchan % info.nchan:
             raise DspsrAmdError("dsp::Filterbank::make_preparations output nchan=%d not a multiple of input nchan=%d"
                                 % (cfg.nchan, info.nchan))
@@ -840,9 +904,18 @@ class LoadToFold:
             if cfg.freq_res:
                 r.set_frequency_resolution(cfg.freq_res)
             r.match(cfg.nchan)
+        if cfg.convolve_when == "before":
+            # Convolution::prepare -> Dedispersion::match(input): ONE response per input channel, over its whole width
+            r = Dedispersion(info.centre_frequency, info.bandwidth, cfg.dispersion_measure, input_nchan=info.nchan, ndim=info.ndim)
+            if cfg.freq_res:
+                r.set_frequency_resolution(cfg.freq_res)
+            r.match(info.nchan)
         self.response = r
         nsub = cfg.nchan // info.nchan
         self.in_nchan, self.nchan_out = info.nchan, cfg.nchan
+        if cfg.convolve_when == "before":
+            self._init_before(device, r, nsub)
+            return
         self.fb = FilterbankThenConvolution(self.ctx, nsub, info.nchan, info.npol, info.ndim == 1, r, max_parts=cfg.max_parts,
                                             parts_per_block=cfg.parts_per_block,
                                             fused_fold=(_lib.FUSED_NEVER if not cfg.fused_fold else
@@ -862,6 +935,30 @@ class LoadToFold:
                                     dtype=torch.float32, device="cuda:%d" % device)
         self.fused_mode = self.fb.fold_is_fused() if (cfg.fused_fold and cfg.ndim == 4) else 0
         self.fused_fold = self.fused_mode != 0
+        self.optime, self.dumps, self._dump_cplx = {}, {}, None
+        self.hits = np.zeros(cfg.nbin, dtype=np.uint32)
+        self.integration_length, self.ndat_total = 0.0, 0
+        self.nsamples_in, self.ndat_out, self.subints = 0, 0, []
+
+    def _init_before(self, device, r, nsub):
+        torch, cfg, info = self.torch, self.cfg, self.info
+        self.fb = ConvolutionThenFilterbank(self.ctx, nsub, info.nchan, info.npol, info.ndim == 1, r, max_parts=cfg.max_parts,
+                                            parts_per_block=cfg.parts_per_block)
+        self.nkeep, self.nsamp_step, self.nsamp_overlap = self.fb.nkeep, self.fb.nsamp_step, self.fb.nsamp_overlap
+        self.npol_out = 4 // cfg.ndim
+        self.fold = FoldEngine(self.ctx)
+        self.fold.set_shape(self.nchan_out, self.npol_out, cfg.ndim, cfg.nbin)
+        self.scale8 = eight_bit_scale()
+        self.layout = _lib.RAW_CASPSR if info.machine == "CASPSR" else _lib.RAW_GENERIC
+        conv_rate = info.rate * (0.5 if info.ndim == 1 else 1.0)                           # Convolution.C:266-267
+        self.out_rate = conv_rate / float(nsub)                                            # Filterbank.C:338-339
+        self.out_start = info.start_seconds + r.impulse_pos / conv_rate                   # Convolution.C:300
+        nsamp_fft = 2 * r.ndat if info.ndim == 1 else r.ndat
+        self.scalefac = float(nsamp_fft) * float(r.ndat) * float(nsub)                    # Convolution.C:305, Filterbank.C:124-125
+        self.sample_delay, self.sd_carried, self.sd_head, self.sd_short = None, 0, 0, 0
+        self.detected = torch.empty((self.nchan_out, self.npol_out, cfg.parts_per_block * self.nkeep * cfg.ndim),
+                                    dtype=torch.float32, device="cuda:%d" % device)
+        self.fused_mode, self.fused_fold = 0, False
         self.optime, self.dumps, self._dump_cplx = {}, {}, None
         self.hits = np.zeros(cfg.nbin, dtype=np.uint32)
         self.integration_length, self.ndat_total = 0.0, 0

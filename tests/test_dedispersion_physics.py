@@ -10,6 +10,7 @@ Dedispersion.C) -- and pushed through the restated chain.  If every convention i
     behind the convolving filterbank, c widths behind the non-convolving one (its channels are centred on the transform's bins:
     Filterbank.C:341-348 sets dc_centred for freq_res = 1), in natural FFT order (band swapped) for complex-sampled input
     (Filterbank.C:358-364), running down in frequency for a negative bandwidth,
+  * `-F N:B` (Config::Before: the whole band dedispersed first, then channelised) gives sharp pulses at ONE phase in all channels,
   * and without the response (Config::Never) the pulse stays smeared.
 
 A wrong sign, a missing or doubled band swap, a half-channel error in the chirp's reference frequency or an inverted band each
@@ -95,6 +96,19 @@ def test_dispersion_law_pins_the_conventions_oracle(oracle, name, ndim, bw):
     never = _profile(o, fb1, obs1.rate, obs1.start_seconds, period, nbin)
     sharp = lambda q: np.array([q[c].max() / q[c].std() for c in range(nchan) if c not in edge])
     assert (sharp(never) < 0.8 * sharp(after)).all(), (sharp(never), sharp(after))
+    # -F N:B (Config::Before): the whole band dedispersed to its centre frequency first, then channelised: every channel's pulse
+    # sharp AND at the phase of the band centre -- no delay between the channels is left
+    rb = o.Dedispersion()
+    rb.set_frequency_resolution(65536)                                   # (the optimal length, 2^19, is longer than the test signal)
+    rb.match(obs)
+    cb = o.convolution(un, rb.ndat, rb.impulse_pos, rb.impulse_neg, rb.buffer, ndim == 1, dtype=np.float64)
+    obs_c = o.Observation(**obs.__dict__)
+    obs_c.ndim, obs_c.tsamp_us = 2, obs.tsamp_us * (2 if ndim == 1 else 1)
+    planb = o.filterbank_plan(obs_c, nchan, None, 1)
+    fbb = o.filterbank(np.ascontiguousarray(cb).view(np.float64), planb, None, dtype=np.float64)
+    obsb = o.filterbank_output_observation(obs_c, planb)
+    before = _profile(o, fbb, obsb.rate, obs.start_seconds + rb.impulse_pos / obs_c.rate, period, nbin)
+    _check(before, np.full(nchan, 0.5 * nbin), nbin, skip=edge, sharp=True)
     # a response with the wrong ordering (the per-channel swap of Response::match left out) does not sharpen
     bad = r1.buffer.reshape(nchan, 2, -1)[:, ::-1, :].reshape(-1).copy()
     cvb = o.convolution(np.ascontiguousarray(fb1).view(np.float64), r1.ndat, r1.impulse_pos, r1.impulse_neg, bad, False, dtype=np.float64)
@@ -120,9 +134,10 @@ def test_dispersion_law_pins_the_conventions_product(name, ndim, bw):
     edge = (nchan // 2,) if cplx else (0,)
     bps = 2 * ndim                                                       # bytes per time sample (two polarisations)
     sharpness = {}
-    for when in ("during", "after", "never"):
-        cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=4, parts_per_block=4,
-                              max_parts=2, convolve_when=when)
+    for when in ("during", "after", "before", "never"):
+        cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=4,
+                              parts_per_block=1 if when == "before" else 4, max_parts=2, convolve_when=when,
+                              freq_res=65536 if when == "before" else 0)
         lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
         step = cfg.parts_per_block * lt.nsamp_step
         nblocks = (ndat - lt.nsamp_overlap) // step
@@ -135,7 +150,7 @@ def test_dispersion_law_pins_the_conventions_product(name, ndim, bw):
         p = s["profile_dev"].cpu().numpy().reshape(nchan, nbin, 4).astype(np.float64)
         prof = (p[:, :, 0] + p[:, :, 1]) / s["hits"][None, :]
         prof -= prof.mean(axis=1, keepdims=True)
-        exp = _expected_bins(freq, bw, nchan, dm, period, nbin, cplx, when != "during")
+        exp = _expected_bins(freq, bw, nchan, dm, period, nbin, cplx, when != "during") if when != "before" else np.full(nchan, 0.5 * nbin)
         sharpness[when] = np.array([prof[c].max() / prof[c].std() for c in range(nchan) if c not in edge])
         if when != "never":
             _check(prof, exp, nbin, skip=() if when == "during" else edge, sharp=True)

@@ -298,3 +298,52 @@ def test_convolution_of_many_channels_as_one_launch_group(oracle, gpu, nchan, M,
         assert np.abs(got - ref).max() <= 8 * tol * rms
         assert np.abs(d_ - want).max() <= 1e-5 * np.abs(want).max()
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(dets[0], dets[1])         # grouped == loop, bit for bit
+
+
+@pytest.mark.parametrize("ndim", [1, 2])
+def test_pipeline_convolution_then_filterbank(oracle, gpu, ndim):
+    """`dspsr -F 16:B` (Config::Before): dsp::Convolution of the whole input channel, then the non-convolving filterbank on the
+    dedispersed complex rows -- LoadToFold against the oracle chain (Convolution.C, then Filterbank.C with freq_res = 1)."""
+    dspsr_amd, _ = gpu
+    from dspsr_amd import pipeline, synth
+    o = oracle
+    freq, bw, dm, period, nchan, nbin, M = 1382.0, -16.0, 30.0, 0.004, 16, 64, 32768
+    tsamp = 1.0 / 32.0 if ndim == 1 else 1.0 / 16.0
+    cfg = pipeline.Config(nchan=nchan, dispersion_measure=dm, nbin=nbin, folding_period=period, ndim=4, parts_per_block=1,
+                          max_parts=2, convolve_when="before", freq_res=M)
+    info = pipeline.InputInfo(centre_frequency=freq, bandwidth=bw, ndim=ndim, tsamp_us=tsamp, machine="DADA")
+    lt = pipeline.LoadToFold(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    nblocks = 3
+    step = cfg.parts_per_block * lt.nsamp_step
+    ndat = nblocks * step + lt.nsamp_overlap
+    raw = synth.voltages(ndat, freq, bw, tsamp, dm, period, ndim=ndim)
+    d_raw = torch.from_numpy(raw).cuda()
+    bps = 2 * ndim
+    for b in range(nblocks):
+        lt.process_block(d_raw[bps * b * step: bps * (b * step + step + lt.nsamp_overlap)])
+    lt.finish_subint()
+    lt.synchronize()
+    got = lt.subints[0]["profile_dev"].cpu().numpy().reshape(nchan, 1, nbin, 4)
+    obs = o.Observation(centre_frequency=freq, bandwidth=bw, tsamp_us=tsamp, dispersion_measure=dm, ndim=ndim)
+    r = o.Dedispersion()
+    r.set_frequency_resolution(M)
+    r.match(obs)
+    assert np.abs(r.buffer - lt.response.kernel).max() <= 1.2e-7 and (r.impulse_pos, r.impulse_neg) == (lt.response.impulse_pos, lt.response.impulse_neg)
+    cv = o.convolution(o.unpack_8bit(raw, obs), r.ndat, r.impulse_pos, r.impulse_neg, r.buffer, ndim == 1, dtype=np.float64)
+    obs_c = o.Observation(**obs.__dict__)
+    obs_c.ndim, obs_c.tsamp_us = 2, tsamp * (2 if ndim == 1 else 1)
+    plan = o.filterbank_plan(obs_c, nchan, None, 1)
+    fb = o.filterbank(np.ascontiguousarray(cv).view(np.float64), plan, None, dtype=np.float64)
+    fobs = o.filterbank_output_observation(obs_c, plan)
+    fobs.start_seconds = obs.start_seconds + r.impulse_pos / obs_c.rate
+    det = o.detect_layout(o.detect_products(fb, "Coherence"), 4)
+    ps = o.PhaseSeries(nchan, 1, 4, nbin, data=np.zeros((nchan, 1, nbin, 4), np.float64))
+    fcfg = o.FoldConfig(nbin=nbin, folding_period=period)
+    per_block = cfg.parts_per_block * lt.nkeep
+    assert nblocks * per_block <= det.shape[2]
+    for b in range(nblocks):
+        o.fold(det, fobs, fcfg, ps, idat_start=b * per_block, ndat_fold=per_block)
+    assert np.array_equal(lt.subints[0]["hits"], ps.hits)
+    assert np.abs(got - ps.data).max() <= 1e-5 * np.abs(ps.data).max()
+    assert abs(lt.out_rate - fobs.rate) <= 1e-9 * fobs.rate and abs(lt.out_start - fobs.start_seconds) <= 1e-12
+    lt.close()

@@ -4,6 +4,7 @@ dspsr_amd.dada.fold_file for trying the engine on a DADA file; not a re-implemen
 
   dspsr_amd_fold.py -F 1024:D -D 1000 -b 1024 -c 0.0893 [-x 4096] [-L 10 | -s | -turns N] [-P polyco] [-K] [-d 4] [-r]
   dspsr_amd_fold.py -F 128 ...   (no `:D`: filterbank, THEN coherent dedispersion per channel -- Filterbank::Config::After; -D 0: none)
+  dspsr_amd_fold.py -F 128:B ... (coherent dedispersion of the whole band, THEN the filterbank -- Filterbank::Config::Before)
                     [--dump Detection] [--dump Fold] [-O out_prefix] file.dada
 
 Every completed sub-integration is written as <prefix>_<n>.ps (the PhaseSeries hand-off file of INTEGRATION.md:
@@ -34,9 +35,10 @@ def main():
     ap.add_argument("-O", dest="prefix", default="dspsr_amd", help="output file name prefix")
     ap.add_argument("--cuda", dest="device", type=int, default=0, help="device id (the reference's spelling)")
     a = ap.parse_args()
-    when = "during" if a.fb.endswith(":D") else "after"
-    if ":" in a.fb and not a.fb.endswith(":D"):
-        sys.exit("-F nchan:D (coherent dedispersion During the filterbank) or -F nchan (After it) are on this path; not %s" % a.fb)
+    when = "during" if a.fb.endswith(":D") else "before" if a.fb.endswith(":B") else "after"
+    if ":" in a.fb and when == "after":
+        sys.exit("-F nchan:D (coherent dedispersion During the filterbank), -F nchan (After it) or -F nchan:B (Before it) are on this "
+                 "path; not %s" % a.fb)
     import torch
     from dspsr_amd import dada, pipeline
     hdr, _ = dada.read_header(a.file)
