@@ -95,6 +95,12 @@ WORKLOADS = {
     "after8k": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=128, dm=67.99, freq_res=8192, nbin=512,
                     machine="CASPSR", when="after", parts_per_block=256, max_parts=256,
                     cmd="dspsr -F 128 -x 8192 -D 67.99 -b 512 (filterbank, THEN convolution in one tile pass: Config::After)"),
+    # the HEADLINE's band, channel count, DM and response length through Config::After (`-F 1024` without `:D`): k_fb_plain + the one-pass
+    # convolution of 4096 points per channel (79 % of each transform kept) + Fold -- not the BASELINE metric (the channel filters differ
+    # from the convolving filterbank's), a measure of what the other route costs on the same data
+    "after1k": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=1024, dm=1000.0, freq_res=4096, nbin=1024,
+                    machine="CASPSR", when="after", parts_per_block=64, max_parts=64,
+                    cmd="dspsr -F 1024 -x 4096 -D 1000 -b 1024 (filterbank, THEN convolution in one tile pass: Config::After on the headline's band)"),
     # the filterbank alone (Filterbank::Config::Never: `dspsr -F 128` with coherent dedispersion switched off, or any DM-0 source):
     # k_fb_plain writing the detected rows, then Fold -- the roofline of the non-convolving filterbank kernel itself
     "plain": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=128, dm=0.0, freq_res=1, nbin=512,
@@ -1165,7 +1171,7 @@ def main():
                                                 "replicas so that N = 1 agrees with the single-GPU record" % world)
         if world == 1:
             others = []
-            for w in ("cfg1", "cfg1opt", "cfg2", "cfg3", "odd_nchan", "odd_fres", "after", "after8k", "plain"):
+            for w in ("cfg1", "cfg1opt", "cfg2", "cfg3", "odd_nchan", "odd_fres", "after", "after8k", "after1k", "plain"):
                 others.append(brief(run_fold_workload(w, short, *ctx, steps=2 * ssteps, warmup=swarm, full=False)))
             sm = argparse.Namespace(**vars(args))
             sm.steps, sm.warmup, sm.no_cpu_baseline = 2 * ssteps, swarm, True
