@@ -12,20 +12,19 @@
 // polarisations) or consecutive parts (one), so a tile covers T/2 or T consecutive parts and the read-back walks the PARTS with
 // consecutive lanes: every store instruction writes runs of consecutive output samples of a channel row (FPT order).
 // Every input form of the convolving filterbank is taken (float32 rows, generic 8-bit real / complex with any number of input
-// channels, CASPSR, 16-bit UWB) through the same fetch / decode helpers (fb_common.h).
+// channels, CASPSR, 16-bit UWB); the form is decided once per kernel (see F_WORD ... F_HALF below).
 #include "fb_common.h"
 
 namespace dspsr_amd {
 
 struct PlainParams {
-  FbGeom g;                 // (real_input, npol: what fetch_pair / decode_pair read)
+  FbGeom g;                 // (real_input, npol)
   FbIn in;
   FbOut out;                // kind 0 (none), 1 (complex rows), 2 (detected)
   const cf* kern;           // [input_nchan][C] or null
   uint64_t in_chan_stride;  // float rows: floats from one input channel's rows to the next
   uint64_t npart;
   uint32_t input_nchan;
-  int logT;                 // columns per tile
 };
 
 // Input forms, decided ONCE per kernel (uniform) so that the loads of a tile are one straight-line burst: with the form looked up
@@ -421,8 +420,8 @@ int fb_plain_launch(dspsr_amd_ctx* ctx, int logC, bool real_input, uint32_t npol
   p.in_chan_stride = in_chan_stride;
   p.npart = npart;
   p.input_nchan = input_nchan;
-  p.logT = lp - logC;
-  const uint32_t tile_parts = npol == 2 ? (1u << (p.logT - 1)) : (1u << p.logT);
+  const int logT = lp - logC;                        // columns per tile: (part, polarisation) pairs, or parts
+  const uint32_t tile_parts = npol == 2 ? (1u << (logT - 1)) : (1u << logT);
   const uint64_t total = ((npart + tile_parts - 1) / tile_parts) * input_nchan;
   if (total >= (1ull << 31)) return DSPSR_AMD_EINVAL;
   const size_t lds = lds_total_words_host(1u << lp, logC) * sizeof(cf);
