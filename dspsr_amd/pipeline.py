@@ -1485,9 +1485,9 @@ class LoadToFilCoherent:
             raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: PPQQ / Coherence need two input polarisations")
         if cfg.nchan % info.nchan:
             raise DspsrAmdError("dsp::Filterbank::make_preparations output nchan=%d not a multiple of input nchan=%d" % (cfg.nchan, info.nchan))
-        if cfg.dispersion_measure == 0.0 and not cfg.freq_res:
-            raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: -F N:D with a dispersion measure, or -F N -x M (with neither digifil "
-                                "takes the TFPFilterbank: dspsr_amd.LoadToFil)")
+        if cfg.dispersion_measure == 0.0 and not cfg.freq_res and cfg.npol <= 2:
+            raise DspsrAmdError("dspsr_amd.LoadToFilCoherent: -F N:D with a dispersion measure, -F N -x M, or -d 4 (with none of them "
+                                "digifil takes the TFPFilterbank: dspsr_amd.LoadToFil)")
         self.ctx = Context(device, stream)
         nsub = cfg.nchan // info.nchan
         if cfg.dispersion_measure != 0.0:
@@ -1499,8 +1499,10 @@ class LoadToFilCoherent:
         else:
             # -F N -x M without :D (LoadToFil.C:199-216): the convolving filterbank with no response -- nothing is discarded
             # (Filterbank.C:139-155: freq_res as set, nfilt 0)
+            # -F N -d 4 with neither (LoadToFil.C:205-207: `npol > 2` takes the Filterbank too): its default freq_res = 1, the
+            # non-convolving filterbank (Filterbank.C:614-623)
             from types import SimpleNamespace
-            r, kernel = SimpleNamespace(ndat=cfg.freq_res, impulse_pos=0, impulse_neg=0, kernel=None), None
+            r, kernel = SimpleNamespace(ndat=cfg.freq_res or 1, impulse_pos=0, impulse_neg=0, kernel=None), None
         self.response = r
         self.fb = FilterbankEngine(self.ctx).setup(nsub, r.ndat, r.impulse_pos, r.impulse_neg, info.nchan, info.npol, info.ndim == 1,
                                                    kernel, max_parts=cfg.max_parts)

@@ -270,6 +270,8 @@ def test_digifil_coherent_chain_against_the_oracle(oracle, gpu, nbit, npol, fscr
     (8, 1, 0, 0.5, 1024, True),         # -K: SampleDelay between the filterbank and Detection (:236-247), delays of some thousand samples
     (2, 2, 2, 0.5, 1024, True),         # -K -f 2 -d 2
     (8, 1, 0, 0.0, 256, False),         # -F 64 -x 256 without :D: convolving filterbank, no response (:199-216)
+    (8, 4, 0, 0.0, 0, False),           # -F 64 -d 4 with neither -x nor :D: `npol > 2` takes dsp::Filterbank with its default freq_res = 1 --
+                                        # the NON-CONVOLVING filterbank (:205-207, Filterbank.C:614-623), Coherence products, ndim 1
 ])
 def test_digifil_coherent_other_options_against_the_oracle(oracle, gpu, nbit, npol, fscrunch, dm, freq_res, interchan):
     """The same three-block comparison for the remaining options of the convolving branch."""
@@ -277,7 +279,8 @@ def test_digifil_coherent_other_options_against_the_oracle(oracle, gpu, nbit, np
     from dspsr_amd import pipeline
     rng = np.random.default_rng(48)
     info = pipeline.InputInfo(centre_frequency=1382.0, bandwidth=-400.0, nchan=1, npol=2, ndim=1, tsamp_us=0.00125, machine="DADA")
-    cfg = pipeline.SearchConfig(nchan=64, tscrunch=16, nbit=nbit, rescale_seconds=2e-4, dispersion_measure=dm, freq_res=freq_res, parts_per_block=6,
+    ppb = 6 if freq_res else 6 * 1024                      # (freq_res = 1: one output sample per part)
+    cfg = pipeline.SearchConfig(nchan=64, tscrunch=16, nbit=nbit, rescale_seconds=2e-4, dispersion_measure=dm, freq_res=freq_res, parts_per_block=ppb,
                                 max_parts=4, npol=npol, fscrunch=fscrunch, dedisperse=interchan)
     lf = pipeline.LoadToFilCoherent(cfg, info, device=0, stream=torch.cuda.current_stream().cuda_stream)
     assert not lf.fused or (npol == 1 and not interchan)
@@ -287,21 +290,21 @@ def test_digifil_coherent_other_options_against_the_oracle(oracle, gpu, nbit, np
         od = oracle.Dedispersion()
         od.set_frequency_resolution(freq_res)
         od.match(obs, 64)
-    plan = oracle.filterbank_plan(obs, 64, od, freq_res=freq_res)
+    plan = oracle.filterbank_plan(obs, 64, od, freq_res=freq_res or 1)
     assert (plan.nkeep, plan.nsamp_step) == (lf.nkeep, lf.nsamp_step)
     delays = None
     if interchan:
         delays = oracle.dedispersion_sample_delays(obs, 64, lf.fb_rate)
-        assert 1000 < lf.sample_delay.total_delay < 6 * lf.nkeep and lf.sample_delay.total_delay == int(max(delays) - min(delays))
+        assert 1000 < lf.sample_delay.total_delay < ppb * lf.nkeep and lf.sample_delay.total_delay == int(max(delays) - min(delays))
     dig = oracle.DigifilCoherent(tscrunch=16, fscrunch=fscrunch, nbit=nbit, npol_out=npol, rescale_interval=int(2e-4 * lf.out_rate), flip_band=False,
                                  delays=delays)
-    nblk = 6 * lf.nsamp_step + lf.nsamp_overlap
-    stream = np.clip(np.rint(rng.standard_normal((3 * 6 * lf.nsamp_step + lf.nsamp_overlap) * 2) * 24.0), -128, 127).astype(np.int8)
+    nblk = ppb * lf.nsamp_step + lf.nsamp_overlap
+    stream = np.clip(np.rint(rng.standard_normal((3 * ppb * lf.nsamp_step + lf.nsamp_overlap) * 2) * 24.0), -128, 127).astype(np.int8)
     total = 0
     for b in range(3):
-        raw = stream[b * 6 * lf.nsamp_step * 2:(b * 6 * lf.nsamp_step + nblk) * 2]
+        raw = stream[b * ppb * lf.nsamp_step * 2:(b * ppb * lf.nsamp_step + nblk) * 2]
         got = lf.process_block(torch.from_numpy(raw.copy()).cuda()).cpu().numpy()
-        fbo = oracle.filterbank(oracle.unpack_8bit(raw, obs), plan, lf.response.kernel, npart=6, dtype=np.float64).astype(np.complex64)
+        fbo = oracle.filterbank(oracle.unpack_8bit(raw, obs), plan, lf.response.kernel, npart=ppb, dtype=np.float64).astype(np.complex64)
         want = dig.process(fbo)
         got = got.view(want.dtype).reshape(want.shape)
         d = np.abs(got.astype(np.int64) - want.astype(np.int64))
