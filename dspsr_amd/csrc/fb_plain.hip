@@ -42,25 +42,35 @@ enum { F_WORD = 0, F_CASPSR, F_FLOAT, F_BYTES, F_UWB, F_HALF };
 // points per workgroup tile: 2^13 (256 threads, two workgroups per compute unit) up to 256 channels, 2^14 above (runs of 128 bytes
 // per channel row at 512 channels, 64 at 1024: measured 2.26 -> see profiles/r05_experiments.txt item 8); at most 512 columns (the staged image must fit the exchange buffer).  A function of the channel
 // count alone, so the column count is a compile-time constant of every instantiation (LDS addresses fold into immediates).
-constexpr int plain_log_points(int logC) { return (logC <= 8 ? 13 : 14) < logC + 9 ? (logC <= 8 ? 13 : 14) : logC + 9; }
+constexpr int plain_log_points(int logC, int mode = 0)
+{
+  (void)mode;       // (2^13-point tiles of one polarisation at 1024 channels, two workgroups per compute unit: 2.55 against 1.95 ms)
+  const int lp = logC <= 8 ? 13 : 14;
+  return lp < logC + 9 ? lp : logC + 9;
+}
 
 // MODE 0: real input, two polarisations (column pair = the two polarisations of one part)
 //      1: real input, one polarisation  (column pair = two consecutive parts)
 //      2: complex input                 (column pair = the two polarisations of one part, or two consecutive parts)
+//      3: real input, two polarisations in the data, ONE per tile (column pair = two consecutive parts of that polarisation; the
+//         tile of the other polarisation is the next work item): twice the parts per tile, i.e. twice the bytes a tile writes to a
+//         channel row -- for channel counts whose rows would otherwise receive less than a cache line per tile (complex rows only:
+//         Detection needs both polarisations in one thread)
 template <int LOGF, int MODE>
 __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf* __restrict__ tw)
 {
   typedef FftPlan<LOGF> P;
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   uint32_t tid = threadIdx.x;
-  constexpr int logT = plain_log_points(LOGF) - LOGF, loghT = logT - 1;
-  constexpr uint32_t nt = 1u << (plain_log_points(LOGF) - LOG_PTS);
+  constexpr int logT = plain_log_points(LOGF, MODE) - LOGF, loghT = logT - 1;
+  constexpr uint32_t nt = 1u << (plain_log_points(LOGF, MODE) - LOG_PTS);
   constexpr uint32_t C = 1u << LOGF;
   constexpr uint32_t T = 1u << logT, hT = T >> 1;
-  const bool two_pol = p.g.npol == 2;                                     // uniform
+  const bool two_pol = MODE != 3 && p.g.npol == 2;                        // uniform: both polarisations in a tile
+  constexpr uint32_t NPS = MODE == 3 ? 2u : 1u;                           // polarisation tiles per time range
   const uint32_t tile_parts = two_pol ? hT : T;
   const uint32_t ntile = (uint32_t)((p.npart + tile_parts - 1) / tile_parts);
-  const uint32_t total = ntile * p.input_nchan;
+  const uint32_t total = ntile * p.input_nchan * NPS;
   const uint32_t ltw_off = lds_pad(PTS * nt) + 8;
   ltw_fill<LOGF>(lds, ltw_off, tw, tid, nt);
   // time samples (real: of the 2C-sample part; complex: of the C-sample part) between parts
@@ -68,14 +78,14 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
 
   // the input form (uniform)
   int form;
-  if (MODE == 0) form = p.in.kind == 0 ? F_FLOAT : p.in.kind == 2 ? F_CASPSR : (p.in.nchan == 1 && (((uintptr_t)p.in.base) & 3) == 0) ? F_WORD : F_BYTES;
+  if (MODE == 0 || MODE == 3) form = p.in.kind == 0 ? F_FLOAT : p.in.kind == 2 ? F_CASPSR : (p.in.nchan == 1 && (((uintptr_t)p.in.base) & 3) == 0) ? F_WORD : F_BYTES;
   else if (MODE == 1) form = p.in.kind == 0 ? F_FLOAT : F_BYTES;
   else form = p.in.kind == 0 ? F_FLOAT : p.in.kind == 4 ? F_UWB : (((uintptr_t)p.in.base) & 1) == 0 ? F_HALF : F_BYTES;
   const uint64_t last_part = p.npart - 1;
   // columns of element (g2, i) of this thread: pair index, position; the parts of a ragged last tile are clamped to the last part
   // (loaded again, never stored), so no load is conditional
   auto fetch = [&](const uint32_t item, Raw4 (&raw)[NPAIR]) {
-    const uint32_t tile = item % ntile, ichan = item / ntile;
+    const uint32_t pol = item % NPS, tile = (item / NPS) % ntile, ichan = item / (NPS * ntile);
     // first input sample of the two columns of pair h (computed where it is used: kept in arrays, the sixteen 64-bit pairs spilled)
     auto samp = [&](const int h, uint64_t& sa, uint64_t& sb) {
       const int g2 = 2 * (h / P::R1), i = h % P::R1;
@@ -126,18 +136,35 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
           raw[h].w[0] = q[0]; raw[h].w[1] = q[1]; raw[h].w[2] = q[skip]; raw[h].w[3] = q[skip + 1];
         }
       }
-    } else if constexpr (MODE == 1) {
+    } else if constexpr (MODE == 1 || MODE == 3) {
+      // one polarisation per tile: MODE 1 the data's only one, MODE 3 polarisation `pol` of two
       if (form == F_FLOAT) {
-        const float* x = (const float*)p.in.base + (uint64_t)ichan * p.in_chan_stride;
+        const float* x = (const float*)p.in.base + (uint64_t)ichan * p.in_chan_stride + (uint64_t)pol * p.in.pol_stride;
 #pragma unroll
         for (int h = 0; h < NPAIR; h++) {
           uint64_t sa, sb; samp(h, sa, sb);
           raw[h].w[0] = __float_as_uint(x[sa]); raw[h].w[1] = __float_as_uint(x[sa + 1]);
           raw[h].w[2] = __float_as_uint(x[sb]); raw[h].w[3] = __float_as_uint(x[sb + 1]);
         }
+      } else if (MODE == 3 && form == F_WORD) {             // (p0[2n], p1[2n], p0[2n+1], p1[2n+1]) of the pair's two parts
+        const uint8_t* b = (const uint8_t*)p.in.base;
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) {
+          uint64_t sa, sb; samp(h, sa, sb);
+          raw[h].w[0] = *(const uint32_t*)(b + 2 * sa);
+          raw[h].w[1] = *(const uint32_t*)(b + 2 * sb);
+        }
+      } else if (MODE == 3 && form == F_CASPSR) {           // (x[2n], x[2n+1]) of this polarisation: one half word per part
+        const uint8_t* b = (const uint8_t*)p.in.base + 4 * pol;
+#pragma unroll
+        for (int h = 0; h < NPAIR; h++) {
+          uint64_t sa, sb; samp(h, sa, sb);
+          raw[h].w[0] = *(const uint16_t*)(b + (sa >> 2) * 8 + (sa & 3));
+          raw[h].w[1] = *(const uint16_t*)(b + (sb >> 2) * 8 + (sb & 3));
+        }
       } else {
-        const uint64_t skip = p.in.nchan;
-        const uint8_t* b = (const uint8_t*)p.in.base + ichan;
+        const uint64_t skip = (uint64_t)p.in.nchan * NPS;
+        const uint8_t* b = (const uint8_t*)p.in.base + (uint64_t)ichan * NPS + pol;
 #pragma unroll
         for (int h = 0; h < NPAIR; h++) {
           uint64_t sa, sb; samp(h, sa, sb);
@@ -191,7 +218,7 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
     }
   };
   const float scale = p.in.scale;
-  auto decode = [&](const Raw4 (&raw)[NPAIR], cx2 (&x)[NPAIR]) {
+  auto decode = [&](const Raw4 (&raw)[NPAIR], cx2 (&x)[NPAIR], [[maybe_unused]] const uint32_t pol) {
     if constexpr (MODE == 0) {
       if (form == F_WORD) {
 #pragma unroll
@@ -220,12 +247,20 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
           x[h].y = (v2f){cvt8((int8_t)raw[h].w[2], scale), cvt8((int8_t)raw[h].w[3], scale)};
         }
       }
-    } else if constexpr (MODE == 1) {
+    } else if constexpr (MODE == 1 || MODE == 3) {
 #pragma unroll
       for (int h = 0; h < NPAIR; h++) {                       // (xa[2n], xa[2n+1], xb[2n], xb[2n+1]) of parts a, b
         if (form == F_FLOAT) {
           x[h].x = (v2f){__uint_as_float(raw[h].w[0]), __uint_as_float(raw[h].w[2])};
           x[h].y = (v2f){__uint_as_float(raw[h].w[1]), __uint_as_float(raw[h].w[3])};
+        } else if (MODE == 3 && form == F_WORD) {             // byte `pol` = x[2n], byte 2 + `pol` = x[2n+1] of each part's word
+          const uint32_t wa = raw[h].w[0] >> (8 * pol), wb = raw[h].w[1] >> (8 * pol);
+          x[h].x = (v2f){cvt8((int8_t)(wa & 0xff), scale), cvt8((int8_t)(wb & 0xff), scale)};
+          x[h].y = (v2f){cvt8((int8_t)((wa >> 16) & 0xff), scale), cvt8((int8_t)((wb >> 16) & 0xff), scale)};
+        } else if (MODE == 3 && form == F_CASPSR) {
+          const uint32_t wa = raw[h].w[0], wb = raw[h].w[1];
+          x[h].x = (v2f){cvt8((int8_t)(wa & 0xff), scale), cvt8((int8_t)(wb & 0xff), scale)};
+          x[h].y = (v2f){cvt8((int8_t)((wa >> 8) & 0xff), scale), cvt8((int8_t)((wb >> 8) & 0xff), scale)};
         } else {
           x[h].x = (v2f){cvt8((int8_t)raw[h].w[0], scale), cvt8((int8_t)raw[h].w[2], scale)};
           x[h].y = (v2f){cvt8((int8_t)raw[h].w[1], scale), cvt8((int8_t)raw[h].w[3], scale)};
@@ -264,7 +299,7 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
   for (;;) {
     asm volatile("" : "+v"(tid));
     cx2 x[NPAIR];
-    decode(raw, x);
+    decode(raw, x, item % NPS);
     const bool more = persistent_item(blockIdx.x, gridDim.x, ++jrun, 8u, total, next);
     fetch(more ? next : item, raw);      // unconditional: a conditional prefetch is waited for where it is issued (fb_inv_chan.h)
 
@@ -278,7 +313,7 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
     __syncthreads();
 
     // read-back: consecutive lanes = consecutive column pairs (parts) of one bin (pair)
-    const uint32_t tile = item % ntile, ichan = item / ntile;
+    const uint32_t pol = item % NPS, tile = (item / NPS) % ntile, ichan = item / (NPS * ntile);
     const uint32_t chan0 = p.out.chan0 + ichan * C;
     const cf* __restrict__ kern = p.kern ? p.kern + (uint64_t)ichan * C : nullptr;
     const FbOut& out = p.out;
@@ -311,8 +346,9 @@ __global__ __launch_bounds__(512) void k_fb_plain(const PlainParams p, const cf*
         }
       } else {
         const uint64_t pa = (uint64_t)tile * T + 2 * j;
-        if (pa < p.npart) *(float2*)(row + pa * out.part_step) = a;
-        if (pa + 1 < p.npart) *(float2*)(row + (pa + 1) * out.part_step) = b;
+        float* __restrict__ prow = row + (uint64_t)pol * out.pol_stride;                   // (MODE 3: this tile's polarisation)
+        if (pa < p.npart) *(float2*)(prow + pa * out.part_step) = a;
+        if (pa + 1 < p.npart) *(float2*)(prow + (pa + 1) * out.part_step) = b;
       }
     };
     if constexpr (MODE == 2) {
@@ -386,8 +422,18 @@ template <int... I> static kplain_t pick_plain(int logf, int mode, iseq<I...>)
   static const kplain_t m0[] = {k_fb_plain<I + 1, 0>...};
   static const kplain_t m1[] = {k_fb_plain<I + 1, 1>...};
   static const kplain_t m2[] = {k_fb_plain<I + 1, 2>...};
+  static const kplain_t m3[] = {k_fb_plain<I + 1, 3>...};
   if (logf < 1 || logf > (int)sizeof...(I)) return nullptr;
-  return mode == 0 ? m0[logf - 1] : mode == 1 ? m1[logf - 1] : m2[logf - 1];
+  return mode == 0 ? m0[logf - 1] : mode == 1 ? m1[logf - 1] : mode == 2 ? m2[logf - 1] : m3[logf - 1];
+}
+
+// Polarisation-split tiles (MODE 3) where a two-polarisation tile gives a channel row 32 bytes or less: from 2048 channels on
+// (2^14-point tiles hold 4 parts of two polarisations there, 8 parts of one), complex rows only.  Measured per 2^29 samples, two-
+// polarisation / split tiles: 1024 channels 1.95 / 2.00 ms (64 against 128 bytes per row: not what bounds it), 2048 channels 3.34 / 2.59,
+// 8192 channels 11.9 / 8.3 (profiles/r05_experiments.txt item 8)
+static bool plain_pol_split(int logC, bool real_input, uint32_t npol, int out_kind)
+{
+  return real_input && npol == 2 && logC >= 11 && (out_kind == 0 || out_kind == 1);
 }
 
 int fb_plain_check(dspsr_amd_ctx* ctx, int logC, bool real_input, uint32_t npol, size_t* lds_bytes)
@@ -398,17 +444,21 @@ int fb_plain_check(dspsr_amd_ctx* ctx, int logC, bool real_input, uint32_t npol,
   const int lp = plain_log_points(logC);
   const size_t lds = lds_total_words_host(1u << lp, logC) * sizeof(cf);
   if (lds_bytes) *lds_bytes = lds;
-  const hipError_t e = dspsr_amd_allow_lds((const void*)k, lds);
+  hipError_t e = dspsr_amd_allow_lds((const void*)k, lds);
+  if (e == hipSuccess && plain_pol_split(logC, real_input, npol, 1))
+    e = dspsr_amd_allow_lds((const void*)pick_plain(logC, 3, mkseq<MAX_LOGF>::type()),
+                            lds_total_words_host(1u << plain_log_points(logC, 3), logC) * sizeof(cf));
   return e == hipSuccess ? DSPSR_AMD_OK : DSPSR_AMD_EHIP;
 }
 
 int fb_plain_launch(dspsr_amd_ctx* ctx, int logC, bool real_input, uint32_t npol, uint32_t input_nchan, const cf* kern,
                     const FbIn& in, const FbOut& out, uint64_t in_chan_stride, uint64_t npart)
 {
-  const int mode = real_input ? (npol == 2 ? 0 : 1) : 2;
+  const bool split = plain_pol_split(logC, real_input, npol, out.kind);
+  const int mode = split ? 3 : real_input ? (npol == 2 ? 0 : 1) : 2;
   kplain_t k = pick_plain(logC, mode, mkseq<MAX_LOGF>::type());
   if (!k) return DSPSR_AMD_EINVAL;
-  const int lp = plain_log_points(logC);
+  const int lp = plain_log_points(logC, mode);
   PlainParams p = {};
   p.g.real_input = real_input ? 1 : 0;
   p.g.npol = (int)npol;
@@ -421,8 +471,8 @@ int fb_plain_launch(dspsr_amd_ctx* ctx, int logC, bool real_input, uint32_t npol
   p.npart = npart;
   p.input_nchan = input_nchan;
   const int logT = lp - logC;                        // columns per tile: (part, polarisation) pairs, or parts
-  const uint32_t tile_parts = npol == 2 ? (1u << (logT - 1)) : (1u << logT);
-  const uint64_t total = ((npart + tile_parts - 1) / tile_parts) * input_nchan;
+  const uint32_t tile_parts = (npol == 2 && !split) ? (1u << (logT - 1)) : (1u << logT);
+  const uint64_t total = ((npart + tile_parts - 1) / tile_parts) * input_nchan * (split ? 2 : 1);
   if (total >= (1ull << 31)) return DSPSR_AMD_EINVAL;
   const size_t lds = lds_total_words_host(1u << lp, logC) * sizeof(cf);
   const uint32_t wgs = ctx->ncu * (2 * lds + 1024 <= 160 * 1024 ? 2u : 1u);
