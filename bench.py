@@ -972,11 +972,11 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
         group = {2: ("k_raw_cols+k_fwd_col1+k_rows_inv<.,.,false>", "k_raw_cols+k_fwd_col1+k_rows_inv<.,.,true>"),
                  3: ("k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,false>", "k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_chan<.,true>"),
                  4: ("k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b", "k_raw_transpose+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b<.,true>+k_fold_segsum"),
-                 # Config::After: the non-convolving filterbank, then the convolution's passes on float rows
-                 5: ("k_fb_plain+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b", "k_fb_plain+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b<.,true>+k_fold_segsum"),
-                 1: ("k_fb_plain", "k_fb_plain"),
-                 2: ("k_fb_plain+k_conv1", "k_fb_plain+k_conv1"),
                  }.get(npass, ("%d tile passes" % npass,) * 2)
+        if getattr(cfg, "convolve_when", "during") in ("after", "never"):
+            # Config::After / Never: the non-convolving filterbank, then the convolution on its float rows (one tile pass or four)
+            group = {1: ("k_fb_plain",) * 2, 2: ("k_fb_plain+k_conv1",) * 2,
+                     5: ("k_fb_plain+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b",) * 2}.get(npass, ("k_fb_plain + %d tile passes" % (npass - 1),) * 2)
         exch = ("dspsr_amd_reduce_profiles_* (RCCL behind the C-ABI, csrc/comm.hip), snapshot on the compute stream, collective "
                 "on its own stream" if rccl is not None else
                 "torch.distributed (gloo rehearsal on one device)" if world > 1 and single else

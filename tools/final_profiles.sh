@@ -8,6 +8,15 @@ mkdir -p $R/gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp && cd $R
 WL=${WL:-target cfg1 cfg1opt cfg2 cfg3 cfg4 cfg5 cfg5c odd_nchan odd_fres after after8k after1k plain fold}
 PHASE=${PHASE:-all}      # stats | pmc | all (a call on the GPU box is limited to 20 minutes: run the two phases as two calls if need be)
+# the counters first: the bench lines of the stats phase quote the traffic files of THIS build (bench.py refuses any other)
+if [ $PHASE != stats ]; then
+for w in $WL; do
+  bash tools/pmc_traffic.sh $T $w > gpurun_out/$T/pmc_$w.txt 2>&1 || { echo "pmc $w failed"; tail -3 gpurun_out/$T/pmc_$w.txt; exit 1; }
+  head -1 gpurun_out/$T/pmc_$w.txt | cut -c1-400
+  rm -rf gpurun_out/$T/pmc_${w}_*_SIZE
+  cp gpurun_out/$T/${w}_traffic.json profiles/${T}_${w}_traffic.json     # on the box: the stats phase's bench lines then carry this build's traffic
+done
+fi
 if [ $PHASE != pmc ]; then
 for w in $WL; do
   a="--workload $w"; [ $w = target ] && a="--no-companions --no-h2d"
@@ -18,12 +27,5 @@ for w in $WL; do
   rm -rf gpurun_out/$T/prof_$w
   echo "== $w: $(grep -o '"value": [0-9.]*' gpurun_out/$T/${w}_bench.json | head -1) $(grep -o '"frac": [0-9.]*' gpurun_out/$T/${w}_bench.json | head -1)"
   head -6 gpurun_out/$T/${w}_kernel_stats.txt
-done
-fi
-if [ $PHASE != stats ]; then
-for w in $WL; do
-  bash tools/pmc_traffic.sh $T $w > gpurun_out/$T/pmc_$w.txt 2>&1 || { echo "pmc $w failed"; tail -3 gpurun_out/$T/pmc_$w.txt; exit 1; }
-  head -1 gpurun_out/$T/pmc_$w.txt | cut -c1-400
-  rm -rf gpurun_out/$T/pmc_${w}_*_SIZE
 done
 fi

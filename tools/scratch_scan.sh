@@ -5,7 +5,7 @@
 # touching wgfft.h or a pass.
 D=${1:-$(dirname "$0")/../dspsr_amd/csrc}
 cd "$D"
-for u in tfp fold fb_fwd_cols fb_fwd_rows fb_inv_chan fb_inv_chan_fold fb_inv_chan_search fb_two_pass fb_four_pass detect rescale scrunch sample_delay comm context; do
+for u in tfp fold fb_plain fb_conv1 fb_fwd_cols fb_fwd_rows fb_inv_chan fb_inv_chan_fold fb_inv_chan_search fb_two_pass fb_four_pass detect rescale scrunch sample_delay comm context; do
   [ -f $u.hip ] || continue
   s=$(grep "^SCHED_$u " Makefile | sed 's/^[^=]*= *//')
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on $s -Rpass-analysis=kernel-resource-usage -c -o /tmp/scan_$$_$u.o $u.hip 2>&1 \
