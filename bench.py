@@ -975,7 +975,7 @@ def run_fold_workload(name, args, torch, dist, rank, world, local_rank, single, 
                  }.get(npass, ("%d tile passes" % npass,) * 2)
         if getattr(cfg, "convolve_when", "during") in ("after", "never"):
             # Config::After / Never: the non-convolving filterbank, then the convolution on its float rows (one tile pass or four)
-            group = {1: ("k_fb_plain",) * 2, 2: ("k_fb_plain+k_conv1",) * 2,
+            group = {1: ("k_fb_plain",) * 2, 2: ("k_fb_plain+k_conv1",) * 2, 4: ("k_fb_plain+k_conv3_a+k_conv3_b+k_conv3_c",) * 2,
                      5: ("k_fb_plain+k_fwd_cols+k_fwd_rows+k_inv_a+k_inv_b",) * 2}.get(npass, ("k_fb_plain + %d tile passes" % (npass - 1),) * 2)
         exch = ("dspsr_amd_reduce_profiles_* (RCCL behind the C-ABI, csrc/comm.hip), snapshot on the compute stream, collective "
                 "on its own stream" if rccl is not None else

@@ -60,6 +60,10 @@ struct dspsr_amd_filterbank_impl {
   dspsr_amd_filterbank* batch = nullptr;   // dsp::Convolution on many channels (nchan_subband = 1, complex float rows): the inverse passes of a
                              // filterbank of `batch->cfg.nchan_subband` channels per group, see fb_run_batched
   int conv1_logM = -1;       // >= 0: dsp::Convolution shapes with n_fft <= 8192 on complex float rows run in ONE tile pass (fb_conv1.hip)
+  int conv3_logM = -1;       // >= 0: ... with 2^14 <= n_fft <= 2^18 in THREE tile passes (fb_conv3.hip), launch groups of conv3_ch channels x
+  uint32_t conv3_ch = 0, conv3_parts = 0;    //   conv3_parts parts through the scratch blocks S1 / S2
+  cf* S1 = nullptr;
+  cf* S2 = nullptr;
   cf* kernel_nat = nullptr;  // ... its response in natural order when `kernel` is stored in the blocked order of the four-pass kernels
   int plain_logC = -1;       // >= 0: freq_res = 1, the non-convolving filterbank (fb_plain.hip): no scratch, one launch per call
   cf* Xp = nullptr;          // the combined spectrum in pseudo-channel order (k_sub_combine writes it there)
@@ -424,12 +428,34 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   if (cfg->nchan_subband == 1 && !cfg->real_input && cfg->npol == 2 && cfg->force_four_pass == 0 && !msub && nsub == 1 &&
       g.logMf >= 6 && g.logMf <= 13 && fb_conv1_check(g.logMf, nullptr) == DSPSR_AMD_OK)
     fb->conv1_logM = g.logMf;
+  // The same with a response of 2^14 ... 2^17 points: three tile passes instead of four -- the forward transform's second pass and the
+  // inverse transform's first one run along the same rows and are one pass (fb_conv3.hip).  Launch groups of channels x parts that fill
+  // about 2 GB per scratch buffer.
+  if (fb->conv1_logM < 0 && cfg->nchan_subband == 1 && !cfg->real_input && cfg->npol == 2 && cfg->force_four_pass == 0 && !msub && nsub == 1 &&
+      g.logMf >= CONV3_MIN_LOGM && g.logMf <= CONV3_MAX_LOGM && fb_conv3_check(g.logMf) == DSPSR_AMD_OK) {
+    const uint64_t seq_bytes = (2ull << g.logMf) * sizeof(cf);           // one (channel, part), both polarisations
+    uint64_t max_seq = (2ull << 30) / seq_bytes;
+    uint64_t np = fb->max_parts < max_seq ? fb->max_parts : max_seq;
+    if (np < 1) np = 1;
+    uint64_t ch = max_seq / np;
+    if (ch < 1) ch = 1;
+    if (ch > cfg->input_nchan) ch = cfg->input_nchan;
+    if (hipMalloc((void**)&fb->S1, np * ch * seq_bytes) == hipSuccess && hipMalloc((void**)&fb->S2, np * ch * seq_bytes) == hipSuccess) {
+      fb->conv3_logM = g.logMf;
+      fb->conv3_ch = (uint32_t)ch;
+      fb->conv3_parts = (uint32_t)np;
+    } else {
+      if (fb->S1) (void)hipFree(fb->S1);
+      fb->S1 = fb->S2 = nullptr;
+      (void)hipGetLastError();
+    }
+  }
   // dsp::Convolution behind a filterbank (nchan_subband = 1 on many input channels, `dspsr -F N`): one launch group per input channel
   // holds parts x 2 x freq_res points -- a tile or two per compute unit and four launches per channel.  The channels of a GROUP run
   // as one launch group instead (fb_run_batched): forward passes on the group's (part, pol, channel) sequences with this object's
   // per-channel geometry, inverse passes of a `group`-channel filterbank object (natural spectrum order) on the spectra laid side
   // by side.  Complex float32 rows read in place by pass 1; other inputs keep the loop over the channels.
-  if (fb->conv1_logM < 0 && cfg->nchan_subband == 1 && !cfg->real_input && cfg->npol == 2 && cfg->input_nchan >= 4 && cfg->force_four_pass != 2 &&
+  if (fb->conv1_logM < 0 && fb->conv3_logM < 0 && cfg->nchan_subband == 1 && !cfg->real_input && cfg->npol == 2 && cfg->input_nchan >= 4 && cfg->force_four_pass != 2 &&
       g.four_pass && !g.xblocked && !msub && nsub == 1 && !(g.logR >= 6 && g.logT1 <= 4) && fb->k1_w4) {
     uint32_t ch = 1;
     while (ch < 64 && cfg->input_nchan % (2 * ch) == 0) ch *= 2;
@@ -464,6 +490,8 @@ extern "C" void dspsr_amd_filterbank_destroy(dspsr_amd_filterbank* fb)
   if (fb->X) (void)hipFree(fb->X);
   if (fb->kernel) (void)hipFree(fb->kernel);
   if (fb->kernel_nat) (void)hipFree(fb->kernel_nat);
+  if (fb->S1) (void)hipFree(fb->S1);
+  if (fb->S2) (void)hipFree(fb->S2);
   if (fb->Rt) (void)hipFree(fb->Rt);
   if (fb->det) (void)hipFree(fb->det);
   if (fb->fpart) (void)hipFree(fb->fpart);
@@ -493,8 +521,8 @@ extern "C" int dspsr_amd_filterbank_set_kernel(dspsr_amd_filterbank* fb, const f
     return fb_fail(fb->ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_set_kernel: hipMalloc failed");
   const cf* src = (const cf*)kernel_host;
   std::vector<cf> perm;
-  if (fb->conv1_logM >= 0 && fb->g.xblocked) {
-    // (the one-pass convolution reads the response in natural order; the four-pass kernels of this geometry take it blocked)
+  if ((fb->conv1_logM >= 0 || fb->conv3_logM >= 0) && fb->g.xblocked) {
+    // (the one-pass and three-pass convolutions read the response in natural order; the four-pass kernels of this geometry take it blocked)
     if (!fb->kernel_nat && hipMalloc((void**)&fb->kernel_nat, expect * sizeof(cf)) != hipSuccess)
       return fb_fail(fb->ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_set_kernel: hipMalloc failed");
     if (hipMemcpy(fb->kernel_nat, src, expect * sizeof(cf), hipMemcpyHostToDevice) != hipSuccess)
@@ -680,6 +708,23 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
     const int rc = fb_conv1_launch(ctx, fb->conv1_logM, (const float*)in.base, in_chan_stride_bytes_or_floats, in.pol_stride, 2 * in.part_step, kern, out,
                                    fb->cfg.input_nchan, g.nfilt_pos, g.nkeep, npart);
     if (rc != DSPSR_AMD_OK) return fb_fail(ctx, rc, "dspsr_amd_filterbank_perform: launch of the one-pass convolution failed");
+    return DSPSR_AMD_OK;
+  }
+  if (fb->conv3_logM >= 0 && in.kind == 0 && (out.kind == 0 || out.kind == 1 || out.kind == 2) && (in_chan_stride_bytes_or_floats % 2) == 0 &&
+      (in.pol_stride % 2) == 0 && ((uintptr_t)in.base % 8) == 0) {
+    const cf* kern = fb->kernel ? (fb->g.xblocked ? fb->kernel_nat : fb->kernel) : nullptr;
+    for (uint32_t c0 = 0; c0 < fb->cfg.input_nchan; c0 += fb->conv3_ch) {
+      const uint32_t nc = fb->cfg.input_nchan - c0 < fb->conv3_ch ? fb->cfg.input_nchan - c0 : fb->conv3_ch;
+      FbOut co = out;
+      co.chan0 = out.chan0 + c0;
+      for (uint64_t part0 = 0; part0 < npart; part0 += fb->conv3_parts) {
+        const uint32_t np = (uint32_t)(npart - part0 < fb->conv3_parts ? npart - part0 : fb->conv3_parts);
+        const int rc = fb_conv3_launch(ctx, fb->conv3_logM, (const float*)in.base + (uint64_t)c0 * in_chan_stride_bytes_or_floats,
+                                       in_chan_stride_bytes_or_floats, in.pol_stride, 2 * in.part_step, kern ? kern + (uint64_t)c0 * fb->N : nullptr, co,
+                                       nc, g.nfilt_pos, g.nkeep, part0, np, fb->S1, fb->S2);
+        if (rc != DSPSR_AMD_OK) return fb_fail(ctx, rc, "dspsr_amd_filterbank_perform: launch of the three-pass convolution failed");
+      }
+    }
     return DSPSR_AMD_OK;
   }
   if (fb->batch && in.kind == 0 && (out.kind == 0 || out.kind == 1 || out.kind == 2) && (in_chan_stride_bytes_or_floats % 2) == 0)
@@ -1182,6 +1227,7 @@ extern "C" int dspsr_amd_filterbank_npass(const dspsr_amd_filterbank* fb, int ra
   if (!fb) return 0;
   if (fb->plain_logC >= 0) return 1;
   if (fb->conv1_logM >= 0 && !raw_input) return 1;
+  if (fb->conv3_logM >= 0 && !raw_input) return 3;
   if (fb->g.four_pass) return 4;
   return fb->two_pass && raw_input ? 2 : 3;
 }
