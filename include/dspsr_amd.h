@@ -102,10 +102,10 @@ typedef struct {
   uint32_t real_input;      /* 1: Signal::Nyquist (ndim 1), 0: Signal::Analytic (ndim 2) */
   uint32_t max_parts;       /* parts processed per launch group (scratch is sized for this); 0 => default */
   uint32_t force_four_pass; /* 0 => passes chosen from the geometry; 1: two-pass inverse (the path of freq_res > 8192 and of
-                               dsp::Convolution) also where the single-pass inverse would do -- and instead of the one-pass
-                               convolution of short responses; 2: never the two-pass path of short responses (complex dual-pol input,
-                               nchan_subband * freq_res^2 <= 2^27: forward and inverse transforms in two tiles), the one-pass
-                               convolution or the grouping of a convolution's channels; same results to rounding in every case */
+                               dsp::Convolution) also where the single-pass inverse would do -- and instead of the one-pass /
+                               three-pass convolution; 2: never the two-pass path of short responses (complex dual-pol input,
+                               nchan_subband * freq_res^2 <= 2^27: forward and inverse transforms in two tiles), the one-pass /
+                               three-pass convolution or the grouping of a convolution's channels; same results to rounding in every case */
   uint32_t fused_fold;      /* dspsr_amd_filterbank_perform_fold: DSPSR_AMD_FUSED_AUTO (fold inside the last filterbank
                                pass when the channel tiles fill the chip), _ALWAYS, _NEVER -- same sums bit for bit */
 } dspsr_amd_filterbank_config;
@@ -191,7 +191,10 @@ int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb);
  *   2  short responses: complex dual-pol 8-bit input with 512 <= freq_res <= 4096 and 2^13 / freq_res <= nchan_subband <=
  *      2^27 / freq_res^2 (upper end: one 50 MHz sub-band with -F 512:D -x 512): column forward pass, then rows + chirp + inverse
  *      transforms in ONE tile -- the spectrum stays on chip;
- *   3  forward columns, forward rows, inverse per channel (freq_res <= 8192);
+ *   3  forward columns, forward rows, inverse per channel (freq_res <= 8192); and (raw_input == 0) the dsp::Convolution shapes above
+ *      with 2^14 <= freq_res <= 2^17 on float32 rows: the forward transform's second pass and the inverse transform's first one run
+ *      along the same rows of the spectrum and are ONE pass, the spectrum never reaches memory (csrc/fb_conv3.hip;
+ *      force_four_pass != 0 keeps the four passes);
  *   4  two-pass inverse (freq_res > 8192, dsp::Convolution shapes, force_four_pass = 1).  dsp::Convolution on >= 4 complex channels
  *      of float32 rows runs GROUPS of channels as one launch group (forward passes per channel, inverse passes of a group-wide
  *      filterbank: the same numbers bit for bit; force_four_pass = 2 keeps the loop over the channels).

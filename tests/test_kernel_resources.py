@@ -79,7 +79,8 @@ HOT = {
     "cfg5": ["k_tfp4k<false, false>", "k_tfp4k<false, true>", "k_tfp4k<true, false>", "k_tfp4k<true, true>",
              "k_tfpm<10, true, true>", "k_tfpm<11, true, true>", "k_tfpm<13, true, true>", "k_tfpm<9, true, true>"],
     "fold": ["k_fold_dense<1, 4>", "k_fold_dense<4, 1>"],
-    "after / after8k / plain": ["k_fb_plain<7, 0>", "k_fb_plain<10, 0>", "k_fb_plain<7, 2>", "k_conv1<13>", "k_conv1<12>", "k_conv1<10>",
+    "after / after8k / plain": ["k_fb_plain<7, 0>", "k_fb_plain<10, 0>", "k_fb_plain<7, 2>", "k_conv1<13>", "k_conv1<12>", "k_conv1<10>", "k_conv3_a<16>", "k_conv3_b<16>", "k_conv3_c<16, 1>", "k_conv3_c<16, 0>",
+                                "k_conv3_a<14>", "k_conv3_b<14>", "k_conv3_b<17>", "k_conv3_c<17, 1>",
                                 "k_fwd_cols<8, 4, 6>", "k_fwd_rows<8, 6>", "k_inv_a<8, false, false, true>", "k_inv_b<8, false, true>"],
 }
 # known spills of the shipped build in kernels the workloads DO launch (none tolerated silently: list them here with the reason)
