@@ -95,6 +95,13 @@ DEV void win_store(__amdgpu_buffer_rsrc_t r, const uint32_t off, const float2 v)
 }
 DEV void win_store(__amdgpu_buffer_rsrc_t r, const uint32_t off, const float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0); }
 
+// passes A and C: workgroup -> first tile.  Consecutive workgroup ids go to consecutive XCDs (8 of them); the workgroups of XCD x take
+// the tiles x * grid / 8 ... of every round, so neighbouring tiles run on the same XCD at about the same time
+DEV uint32_t conv3_first_item()
+{
+  const uint32_t g = gridDim.x, b = blockIdx.x;
+  return (g & 7) ? b : (b & 7) * (g >> 3) + (b >> 3);
+}
 // pass B: every workgroup takes one contiguous range of tiles
 DEV bool conv3_range(const uint32_t total, uint32_t& item, uint32_t& item_end)
 {
@@ -133,9 +140,11 @@ __global__ __launch_bounds__(512) void k_conv3_a(const Conv3Params p, const cf* 
   const uint32_t ltw_off = lds_pad(PTS * nt) + 8;
   ltw_fill<LA>(lds, ltw_off, tw, tid, nt);
   // tiles dealt round robin: the workgroups running at any moment then work on neighbouring tiles -- the pieces of the same rows
-  // (256 bytes per row and tile at M = 65536) are requested at about the same time
+  // (256 bytes per row and tile at M = 65536) are requested at about the same time, and neighbouring tiles by workgroups of ONE
+  // XCD (conv3_first_item): a part starts anywhere in a row, so the pieces straddle cache lines, and the line two neighbours share
+  // is then fetched once into that XCD's L2
   const uint32_t item_end = (p.nchan * p.nparts) << logNbt, istep = gridDim.x;
-  uint32_t item = blockIdx.x;
+  uint32_t item = conv3_first_item();
   if (item >= item_end) return;
   struct Pol2 { cf a, b; };
   auto fetch = [&](const uint32_t it, Pol2 (&raw)[NPAIR]) {
@@ -301,8 +310,10 @@ __global__ __launch_bounds__(512) void k_conv3_c(const Conv3Params p, const cf* 
   constexpr int logNtt = LB - logTC;                                        // tiles per sequence (2^(LM - 13))
   const uint32_t ltw_off = lds_pad(PTS * nt) + 8;
   ltw_fill<LA>(lds, ltw_off, tw, tid, nt);
-  const uint32_t item_end = (p.nchan * p.nparts) << logNtt, istep = gridDim.x;      // round robin, as pass A: neighbouring output runs together
-  uint32_t item = blockIdx.x;
+  // round robin with the neighbours on one XCD, as pass A: the runs of output samples two neighbouring tiles write (512 bytes each at
+  // any 16-byte offset) meet in that XCD's L2 and leave it as whole lines
+  const uint32_t item_end = (p.nchan * p.nparts) << logNtt, istep = gridDim.x;
+  uint32_t item = conv3_first_item();
   if (item >= item_end) return;
   // the tile in memory order: piece `chunk` = [t2 - t2_0][c % TB][pol] of block `chunk` of the sequence
   auto fetch = [&](const uint32_t it, float4 (&y)[NPAIR]) {

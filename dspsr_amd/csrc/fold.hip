@@ -206,22 +206,26 @@ __global__ __launch_bounds__(1024) void k_fold_chunked(const float* __restrict__
           const uint32_t a0 = (s0 + FOLD_MB - 1) / FOLD_MB * FOLD_MB;                // first micro-block boundary >= s0
           const uint32_t a1 = s1 / FOLD_MB * FOLD_MB;                                // last boundary <= s1
           if (a0 >= a1) {                                                            // no whole micro-block inside the run
+#pragma unroll 4
             for (uint32_t h = s0; h < s1; h++)
 #pragma unroll
               for (int r = 0; r < NROW; r++)
 #pragma unroll
                 for (int d = 0; d < NDIM; d++) acc[j][r][d] += fold_lds[r * RS + h * NDIM + d];
           } else {
+#pragma unroll 4
             for (uint32_t h = s0; h < a0; h++)
 #pragma unroll
               for (int r = 0; r < NROW; r++)
 #pragma unroll
                 for (int d = 0; d < NDIM; d++) acc[j][r][d] += fold_lds[r * RS + h * NDIM + d];
+#pragma unroll 4
             for (uint32_t mb = a0 / FOLD_MB; mb < a1 / FOLD_MB; mb++)
 #pragma unroll
               for (int r = 0; r < NROW; r++)
 #pragma unroll
                 for (int d = 0; d < NDIM; d++) acc[j][r][d] += mbs[r * MS + mb * NDIM + d];
+#pragma unroll 4
             for (uint32_t h = a1; h < s1; h++)
 #pragma unroll
               for (int r = 0; r < NROW; r++)

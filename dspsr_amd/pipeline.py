@@ -651,6 +651,7 @@ class FilterbankThenConvolution:
         ndat = npart * self.part_out + self.ovl_out
         if self.channelised is None or self.channelised.shape[2] < 2 * ndat:
             n = max(ndat, self._cap * self.part_out + self.ovl_out)
+            n += (-n) % 64                                  # rows start on 512-byte boundaries: the filterbank's runs of 32 samples are whole lines
             self.channelised = self.torch.empty((self.nchan, self.npol, 2 * n), dtype=self.torch.float32,
                                                 device="cuda:%d" % self.ctx.device)
         self.front.perform_raw(raw, layout, scale, self.channelised, ndat)
