@@ -82,8 +82,8 @@ __global__ __launch_bounds__(512) void k_conv1(const Conv1Params p, const cf* __
         part = part < last_part ? part : last_part;                       // (ragged last tile: loaded again, never stored)
         const float* __restrict__ q = row + part * p.in_step + 2 * n;
         Pol2 r;
-        r.a = ld_stream((const float2*)q);
-        r.b = ld_stream((const float2*)(q + p.pol_stride));
+        r.a = *(const float2*)q;
+        r.b = *(const float2*)(q + p.pol_stride);
         raw[(g2 / 2) * P::R1 + i] = r;
       }
   };

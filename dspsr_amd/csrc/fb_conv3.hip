@@ -159,8 +159,8 @@ __global__ __launch_bounds__(512) void k_conv3_a(const Conv3Params p, const cf* 
         const uint32_t j = (e & (T - 1)) >> 1, a = e >> logT;
         const float* __restrict__ q = row + 2 * ((a << LB) + j);
         Pol2 r;
-        r.a = ld_stream((const float2*)q);
-        r.b = ld_stream((const float2*)(q + p.pol_stride));
+        r.a = *(const float2*)q;
+        r.b = *(const float2*)(q + p.pol_stride);
         raw[(g2 / 2) * P::R1 + i] = r;
       }
   };
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512) void k_conv3_b(const Conv3Params p, const cf* 
     for (int g2 = 0; g2 < P::G1; g2 += 2)
 #pragma unroll
       for (int i = 0; i < P::R1; i++)
-        y[(g2 / 2) * P::R1 + i] = ld_stream((const float4*)&B[first_stage_elem<LB>(tid, logT, g2, i)]);
+        y[(g2 / 2) * P::R1 + i] = *(const float4*)&B[first_stage_elem<LB>(tid, logT, g2, i)];
   };
   // forward last stage: radix RL, pair h = butterflies 2h, 2h + 1 of the thread: column pair u % T, bins d = k * (Fb / RL) + pp
   constexpr int LOGRL = P::REM ? P::REM : 4, RL = 1 << LOGRL, GL = PTS / RL, HL = GL / 2, logPL = LB - LOGRL;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(512) void k_conv3_c(const Conv3Params p, const cf* 
     for (int jj = 0; jj < PTS / 2; jj++) {
       const uint32_t l2 = 2 * (tid + jj * nt);
       const uint32_t chunk = l2 >> (logTC + logTB + 1), within = l2 & ((1u << (logTC + logTB + 1)) - 1);
-      y[jj] = ld_stream((const float4*)&Sq[((uint64_t)chunk << 14) + within]);
+      y[jj] = *(const float4*)&Sq[((uint64_t)chunk << 14) + within];
     }
   };
   float4 y[NPAIR];
