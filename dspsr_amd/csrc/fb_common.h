@@ -556,9 +556,10 @@ int fb_conv1_check(int logM, size_t* lds_bytes);
 int fb_conv1_launch(dspsr_amd_ctx* ctx, int logM, const float* in, uint64_t chan_stride, uint64_t pol_stride, uint64_t in_step,
                     const cf* kern, const FbOut& out, uint32_t nchan, uint32_t nfilt_pos, uint32_t nkeep, uint64_t npart);
 // non-convolving filterbank, freq_res = 1 (fb_plain.hip): kernel choice + dynamic-LDS limit at create time, one launch per call
-// dsp::Convolution in three tile passes (fb_conv3.hip): n_fft = 2^14 ... 2^17 on complex float32 rows with two polarisations
-constexpr int CONV3_MIN_LOGM = 14, CONV3_MAX_LOGM = 17;
+// dsp::Convolution in three tile passes (fb_conv3.hip): n_fft = 2^14 ... 2^21 on complex float32 rows with two polarisations
+constexpr int CONV3_MIN_LOGM = 14, CONV3_MAX_LOGM = 21;
 int fb_conv3_check(int logM);
+void fb_conv3_response_order(int logM, const cf* natural, cf* ordered);      // one channel's response, M bins
 int fb_conv3_launch(dspsr_amd_ctx* ctx, int logM, const float* in, uint64_t chan_stride, uint64_t pol_stride, uint64_t in_step,
                     const cf* kern, const FbOut& out, uint32_t nchan, uint32_t nfilt_pos, uint32_t nkeep, uint64_t part0, uint32_t nparts,
                     cf* S1, cf* S2);

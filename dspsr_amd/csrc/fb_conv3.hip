@@ -1,4 +1,4 @@
-// dsp::Convolution with a response of 2^14 ... 2^17 points in THREE tile passes (round 5).
+// dsp::Convolution with a response of 2^14 ... 2^21 points in THREE tile passes (round 5).
 //
 // Reference: Signal/General/Convolution.C:338-461 -- per (channel, polarisation, part): forward transform of M = n_fft complex samples,
 // x response of the channel (Response.C:385-444), backward transform, samples [nfilt_pos, nfilt_pos + nsamp_step) kept.
@@ -29,7 +29,7 @@ namespace dspsr_amd {
 struct Conv3Params {
   const float* in;                 // rows of the first channel: + chan * chan_stride + pol * pol_stride + part * in_step, (re, im) pairs
   uint64_t chan_stride, pol_stride, in_step;     // floats
-  const cf* kern;                  // [nchan][M] (natural bin order) of the first channel, or null
+  const cf* kern;                  // [nchan][M] of the first channel, every channel in pass-B order (fb_conv3_response_order), or null
   FbOut out;                       // kind 0 (none), 1 (complex rows), 2 (detected); chan0 = output row of the first channel
   cf* S1;
   cf* S2;
@@ -42,17 +42,19 @@ struct Conv3Params {
 // for memory) -- on the last-stage registers of pass B, which runs two transforms per tile with the response in registers, it cost 84
 // bytes of scratch per lane
 constexpr bool TW_IN_C = true;
-// M = Fa * Fb.  Measured per 2^28 samples per polarisation in 128 channels, rows written, (log2 Fa, log2 Fb): 2^14 (7, 7) 7.23 ms, (6, 8)
-// 7.17; 2^15 (7, 8) 7.01, (6, 9) 7.93; 2^16 (8, 8) 7.35, (7, 9) 7.93; 2^17 (8, 9) 8.28, (7, 10) 7.80 -- pass B likes 256-point rows, and
-// passes A / C want at least 32 columns per polarisation (256-byte runs of the input rows)
-constexpr int conv3_la(int lm) { return lm == 17 ? 7 : lm / 2; }
+// M = Fa * Fb.  Measured per 2^28 samples per polarisation in 128 channels (tools/conv_probe.py), (log2 Fa, log2 Fb), detected output:
+// 2^14 (7, 7) / (6, 8) equal; 2^15 (7, 8) 7.0 ms, (6, 9) 7.9; 2^16 (8, 8) 7.4, (7, 9) 7.9; 2^17 (7, 10) 6.4, (8, 9) 6.6; 2^18 (7, 11) 5.7,
+// (8, 10) 6.2, (9, 9) 8.7 (pass A spills); 2^19 (7, 12) 5.0, (8, 11) 5.1; 2^20 (8, 12) 5.4, (7, 13) 6.2; 2^21 (8, 13) 6.6 -- passes A / C want
+// at least 32 columns per polarisation (256-byte runs of the input rows), pass B at least two rows per tile
+// (4096-point rows in pass B -- three full radix-16 stages per transform -- spill 28 bytes per lane: 2^19 takes (8, 11); 2^20 has no other choice)
+constexpr int conv3_la(int lm) { return lm >= 19 ? 8 : lm >= 17 ? 7 : lm / 2; }
 constexpr int conv3_lb(int lm) { return lm - conv3_la(lm); }
 
 // v[k] *= W_L^{+-nb (k pstride + p)} for BOTH halves of the pair (the two polarisations of column nb)
 template <int R, bool CONJ> DEV void conv3_twiddle(cx2 (&v)[R], const uint32_t nb, const uint32_t p, const uint32_t pstride, const int logL)
 {
   const uint32_t Lm = (1u << logL) - 1;
-  const uint32_t a0 = (nb * p) & Lm, d0 = (nb * pstride) & Lm;            // (factors < 2^9 each: 2^17 = 2^8 * 2^9; at 2^18 pass A spilled 92 bytes per lane and the three passes no longer won)
+  const uint32_t a0 = (nb * p) & Lm, d0 = (nb * pstride) & Lm;            // (factors <= 2^13 and 2^8: every product below 2^21)
   constexpr int NP = R >= 16 ? 4 : R >= 8 ? 3 : R >= 4 ? 2 : R >= 2 ? 1 : 0;
   uint32_t j[1 + (NP ? NP : 1)];
   cf t[1 + (NP ? NP : 1)];
@@ -215,7 +217,7 @@ template <int N> struct Conv3BFwd {
 template <int LM>
 __global__ __launch_bounds__(512) void k_conv3_b(const Conv3Params p, const cf* __restrict__ tw)
 {
-  constexpr int LA = conv3_la(LM), LB = conv3_lb(LM), logT = 14 - LB, logTB = 13 - LB;
+  constexpr int LB = conv3_lb(LM), logT = 14 - LB, logTB = 13 - LB;
   typedef FftPlan<LB> P;
   static_assert(P::NS >= 2, "k_conv3_b: at least two stages");
   extern __shared__ __attribute__((aligned(16))) cf lds[];
@@ -253,12 +255,14 @@ __global__ __launch_bounds__(512) void k_conv3_b(const Conv3Params p, const cf* 
       for (int q = 0; q < NPAIR; q++) kk[q] = make_float2(1.f, 0.f);
       return;
     }
-    const cf* __restrict__ kc = p.kern + ((uint64_t)chan << LM) + (blk << logTB);
+    // the response lies in the order of the tiles: bin c + Fa d of a channel at [c / TB][d][c % TB] (fb_conv3_response_order), so the
+    // lanes of a load -- neighbouring c, then neighbouring d -- read consecutive elements
+    const cf* __restrict__ kc = p.kern + ((uint64_t)chan << LM) + ((uint64_t)blk << (LB + logTB));
 #pragma unroll
     for (int h = 0; h < HL; h++) {
       const uint32_t u = GL * tid + 2 * h, cl = (u & (T - 1)) >> 1, pp = (u >> logT) & ((1u << logPL) - 1);
 #pragma unroll
-      for (int k = 0; k < RL; k++) kk[h * RL + k] = kc[cl + (((uint32_t)k << logPL) + pp) * (1u << LA)];
+      for (int k = 0; k < RL; k++) kk[h * RL + k] = kc[(((((uint32_t)k << logPL) + pp)) << logTB) + cl];
     }
   };
   float4 y[NPAIR];
@@ -406,6 +410,16 @@ template <int... I> static Conv3Kernels pick_conv3(int logm, iseq<I...>)
   return Conv3Kernels{nullptr, nullptr, {nullptr, nullptr, nullptr, nullptr}};
 }
 static Conv3Kernels conv3_kernels(int logm) { return pick_conv3(logm, mkseq<CONV3_MAX_LOGM - CONV3_MIN_LOGM + 1>::type()); }
+
+void fb_conv3_response_order(int logM, const cf* natural, cf* ordered)
+{
+  const int la = conv3_la(logM), lb = conv3_lb(logM), ltb = 13 - lb;
+  const uint32_t Fa = 1u << la, Fb = 1u << lb, TB = 1u << ltb;
+  for (uint32_t blk = 0; blk < Fa / TB; blk++)
+    for (uint32_t d = 0; d < Fb; d++)
+      for (uint32_t cl = 0; cl < TB; cl++)
+        ordered[(((uint64_t)blk << lb) + d) * TB + cl] = natural[(uint64_t)d * Fa + blk * TB + cl];
+}
 
 static size_t conv3_lds(int logF) { return lds_total_words_host(1u << 14, logF) * sizeof(cf); }
 

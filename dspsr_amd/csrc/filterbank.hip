@@ -60,7 +60,7 @@ struct dspsr_amd_filterbank_impl {
   dspsr_amd_filterbank* batch = nullptr;   // dsp::Convolution on many channels (nchan_subband = 1, complex float rows): the inverse passes of a
                              // filterbank of `batch->cfg.nchan_subband` channels per group, see fb_run_batched
   int conv1_logM = -1;       // >= 0: dsp::Convolution shapes with n_fft <= 8192 on complex float rows run in ONE tile pass (fb_conv1.hip)
-  int conv3_logM = -1;       // >= 0: ... with 2^14 <= n_fft <= 2^18 in THREE tile passes (fb_conv3.hip), launch groups of conv3_ch channels x
+  int conv3_logM = -1;       // >= 0: ... with 2^14 <= n_fft <= 2^21 in THREE tile passes (fb_conv3.hip), launch groups of conv3_ch channels x
   uint32_t conv3_ch = 0, conv3_parts = 0;    //   conv3_parts parts through the scratch blocks S1 / S2
   cf* S1 = nullptr;
   cf* S2 = nullptr;
@@ -428,7 +428,7 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
   if (cfg->nchan_subband == 1 && !cfg->real_input && cfg->npol == 2 && cfg->force_four_pass == 0 && !msub && nsub == 1 &&
       g.logMf >= 6 && g.logMf <= 13 && fb_conv1_check(g.logMf, nullptr) == DSPSR_AMD_OK)
     fb->conv1_logM = g.logMf;
-  // The same with a response of 2^14 ... 2^17 points: three tile passes instead of four -- the forward transform's second pass and the
+  // The same with a response of 2^14 ... 2^21 points: three tile passes instead of four -- the forward transform's second pass and the
   // inverse transform's first one run along the same rows and are one pass (fb_conv3.hip).  Launch groups of channels x parts that fill
   // about 2 GB per scratch buffer.
   if (fb->conv1_logM < 0 && cfg->nchan_subband == 1 && !cfg->real_input && cfg->npol == 2 && cfg->force_four_pass == 0 && !msub && nsub == 1 &&
@@ -521,8 +521,16 @@ extern "C" int dspsr_amd_filterbank_set_kernel(dspsr_amd_filterbank* fb, const f
     return fb_fail(fb->ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_set_kernel: hipMalloc failed");
   const cf* src = (const cf*)kernel_host;
   std::vector<cf> perm;
-  if ((fb->conv1_logM >= 0 || fb->conv3_logM >= 0) && fb->g.xblocked) {
-    // (the one-pass and three-pass convolutions read the response in natural order; the four-pass kernels of this geometry take it blocked)
+  if (fb->conv3_logM >= 0) {
+    // the three-pass convolution reads the response in the order of its pass-B tiles (fb_conv3_response_order: whole lines per load)
+    if (!fb->kernel_nat && hipMalloc((void**)&fb->kernel_nat, expect * sizeof(cf)) != hipSuccess)
+      return fb_fail(fb->ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_set_kernel: hipMalloc failed");
+    std::vector<cf> ord(expect);
+    for (uint32_t c = 0; c < fb->cfg.input_nchan; c++) fb_conv3_response_order(fb->conv3_logM, src + (uint64_t)c * fb->N, ord.data() + (uint64_t)c * fb->N);
+    if (hipMemcpy(fb->kernel_nat, ord.data(), expect * sizeof(cf), hipMemcpyHostToDevice) != hipSuccess)
+      return fb_fail(fb->ctx, DSPSR_AMD_EHIP, "dspsr_amd_filterbank_set_kernel: copy of the response failed");
+  } else if (fb->conv1_logM >= 0 && fb->g.xblocked) {
+    // (the one-pass convolution reads the response in natural order; the four-pass kernels of this geometry take it blocked)
     if (!fb->kernel_nat && hipMalloc((void**)&fb->kernel_nat, expect * sizeof(cf)) != hipSuccess)
       return fb_fail(fb->ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_set_kernel: hipMalloc failed");
     if (hipMemcpy(fb->kernel_nat, src, expect * sizeof(cf), hipMemcpyHostToDevice) != hipSuccess)
@@ -712,7 +720,7 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   }
   if (fb->conv3_logM >= 0 && in.kind == 0 && (out.kind == 0 || out.kind == 1 || out.kind == 2) && (in_chan_stride_bytes_or_floats % 2) == 0 &&
       (in.pol_stride % 2) == 0 && ((uintptr_t)in.base % 8) == 0) {
-    const cf* kern = fb->kernel ? (fb->g.xblocked ? fb->kernel_nat : fb->kernel) : nullptr;
+    const cf* kern = fb->kernel ? fb->kernel_nat : nullptr;             // (in pass-B order, see set_kernel)
     for (uint32_t c0 = 0; c0 < fb->cfg.input_nchan; c0 += fb->conv3_ch) {
       const uint32_t nc = fb->cfg.input_nchan - c0 < fb->conv3_ch ? fb->cfg.input_nchan - c0 : fb->conv3_ch;
       FbOut co = out;

@@ -192,7 +192,7 @@ int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb);
  *      2^27 / freq_res^2 (upper end: one 50 MHz sub-band with -F 512:D -x 512): column forward pass, then rows + chirp + inverse
  *      transforms in ONE tile -- the spectrum stays on chip;
  *   3  forward columns, forward rows, inverse per channel (freq_res <= 8192); and (raw_input == 0) the dsp::Convolution shapes above
- *      with 2^14 <= freq_res <= 2^17 on float32 rows: the forward transform's second pass and the inverse transform's first one run
+ *      with 2^14 <= freq_res <= 2^21 on float32 rows: the forward transform's second pass and the inverse transform's first one run
  *      along the same rows of the spectrum and are ONE pass, the spectrum never reaches memory (csrc/fb_conv3.hip;
  *      force_four_pass != 0 keeps the four passes);
  *   4  two-pass inverse (freq_res > 8192, dsp::Convolution shapes, force_four_pass = 1).  dsp::Convolution on >= 4 complex channels

@@ -83,11 +83,11 @@ for i in range(ncases):
         npart = int(rng.integers(1, max(2, min(6000, (1 << 19) // (C * kw.get("input_nchan", 1))))))
     elif fam == 1:
         # dsp::Convolution on many channels (nchan_subband = 1, complex float rows): groups of channels as one launch group
-        logM = int(rng.integers(4, 19))          # (one tile pass up to 2^13, three for 2^14 ... 2^17: csrc/fb_conv1.hip, fb_conv3.hip)
+        logM = int(rng.integers(4, 23))          # (one tile pass up to 2^13, three for 2^14 ... 2^21: csrc/fb_conv1.hip, fb_conv3.hip)
         C, M = 1, 1 << logM
         pos, neg = int(rng.integers(0, max(1, M // 3))), int(rng.integers(0, max(1, M // 3)))
         kw = dict(npol=2, real=False, use_raw=False, max_parts=int(rng.integers(1, 5)), seed=int(rng.integers(1, 1000)),
-                  input_nchan=int(rng.choice([1, 3, 4, 6, 8, 12, 16, 20, 32, 64] if logM <= 14 else [1, 2, 3, 4, 6, 8])), four_pass=int(rng.choice([0, 0, 0, 2])))
+                  input_nchan=int(rng.choice([1, 3, 4, 6, 8, 12, 16, 20, 32, 64] if logM <= 14 else [1, 2, 3, 4, 6, 8] if logM <= 18 else [1, 2, 3])), four_pass=int(rng.choice([0, 0, 0, 2])))
         npart = int(rng.integers(1, 7)) if logM + int(np.log2(kw["input_nchan"])) <= 17 else int(rng.integers(1, 3))
     desc = "C=%d M=%d nfilt=(%d,%d) npart=%d %s" % (C, M, pos, neg, npart, kw)
     try:

@@ -80,7 +80,8 @@ HOT = {
              "k_tfpm<10, true, true>", "k_tfpm<11, true, true>", "k_tfpm<13, true, true>", "k_tfpm<9, true, true>"],
     "fold": ["k_fold_dense<1, 4>", "k_fold_dense<4, 1>"],
     "after / after8k / plain": ["k_fb_plain<7, 0>", "k_fb_plain<10, 0>", "k_fb_plain<7, 2>", "k_conv1<13>", "k_conv1<12>", "k_conv1<10>", "k_conv3_a<16>", "k_conv3_b<16>", "k_conv3_c<16, 1>", "k_conv3_c<16, 0>",
-                                "k_conv3_a<14>", "k_conv3_b<14>", "k_conv3_b<17>", "k_conv3_c<17, 1>",
+                                "k_conv3_a<14>", "k_conv3_b<14>", "k_conv3_b<17>", "k_conv3_c<17, 1>", "k_conv3_a<19>", "k_conv3_b<19>", "k_conv3_c<19, 1>", "k_conv3_b<20>",
+                                "k_conv3_a<21>", "k_conv3_b<21>", "k_conv3_c<21, 1>",
                                 "k_fwd_cols<8, 4, 6>", "k_fwd_rows<8, 6>", "k_inv_a<8, false, false, true>", "k_inv_b<8, false, true>"],
 }
 # known spills of the shipped build in kernels the workloads DO launch (none tolerated silently: list them here with the reason)
@@ -89,6 +90,7 @@ TOLERATED = {
     "k_fwd_cols_dual<1>": 24,        # cfg1opt pass 1: 20 bytes since round 3
     "k_conv1<13>": 20,               # after8k: one part per 2^14-point tile, four radix stages per transform (r05 experiments 10); 12 bytes with
                                      #   non-temporal loads, 20 with plain ones -- and 2914 -> 2745 us per block (experiments 11 g)
+    "k_conv3_b<20>": 28,             # n_fft = 2^20: 4096-point rows, three full radix-16 stages per transform; still 2.8x the four passes
     "k_fb_plain<7, 0>": 32,          # raw words of the less common input forms parked during the decode (228 VGPRs; the sixteen 64-bit
     "k_fb_plain<10, 0>": 32,         #   sample indices as arrays had cost 48-64 bytes and 7 % of the kernel: r05 experiments 8)
     "k_fb_plain<7, 2>": 16,

@@ -1,5 +1,5 @@
 """dsp::Convolution on many channels (nchan_subband = 1, complex float32 rows) by itself: one tile pass (csrc/fb_conv1.hip, n_fft <= 8192)
-and three (csrc/fb_conv3.hip, 2^14 ... 2^17) against the four tile passes (grouped channels), per response length.  HIP events on the launch stream.
+and three (csrc/fb_conv3.hip, 2^14 ... 2^21) against the four tile passes (grouped channels), per response length.  HIP events on the launch stream.
   python tools/conv_probe.py [log2 points per polarisation] [n_fft,n_fft,...] [rows,detected,none]"""
 import os
 import sys
@@ -16,7 +16,7 @@ def main():
     ctx = dspsr_amd.Context(0, torch.cuda.current_stream().cuda_stream)
     nchan = 128
     print("build", dspsr_amd.build_id(), "complex samples per polarisation 2^%d in %d channels" % (lg, nchan))
-    for M in [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else (256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144):
+    for M in [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else (256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576, 2097152):
         nfilt = (M // 10, M // 10)
         step = M - sum(nfilt)
         npart = (1 << lg) // nchan // step
@@ -26,7 +26,7 @@ def main():
         kernel = np.exp(1j * rng.uniform(-np.pi, np.pi, nchan * M)).astype(np.complex64)
         out = torch.empty((nchan, 2, 2 * npart * step), dtype=torch.float32, device="cuda")
         det = torch.empty((nchan, 1, 4 * npart * step), dtype=torch.float32, device="cuda")
-        for ffp, name in ((0, "one pass" if M <= 8192 else "three" if M <= 131072 else "auto"), (1, "four passes")):
+        for ffp, name in ((0, "one pass" if M <= 8192 else "three" if M <= 2097152 else "auto"), (1, "four passes")):
             eng = dspsr_amd.FilterbankEngine(ctx).setup(1, M, nfilt[0], nfilt[1], nchan, 2, False, kernel, max_parts=min(npart, 256),
                                                         force_four_pass=ffp)
             for what in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("rows", "detected", "none")):
