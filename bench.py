@@ -101,6 +101,11 @@ WORKLOADS = {
     "after1k": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=1024, dm=1000.0, freq_res=4096, nbin=1024,
                     machine="CASPSR", when="after", parts_per_block=64, max_parts=64,
                     cmd="dspsr -F 1024 -x 4096 -D 1000 -b 1024 (filterbank, THEN convolution in one tile pass: Config::After on the headline's band)"),
+    # few wide channels, long responses: `dspsr -F 8` on the same band needs 2^20 points per 50 MHz channel -- the three-pass
+    # convolution at the other end of its range (csrc/fb_conv3.hip: 256-point columns, 4096-point rows)
+    "after8c": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=8, dm=67.99, freq_res=1 << 20, nbin=512,
+                    machine="CASPSR", when="after", parts_per_block=16, max_parts=16,
+                    cmd="dspsr -F 8 -x 1048576 -D 67.99 -b 512 (filterbank, THEN convolution in three tile passes: Config::After)"),
     # the filterbank alone (Filterbank::Config::Never: `dspsr -F 128` with coherent dedispersion switched off, or any DM-0 source):
     # k_fb_plain writing the detected rows, then Fold -- the roofline of the non-convolving filterbank kernel itself
     "plain": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=128, dm=0.0, freq_res=1, nbin=512,

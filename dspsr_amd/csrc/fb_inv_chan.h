@@ -338,7 +338,10 @@ __global__ __launch_bounds__(512) void k_inv_chan(const FbGeom g, const cf* __re
         for (int k = 0; k < R; k++) {
           const int32_t t = t0 + (int32_t)(k * pstride);
           if ((uint32_t)t >= g.nkeep) continue;
-          ts_stage((float*)lds, out, tsp, col >> 1, (uint32_t)t, cx2_lo(v[k]), cx2_hi(v[k]));
+          // (one polarisation: the pair's second half is not a signal -- for real input the other output of the Hermitian split,
+          //  zero but for rounding, 1e-7 of the spectrum's scale: its power moved the sum by an ulp where a sample is small,
+          //  tests/fuzz_search.py 300 702 case 68)
+          ts_stage((float*)lds, out, tsp, col >> 1, (uint32_t)t, cx2_lo(v[k]), g.npol == 1 ? make_float2(0.f, 0.f) : cx2_hi(v[k]));
         }
         return;
       }

@@ -8,31 +8,47 @@
 namespace dspsr_amd {
 
 // One thread per output sample; the rows are a STREAM (see dspsr_amd.h): the first c0 samples of output 0 are already in `carry`,
-// the samples behind the last complete output go to `carry`.  blockIdx.y (+ k gridDim.y) = row (chan * npol + pol).
+// the samples behind the last complete output go to `carry` (summed by the thread of output 0, see below).  blockIdx.y (+ k gridDim.y) = row (chan * npol + pol).
 __global__ __launch_bounds__(256) void k_tscrunch_fpt(const float* __restrict__ in, const uint64_t ics, const uint64_t ips,
                                                       float* __restrict__ out, const uint64_t ocs, const uint64_t ops, const uint32_t npol,
                                                       const uint32_t ndim, const uint64_t ndat_in, const uint32_t sf, const uint32_t c0,
                                                       float* __restrict__ carry, const uint64_t nout, const uint32_t rem, const uint32_t nrow)
 {
-  const uint64_t ngroup = nout + (rem ? 1 : 0);
+  // The thread of output 0 reads the carry and the partial group behind the last complete output REPLACES it: both belong to the same
+  // thread (read first, then written).  With the partial group on a thread of its own -- another workgroup when the outputs of a row
+  // need more than one -- the new carry could land before output 0 had read the old one (tests/fuzz_search.py 300 702, case 246: sample
+  // 91 of 1729 rows wrong with 2048 channels, four-pass kernels, a call that begins and ends inside an output sample).
+  const uint64_t nown = nout ? nout : 1;
   for (uint32_t row = blockIdx.y; row < nrow; row += gridDim.y) {
   const uint32_t chan = row / npol, pol = row % npol;
   const float* __restrict__ x = in + chan * ics + pol * ips;
   float* __restrict__ y = out + chan * ocs + pol * ops;
   // one thread per (output sample, dimension): consecutive threads = the dimensions of a sample, then the next sample
-  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < ngroup * ndim; w += (uint64_t)gridDim.x * blockDim.x) {
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nown * ndim; w += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t o = w / ndim;
     const uint32_t d = (uint32_t)(w - o * ndim);
-    // stream samples [o*sf, (o+1)*sf) = input samples [o*sf - c0, ...) ; the last group holds `rem` samples only
-    const uint64_t s0 = o * sf, s1 = o < nout ? s0 + sf : s0 + rem;
-    uint64_t i = s0 < c0 ? 0 : s0 - c0;
-    const uint64_t i1 = s1 - c0;
-    float acc;
-    if (o == 0 && c0) acc = carry[(uint64_t)row * ndim + d];
-    else { acc = x[i * ndim + d]; i++; }
-    for (; i < i1; i++) acc = __fadd_rn(acc, x[i * ndim + d]);
-    if (o < nout) y[o * ndim + d] = acc;
-    else carry[(uint64_t)row * ndim + d] = acc;
+    if (o < nout) {
+      // stream samples [o*sf, (o+1)*sf) = input samples [o*sf - c0, ...)
+      const uint64_t s0 = o * sf;
+      uint64_t i = s0 < c0 ? 0 : s0 - c0;
+      const uint64_t i1 = s0 + sf - c0;
+      float acc;
+      if (o == 0 && c0) acc = carry[(uint64_t)row * ndim + d];
+      else { acc = x[i * ndim + d]; i++; }
+      for (; i < i1; i++) acc = __fadd_rn(acc, x[i * ndim + d]);
+      y[o * ndim + d] = acc;
+    }
+    if (o == 0 && rem) {
+      // the open group: stream samples [nout*sf, nout*sf + rem); it starts from the carry when no output was completed
+      const uint64_t s0 = nout * sf;
+      uint64_t i = s0 < c0 ? 0 : s0 - c0;
+      const uint64_t i1 = s0 + rem - c0;
+      float acc;
+      if (nout == 0 && c0) acc = carry[(uint64_t)row * ndim + d];
+      else { acc = x[i * ndim + d]; i++; }
+      for (; i < i1; i++) acc = __fadd_rn(acc, x[i * ndim + d]);
+      carry[(uint64_t)row * ndim + d] = acc;
+    }
   }
   }
 }

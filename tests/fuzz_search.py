@@ -1,4 +1,4 @@
-"""tests/fuzz_search.py [ncases] [seed] : random geometries of digifil's convolving branch (dspsr_amd_filterbank_perform_search) -- the
+"""tests/fuzz_search.py [ncases] [seed] [case,case,...] : random geometries of digifil's convolving branch (dspsr_amd_filterbank_perform_search) -- the
 square-law + time-scrunch epilogue of the inverse pass must equal the oracle's Detection::square_law + TScrunch (float32, sequential
 sums) applied to the SAME object's complex output BIT FOR BIT, as a stream over several calls of random part counts, for Intensity
 and PPQQ, any scrunch factor, real / complex input, 1 or 2 polarisations, several input channels, three-pass / two-pass /
@@ -21,6 +21,7 @@ spec.loader.exec_module(oracle)
 import dspsr_amd
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+only = [int(a) for a in sys.argv[3].split(",")] if len(sys.argv) > 3 else None       # replay: run these case numbers of the sequence only
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = dspsr_amd.Context(0, torch.cuda.current_stream().cuda_stream)
 bad = 0
@@ -56,8 +57,12 @@ for i in range(ncases):
     parts = [int(rng.integers(1, 7)) for _ in range(int(rng.integers(1, 4)))]
     desc = "C=%d M=%d nfilt=(%d,%d) real=%d npol=%d in_nchan=%d sf=%d %s max_parts=%d parts=%s force=%d" % (
         C, M, pos, neg, real, npol, input_nchan, sf, state_name, maxp, parts, force)
+    kseed = int(rng.integers(1, 1 << 30))
+    if only is not None and i not in only:
+        continue
+    desc = "#%d %s kseed=%d" % (i, desc, kseed)
     try:
-        krng = np.random.default_rng(int(rng.integers(1, 1 << 30)))
+        krng = np.random.default_rng(kseed)
         kernel = np.exp(1j * krng.uniform(-np.pi, np.pi, input_nchan * C * M)).astype(np.complex64)
         fb = dspsr_amd.FilterbankEngine(ctx).setup(C, M, pos, neg, input_nchan, npol, real, kernel, max_parts=maxp, force_four_pass=force)
         carry = torch.zeros((nchan, npo), dtype=torch.float32, device="cuda")
@@ -77,19 +82,30 @@ for i in range(ncases):
             nout, cc = fb.perform_search(out, carry, cc, npart, sf, state, raw=raw, layout=dspsr_amd.RAW_GENERIC, scale=0.0123)
             got.append(out[:, :, :nout].cpu().numpy())
         fused = fb.search_is_fused()
+        fb_nkeep = fb.nkeep
         fb.close()
         all_det = np.concatenate(dets, axis=2)
         want = oracle.tscrunch_fpt(all_det, sf) if sf > 1 else all_det
         got = np.concatenate(got, axis=2)
         assert got.shape == want.shape, (got.shape, want.shape)
         assert cc == all_det.shape[2] % sf
-        assert np.array_equal(got, want), "max diff %g at %s" % (np.abs(got - want).max(), np.unravel_index(np.argmax(np.abs(got - want)), got.shape))
+        if not np.array_equal(got, want):
+            bad_el = np.argwhere(got != want)
+            rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
+            if os.environ.get("FUZZ_SEARCH_DUMP"):
+                cat = np.concatenate([d for d in dets], axis=2)
+                for (a, b, c_) in bad_el[:8]:
+                    print("   mismatch chan %d pol %d out %d: got %.9g want %.9g (sf %d, first stream sample %d, nkeep %d)" % (
+                        a, b, c_, got[a, b, c_], want[a, b, c_], sf, c_ * sf, fb_nkeep), flush=True)
+            raise AssertionError("max diff %g at %s; %d of %d elements differ, max relative %.3g; channels %s; samples %d..%d" % (
+                np.abs(got - want).max(), np.unravel_index(np.argmax(np.abs(got - want)), got.shape), len(bad_el), got.size, rel.max(),
+                sorted(set(bad_el[:, 0].tolist()))[:12], bad_el[:, 2].min(), bad_el[:, 2].max()))
         print("ok   ", desc, "fused=%d" % fused, flush=True)
     except dspsr_amd.DspsrAmdError as e:
         print("refused", desc, "--", str(e)[:100], flush=True)
     except AssertionError as e:
         bad += 1
-        print("FAIL ", desc, "--", str(e)[:200], flush=True)
+        print("FAIL ", desc, "--", str(e)[:400], flush=True)
     except Exception:
         bad += 1
         print("ERROR", desc, flush=True)

@@ -49,6 +49,29 @@ def test_tscrunch_fpt_stream_bit_exact(oracle, gpu, nchan, npol, sf, blocks):
         dspsr_amd.tscrunch_fpt(ctx, blk, blk, sf, carry, 0)                 # in place: refused
 
 
+def test_tscrunch_fpt_carry_read_before_it_is_replaced(oracle, gpu):
+    """A block that begins AND ends inside an output sample, with more outputs per row than one workgroup holds and thousands of rows:
+    output 0 reads the carry, the open group at the end replaces it.  (Round 5: the two were different threads -- on the GPU the new
+    carry could land before output 0 had read the old one; tests/fuzz_search.py 300 702 case 246, 1729 rows wrong.  One thread does both.)"""
+    dspsr_amd, ctx = gpu
+    rng = np.random.default_rng(43)
+    nchan, npol, sf = 2048, 2, 3
+    blocks = (274, 822, 1000, 2)
+    x = (rng.standard_normal((nchan, npol, sum(blocks))).astype(np.float32) ** 2) * 100
+    want = oracle.tscrunch_fpt(x, sf)
+    for rep in range(3):
+        carry = torch.zeros((nchan, npol), dtype=torch.float32, device="cuda")
+        cc, got, pos = 0, [], 0
+        for n in blocks:
+            blk = torch.from_numpy(np.ascontiguousarray(x[:, :, pos:pos + n])).cuda()
+            out = torch.full((nchan, npol, (cc + n) // sf + 1), -1.0, dtype=torch.float32, device="cuda")
+            nout, cc = dspsr_amd.tscrunch_fpt(ctx, blk, out, sf, carry, cc)
+            got.append(out[:, :, :nout].cpu().numpy())
+            pos += n
+        got = np.concatenate(got, axis=2)
+        assert got.shape == want.shape and np.array_equal(got, want)
+
+
 def test_fscrunch_fpt_bit_exact(oracle, gpu):
     dspsr_amd, ctx = gpu
     rng = np.random.default_rng(42)
@@ -211,6 +234,34 @@ def test_perform_search_single_pol_and_multi_channel_input(oracle, gpu, npol, in
         assert got.shape == want.shape and want.shape[2] > 0
         assert np.array_equal(got, want), (state_name, np.abs(got - want).max())
     fb.close()
+
+
+def test_perform_search_real_single_pol_adds_nothing_for_the_missing_polarisation(oracle, gpu):
+    """Real input with ONE polarisation: the Hermitian split of the packed transform still has a second output -- zero but for rounding,
+    1e-7 of the spectrum's scale.  Intensity is Re^2 + Im^2 of the one polarisation (Detection.C:218-320), bit for bit: where a sample is
+    small against that scale the other output's power moved the sum by an ulp (round 5, tests/fuzz_search.py 300 702 case 68: 2 of 4.6 M
+    samples).  Random phases as the response, so the channel samples span four decades."""
+    dspsr_amd, ctx = gpu
+    C, M, pos, neg = 128, 4096, 1050, 19
+    krng = np.random.default_rng(961203071)
+    kernel = np.exp(1j * krng.uniform(-np.pi, np.pi, C * M)).astype(np.complex64)
+    fb = dspsr_amd.FilterbankEngine(ctx).setup(C, M, pos, neg, 1, 1, True, kernel, max_parts=3)
+    assert fb.search_is_fused()
+    carry = torch.zeros((C, 1), dtype=torch.float32, device="cuda")
+    cc, got, dets = 0, [], []
+    for npart in (6, 5, 1):
+        nsamp = npart * fb.nsamp_step + fb.nsamp_overlap
+        raw = torch.from_numpy(np.clip(np.rint(krng.standard_normal(nsamp) * 24.0), -128, 127).astype(np.int8)).cuda()
+        cplx = torch.zeros((C, 1, 2 * npart * fb.nkeep), dtype=torch.float32, device="cuda")
+        fb.perform_raw(raw, dspsr_amd.RAW_GENERIC, 0.0123, cplx, npart)
+        c = cplx.cpu().numpy().view(np.complex64)
+        dets.append((c.real * c.real + c.imag * c.imag).astype(np.float32))
+        out = torch.full((C, 1, cc + npart * fb.nkeep + 1), -1.0, dtype=torch.float32, device="cuda")
+        nout, cc = fb.perform_search(out, carry, cc, npart, 1, dspsr_amd.INTENSITY, raw=raw, layout=dspsr_amd.RAW_GENERIC, scale=0.0123)
+        got.append(out[:, :, :nout].cpu().numpy())
+    fb.close()
+    want, got = np.concatenate(dets, axis=2), np.concatenate(got, axis=2)
+    assert got.shape == want.shape and np.array_equal(got, want), np.argwhere(got != want)[:4]
 
 
 def test_perform_search_two_pass_geometry(oracle, gpu):
