@@ -101,11 +101,12 @@ WORKLOADS = {
     "after1k": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=1024, dm=1000.0, freq_res=4096, nbin=1024,
                     machine="CASPSR", when="after", parts_per_block=64, max_parts=64,
                     cmd="dspsr -F 1024 -x 4096 -D 1000 -b 1024 (filterbank, THEN convolution in one tile pass: Config::After on the headline's band)"),
-    # few wide channels, long responses: `dspsr -F 8` on the same band needs 2^20 points per 50 MHz channel -- the three-pass
-    # convolution at the other end of its range (csrc/fb_conv3.hip: 256-point columns, 4096-point rows)
-    "after8c": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=8, dm=67.99, freq_res=1 << 20, nbin=512,
-                    machine="CASPSR", when="after", parts_per_block=16, max_parts=16,
-                    cmd="dspsr -F 8 -x 1048576 -D 67.99 -b 512 (filterbank, THEN convolution in three tile passes: Config::After)"),
+    # few wide channels, long responses: `dspsr -F 8` on the same band smears 885k samples per 50 MHz channel -- 2^21 points, the
+    # three-pass convolution at the other end of its range (csrc/fb_conv3.hip: 256-point columns, 8192-point rows; 58 % of each
+    # transform kept)
+    "after8c": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=8, dm=67.99, freq_res=1 << 21, nbin=512,
+                    machine="CASPSR", when="after", parts_per_block=8, max_parts=8,
+                    cmd="dspsr -F 8 -x 2097152 -D 67.99 -b 512 (filterbank, THEN convolution in three tile passes: Config::After)"),
     # the filterbank alone (Filterbank::Config::Never: `dspsr -F 128` with coherent dedispersion switched off, or any DM-0 source):
     # k_fb_plain writing the detected rows, then Fold -- the roofline of the non-convolving filterbank kernel itself
     "plain": dict(freq=1382.0, bw=-400.0, in_nchan=1, ndim=1, tsamp_us=0.00125, nchan=128, dm=0.0, freq_res=1, nbin=512,
@@ -1176,7 +1177,7 @@ def main():
                                                 "replicas so that N = 1 agrees with the single-GPU record" % world)
         if world == 1:
             others = []
-            for w in ("cfg1", "cfg1opt", "cfg2", "cfg3", "odd_nchan", "odd_fres", "after", "after8k", "after1k", "plain"):
+            for w in ("cfg1", "cfg1opt", "cfg2", "cfg3", "odd_nchan", "odd_fres", "after", "after8k", "after1k", "after8c", "plain"):
                 others.append(brief(run_fold_workload(w, short, *ctx, steps=2 * ssteps, warmup=swarm, full=False)))
             sm = argparse.Namespace(**vars(args))
             sm.steps, sm.warmup, sm.no_cpu_baseline = 2 * ssteps, swarm, True

@@ -5,10 +5,10 @@ library has not been built -- there is no CPU fallback."""
 from ._lib import (lib, LIB_PATH, RAW_GENERIC, RAW_CASPSR, RAW_UWB16, COHERENCE, STOKES, INTENSITY, PPQQ,  # noqa: F401
                    FUSED_AUTO, FUSED_ALWAYS, FUSED_NEVER)
 from .engine import (Communicator, Context, ConvolutionEngine, Dedispersion, DetectionEngine, DspsrAmdError, FilterbankEngine, FoldEngine, Rescale, SampleDelay, add_fpt, copy_data_fpt, dedispersion_sample_delays, fscrunch_fpt, pscrunch_tfp, sigproc_digitize, sigproc_digitize_fpt, tscrunch_fpt,  # noqa: F401
-                     eight_bit_scale, fold_binplan, optimal_fft_length, tfp_filterbank)
+                     eight_bit_scale, fold_binplan, fold_binplan_runs, optimal_fft_length, tfp_filterbank)
 
 __all__ = ["Communicator", "Context", "ConvolutionEngine", "Dedispersion", "DetectionEngine", "DspsrAmdError", "FilterbankEngine", "FoldEngine", "Rescale", "SampleDelay", "add_fpt", "copy_data_fpt", "dedispersion_sample_delays", "fscrunch_fpt", "pscrunch_tfp", "sigproc_digitize", "sigproc_digitize_fpt", "tscrunch_fpt",
-           "eight_bit_scale", "fold_binplan", "optimal_fft_length", "tfp_filterbank", "lib", "LIB_PATH", "build_id"]
+           "eight_bit_scale", "fold_binplan", "fold_binplan_runs", "optimal_fft_length", "tfp_filterbank", "lib", "LIB_PATH", "build_id"]
 
 
 def build_id() -> str:

@@ -126,6 +126,7 @@ SYMBOLS = {
     "dspsr_amd_optimal_fft_length": (_u64, [_u64, _u64]),
     "dspsr_amd_eight_bit_scale": (_d, [_d]),
     "dspsr_amd_fold_binplan": (_i, [_d, _d, _u32, _u64, _vp, _vp]),
+    "dspsr_amd_fold_binplan_runs": (_i, [_d, _d, _u32, _u64, _vp, _vp, _vp, _u64, _vp, _vp]),
 }
 
 

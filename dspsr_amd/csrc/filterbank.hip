@@ -1244,7 +1244,7 @@ extern "C" int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb
 {
   // (short responses of dsp::Convolution shapes: Detection inside the one-pass kernel, Fold as a launch of its own -- the segment-sum
   //  fold belongs to the four-pass kernels)
-  if (fb && fb->conv1_logM >= 0) return 0;
+  if (fb && (fb->conv1_logM >= 0 || fb->conv3_logM >= 0)) return 0;     // (the three-pass convolution likewise: Detection in pass C, Fold behind it)
   if (!fb || fb->msub || fb->plain_logC >= 0) return 0;            // (freq_res = 3 * 2^k / 5 * 2^k: the last step is a pass of its own, k_time_combine)
   // (segment sums pay when most of the transform is kept: at -F 64:D -x 16384 only 1817 of 16384 samples are, the unfused pass
   //  writes just those, and the fused one measured 541 against 458 us per 8 parts)

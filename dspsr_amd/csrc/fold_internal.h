@@ -7,6 +7,8 @@
 namespace dspsr_amd {
 struct Interval { uint64_t offset; uint32_t hits; uint32_t pad; };   // sorted by (bin, time)
 struct RunBin { uint32_t ibin, hits; uint64_t offset; };             // FoldCUDA.h:19-24
+// one run of the plan recurrence without walking its samples (host_prep.cpp)
+uint64_t fold_plan_run(double* phi_io, double pps, double double_nbin, uint64_t nmax, uint32_t* ibin_out);
 }  // namespace dspsr_amd
 
 // device plan, double-buffered so that building/uploading the plan of block i+1 never waits for

@@ -61,6 +61,20 @@ class Context:
             pass
 
 
+def fold_binplan_runs(phi: float, phase_per_sample: float, nbin: int, ndat: int, cap: int = 0):
+    """The plan of fold_binplan as runs (first sample, bin, samples), found run by run (csrc/host_prep.cpp fold_plan_run); hits[nbin]."""
+    cap = cap or max(1, ndat)
+    off, rb, rh = np.empty(cap, dtype=np.uint64), np.empty(cap, dtype=np.uint32), np.empty(cap, dtype=np.uint64)
+    hits = np.zeros(nbin, dtype=np.uint32)
+    n = C.c_uint64()
+    code = lib.dspsr_amd_fold_binplan_runs(phi, phase_per_sample, nbin, ndat, off.ctypes.data_as(C.c_void_p), rb.ctypes.data_as(C.c_void_p),
+                                           rh.ctypes.data_as(C.c_void_p), cap, C.byref(n), hits.ctypes.data_as(C.c_void_p))
+    if code != 0:
+        raise DspsrAmdError("dspsr_amd_fold_binplan_runs failed (%d)" % code)
+    k = min(n.value, cap)
+    return off[:k].copy(), rb[:k].copy(), rh[:k].copy(), hits, n.value
+
+
 # ----------------------------------------------------------------------------------------------
 # host-side preparation
 # ----------------------------------------------------------------------------------------------

@@ -177,7 +177,8 @@ int dspsr_amd_filterbank_perform_detect(dspsr_amd_filterbank* fb, const float* i
  *      pieces of each (channel, bin) in time order -- re-associated like the long-run fold (fold.hip), deterministic; the
  *      detected time series never reaches HBM.  Plans that do not qualify (narrow bins, zero weights, partial folds) take 0;
  *   0  Detection and Fold as separate launches on a block owned by the filterbank object (fewer than 8 tiles,
- *      DSPSR_AMD_FUSED_NEVER, or what the other modes turn down).  Three-pass plans with runs of >= 640 samples per bin
+ *      DSPSR_AMD_FUSED_NEVER, or what the other modes turn down; and every dsp::Convolution object whose float32 rows run in one
+ *      or three tile passes -- complex input, two polarisations, 64 <= freq_res <= 2^21: Detection in their last pass).  Three-pass plans with runs of >= 640 samples per bin
  *      take this path too (fold.hip).
  * DSPSR_AMD_FUSED_ALWAYS forces mode 1 on any three-pass geometry. */
 int dspsr_amd_filterbank_fold_is_fused(const dspsr_amd_filterbank* fb);
@@ -448,6 +449,11 @@ double dspsr_amd_eight_bit_scale(double ja98_spacing);
 /* bin plan of Fold.C:744-787: binplan[ndat] and hits[nbin] += */
 int dspsr_amd_fold_binplan(double phi, double phase_per_sample, uint32_t nbin, uint64_t ndat,
                            uint32_t* binplan_host, uint32_t* hits_host);
+/* the same plan as its runs (first sample, bin, samples; at most `cap` stored, *nruns = how many there are), found per run
+ * instead of per sample -- the values of the recurrence, not an approximation (csrc/host_prep.cpp fold_plan_run); what
+ * dspsr_amd_fold_set_bins builds its plan with */
+int dspsr_amd_fold_binplan_runs(double phi, double phase_per_sample, uint32_t nbin, uint64_t ndat, uint64_t* run_offset,
+                                uint32_t* run_bin, uint64_t* run_hits, uint64_t cap, uint64_t* nruns, uint32_t* hits_host);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@ T=$1
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp && cd $R
-WL=${WL:-target cfg1 cfg1opt cfg2 cfg3 cfg4 cfg5 cfg5c odd_nchan odd_fres after after8k after1k plain fold}
+WL=${WL:-target cfg1 cfg1opt cfg2 cfg3 cfg4 cfg5 cfg5c odd_nchan odd_fres after after8k after1k after8c plain fold}
 PHASE=${PHASE:-all}      # stats | pmc | all (a call on the GPU box is limited to 20 minutes: run the two phases as two calls if need be)
 # the counters first: the bench lines of the stats phase quote the traffic files of THIS build (bench.py refuses any other)
 if [ $PHASE != stats ]; then

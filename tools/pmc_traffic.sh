@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp && cd $R
 MODES="fused unfused"
-if [ "$W" = cfg5 ] || [ "$W" = cfg5c ] || [ "$W" = fold ] || [ "$W" = after ] || [ "$W" = after8k ] || [ "$W" = after1k ] || [ "$W" = plain ]; then MODES="unfused"; fi
+if [ "$W" = cfg5 ] || [ "$W" = cfg5c ] || [ "$W" = fold ] || [ "$W" = after ] || [ "$W" = after8k ] || [ "$W" = after1k ] || [ "$W" = after8c ] || [ "$W" = plain ]; then MODES="unfused"; fi
 for m in $MODES; do
 for c in FETCH_SIZE WRITE_SIZE; do
   d=gpurun_out/$T/pmc_${W}_${m}_$c
