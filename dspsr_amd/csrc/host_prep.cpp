@@ -254,6 +254,13 @@ extern "C" double dspsr_amd_eight_bit_scale(double input_spacing)               
 // In: *phi the state in front of the first sample (not normalised), nmax >= 1 samples available.  Out: the bin of the run, the
 // number of its samples taken (<= nmax), *phi the state in front of the sample behind them.
 namespace dspsr_amd {
+static inline double pow2d(const int e)                      // 2^e for -1022 <= e <= 1023
+{
+  const uint64_t b = (uint64_t)(e + 1023) << 52;
+  double d;
+  memcpy(&d, &b, sizeof d);
+  return d;
+}
 uint64_t fold_plan_run(double* phi_io, const double pps, const double double_nbin, const uint64_t nmax, uint32_t* ibin_out)
 {
   double phi = *phi_io;
@@ -265,30 +272,40 @@ uint64_t fold_plan_run(double* phi_io, const double pps, const double double_nbi
     // sample n of the run has phase phi (in [0, 1), unless the input was not finite) and lies in bin ibin
     bool stepped = false;
     if (pps >= 0.0 && phi >= 0x1p-900 && phi < 1.0) {
-      int e;
-      (void)frexp(phi, &e);                                   // phi in [2^(e-1), 2^e), spacing 2^(e-53)
-      const double r = ldexp(pps, 53 - e);                    // pps / u, exact (a power-of-two scaling) or inf
+      uint64_t bits;
+      memcpy(&bits, &phi, sizeof bits);
+      const int e = (int)((bits >> 52) & 0x7ff) - 1022;        // phi in [2^(e-1), 2^e) (normal: phi >= 2^-900), spacing u = 2^(e-53)
+      const double r = pps * pow2d(53 - e);                    // pps / u: a power-of-two scaling, exact or inf (53 - e <= 953)
       if (r < 0x1p53) {
         const double fl = floor(r), frac = r - fl;
         if (frac != 0.5) {
           const uint64_t Ci = (uint64_t)(frac > 0.5 ? fl + 1.0 : fl);
-          const uint64_t K = (uint64_t)ldexp(phi, 53 - e);      // 2^52 <= K < 2^53, exact
+          const uint64_t K = (bits & 0xfffffffffffffull) | (1ull << 52);      // phi / u: 2^52 <= K < 2^53
           const uint64_t kcap = Ci ? ((1ull << 53) - 1 - K) / Ci : ~0ull;      // phases (K + j Ci) u, j <= kcap, stay in the binade
           if (kcap > 0) {
+            const double u = pow2d(e - 53);
             const uint64_t left = nmax - n - 1;                 // samples behind sample n that may still be taken
             const uint64_t jmax = kcap < left ? kcap : left;
-            auto phase = [&](const uint64_t j) { return ldexp((double)(K + j * Ci), e - 53); };
+            auto in_bin = [&](const uint64_t j) { return (uint32_t)(((double)(K + j * Ci) * u) * double_nbin) == ibin; };
             uint64_t j = jmax;                                  // last j <= jmax whose sample is in the bin (j = 0 is)
-            if ((uint32_t)(phase(jmax) * double_nbin) != ibin) {
-              uint64_t lo = 0, hi = jmax;                       // bin(lo) == ibin, bin(hi) != ibin
+            if (!in_bin(jmax)) {
+              // the bin number is monotone in j: bracket the last sample of the bin, starting from where the boundary
+              // (ibin + 1) / nbin should be crossed, then bisect what is left (usually nothing)
+              uint64_t lo = 0, hi = jmax;                       // in_bin(lo), !in_bin(hi)
+              const double est = (((double)ibin + 1.0) / double_nbin - phi) / ((double)Ci * u);
+              if (est >= 2.0 && est < (double)jmax) {
+                const uint64_t g = (uint64_t)est;
+                if (in_bin(g)) { lo = g; if (g + 2 < hi && !in_bin(g + 2)) hi = g + 2; }
+                else { hi = g; if (g >= 2 && in_bin(g - 2)) lo = g - 2; }
+              }
               while (hi - lo > 1) {
                 const uint64_t mid = lo + (hi - lo) / 2;
-                if ((uint32_t)(phase(mid) * double_nbin) == ibin) lo = mid; else hi = mid;
+                if (in_bin(mid)) lo = mid; else hi = mid;
               }
               j = lo;
             }
             n += j + 1;
-            phi = j < kcap ? phase(j + 1) : phase(j) + pps;      // the step out of the binade is the rounded addition itself
+            phi = j < kcap ? (double)(K + (j + 1) * Ci) * u : (double)(K + j * Ci) * u + pps;   // out of the binade: the rounded addition itself
             if (j < jmax || n == nmax) { *phi_io = phi; return n; }      // the next sample is in another bin, or none is left
             stepped = true;
           }
