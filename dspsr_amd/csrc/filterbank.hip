@@ -64,6 +64,7 @@ struct dspsr_amd_filterbank_impl {
   uint32_t conv3_ch = 0, conv3_parts = 0;    //   conv3_parts parts through the scratch blocks S1 / S2
   cf* S1 = nullptr;
   cf* S2 = nullptr;
+  uint64_t conv3_bytes = 0;                  //   bytes of each (allocated on first use; a failed allocation turns the path off)
   cf* kernel_nat = nullptr;  // ... its response in natural order when `kernel` is stored in the blocked order of the four-pass kernels
   int plain_logC = -1;       // >= 0: freq_res = 1, the non-convolving filterbank (fb_plain.hip): no scratch, one launch per call
   cf* Xp = nullptr;          // the combined spectrum in pseudo-channel order (k_sub_combine writes it there)
@@ -440,15 +441,11 @@ extern "C" int dspsr_amd_filterbank_create(dspsr_amd_ctx* ctx, const dspsr_amd_f
     uint64_t ch = max_seq / np;
     if (ch < 1) ch = 1;
     if (ch > cfg->input_nchan) ch = cfg->input_nchan;
-    if (hipMalloc((void**)&fb->S1, np * ch * seq_bytes) == hipSuccess && hipMalloc((void**)&fb->S2, np * ch * seq_bytes) == hipSuccess) {
-      fb->conv3_logM = g.logMf;
-      fb->conv3_ch = (uint32_t)ch;
-      fb->conv3_parts = (uint32_t)np;
-    } else {
-      if (fb->S1) (void)hipFree(fb->S1);
-      fb->S1 = fb->S2 = nullptr;
-      (void)hipGetLastError();
-    }
+    // (the two scratch buffers are allocated by the first call that takes this path: an object fed 8-bit blocks never does)
+    fb->conv3_logM = g.logMf;
+    fb->conv3_ch = (uint32_t)ch;
+    fb->conv3_parts = (uint32_t)np;
+    fb->conv3_bytes = np * ch * seq_bytes;
   }
   // dsp::Convolution behind a filterbank (nchan_subband = 1 on many input channels, `dspsr -F N`): one launch group per input channel
   // holds parts x 2 x freq_res points -- a tile or two per compute unit and four launches per channel.  The channels of a GROUP run
@@ -720,6 +717,15 @@ static int fb_run(dspsr_amd_filterbank* fb, FbIn in, FbOut out, uint64_t npart, 
   }
   if (fb->conv3_logM >= 0 && in.kind == 0 && (out.kind == 0 || out.kind == 1 || out.kind == 2) && (in_chan_stride_bytes_or_floats % 2) == 0 &&
       (in.pol_stride % 2) == 0 && ((uintptr_t)in.base % 8) == 0) {
+    if (!fb->S1) {
+      if (hipMalloc((void**)&fb->S1, fb->conv3_bytes) != hipSuccess || hipMalloc((void**)&fb->S2, fb->conv3_bytes) != hipSuccess) {
+        if (fb->S1) (void)hipFree(fb->S1);
+        fb->S1 = fb->S2 = nullptr;
+        (void)hipGetLastError();
+        return fb_fail(ctx, DSPSR_AMD_ENOMEM, "dspsr_amd_filterbank_perform: hipMalloc of 2 x %llu bytes of scratch for the three-pass convolution failed",
+                       (unsigned long long)fb->conv3_bytes);
+      }
+    }
     const cf* kern = fb->kernel ? fb->kernel_nat : nullptr;             // (in pass-B order, see set_kernel)
     for (uint32_t c0 = 0; c0 < fb->cfg.input_nchan; c0 += fb->conv3_ch) {
       const uint32_t nc = fb->cfg.input_nchan - c0 < fb->conv3_ch ? fb->cfg.input_nchan - c0 : fb->conv3_ch;
