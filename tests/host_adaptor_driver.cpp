@@ -555,6 +555,65 @@ int main ()
       printf ("dspsr -F N: non-convolving FilterbankEngine (freq_res 1) + ConvolutionEngine == direct transforms (%.1e, %.1e of the scale)\n",
               worst / scale_fb, cworst / cscale);
     }
+    // ---------------------------------------------------------------- the same ConvolutionEngine with a response of 16384 points: the
+    // library's three-pass form (csrc/fb_conv3.hip).  Impulses in, so that every output sample is a short sum over the inverse
+    // transform h[m] = sum_k H[k] exp(+2 pi i k m / M) of the channel's response, evaluated directly in double
+    {
+      const unsigned Cq = 3, Mq = 16384, qpos = 900, qneg = 1100, qstep = Mq - qpos - qneg, nq = 3;
+      const uint64_t nin = uint64_t (nq) * qstep + qpos + qneg;
+      dsp::TimeSeries c_h, c_d, y_h, y_d;
+      c_d.set_nchan (Cq); c_d.set_npol (2); c_d.set_ndim (2); c_d.set_state (Signal::Analytic); c_d.set_rate (1e6);
+      c_d.set_memory (dmem); c_d.resize (nin);
+      c_h.internal_match (&c_d);
+      for (unsigned c = 0; c < Cq; c++) for (unsigned p = 0; p < 2; p++) for (uint64_t i = 0; i < 2 * nin; i++) c_h.get_datptr (c, p)[i] = 0.f;
+      struct Imp { uint64_t n; float re, im; };
+      std::vector<Imp> imps;                                             // (the same impulses in every channel and polarisation, other amplitudes)
+      for (unsigned i = 0; i < 7; i++) { Imp m; m.n = (uint64_t (i) * 5231 + 77) % nin; m.re = 1.f + 0.25f * i; m.im = -0.5f + 0.125f * i; imps.push_back (m); }
+      for (unsigned c = 0; c < Cq; c++) for (unsigned p = 0; p < 2; p++) for (size_t i = 0; i < imps.size (); i++) {
+        c_h.get_datptr (c, p)[2 * imps[i].n] = imps[i].re * float (1 + c) * (p ? -1.f : 1.f);
+        c_h.get_datptr (c, p)[2 * imps[i].n + 1] = imps[i].im * float (1 + c);
+      }
+      h2d (ctx, c_d, c_h);
+      dsp::Response qresp;
+      qresp.impulse_pos = qpos; qresp.impulse_neg = qneg; qresp.nchan = Cq; qresp.ndat = Mq;
+      qresp.kernel.resize (2 * size_t (Cq) * Mq);
+      for (size_t k = 0; k < size_t (Cq) * Mq; k++) { const float a = 3.0f * rnd (); qresp.kernel[2 * k] = cosf (a); qresp.kernel[2 * k + 1] = sinf (a); }
+      dsp::Convolution conv;
+      conv.response = &qresp; conv.input = &c_d; conv.nsamp_fft = Mq; conv.nsamp_overlap = qpos + qneg;
+      HIP::ConvolutionEngine cve (ctx);
+      cve.prepare (&conv);
+      y_d.set_nchan (Cq); y_d.set_npol (2); y_d.set_ndim (2); y_d.set_state (Signal::Analytic); y_d.set_rate (1e6);
+      y_d.set_memory (dmem); y_d.resize (uint64_t (nq) * qstep);
+      y_h.internal_match (&y_d);
+      cve.perform (&c_d, &y_d, nq);
+      HIP::check (ctx, dspsr_amd_stream_sync (ctx), "sync");
+      d2h (ctx, y_h, y_d);
+      double qworst = 0, qscale = 0;
+      for (unsigned c = 0; c < Cq; c++) for (unsigned p = 0; p < 2; p++) for (unsigned part = 0; part < nq; part++)
+        for (unsigned t = (c + p + part) % 11; t < qstep; t += 997) {
+          // y[t] of this part = sum over the impulses inside its transform window of a_i h[(t + qpos - n_i) mod M]
+          double re = 0, im = 0;
+          const uint64_t w0 = uint64_t (part) * qstep;
+          for (size_t i = 0; i < imps.size (); i++) {
+            if (imps[i].n < w0 || imps[i].n >= w0 + Mq) continue;
+            const uint64_t m = (uint64_t (t) + qpos + Mq - (imps[i].n - w0)) % Mq;
+            double hr = 0, hi = 0;
+            for (unsigned k = 0; k < Mq; k++) {
+              const double a = 2.0 * M_PI * double ((uint64_t (k) * m) % Mq) / double (Mq);
+              const double kr = qresp.kernel[2 * (size_t (c) * Mq + k)], ki = qresp.kernel[2 * (size_t (c) * Mq + k) + 1];
+              hr += kr * cos (a) - ki * sin (a); hi += kr * sin (a) + ki * cos (a);
+            }
+            const double ar = imps[i].re * double (1 + c) * (p ? -1.0 : 1.0), ai = imps[i].im * double (1 + c);
+            re += ar * hr - ai * hi; im += ar * hi + ai * hr;
+          }
+          const float* got = y_h.get_datptr (c, p) + 2 * (size_t (part) * qstep + t);
+          if (fabs (got[0] - re) > qworst) qworst = fabs (got[0] - re);
+          if (fabs (got[1] - im) > qworst) qworst = fabs (got[1] - im);
+          if (fabs (re) > qscale) qscale = fabs (re);
+        }
+      REQUIRE (qworst <= 4e-6 * qscale && qscale > 0, "ConvolutionEngine with a 16384-point response differs from the direct sums by %g (scale %g)", qworst, qscale);
+      printf ("dspsr -F N: ConvolutionEngine, response of 16384 points (three tile passes) == direct sums (%.1e of the scale)\n", qworst / qscale);
+    }
   }
   catch (Error& error)
   {
