@@ -264,7 +264,7 @@ def test_pipeline_filterbank_then_convolution(oracle, gpu, when, machine):
                                                  (5, 4096, (0, 0), 3), (2, 64, (5, 7), 300), (1, 128, (9, 0), 130),
                                                  (3, 16384, (1000, 900), 4), (2, 32768, (0, 0), 2), (2, 131072, (5000, 4000), 4),
                                                  (2, 262144, (100, 200), 2), (1, 524288, (1000, 1000), 2), (2, 1048576, (30000, 20000), 2),
-                                                 (1, 2097152, (5, 100000), 2), (1, 4194304, (1000, 1000), 1)])
+                                                 (3, 2097152, (5, 100000), 2), (1, 4194304, (1000, 1000), 1)])
 def test_convolution_of_many_channels_as_one_launch_group(oracle, gpu, nchan, M, nfilt, npart):
     """dsp::Convolution behind a filterbank (`dspsr -F N`: nchan_subband = 1 on many complex channels, float32 rows): the channels of a
     group run as ONE launch group -- forward passes per channel, inverse passes of a group-wide filterbank (filterbank.hip
@@ -281,9 +281,10 @@ def test_convolution_of_many_channels_as_one_launch_group(oracle, gpu, nchan, M,
     outs, dets = [], []
     # force_four_pass 1: four tile passes, channels grouped; 2: four tile passes, loop over the channels; 0: the library's choice
     # (one tile pass for n_fft <= 8192, csrc/fb_conv1.hip; three for 2^14 ... 2^21, csrc/fb_conv3.hip; grouped four-pass above)
-    # (n_fft = 2^17 with max_parts = 1024: the three-pass scratch then holds one channel per launch group -- the loop over channel groups)
+    # (n_fft = 2^17 with max_parts = 1024: the three-pass scratch then holds one channel per launch group -- the loop over channel groups;
+    #  n_fft = 2^21 with max_parts = 30: two channels per group, three channels -- a ragged last group)
     for ffp in (1, 2, 0):
-        eng = dspsr_amd.FilterbankEngine(ctx).setup(1, M, nfilt[0], nfilt[1], nchan, 2, False, kernel, max_parts=1024 if M == 131072 else 3,
+        eng = dspsr_amd.FilterbankEngine(ctx).setup(1, M, nfilt[0], nfilt[1], nchan, 2, False, kernel, max_parts=1024 if M == 131072 else 30 if M == 2097152 else 3,
                                                     force_four_pass=ffp)
         assert eng.npass(False) == ((1 if M <= 8192 else 3 if M <= 2097152 else 4) if ffp == 0 else 4)
         out = torch.zeros((nchan, 2, 2 * npart * step), dtype=torch.float32, device="cuda")
